@@ -1,0 +1,187 @@
+"""Platform-stable synthetic checkpoints for parity tests and the benchmark.
+
+No pretrained CoVoMix weights exist (reference README.md:30), and full-width
+weights (VoMix 1.0 GB, HiFi-GAN 48 MB) cannot be committed, so every test and
+bench run regenerates *identical* weights from this recipe:
+
+    value(name) = RandomState(crc32(name) ^ seed).standard_normal(shape) * scale(name) + shift(name)
+
+`numpy.random.RandomState` streams are frozen by NumPy, so the container that
+produced tests/golden/*.npz (by loading these tensors into the *reference*
+modules) and the GPU box see bit-identical parameters.
+
+The recipe de-trivialises the identity-at-init parameters of the reference
+(AdaptiveRMSNorm to_gamma/to_beta acoustic.py:192-196, null_cond :382, HiFi-GAN
+N(0,0.01) conv init vocoder/utils.py:22-25) so that time conditioning, the CFG
+null branch and the vocoder's dynamic range are all exercised.
+
+Parameter names/shapes/order follow the reference modules:
+  acoustic: covomix/covomix_model/acoustic.py:326-406 (CoVoMix.__init__), :250-286 (Transformer)
+  vocoder : covomix/vocoder/models.py:75-98 (Generator.__init__), :11-33 (ResBlock1)
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+Shapes = "OrderedDict[str, Tuple[int, ...]]"
+
+
+def acoustic_param_shapes(dim=1024, dim_cond=160, dim_emb=1024, depth=8, heads=16, dim_head=64,
+                          streams=2, dim_out=80, num_phoneme_tokens=502, conv_k=31,
+                          time_hidden=None) -> Shapes:
+    """Ordered name->shape map in nn.Module.parameters() order of the reference CoVoMix.
+
+    VoMix  (twocondition_oneoutput): dim_cond=160, streams=2, dim_out=80 -> E_in = 2288
+    VoSingle                        : dim_cond=80,  streams=1, dim_out=80 -> E_in = 1184
+    """
+    th = time_hidden or dim * 4
+    e_in = dim_out + streams * dim_emb + dim_cond
+    s = OrderedDict()
+    s["null_cond"] = (dim_cond,)
+    s["sinu_pos_emb.0.weights"] = (dim // 2,)
+    s["sinu_pos_emb.1.weight"] = (th, dim)
+    s["sinu_pos_emb.1.bias"] = (th,)
+    s["to_phoneme_emb.weight"] = (num_phoneme_tokens + 1, dim_emb)
+    s["to_embed.weight"] = (dim, e_in)
+    s["to_embed.bias"] = (dim,)
+    s["conv_embed.dw_conv1d.0.weight"] = (dim, 1, conv_k)
+    s["conv_embed.dw_conv1d.0.bias"] = (dim,)
+    inner = heads * dim_head
+    for i in range(depth):
+        p = f"transformer.layers.{i}"
+        if i + 1 > depth // 2:
+            s[p + ".0.weight"] = (dim, 2 * dim)
+            s[p + ".0.bias"] = (dim,)
+        for n in (1, 3):
+            s[f"{p}.{n}.to_gamma.weight"] = (dim, th)
+            s[f"{p}.{n}.to_gamma.bias"] = (dim,)
+            s[f"{p}.{n}.to_beta.weight"] = (dim, th)
+            s[f"{p}.{n}.to_beta.bias"] = (dim,)
+            if n == 1:
+                s[p + ".2.to_qkv.weight"] = (3 * inner, dim)
+                s[p + ".2.to_out.weight"] = (dim, inner)
+        s[p + ".4.0.weight"] = (4 * dim, dim)
+        s[p + ".4.0.bias"] = (4 * dim,)
+        s[p + ".4.2.weight"] = (dim, 4 * dim)
+        s[p + ".4.2.bias"] = (dim,)
+    s["transformer.final_norm.gamma"] = (dim,)
+    s["to_pred.weight"] = (dim_out, dim)
+    return s
+
+
+def hifigan_param_shapes(h: dict) -> Shapes:
+    """Ordered name->shape map of Generator.state_dict() *before* remove_weight_norm
+    (bias, weight_g, weight_v per conv - the layout a `g_xxxxxxxx` checkpoint has)."""
+    s = OrderedDict()
+    c0 = h["upsample_initial_channel"]
+
+    def conv(name, cout, cin, k, transposed=False):
+        s[name + ".bias"] = (cout,)
+        d0 = cin if transposed else cout
+        s[name + ".weight_g"] = (d0, 1, 1)
+        s[name + ".weight_v"] = (cin, cout, k) if transposed else (cout, cin, k)
+
+    conv("conv_pre", c0, h.get("num_mels", 80), 7)
+    for i, k in enumerate(h["upsample_kernel_sizes"]):
+        conv(f"ups.{i}", c0 // 2 ** (i + 1), c0 // 2 ** i, k, transposed=True)
+    nk = len(h["resblock_kernel_sizes"])
+    ch = c0
+    for i in range(len(h["upsample_rates"])):
+        ch = c0 // 2 ** (i + 1)
+        for j, k in enumerate(h["resblock_kernel_sizes"]):
+            for grp in ("convs1", "convs2"):
+                for m in range(len(h["resblock_dilation_sizes"][j])):
+                    conv(f"resblocks.{i * nk + j}.{grp}.{m}", ch, ch, k)
+    conv("conv_post", 1, ch, 7)
+    return s
+
+
+def _rule(name: str, shape) -> Tuple[float, float]:
+    """(scale, shift) of the recipe for parameter `name`."""
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    # ---- acoustic model
+    if name == "null_cond":
+        return 1.0, 0.0
+    if name.endswith("to_gamma.weight"):
+        return 0.015, 0.0
+    if name.endswith("to_gamma.bias"):
+        return 0.1, 1.0
+    if name.endswith("to_beta.weight"):
+        return 0.01, 0.0
+    if name.endswith("to_beta.bias"):
+        return 0.1, 0.0
+    if name.endswith("final_norm.gamma"):
+        return 0.1, 1.0
+    if name == "sinu_pos_emb.0.weights" or name == "to_phoneme_emb.weight":
+        return 1.0, 0.0
+    # ---- vocoder (weight-norm parametrisation)
+    if name.endswith(".weight_g"):
+        g = 0.3 if name.startswith("conv_post") else 1.2
+        return 0.2 * g, g
+    if name.endswith(".weight_v"):
+        return 1.0, 0.0
+    # ---- generic
+    if name.endswith(".bias"):
+        return 0.02, 0.0
+    return 1.0 / np.sqrt(max(fan_in, 1)), 0.0
+
+
+def synth_array(name: str, shape, seed: int = 0) -> np.ndarray:
+    rs = np.random.RandomState((zlib.crc32(name.encode()) ^ seed) & 0xFFFFFFFF)
+    scale, shift = _rule(name, tuple(shape))
+    a = rs.standard_normal(tuple(shape)) * scale + shift
+    return a.astype(np.float32)
+
+
+def synth_state_dict(shapes: Shapes, seed: int = 0) -> "Dict[str, np.ndarray]":
+    return OrderedDict((k, synth_array(k, v, seed)) for k, v in shapes.items())
+
+
+def rotary_inv_freq(dim_head: int = 64, theta: float = 10000.0) -> np.ndarray:
+    """The `transformer.rotary_emb.inv_freq` buffer (acoustic.py:117-120), computed the
+    way torch does it in fp32: 1 / theta ** (arange(0, d, 2) / d)."""
+    import torch
+    return (1.0 / (theta ** (torch.arange(0, dim_head, 2).float() / dim_head))).numpy()
+
+
+HIFIGAN_COVOMIX_CONFIG = {
+    # hifi-gan/config_covomix.json:1-37 (the fields Generator reads)
+    "resblock": "1",
+    "upsample_rates": [5, 4, 4, 2],
+    "upsample_kernel_sizes": [8, 8, 4, 4],
+    "upsample_initial_channel": 500,
+    "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    "num_mels": 80,
+    "sampling_rate": 8000,
+    "hop_size": 160,
+}
+
+
+def synthetic_inputs(kind: str, batch: int, frames: int, prompt: int, seed: int = 1234):
+    """SURVEY.md section 8(d) synthetic inputs (seeded torch CPU generator).
+
+    kind = 'vomix'   : ids [B,T,2] (stream B is 157 on alternate 100-frame turns), cond [B,T,160]
+    kind = 'vosingle': ids [B,T], cond [B,T,80]
+    Returns dict(phoneme_ids, cond, mask, y0).  mel ~ N(-6, 2^2) clipped to [-11.52, 2].
+    """
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    two = kind == "vomix"
+    cdim = 160 if two else 80
+    ids = torch.randint(0, 501, (batch, frames, 2) if two else (batch, frames), generator=g)
+    if two:
+        turn = (torch.arange(frames) // 100) % 2
+        ids[:, turn == 0, 1] = 157
+        ids[:, turn == 1, 0] = 157
+    mel = (torch.randn(batch, frames, cdim, generator=g) * 2.0 - 6.0).clamp(-11.52, 2.0)
+    cond = torch.zeros(batch, frames, cdim)
+    cond[:, :prompt] = mel[:, :prompt]
+    mask = torch.zeros(batch, frames, dtype=torch.bool)
+    mask[:, prompt:] = True
+    y0 = torch.randn(batch, frames, 80, generator=g)
+    return dict(phoneme_ids=ids, cond=cond, mask=mask, y0=y0)
