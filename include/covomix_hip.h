@@ -1,0 +1,146 @@
+/* covomix_hip.h - C ABI of libcovomix_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the build.  The reference has no native
+ * code on this path - its contract is the PyTorch semantics of the modules cited
+ * below (paths relative to /root/reference) - so every entry point here names the
+ * reference computation it replaces.  Conventions:
+ *   - plain C symbols; device pointers + explicit shapes/strides; a hipStream_t
+ *     (passed as void*) on which the work is enqueued; no hidden allocation, no
+ *     global mutable state besides a thread-local last-error string;
+ *   - return 0 on success, CVX_EINVAL on a shape/alignment error, CVX_EHIP when
+ *     the HIP runtime reported a launch error (message via cvx_last_error_string);
+ *   - all floating-point data is fp32 row-major; token ids are int64.
+ * Weights are borrowed (never copied or freed by the library).
+ */
+#ifndef COVOMIX_HIP_H
+#define COVOMIX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVX_OK      0
+#define CVX_EINVAL (-22)
+#define CVX_EHIP   (-5)
+
+#define CVX_ACT_NONE 0
+#define CVX_ACT_GELU 1   /* exact erf GELU  (nn.GELU default, acoustic.py:159,244) */
+#define CVX_ACT_SILU 2   /* SiLU            (time MLP, acoustic.py:364)            */
+#define CVX_ACT_TANH 3
+
+typedef void* cvx_stream_t;   /* hipStream_t */
+
+int         cvx_version(void);
+const char* cvx_last_error_string(void);
+
+/* ------------------------------------------------------------------------
+ * C[M,N] = epilogue( [A | A2][M,K] * W[N,K]^T )      fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *
+ * Replaces every nn.Linear on the path: to_embed (acoustic.py:503-505), to_qkv /
+ * to_out (:225-237), FeedForward (:241-246), skip combiner on cat(x, skip)
+ * (:306-310, expressed as a K-split over two inputs: columns [0,K1) come from A,
+ * [K1,K) from A2), to_pred (:516), the time MLP (:361-365) and the to_gamma /
+ * to_beta projections (:200).
+ * epilogue order:  v = acc + bias[n];  v = act(v);
+ *                  RoPE (half-split, acoustic.py:132-137) on columns [0,rope_cols):
+ *                       64-wide heads, position = row % rope_T, tables cos/sin[rope_T][32];
+ *                  v += residual[m,n];  C[m,n] = v.
+ * Requirements: K % 4 == 0, lda/lda2/ldw % 4 == 0, 16-byte aligned A/A2/W,
+ *               K1 % 32 == 0 when A2 != NULL, rope_cols % 64 == 0.
+ */
+typedef struct {
+    const float* A;   int64_t lda;
+    const float* A2;  int64_t lda2;  int32_t K1;
+    const float* W;   int64_t ldw;
+    float*       C;   int64_t ldc;
+    const float* bias;
+    const float* residual; int64_t ldr;
+    int32_t M, N, K;
+    int32_t act;
+    const float* rope_cos; const float* rope_sin; int32_t rope_T; int32_t rope_cols;
+} cvx_gemm_args;
+int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s);
+
+/* y[r,:] = x[r,:] / max(||x[r,:]||_2, eps) * scale * gamma[g,:] + beta[g,:],  g = r / rows_per_group
+ * AdaptiveRMSNorm.forward (acoustic.py:198-204) with gamma/beta = the already projected
+ * to_gamma/to_beta(time_emb) rows; RMSNorm.forward (:175) when beta == NULL and one group.
+ * D % 4 == 0. */
+int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                       int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
+                       cvx_stream_t s);
+
+/* out[b,t,h*64+d] = softmax_j( q[b,h,t,:] . k[b,h,j,:] * scale ) @ v[b,h,j,d]
+ * Attend.forward non-flash branch (attend.py:108-126) without materialising the T x T
+ * scores.  qkv is the to_qkv output [Bt, T, 3*H*64] (q | k | v, heads contiguous
+ * 64-blocks, acoustic.py:227-229) with RoPE already applied to q and k (GEMM epilogue).
+ * Head dim is fixed at 64 (every shipped config, running_command/Acous_*.sh). */
+int cvx_attention_f32(const float* qkv, float* out, int32_t Bt, int32_t T, int32_t H,
+                      float scale, cvx_stream_t s);
+
+/* y[b,t,c] = GELU( bias[c] + sum_k w[c,k] * x[b,t+k-K/2,c] ) + x[b,t,c]
+ * ConvPositionEmbed + residual (acoustic.py:141-161, :508), channels-last, K == 31. */
+int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
+                              int32_t Bt, int32_t T, int32_t C, cvx_stream_t s);
+
+/* v = f_c*(1+s) - s*f_n   (f_n == NULL: v = f_c)        CFG combine, acoustic.py:428
+ * out = y + coef*v ; out2, out3 = optional extra copies  ODE stage update (torchdiffeq midpoint:
+ * y_mid = y + f0*dt/2, y1 = y + dt*f_mid); `out` may alias `y`. */
+int cvx_cfg_combine_axpy_f32(const float* f_c, const float* f_n, const float* y, float cond_scale,
+                             float coef, float* out, float* out2, float* out3, int64_t n, cvx_stream_t s);
+
+/* rows of [ emb(ids[m,0]) | emb(ids[m,1]) ... | cond[m,:] ]  -> out[M, S*E + Cc]
+ * (the step-invariant columns of the to_embed input, acoustic.py:496-503).
+ * ids == NULL: every id is `null_id`; cond_row != NULL: cond is that single broadcast row
+ * (CFG null substitution, acoustic.py:473-494). */
+int cvx_embed_gather_f32(const int64_t* ids, int32_t S, const float* table, int32_t E, int32_t n_rows_table,
+                         const float* cond, const float* cond_row, int32_t Cc, int64_t null_id,
+                         float* out, int64_t M, cvx_stream_t s);
+
+/* out[i, :] = cat( sin(t_i * w * 2pi), cos(t_i * w * 2pi) )   LearnedSinusoidalPosEmb (acoustic.py:107-111) */
+int cvx_time_fourier_f32(const float* times, const float* w, float* out, int32_t n, int32_t half,
+                         cvx_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * HiFi-GAN generator (covomix/vocoder/models.py:75-125, hifi-gan/config_covomix.json)
+ *
+ * One implicit-GEMM fp32-MFMA kernel covers Conv1d (dilated, "same" padding) and
+ * ConvTranspose1d (as a stride-1 conv over the zero-stuffed input with the flipped
+ * kernel):  out[b,co,l] = ((bias[co] + sum_{ci,kk} Wp[co,ci,kk] * z[b,ci,l + kk*dil - pad]
+ *                          + res[b,co,l]) + accum[b,co,l]) * out_scale
+ *   z = leaky_relu(x, in_slope) zero-stuffed by `up` (up == 1: plain conv), zero outside.
+ * Wp is the packed weight produced by cvx_hifigan_pack_weight_f32 (host-side layout
+ * [co_blk][ci_chunk][kk][CO_T][16]).  res / accum may be NULL; accum may alias out.
+ * Covers conv_pre (:81), ups[i] preceded by leaky_relu (:102-103), every ResBlock1
+ * conv with its preceding leaky_relu and residual add (:35-42) and the
+ * xs accumulate / divide by num_kernels (:104-110). */
+typedef struct {
+    const float* x;  int32_t B, Cin, Lin;
+    const float* Wp; const float* bias;
+    float* out;      int32_t Cout, Lout;
+    int32_t ksize, dil, pad, up;
+    float in_slope;
+    const float* res; const float* accum; float out_scale;
+} cvx_conv_args;
+int     cvx_hifigan_conv1d_f32(const cvx_conv_args* a, cvx_stream_t s);
+/* number of floats of the packed weight for (Cout, Cin, ksize) */
+int64_t cvx_hifigan_packed_weight_floats(int32_t Cout, int32_t Cin, int32_t ksize);
+/* host-side (CPU) packing of a Conv1d weight [Cout,Cin,k] (transposed == 0) or a
+ * ConvTranspose1d weight [Cin,Cout,k] (transposed != 0, kernel flipped) into Wp. */
+int     cvx_hifigan_pack_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize,
+                                    int32_t transposed, float* Wp);
+
+/* y[b,0,l] = tanh( bias + sum_{ci,k} w[ci,k] * leaky_relu(x[b,ci,l+k-3], slope) )
+ * final leaky_relu (default slope 0.01, models.py:112) + conv_post + tanh (:113-114). ksize == 7. */
+int cvx_hifigan_post_f32(const float* x, const float* w, float bias, float* y,
+                         int32_t B, int32_t Cin, int32_t L, float slope, cvx_stream_t s);
+
+/* pcm[i] = (int16) trunc( wav[i] * 32768 )   mel_decode_to_wav tail (monologue_generation.py:55-57),
+ * numpy astype('int16') semantics for in-range values (C truncation toward zero). */
+int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVOMIX_HIP_H */

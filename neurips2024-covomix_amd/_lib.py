@@ -1,0 +1,98 @@
+"""ctypes binding of libcovomix_hip.so (the C ABI declared in include/covomix_hip.h).
+
+There is NO fallback: if the shared library has not been built (or cannot be loaded)
+every op raises.  `torch` must be imported first so that the library's
+`libamdhip64.so.7` dependency resolves to the HIP runtime PyTorch already loaded
+(one runtime per process => torch's streams are valid stream handles here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the kernels share with torch)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcovomix_hip.so")
+
+_f32p = C.POINTER(C.c_float)
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("A2", C.c_void_p), ("lda2", C.c_int64), ("K1", C.c_int32),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("act", C.c_int32),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_T", C.c_int32), ("rope_cols", C.c_int32),
+    ]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("B", C.c_int32), ("Cin", C.c_int32), ("Lin", C.c_int32),
+        ("Wp", C.c_void_p), ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("Cout", C.c_int32), ("Lout", C.c_int32),
+        ("ksize", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32),
+        ("in_slope", C.c_float),
+        ("res", C.c_void_p), ("accum", C.c_void_p), ("out_scale", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/covomix_hip.h
+SIGNATURES = {
+    "cvx_version": (C.c_int, []),
+    "cvx_last_error_string": (C.c_char_p, []),
+    "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "cvx_adarmsnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                     C.c_int64, C.c_float, C.c_float, C.c_void_p]),
+    "cvx_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "cvx_dwconv31_gelu_res_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_void_p]),
+    "cvx_cfg_combine_axpy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvx_embed_gather_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvx_time_fourier_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "cvx_hifigan_conv1d_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "cvx_hifigan_packed_weight_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "cvx_hifigan_pack_weight_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "cvx_hifigan_post_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_void_p]),
+    "cvx_wav_to_int16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+class CovomixHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises loudly if it is missing - there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CovomixHipError(
+            f"{LIB_PATH} not found: the gfx950 HIP library has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "covomix_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI drift; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().cvx_last_error_string()
+        raise CovomixHipError(f"{what or 'covomix_hip'} failed (rc={rc}): {msg.decode() if msg else ''}")

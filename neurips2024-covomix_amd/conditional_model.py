@@ -1,0 +1,149 @@
+"""`CoVoMixModel` facade - the Python-level drop-in boundary.
+
+Mirrors the inference surface of the reference LightningModule
+(covomix/conditional_model.py:38-321) without Lightning / torch_ema / diffusers:
+
+    model = CoVoMixModel.load_from_checkpoint(ckpt, base_dir='', batch_size=16, num_workers=0)
+    model.eval()                  # swaps in the EMA shadow weights (conditional_model.py:203-217)
+    model = model.to(device)
+    mel = model.synthesis_sample(phoneme_ids=..., cond=..., mask=..., cond_scale=0.7)   # :295-302
+
+Checkpoint layout accepted (what Lightning's ModelCheckpoint + on_save_checkpoint write, :150,:200-201):
+    ckpt['state_dict']        keys 'cfm_wrapper.CoVoMix.<param>'
+    ckpt['hyper_parameters']  dict (may reference classes such as covomix.data_module.SpecsDataModule
+                              that do not exist here -> unpickled as inert stubs)
+    ckpt['ema']               torch_ema state: {'decay','num_updates','shadow_params': [...], 'collected_params'}
+                              with shadow_params in nn.Module.parameters() order
+If 'ema' is missing the plain state_dict is used, with a warning (:192-198).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import types
+import warnings
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from .acoustic import FlowMatchingSampler, VectorField
+
+_PREFIX = "cfm_wrapper.CoVoMix."
+
+
+class _StubUnpickler(pickle.Unpickler):
+    """Unpickler that turns references to classes/functions of modules that are not installed here
+    (pytorch_lightning callbacks, covomix.data_module.SpecsDataModule, ...) into inert placeholders."""
+
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            return type(name, (), {"__module__": module, "__init__": lambda self, *a, **k: None,
+                                   "__setstate__": lambda self, s: None})
+
+
+_stub_pickle = types.SimpleNamespace(Unpickler=_StubUnpickler, load=lambda f, **kw: _StubUnpickler(f, **kw).load(),
+                                     __name__="covomix_amd_stub_pickle")
+
+
+def _torch_load(path: str):
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_stub_pickle)
+
+
+def parameter_order(sd_keys) -> list:
+    """Names in nn.Module.parameters() order for the reference CoVoMix (buffers such as
+    rotary_emb.inv_freq are not parameters)."""
+    return [k for k in sd_keys if not k.endswith("rotary_emb.inv_freq")]
+
+
+class CoVoMixModel:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], hparams: Optional[dict] = None,
+                 ema_shadow: Optional[list] = None, nfe: int = 32, ode_method: str = "midpoint"):
+        """state_dict: un-prefixed CoVoMix parameter names (acoustic.py:326-406)."""
+        self.hparams = dict(hparams or {})
+        if self.hparams.get("text2semantic"):
+            raise NotImplementedError("text2semantic checkpoints are outside this build's hot path (SURVEY.md section 8f N1)")
+        if self.hparams.get("twocondition_twooutput"):
+            raise NotImplementedError("twocondition_twooutput is not supported (SURVEY.md section 8f N2)")
+        self._raw = OrderedDict((k, v.detach().cpu()) for k, v in state_dict.items())
+        self._ema = None
+        if ema_shadow is not None:
+            names = parameter_order(self._raw.keys())
+            if len(names) != len(ema_shadow):
+                raise ValueError(f"EMA has {len(ema_shadow)} shadow params, model has {len(names)} parameters")
+            self._ema = OrderedDict(self._raw)
+            for n, t in zip(names, ema_shadow):
+                if tuple(t.shape) != tuple(self._raw[n].shape):
+                    raise ValueError(f"EMA shadow param shape mismatch at {n}")
+                self._ema[n] = t.detach().cpu()
+        self._error_loading_ema = ema_shadow is None
+        self._use_ema = False
+        self.device = torch.device("cpu")
+        self.nfe, self.ode_method = nfe, ode_method
+        self._field: Optional[VectorField] = None
+
+    # ---- construction ---------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, base_dir='', batch_size=16, num_workers=0, **kwargs):
+        assert os.path.isfile(checkpoint_path), checkpoint_path      # mirrors monologue_generation.py:46
+        ckpt = _torch_load(checkpoint_path)
+        sd = OrderedDict((k[len(_PREFIX):], v) for k, v in ckpt["state_dict"].items() if k.startswith(_PREFIX))
+        if not sd:
+            raise KeyError(f"no '{_PREFIX}*' entries in checkpoint state_dict")
+        ema = ckpt.get("ema")
+        shadow = None
+        if ema is not None:
+            shadow = ema["shadow_params"]
+        else:
+            warnings.warn("EMA state_dict not found in checkpoint!")
+        hp = ckpt.get("hyper_parameters", {})
+        hp = {k: v for k, v in dict(hp).items() if isinstance(v, (int, float, str, bool, type(None)))}
+        return cls(sd, hparams=hp, ema_shadow=shadow, **kwargs)
+
+    @classmethod
+    def from_state_dict(cls, state_dict, **kwargs):
+        return cls(state_dict, **kwargs)
+
+    # ---- nn.Module-like surface -------------------------------------------------------------
+    def train(self, mode: bool = True, no_ema: bool = False):
+        use = (not mode) and (not no_ema) and (not self._error_loading_ema)
+        if use != self._use_ema:
+            self._use_ema = use
+            self._field = None
+        return self
+
+    def eval(self, no_ema: bool = False):
+        return self.train(False, no_ema=no_ema)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device != self.device:
+            self.device = device
+            self._field = None
+        return self
+
+    def active_state_dict(self) -> Dict[str, torch.Tensor]:
+        return self._ema if (self._use_ema and self._ema is not None) else self._raw
+
+    def _get_field(self) -> VectorField:
+        if self._field is None:
+            if self.device.type != "cuda":
+                from ._lib import CovomixHipError
+                raise CovomixHipError("CoVoMixModel must be on a GPU (`.to('cuda')`): covomix_amd has no CPU path")
+            self._field = VectorField(self.active_state_dict(), self.device)
+        return self._field
+
+    # ---- sampling -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def synthesis_sample(self, phoneme_ids, cond, mask, cond_scale, y0=None):
+        """reference conditional_model.py:295-302 -> ConditionalFlowMatcherWrapper.sample.
+        `mask` is accepted and unused, exactly as in the reference (acoustic.py:597-688).
+        `y0` (optional) fixes the initial noise; parity is defined given y0."""
+        sampler = FlowMatchingSampler(self._get_field(), nfe=self.nfe, method=self.ode_method)
+        out = sampler.sample(phoneme_ids=phoneme_ids, cond=cond, mask=mask, cond_scale=cond_scale, y0=y0)
+        return out.to(cond.device) if cond.device != out.device else out
+
+    def synthesis_sample_text2semantic(self, *a, **k):
+        raise NotImplementedError("text2semantic AR decoding is a 'next' row (SURVEY.md section 8f N1), not built yet")

@@ -1,0 +1,288 @@
+// Memory-bound kernels of the CoVoMix vector field + library-wide error plumbing (gfx950).
+//   cvx_adarmsnorm_f32          AdaptiveRMSNorm / RMSNorm       (acoustic.py:165-204)
+//   cvx_dwconv31_gelu_res_f32   ConvPositionEmbed + residual    (acoustic.py:141-161, :508)
+//   cvx_cfg_combine_axpy_f32    CFG combine + ODE stage update  (acoustic.py:428; torchdiffeq midpoint)
+//   cvx_embed_gather_f32        step-invariant to_embed columns (acoustic.py:473-503)
+//   cvx_time_fourier_f32        LearnedSinusoidalPosEmb         (acoustic.py:107-111)
+//   cvx_wav_to_int16            mel_decode_to_wav tail          (monologue_generation.py:55-57)
+// All are HBM-bound: 16-byte coalesced accesses over the channel axis, wavefront (64-lane)
+// shuffles for the row reduction, no LDS needed.
+#include "cvx_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------- error string
+static thread_local char g_err[512] = "";
+void cvx_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cvx_last_error_string(void) { return g_err; }
+extern "C" int cvx_version(void) { return 100; }
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- AdaRMSNorm
+// one wavefront per row; the row stays in registers when D <= 256*NV.
+template <int NV>
+__global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int64_t rows, int D, int64_t rows_per_group, float scale, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const int64_t g = row / rows_per_group;
+    const float* gr = gamma + g * D;
+    const float* br = beta ? beta + g * D : nullptr;
+    float* yr = y + row * D;
+    const int nvec = D >> 2;
+
+    f32x4 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = scale / fmaxf(sqrtf(ss), eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(gr + 4 * j);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[i][e] * inv * gg[e];
+            if (br) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(br + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += bb[e];
+            }
+            *reinterpret_cast<f32x4*>(yr + 4 * j) = o;
+        }
+    }
+}
+
+// generic-D fallback: two passes over the row (second pass hits L1/L2)
+__global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                int64_t rows, int D, int64_t rows_per_group, float scale, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const int64_t g = row / rows_per_group;
+    float ss = 0.f;
+    for (int j = lane; j < (D >> 2); j += 64) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+        ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+    }
+    ss = wave_sum(ss);
+    const float inv = scale / fmaxf(sqrtf(ss), eps);
+    for (int j = lane; j < (D >> 2); j += 64) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + g * D + 4 * j);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = t[e] * inv * gg[e];
+        if (beta) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + g * D + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += bb[e];
+        }
+        *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
+    }
+}
+
+// ---------------------------------------------------------------- depthwise conv k=31 + GELU + residual
+// channels-last [Bt,T,C]: a thread owns one channel and TT consecutive frames; every global
+// access is a 256-byte coalesced row segment across the block's 64 channels x 4... (one wave = 64 channels).
+constexpr int DW_K = 31;
+constexpr int DW_TT = 32;
+__global__ __launch_bounds__(256) void dwconv31_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int T, int C)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int t0 = blockIdx.y * DW_TT;
+    const int64_t base = (int64_t)blockIdx.z * T * C;
+    float wk[DW_K];
+#pragma unroll
+    for (int k = 0; k < DW_K; ++k) wk[k] = w[c * DW_K + k];
+    float acc[DW_TT];
+#pragma unroll
+    for (int o = 0; o < DW_TT; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DW_TT + DW_K - 1; ++i) {
+        const int t = t0 + i - DW_K / 2;
+        const float xv = (t >= 0 && t < T) ? x[base + (int64_t)t * C + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < DW_K; ++k) {
+            const int o = i - k;                       // output frame (relative) fed by tap k
+            if (o >= 0 && o < DW_TT) acc[o] = fmaf(wk[k], xv, acc[o]);
+        }
+    }
+    const float bc = bias[c];
+#pragma unroll
+    for (int o = 0; o < DW_TT; ++o) {
+        const int t = t0 + o;
+        if (t < T) {
+            const int64_t idx = base + (int64_t)t * C + c;
+            y[idx] = gelu_erf(acc[o] + bc) + x[idx];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- CFG combine + axpy
+__global__ __launch_bounds__(256) void cfg_axpy_kernel(const float* __restrict__ fc, const float* __restrict__ fn,
+                                                      const float* y, float s, float coef,   // out may alias y
+                                                      float* out, float* __restrict__ out2,
+                                                      float* __restrict__ out3, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = fc[i];
+    if (fn) v = v * (1.0f + s) - s * fn[i];
+    const float o = y[i] + v * coef;
+    out[i] = o;
+    if (out2) out2[i] = o;
+    if (out3) out3[i] = o;
+}
+
+// ---------------------------------------------------------------- embedding gather
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, int S,
+                                                          const float* __restrict__ table, int E, int n_rows_table,
+                                                          const float* __restrict__ cond, const float* __restrict__ cond_row,
+                                                          int Cc, int64_t null_id, float* __restrict__ out)
+{
+    const int64_t m = blockIdx.x;
+    const int width = S * E + Cc;
+    float* o = out + m * width;
+    for (int j = threadIdx.x; j < width; j += 256) {
+        float v;
+        if (j < S * E) {
+            const int s = j / E, e = j - s * E;
+            int64_t id = ids ? ids[m * S + s] : null_id;
+            id = id < 0 ? 0 : (id >= n_rows_table ? n_rows_table - 1 : id);
+            v = table[id * E + e];
+        } else {
+            const int cidx = j - S * E;
+            v = cond_row ? cond_row[cidx] : cond[m * Cc + cidx];
+        }
+        o[j] = v;
+    }
+}
+
+// ---------------------------------------------------------------- time Fourier features
+__global__ __launch_bounds__(256) void time_fourier_kernel(const float* __restrict__ times, const float* __restrict__ w,
+                                                          float* __restrict__ out, int half)
+{
+    const int i = blockIdx.x;
+    const float t = times[i];
+    for (int j = threadIdx.x; j < half; j += 256) {
+        const float ang = t * w[j] * 2.0f * 3.14159265358979323846f;
+        out[(int64_t)i * 2 * half + j] = sinf(ang);
+        out[(int64_t)i * 2 * half + half + j] = cosf(ang);
+    }
+}
+
+// ---------------------------------------------------------------- float wav -> int16 PCM
+__global__ __launch_bounds__(256) void wav_to_int16_kernel(const float* __restrict__ wav, int16_t* __restrict__ pcm, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = wav[i] * 32768.0f;
+    pcm[i] = (int16_t)(int32_t)v;     // trunc toward zero, wrap like numpy astype on x86
+}
+
+}  // namespace
+
+extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                  int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
+                                  cvx_stream_t s)
+{
+    CVX_REQUIRE(x && gamma && y, "adarmsnorm: null pointer");
+    CVX_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0 && rows_per_group > 0, "adarmsnorm: bad shape rows=%ld D=%d", (long)rows, D);
+    if (rows == 0) return CVX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
+    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
+    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
+    CVX_CHECK_LAUNCH("cvx_adarmsnorm_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
+                                         int32_t Bt, int32_t T, int32_t C, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && w && bias && y, "dwconv31: null pointer");
+    CVX_REQUIRE(Bt >= 0 && T > 0 && C > 0, "dwconv31: bad shape");
+    CVX_REQUIRE(x != y, "dwconv31: in-place operation is not supported");
+    if (Bt == 0) return CVX_OK;
+    dim3 grid((C + 255) / 256, (T + DW_TT - 1) / DW_TT, Bt);
+    hipLaunchKernelGGL(dwconv31_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, w, bias, y, T, C);
+    CVX_CHECK_LAUNCH("cvx_dwconv31_gelu_res_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_cfg_combine_axpy_f32(const float* f_c, const float* f_n, const float* y, float cond_scale,
+                                        float coef, float* out, float* out2, float* out3, int64_t n, cvx_stream_t s)
+{
+    CVX_REQUIRE(f_c && y && out && n >= 0, "cfg_axpy: bad arguments");
+    if (n == 0) return CVX_OK;
+    hipLaunchKernelGGL(cfg_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       f_c, f_n, y, cond_scale, coef, out, out2, out3, n);
+    CVX_CHECK_LAUNCH("cvx_cfg_combine_axpy_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_embed_gather_f32(const int64_t* ids, int32_t S, const float* table, int32_t E, int32_t n_rows_table,
+                                    const float* cond, const float* cond_row, int32_t Cc, int64_t null_id,
+                                    float* out, int64_t M, cvx_stream_t s)
+{
+    CVX_REQUIRE(table && out && S > 0 && E > 0 && Cc >= 0 && M >= 0, "embed_gather: bad arguments");
+    CVX_REQUIRE(cond || cond_row || Cc == 0, "embed_gather: cond and cond_row both null");
+    if (M == 0) return CVX_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)M), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       ids, S, table, E, n_rows_table, cond, cond_row, Cc, null_id, out);
+    CVX_CHECK_LAUNCH("cvx_embed_gather_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_time_fourier_f32(const float* times, const float* w, float* out, int32_t n, int32_t half, cvx_stream_t s)
+{
+    CVX_REQUIRE(times && w && out && n >= 0 && half > 0, "time_fourier: bad arguments");
+    if (n == 0) return CVX_OK;
+    hipLaunchKernelGGL(time_fourier_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(s), times, w, out, half);
+    CVX_CHECK_LAUNCH("cvx_time_fourier_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s)
+{
+    CVX_REQUIRE(wav && pcm && n >= 0, "wav_to_int16: bad arguments");
+    if (n == 0) return CVX_OK;
+    hipLaunchKernelGGL(wav_to_int16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), wav, pcm, n);
+    CVX_CHECK_LAUNCH("cvx_wav_to_int16");
+    return CVX_OK;
+}

@@ -1,0 +1,182 @@
+"""Torch-tensor front ends of the C-ABI kernels.  Tensors are only device memory +
+a stream here; every FLOP of the hot path happens in libcovomix_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, GemmArgs
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.CovomixHipError("covomix_amd ops need tensors on the GPU (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
+         a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0) -> torch.Tensor:
+    """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
+    inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix."""
+    _chk_f32(a, w, out, bias, residual, a2)
+    M = a.shape[0]
+    N = w.shape[0]
+    k1 = a.shape[1]
+    K = k1 + (a2.shape[1] if a2 is not None else 0)
+    assert w.shape[1] == K, f"gemm: K mismatch ({w.shape[1]} vs {K})"
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and out.shape == (M, N)
+    g = GemmArgs()
+    g.A, g.lda = a.data_ptr(), a.stride(0)
+    if a2 is not None:
+        assert a2.shape[0] == M and a2.stride(1) == 1
+        g.A2, g.lda2, g.K1 = a2.data_ptr(), a2.stride(0), k1
+    else:
+        g.A2, g.lda2, g.K1 = None, 0, 0
+    g.W, g.ldw = w.data_ptr(), w.stride(0)
+    g.C, g.ldc = out.data_ptr(), out.stride(0)
+    g.bias = _p(bias)
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
+    else:
+        g.residual, g.ldr = None, 0
+    g.M, g.N, g.K, g.act = M, N, K, act
+    if rope is not None:
+        cos, sin = rope
+        _chk_f32(cos, sin)
+        g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = cos.data_ptr(), sin.data_ptr(), cos.shape[0], rope_cols
+    else:
+        g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
+    _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
+    return out
+
+
+def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: torch.Tensor,
+               rows_per_group: Optional[int] = None, eps: float = 1e-12) -> torch.Tensor:
+    _chk_f32(x, gamma, beta, out)
+    assert x.is_contiguous() and out.is_contiguous() and gamma.stride(-1) == 1
+    D = x.shape[-1]
+    rows = x.numel() // D
+    rpg = rows if rows_per_group is None else rows_per_group
+    _lib.check(_lib.load().cvx_adarmsnorm_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), out.data_ptr(), rows, D, rpg,
+                                              float(D) ** 0.5, eps, _stream()), "cvx_adarmsnorm_f32")
+    return out
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, Bt: int, T: int, H: int, scale: float) -> torch.Tensor:
+    _chk_f32(qkv, out)
+    assert qkv.is_contiguous() and out.is_contiguous()
+    assert qkv.numel() == Bt * T * 3 * H * 64 and out.numel() == Bt * T * H * 64
+    _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), out.data_ptr(), Bt, T, H, scale, _stream()),
+               "cvx_attention_f32")
+    return out
+
+
+def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor,
+                      Bt: int, T: int) -> torch.Tensor:
+    _chk_f32(x, w, bias, out)
+    C_ = x.shape[-1]
+    assert x.is_contiguous() and out.is_contiguous() and w.is_contiguous() and w.numel() == C_ * 31
+    _lib.check(_lib.load().cvx_dwconv31_gelu_res_f32(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                     Bt, T, C_, _stream()), "cvx_dwconv31_gelu_res_f32")
+    return out
+
+
+def cfg_combine_axpy(f_c, f_n, y, cond_scale: float, coef: float, out, out2=None, out3=None) -> None:
+    _chk_f32(f_c, f_n, y, out, out2, out3)
+    n = y.numel()
+    assert f_c.numel() == n and out.numel() == n and (f_n is None or f_n.numel() == n)
+    for t in (f_c, f_n, y, out, out2, out3):
+        assert t is None or t.is_contiguous()
+    _lib.check(_lib.load().cvx_cfg_combine_axpy_f32(f_c.data_ptr(), _p(f_n), y.data_ptr(), cond_scale, coef,
+                                                    out.data_ptr(), _p(out2), _p(out3), n, _stream()),
+               "cvx_cfg_combine_axpy_f32")
+
+
+def embed_gather(ids: Optional[torch.Tensor], streams: int, table: torch.Tensor, cond: Optional[torch.Tensor],
+                 cond_row: Optional[torch.Tensor], cond_dim: int, null_id: int, out: torch.Tensor, M: int) -> torch.Tensor:
+    _chk_f32(table, cond, cond_row, out)
+    if ids is not None:
+        assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == M * streams
+    E = table.shape[1]
+    assert out.is_contiguous() and out.numel() == M * (streams * E + cond_dim)
+    _lib.check(_lib.load().cvx_embed_gather_f32(_p(ids), streams, table.data_ptr(), E, table.shape[0], _p(cond),
+                                                _p(cond_row), cond_dim, null_id, out.data_ptr(), M, _stream()),
+               "cvx_embed_gather_f32")
+    return out
+
+
+def time_fourier(times: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _chk_f32(times, w, out)
+    n, half = times.numel(), w.numel()
+    assert out.is_contiguous() and out.numel() == n * 2 * half
+    _lib.check(_lib.load().cvx_time_fourier_f32(times.data_ptr(), w.data_ptr(), out.data_ptr(), n, half, _stream()),
+               "cvx_time_fourier_f32")
+    return out
+
+
+def hifigan_conv1d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
+                   cout: int, ksize: int, dil: int = 1, pad: int = 0, up: int = 1, in_slope: float = 1.0,
+                   res=None, accum=None, out_scale: float = 1.0) -> torch.Tensor:
+    _chk_f32(x, wp, bias, out, res, accum)
+    B, Cin, Lin = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape[0] == B and out.shape[1] == cout
+    a = ConvArgs()
+    a.x, a.B, a.Cin, a.Lin = x.data_ptr(), B, Cin, Lin
+    a.Wp, a.bias = wp.data_ptr(), _p(bias)
+    a.out, a.Cout, a.Lout = out.data_ptr(), cout, out.shape[2]
+    a.ksize, a.dil, a.pad, a.up = ksize, dil, pad, up
+    a.in_slope = in_slope
+    a.res, a.accum, a.out_scale = _p(res), _p(accum), out_scale
+    _lib.check(_lib.load().cvx_hifigan_conv1d_f32(C.byref(a), _stream()), "cvx_hifigan_conv1d_f32")
+    return out
+
+
+def hifigan_pack_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """Host-side packing of a folded conv weight into the kernel's [co_blk][chunk][k][co][16] layout."""
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    if transposed:
+        cin, cout, k = w.shape
+    else:
+        cout, cin, k = w.shape
+    lib = _lib.load()
+    n = lib.cvx_hifigan_packed_weight_floats(cout, cin, k)
+    wp = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.cvx_hifigan_pack_weight_f32(w.data_ptr(), cout, cin, k, int(transposed), wp.data_ptr()),
+               "cvx_hifigan_pack_weight_f32")
+    return wp
+
+
+def hifigan_post(x: torch.Tensor, w: torch.Tensor, bias: float, out: torch.Tensor, slope: float = 0.01) -> torch.Tensor:
+    _chk_f32(x, w, out)
+    B, Cin, L = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.numel() == B * L and w.numel() == Cin * 7
+    _lib.check(_lib.load().cvx_hifigan_post_f32(x.data_ptr(), w.data_ptr(), bias, out.data_ptr(), B, Cin, L, slope,
+                                                _stream()), "cvx_hifigan_post_f32")
+    return out
+
+
+def wav_to_int16(wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_f32(wav)
+    assert wav.is_contiguous()
+    if out is None:
+        out = torch.empty(wav.shape, dtype=torch.int16, device=wav.device)
+    _lib.check(_lib.load().cvx_wav_to_int16(wav.data_ptr(), out.data_ptr(), wav.numel(), _stream()), "cvx_wav_to_int16")
+    return out

@@ -1,0 +1,188 @@
+"""HiFi-GAN generator on the MI355X kernels - drop-in for the reference `Generator`.
+
+Mirrors covomix/vocoder/models.py:75-125 (Generator), :11-48 (ResBlock1) and
+covomix/vocoder/env.py:5-8 (AttrDict) of the reference:
+
+    h = AttrDict(json.load(open('vocoder_config.json')))
+    generator = Generator(h).to(device)
+    generator.load_state_dict(torch.load(ckpt)['generator'])      # weight_g / weight_v / bias
+    generator.eval(); generator.remove_weight_norm()
+    wav = generator(mel)            # mel [B,80,T] -> [B,1,160T+32];  [80,T] -> [1,160T+32]
+
+Only resblock == '1' (what config_covomix.json selects) is implemented.  Each conv launch
+fuses the preceding leaky_relu, bias, the ResBlock residual add and the running
+`xs += resblock(x)` / `xs / num_kernels` of Generator.forward (models.py:104-110).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+LRELU_SLOPE = 0.1   # models.py:8
+
+
+class AttrDict(dict):
+    """dict with attribute access (reference env.py:5-8)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+def get_padding(kernel_size: int, dilation: int = 1) -> int:
+    return int((kernel_size * dilation - dilation) / 2)     # vocoder/utils.py:34-35
+
+
+def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """weight = weight_v * weight_g / ||weight_v|| with the norm over every dim but 0
+    (torch._weight_norm, dim=0 - per INPUT channel for ConvTranspose1d).  Load-time plumbing."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_g"):
+            base = k[: -len(".weight_g")]
+            wv = sd[base + ".weight_v"].float()
+            nrm = wv.reshape(wv.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (wv.ndim - 1)))
+            out[base + ".weight"] = wv * (v.float() / nrm)
+        elif not k.endswith(".weight_v"):
+            out[k] = v
+    return out
+
+
+class _Conv:
+    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn")
+
+
+class Generator:
+    def __init__(self, h):
+        if str(h["resblock"]) != "1":
+            raise NotImplementedError("only ResBlock1 (resblock == '1') is supported, as in config_covomix.json")
+        self.h = h
+        self.num_kernels = len(h["resblock_kernel_sizes"])
+        self.num_upsamples = len(h["upsample_rates"])
+        self.device = torch.device("cpu")
+        self._sd: Optional[Dict[str, torch.Tensor]] = None
+        self._has_weight_norm = False
+        self._packed = None
+
+    # ---- nn.Module-like surface used by the reference scripts -------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        self._sd = {k: v.detach().to("cpu") for k, v in sd.items()}
+        self._has_weight_norm = any(k.endswith(".weight_g") for k in self._sd)
+        self._packed = None
+        return self
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device != self.device:
+            self.device = device
+            self._packed = None
+        return self
+
+    def remove_weight_norm(self):
+        print('Removing weight norm...')
+        if self._has_weight_norm:
+            self._sd = fold_weight_norm(self._sd)
+            self._has_weight_norm = False
+            self._packed = None
+        return self
+
+    # ---- weight packing -----------------------------------------------------------------
+    def _conv(self, name: str, dil: int = 1, pad: int = 0, transposed: bool = False, up: int = 1) -> _Conv:
+        sd = self._sd
+        w = sd[name + ".weight"].float()
+        c = _Conv()
+        if transposed:
+            c.cin, c.cout, c.k = w.shape
+            c.pad = c.k - 1 - pad            # stride-1 conv over the zero-stuffed input, flipped kernel
+        else:
+            c.cout, c.cin, c.k = w.shape
+            c.pad = pad
+        c.dil, c.up = dil, up
+        c.wp = ops.hifigan_pack_weight(w, transposed).to(self.device)
+        c.bias = sd[name + ".bias"].float().to(self.device).contiguous()
+        return c
+
+    def _pack(self):
+        if self._sd is None:
+            raise RuntimeError("Generator: load_state_dict() has not been called")
+        if self._has_weight_norm:
+            # the reference can run with weight norm still attached (same function); fold on the fly
+            self._sd = fold_weight_norm(self._sd)
+            self._has_weight_norm = False
+        if self.device.type != "cuda":
+            raise ops._lib.CovomixHipError("Generator must be moved to a GPU (`.to('cuda')`): covomix_amd has no CPU path")
+        h = self.h
+        pk = dict(pre=self._conv("conv_pre", pad=3), ups=[], res=[])
+        for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+            pk["ups"].append(self._conv(f"ups.{i}", pad=(k - u) // 2, transposed=True, up=u))
+            blocks = []
+            for j, (rk, dils) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+                p = f"resblocks.{i * self.num_kernels + j}"
+                blocks.append([(self._conv(f"{p}.convs1.{m}", dil=d, pad=get_padding(rk, d)),
+                                self._conv(f"{p}.convs2.{m}", dil=1, pad=get_padding(rk, 1)))
+                               for m, d in enumerate(dils)])
+            pk["res"].append(blocks)
+        pk["post_w"] = self._sd["conv_post.weight"].float().reshape(-1, 7).contiguous().to(self.device)
+        pk["post_b"] = float(self._sd["conv_post.bias"].float().reshape(-1)[0])
+        self._packed = pk
+
+    # ---- forward ------------------------------------------------------------------------
+    def _run(self, c: _Conv, x: torch.Tensor, out: Optional[torch.Tensor] = None, *, in_slope=1.0, res=None,
+             accum=None, out_scale=1.0) -> torch.Tensor:
+        B, _, lin = x.shape
+        lout = (lin - 1) * c.up + 1 + 2 * c.pad - (c.k - 1) * c.dil
+        if out is None:
+            out = torch.empty(B, c.cout, lout, dtype=torch.float32, device=x.device)
+        return ops.hifigan_conv1d(x, c.wp, c.bias, out, cout=c.cout, ksize=c.k, dil=c.dil, pad=c.pad, up=c.up,
+                                  in_slope=in_slope, res=res, accum=accum, out_scale=out_scale)
+
+    @torch.no_grad()
+    def __call__(self, mel: torch.Tensor) -> torch.Tensor:
+        if self._packed is None:
+            self._pack()
+        pk = self._packed
+        unbatched = mel.ndim == 2
+        x = mel.to(device=self.device, dtype=torch.float32)
+        if unbatched:
+            x = x.unsqueeze(0)
+        x = x.contiguous()
+        x = self._run(pk["pre"], x)
+        for i in range(self.num_upsamples):
+            x = self._run(pk["ups"][i], x, in_slope=LRELU_SLOPE)            # leaky_relu + ConvTranspose1d
+            t = torch.empty_like(x)
+            r = torch.empty_like(x)
+            xs = torch.empty_like(x)
+            nblk = len(pk["res"][i])
+            for j, block in enumerate(pk["res"][i]):
+                cur = x
+                for m, (c1, c2) in enumerate(block):
+                    self._run(c1, cur, t, in_slope=LRELU_SLOPE)
+                    if m + 1 < len(block):
+                        self._run(c2, t, r, in_slope=LRELU_SLOPE, res=cur)
+                        cur = r
+                    else:                                                    # last pair: fold into xs
+                        self._run(c2, t, xs, in_slope=LRELU_SLOPE, res=cur, accum=xs if j > 0 else None,
+                                  out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0)
+            x = xs
+        B, _, L = x.shape
+        y = torch.empty(B, 1, L, dtype=torch.float32, device=x.device)
+        ops.hifigan_post(x, pk["post_w"], pk["post_b"], y, slope=0.01)       # F.leaky_relu default slope (:112)
+        return y.squeeze(0) if unbatched else y
+
+    forward = __call__
+
+
+def mel_decode_to_wav(generator: Generator, mel: torch.Tensor):
+    """reference monologue_generation.py:52-59: generator(mel) -> squeeze -> *32768 -> int16 numpy."""
+    y = generator(mel)
+    pcm = ops.wav_to_int16(y.squeeze().contiguous())
+    return pcm.cpu().numpy()

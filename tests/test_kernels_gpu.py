@@ -1,0 +1,239 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 (fp64 where cheap)
+reference of the same op, on the GPU, called through the C ABI (ctypes)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6   # fp32 MFMA == fmaf chain; differences are summation order only
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import covomix_amd.ops as o
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def randn(*s, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(s))
+    return torch.randn(*s, generator=g).to(dev())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 1024, 1024), (1000, 3072, 1024), (37, 80, 1024),
+                                   (999, 1024, 80), (130, 4096, 1024), (64, 1024, 4096), (5, 128, 64)])
+def test_gemm_plain(ops, M, N, K):
+    a, w = randn(M, K, seed=1), randn(N, K, seed=2) / math.sqrt(K)
+    out = torch.full((M, N), float("nan"), device=dev())
+    ops.gemm(a, w, out)
+    ref = (a.double() @ w.double().T)
+    assert rel_l2(out, ref) < TOL
+    # asymmetric-identity check (transpose detector)
+    eye = torch.eye(K, device=dev())[:M] if M <= K else None
+    if eye is not None:
+        o2 = torch.empty(eye.shape[0], N, device=dev())
+        ops.gemm(eye.contiguous(), w, o2)
+        assert torch.allclose(o2, w.T[: eye.shape[0]], atol=1e-6)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_epilogues(ops, act):
+    M, N, K = 300, 256, 512
+    a, w, b, r = randn(M, K, seed=3), randn(N, K, seed=4) / math.sqrt(K), randn(N, seed=5), randn(M, N, seed=6)
+    out = torch.empty(M, N, device=dev())
+    ops.gemm(a, w, out, bias=b, act=act, residual=r)
+    z = a.double() @ w.double().T + b.double()
+    z = [z, F.gelu(z), F.silu(z)][act] + r.double()
+    assert rel_l2(out, z) < TOL
+    # in-place residual (C aliases residual)
+    c = r.clone()
+    ops.gemm(a, w, c, bias=b, act=act, residual=c)
+    assert rel_l2(c, z) < TOL
+
+
+def test_gemm_split_k_concat_and_strided_w(ops):
+    M, N = 257, 384
+    x, s = randn(M, 256, seed=7), randn(M, 256, seed=8)
+    w = randn(N, 512, seed=9) / math.sqrt(512)
+    b = randn(N, seed=10)
+    out = torch.empty(M, N, device=dev())
+    ops.gemm(x, w, out, bias=b, a2=s)
+    ref = torch.cat((x, s), -1).double() @ w.double().T + b.double()
+    assert rel_l2(out, ref) < TOL
+    # W as a column slice of a wider matrix (to_embed x / rest split) and K=80 tail
+    wide = randn(N, 2288, seed=11) / 40
+    a80 = randn(M, 80, seed=12)
+    ops.gemm(a80, wide[:, :80], out)
+    assert rel_l2(out, a80.double() @ wide[:, :80].double().T) < TOL
+    arest = randn(M, 2208, seed=13)
+    ops.gemm(arest, wide[:, 80:], out, bias=b)
+    assert rel_l2(out, arest.double() @ wide[:, 80:].double().T + b.double()) < TOL
+
+
+def test_gemm_rope_epilogue(ops):
+    Bt, T, H = 3, 77, 2
+    dim = 128
+    x = randn(Bt * T, dim, seed=14)
+    w = randn(3 * H * 64, dim, seed=15) / math.sqrt(dim)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(T).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(dev()).contiguous(), ang.sin().to(dev()).contiguous()
+    out = torch.empty(Bt * T, 3 * H * 64, device=dev())
+    ops.gemm(x, w, out, rope=(cos, sin), rope_cols=2 * H * 64)
+    qkv = (x.double() @ w.double().T).reshape(Bt, T, 3, H, 64).cpu()
+    full = torch.cat((ang, ang), -1).double()[None, :, None, :]
+
+    def rot(t):
+        r = torch.cat((-t[..., 32:], t[..., :32]), -1)
+        return t * full.cos() + r * full.sin()
+    ref = torch.stack((rot(qkv[:, :, 0]), rot(qkv[:, :, 1]), qkv[:, :, 2]), dim=2).reshape(Bt * T, -1)
+    assert rel_l2(out, ref) < TOL
+
+
+def test_gemm_rejects_bad_args(ops):
+    import covomix_amd._lib as L
+    a, w = randn(8, 30), randn(8, 30)
+    with pytest.raises(L.CovomixHipError):
+        ops.gemm(a, w, torch.empty(8, 8, device=dev()))          # K % 4 != 0
+
+
+@pytest.mark.parametrize("D", [1024, 128, 512, 2048])
+def test_adarmsnorm(ops, D):
+    rows = 333
+    x, g, b = randn(rows, D, seed=20), randn(D, seed=21), randn(D, seed=22)
+    y = torch.empty_like(x)
+    ops.adarmsnorm(x, g, b, y)
+    ref = F.normalize(x.double(), dim=-1) * D ** 0.5 * g.double() + b.double()
+    assert rel_l2(y, ref) < TOL
+    ops.adarmsnorm(x, g, None, y)
+    assert rel_l2(y, F.normalize(x.double(), dim=-1) * D ** 0.5 * g.double()) < TOL
+    # per-group gamma/beta (per-batch times) and an all-zero row (eps clamp)
+    x2 = x[:300].clone().contiguous(); x2[7] = 0
+    g2, b2 = randn(3, D, seed=23), randn(3, D, seed=24)
+    y2 = torch.empty_like(x2)
+    ops.adarmsnorm(x2, g2, b2, y2, rows_per_group=100)
+    ref2 = F.normalize(x2.double().reshape(3, 100, D), dim=-1) * D ** 0.5 * g2.double()[:, None] + b2.double()[:, None]
+    assert rel_l2(y2, ref2.reshape(300, D)) < TOL
+    assert torch.isfinite(y2).all()
+
+
+@pytest.mark.parametrize("Bt,T,H", [(2, 128, 2), (1, 37, 1), (3, 200, 2), (2, 1000, 1), (1, 129, 3)])
+def test_attention(ops, Bt, T, H):
+    qkv = randn(Bt, T, 3 * H * 64, seed=30)
+    qkv[..., : 2 * H * 64] *= 1.5
+    out = torch.full((Bt, T, H * 64), float("nan"), device=dev())
+    ops.attention(qkv.contiguous(), out, Bt, T, H, 0.125)
+    q, k, v = qkv.double().reshape(Bt, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(Bt, T, H * 64)
+    assert rel_l2(out, ref) < 5e-6
+
+
+def test_attention_forced_rescale(ops):
+    """A late key that dominates one query forces the online-softmax rescale branch."""
+    Bt, T, H = 1, 160, 1
+    qkv = randn(Bt, T, 192, seed=31)
+    qkv[0, 5, :64] = 3.0
+    qkv[0, 140, 64:128] = 4.0        # key 140 spikes against query 5 in a late tile
+    out = torch.empty(Bt, T, 64, device=dev())
+    ops.attention(qkv.contiguous(), out, Bt, T, H, 0.125)
+    q, k, v = qkv.double().reshape(Bt, T, 3, 1, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(Bt, T, 64)
+    assert rel_l2(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("Bt,T,C", [(2, 100, 1024), (1, 31, 128), (3, 65, 256)])
+def test_dwconv31(ops, Bt, T, C):
+    x, w, b = randn(Bt, T, C, seed=40), randn(C, 31, seed=41) / 5, randn(C, seed=42)
+    y = torch.empty_like(x)
+    ops.dwconv31_gelu_res(x, w, b, y, Bt, T)
+    xd = x.double().transpose(1, 2)
+    ref = F.gelu(F.conv1d(xd, w.double()[:, None, :], b.double(), padding=15, groups=C)).transpose(1, 2) + x.double()
+    assert rel_l2(y, ref) < TOL
+
+
+def test_cfg_axpy_gather_fourier_int16(ops):
+    n = 12345
+    fc, fn, y = randn(n, seed=50), randn(n, seed=51), randn(n, seed=52)
+    o1, o2, o3 = (torch.empty(n, device=dev()) for _ in range(3))
+    ops.cfg_combine_axpy(fc, fn, y, 0.7, 0.03125, o1, o2, o3)
+    ref = y + (fc * 1.7 - 0.7 * fn) * 0.03125
+    assert rel_l2(o1, ref) < 1e-6 and torch.equal(o1, o2) and torch.equal(o1, o3)
+    yy = y.clone()
+    ops.cfg_combine_axpy(fc, None, yy, 1.0, 0.5, yy)              # in place, no null branch
+    assert rel_l2(yy, y + fc * 0.5) < 1e-6
+    # gather
+    M, S, E, Cc = 50, 2, 64, 160
+    table = randn(503, E, seed=53)
+    ids = torch.randint(0, 502, (M, S), generator=torch.Generator().manual_seed(1)).to(dev())
+    cond = randn(M, Cc, seed=54)
+    out = torch.empty(M, S * E + Cc, device=dev())
+    ops.embed_gather(ids, S, table, cond, None, Cc, 502, out, M)
+    ref = torch.cat((table[ids].reshape(M, -1), cond), -1)
+    assert torch.equal(out, ref)
+    row = randn(Cc, seed=55)
+    ops.embed_gather(None, S, table, None, row, Cc, 502, out, M)
+    ref = torch.cat((table[502].repeat(M, S), row.expand(M, Cc)), -1)
+    assert torch.equal(out, ref)
+    # fourier
+    t = torch.tensor([0.0, 0.03125, 0.5, 0.96875], device=dev())
+    w = randn(512, seed=56)
+    f = torch.empty(4, 1024, device=dev())
+    ops.time_fourier(t, w, f)
+    ang = t[:, None] * w[None, :] * 2 * math.pi
+    assert torch.allclose(f, torch.cat((ang.sin(), ang.cos()), -1), atol=2e-6)
+    # int16 (numpy astype semantics)
+    wav = torch.tensor([0.0, 0.5, -0.5, 0.99999, -1.0, 1e-6, -3.0517578e-05 * 1.5], device=dev())
+    pcm = ops.wav_to_int16(wav)
+    assert (pcm.cpu().numpy() == (wav.cpu() * 32768.0).numpy().astype("int16")).all()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L,k,d", [(2, 80, 500, 50, 7, 1), (1, 250, 250, 251, 11, 5), (2, 125, 125, 300, 3, 3),
+                                               (1, 62, 62, 1000, 7, 1), (2, 31, 31, 700, 11, 3), (1, 16, 64, 33, 3, 1)])
+def test_hifigan_conv1d(ops, B, Cin, Cout, L, k, d):
+    x = randn(B, Cin, L, seed=60)
+    w = randn(Cout, Cin, k, seed=61) / math.sqrt(Cin * k)
+    b = randn(Cout, seed=62)
+    pad = (k * d - d) // 2
+    wp = ops.hifigan_pack_weight(w, False).to(dev())
+    out = torch.full((B, Cout, L), float("nan"), device=dev())
+    ops.hifigan_conv1d(x, wp, b, out, cout=Cout, ksize=k, dil=d, pad=pad, in_slope=0.1)
+    ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=d, padding=pad)
+    assert rel_l2(out, ref) < TOL
+    res, acc = randn(B, Cout, L, seed=63), randn(B, Cout, L, seed=64)
+    o2 = acc.clone()
+    ops.hifigan_conv1d(x, wp, b, o2, cout=Cout, ksize=k, dil=d, pad=pad, in_slope=0.1, res=res, accum=o2, out_scale=1 / 3)
+    assert rel_l2(o2, (ref + res.double() + acc.double()) / 3) < TOL
+
+
+@pytest.mark.parametrize("Cin,Cout,L,k,u", [(500, 250, 50, 8, 5), (250, 125, 101, 8, 4), (125, 62, 64, 4, 4), (62, 31, 200, 4, 2)])
+def test_hifigan_conv_transpose(ops, Cin, Cout, L, k, u):
+    B = 2
+    x = randn(B, Cin, L, seed=70)
+    w = randn(Cin, Cout, k, seed=71) / math.sqrt(Cin * k / u)
+    b = randn(Cout, seed=72)
+    p = (k - u) // 2
+    lout = (L - 1) * u - 2 * p + k
+    wp = ops.hifigan_pack_weight(w, True).to(dev())
+    out = torch.full((B, Cout, lout), float("nan"), device=dev())
+    ops.hifigan_conv1d(x, wp, b, out, cout=Cout, ksize=k, dil=1, pad=k - 1 - p, up=u, in_slope=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=p)
+    assert rel_l2(out, ref) < TOL
+
+
+def test_hifigan_post(ops):
+    B, C, L = 2, 31, 999
+    x, w = randn(B, C, L, seed=80), randn(1, C, 7, seed=81) / 10
+    y = torch.empty(B, 1, L, device=dev())
+    ops.hifigan_post(x, w.reshape(C, 7).contiguous(), 0.05, y)
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x.double(), 0.01), w.double(), torch.tensor([0.05], dtype=torch.float64, device=dev()), padding=3))
+    assert rel_l2(y, ref) < TOL
