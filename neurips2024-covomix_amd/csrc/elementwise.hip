@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
 // channels-last [Bt,T,C]: a thread owns one channel and TT consecutive frames; every global
 // access is a 256-byte coalesced row segment across the block's 64 channels x 4... (one wave = 64 channels).
 constexpr int DW_K = 31;
-constexpr int DW_TT = 32;
+constexpr int DW_TT = 16;
 __global__ __launch_bounds__(256) void dwconv31_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       int T, int C)
@@ -127,27 +127,21 @@ __global__ __launch_bounds__(256) void dwconv31_kernel(const float* __restrict__
     float wk[DW_K];
 #pragma unroll
     for (int k = 0; k < DW_K; ++k) wk[k] = w[c * DW_K + k];
-    float acc[DW_TT];
-#pragma unroll
-    for (int o = 0; o < DW_TT; ++o) acc[o] = 0.f;
+    // window of DW_TT + 30 frames held in registers; every index below is a compile-time constant
+    float xs[DW_TT + DW_K - 1];
 #pragma unroll
     for (int i = 0; i < DW_TT + DW_K - 1; ++i) {
         const int t = t0 + i - DW_K / 2;
-        const float xv = (t >= 0 && t < T) ? x[base + (int64_t)t * C + c] : 0.f;
-#pragma unroll
-        for (int k = 0; k < DW_K; ++k) {
-            const int o = i - k;                       // output frame (relative) fed by tap k
-            if (o >= 0 && o < DW_TT) acc[o] = fmaf(wk[k], xv, acc[o]);
-        }
+        xs[i] = (t >= 0 && t < T) ? x[base + (int64_t)t * C + c] : 0.f;
     }
     const float bc = bias[c];
 #pragma unroll
     for (int o = 0; o < DW_TT; ++o) {
+        float acc = bc;
+#pragma unroll
+        for (int k = 0; k < DW_K; ++k) acc = fmaf(wk[k], xs[o + k], acc);
         const int t = t0 + o;
-        if (t < T) {
-            const int64_t idx = base + (int64_t)t * C + c;
-            y[idx] = gelu_erf(acc[o] + bc) + x[idx];
-        }
+        if (t < T) y[base + (int64_t)t * C + c] = gelu_erf(acc) + xs[o + DW_K / 2];
     }
 }
 

@@ -1,0 +1,199 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; host-side logic (time grid,
+checkpoint loader incl. EMA + stub unpickling, DP sharding + gloo broadcast, loud failure without GPU)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_exports_every_header_symbol():
+    from covomix_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "covomix_hip.h")).read()
+    declared = set(re.findall(r"\b(cvx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no symbols parsed from the header"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cvx_version() >= 100
+    assert lib.cvx_hifigan_packed_weight_floats(250, 250, 11) == 4 * 16 * 11 * 64 * 16
+
+
+def test_pack_weight_layout_cpu():
+    """cvx_hifigan_pack_weight_f32 is host code: check the documented layout, incl. the transposed flip."""
+    from covomix_amd import ops
+    w = torch.arange(3 * 5 * 4, dtype=torch.float32).reshape(3, 5, 4)          # [Cout=3, Cin=5, k=4]
+    wp = ops.hifigan_pack_weight(w, False).reshape(1, 1, 4, 32, 16)
+    for co in range(3):
+        for ci in range(5):
+            for k in range(4):
+                assert wp[0, 0, k, co, ci] == w[co, ci, k]
+    assert wp[0, 0, :, 3:, :].abs().sum() == 0 and wp[0, 0, :, :, 5:].abs().sum() == 0
+    wt = torch.arange(5 * 3 * 4, dtype=torch.float32).reshape(5, 3, 4)          # ConvT [Cin=5, Cout=3, k=4]
+    wpt = ops.hifigan_pack_weight(wt, True).reshape(1, 1, 4, 32, 16)
+    for co in range(3):
+        for ci in range(5):
+            for k in range(4):
+                assert wpt[0, 0, k, co, ci] == wt[ci, co, 3 - k]
+
+
+def test_ops_fail_loudly_without_gpu():
+    from covomix_amd import _lib, ops
+    from covomix_amd.conditional_model import CoVoMixModel
+    from covomix_amd.vocoder import AttrDict, Generator
+    import covomix_amd.synthetic as syn
+    a = torch.zeros(4, 4)
+    with pytest.raises(_lib.CovomixHipError):
+        ops.gemm(a, a, a.clone())
+    shapes = syn.acoustic_param_shapes(dim=128, dim_cond=160, dim_emb=64, depth=2, heads=2, streams=2)
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes).items()}
+    m = CoVoMixModel.from_state_dict(sd).eval()
+    with pytest.raises(_lib.CovomixHipError):
+        m.synthesis_sample(torch.zeros(1, 8, 2, dtype=torch.long), torch.zeros(1, 8, 160), None, 0.7)
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG); h["upsample_initial_channel"] = 32
+    g = Generator(AttrDict(h))
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h)).items()})
+    g.remove_weight_norm()
+    with pytest.raises(_lib.CovomixHipError):
+        g(torch.zeros(80, 10))
+
+
+def test_missing_library_message(tmp_path, monkeypatch):
+    from covomix_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CovomixHipError, match="no CPU"):
+        _lib.load()
+
+
+def test_evaluation_times_match_oracle_grid():
+    import covomix_oracle as orc
+    from covomix_amd.acoustic import evaluation_times
+    t, dts = evaluation_times(32, "midpoint")
+    g = orc.fixed_grid(0.0625)
+    assert len(dts) == 16 and all(d == 0.0625 for d in dts)
+    exp = []
+    for a, b in zip(g[:-1], g[1:]):
+        exp += [float(a), float(a + 0.5 * (b - a))]
+    assert t.tolist() == exp
+    t, dts = evaluation_times(10, "euler")
+    assert t.numel() == 10 and abs(sum(dts) - 1.0) < 1e-6
+    with pytest.raises(ValueError):
+        evaluation_times(7, "midpoint")
+
+
+def _fake_ckpt(path, with_ema=True):
+    import covomix_amd.synthetic as syn
+    shapes = syn.acoustic_param_shapes(dim=128, dim_cond=80, dim_emb=64, depth=2, heads=2, streams=1)
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
+    full = {"cfm_wrapper.CoVoMix." + k: v for k, v in sd.items()}
+    full["cfm_wrapper.CoVoMix.transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
+    ema = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=7).items()}
+
+    # a hyper_parameters entry that references a class from a module that is NOT importable here,
+    # like Lightning's save_hyperparameters does with data_module_cls (conditional_model.py:150)
+    import types
+    fake = types.ModuleType("covomix_fake_data_module")
+    class SpecsDataModule:  # noqa: E306
+        pass
+    SpecsDataModule.__module__ = "covomix_fake_data_module"
+    SpecsDataModule.__qualname__ = "SpecsDataModule"
+    fake.SpecsDataModule = SpecsDataModule
+    sys.modules["covomix_fake_data_module"] = fake
+    ckpt = {"state_dict": full,
+            "hyper_parameters": {"CoVoMix_dim": 80, "CoVoMix_depth": 2, "text2semantic": False,
+                                 "twocondition_oneoutput": False, "data_module_cls": SpecsDataModule}}
+    if with_ema:
+        ckpt["ema"] = {"decay": 0.999, "num_updates": 10, "shadow_params": list(ema.values()), "collected_params": None}
+    torch.save(ckpt, path)
+    del sys.modules["covomix_fake_data_module"]
+    return sd, ema
+
+
+def test_checkpoint_loader_ema_and_stub_unpickle(tmp_path):
+    from covomix_amd.conditional_model import CoVoMixModel
+    p = str(tmp_path / "last.ckpt")
+    sd, ema = _fake_ckpt(p, with_ema=True)
+    m = CoVoMixModel.load_from_checkpoint(p, base_dir='', batch_size=16, num_workers=0)
+    assert m.hparams["CoVoMix_depth"] == 2 and "data_module_cls" not in m.hparams
+    m.eval()
+    act = m.active_state_dict()
+    for k in ema:
+        assert torch.equal(act[k], ema[k])                      # EMA weights are what run
+    assert "transformer.rotary_emb.inv_freq" in act
+    m.eval(no_ema=True)
+    assert torch.equal(m.active_state_dict()["null_cond"], sd["null_cond"])
+    m.train(True)
+    assert torch.equal(m.active_state_dict()["null_cond"], sd["null_cond"])
+    p2 = str(tmp_path / "noema.ckpt")
+    sd2, _ = _fake_ckpt(p2, with_ema=False)
+    with pytest.warns(UserWarning, match="EMA"):
+        m2 = CoVoMixModel.load_from_checkpoint(p2)
+    assert torch.equal(m2.eval().active_state_dict()["null_cond"], sd2["null_cond"])
+    with pytest.raises(AssertionError):
+        CoVoMixModel.load_from_checkpoint(str(tmp_path / "missing.ckpt"))
+
+
+def test_vocoder_fold_matches_oracle_and_api():
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd.vocoder import AttrDict, Generator, fold_weight_norm, get_padding
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG); h["upsample_initial_channel"] = 32
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h)).items()}
+    a, b = fold_weight_norm(sd), orc.fold_weight_norm(sd)
+    assert a.keys() == b.keys() and all(torch.allclose(a[k], b[k], rtol=1e-6, atol=0) for k in a)
+    assert get_padding(11, 5) == 25 and get_padding(3, 1) == 1
+    g = Generator(AttrDict(h))
+    g.load_state_dict(sd)
+    assert g.eval() is g and len(g.state_dict()) == 234
+    g.remove_weight_norm()
+    assert not any(k.endswith("weight_g") for k in g.state_dict())
+    assert AttrDict(h).upsample_rates == [5, 4, 4, 2]
+
+
+def test_sharding_plan():
+    from covomix_amd.dp import batch_equal_length, shard_utterances
+    lengths = [1000] * 64
+    plan = shard_utterances(lengths, 8)
+    assert sorted(sum(plan, [])) == list(range(64)) and all(len(p) == 8 for p in plan)
+    ragged = [500, 120, 977, 33, 500, 500, 64, 800, 120]
+    plan = shard_utterances(ragged, 3)
+    assert sorted(sum(plan, [])) == list(range(9))
+    loads = [sum(ragged[i] for i in p) for p in plan]
+    assert max(loads) - min(loads) <= max(ragged)
+    assert shard_utterances([], 4) == [[], [], [], []]
+    batches = batch_equal_length([0, 4, 5, 1, 8], ragged, max_batch=2)
+    assert batches == [[0, 4], [5], [1, 8]]
+
+
+def test_two_rank_gloo_broadcast_and_shard(tmp_path):
+    """world_size-2 CPU run of the DP plumbing: weight broadcast (rank 1 starts from garbage),
+    disjoint utterance shards, metric reduction."""
+    script = tmp_path / "w.py"
+    script.write_text(f"""
+import os, sys, torch
+sys.path.insert(0, {ROOT!r})
+from covomix_amd import dp
+import covomix_amd.synthetic as syn
+rank, world, local = dp.init_from_env("gloo")
+shapes = syn.acoustic_param_shapes(dim=128, dim_cond=80, dim_emb=64, depth=2, heads=2, streams=1)
+good = {{k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}}
+mine = good if rank == 0 else {{k: torch.full_like(v, float('nan')) for k, v in good.items()}}
+got = dp.broadcast_state_dict(mine, torch.device('cpu'), src=0, bucket_bytes=1 << 18)
+assert all(torch.equal(got[k], good[k]) for k in good), rank
+plan = dp.shard_utterances([100, 200, 300, 400, 500], world)
+frames, secs = dp.reduce_metric(float(sum([100, 200, 300, 400, 500][i] for i in plan[rank])), 1.0 + rank, torch.device('cpu'))
+assert frames == 1500.0 and secs == 2.0
+print('RANK_OK', rank)
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
