@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""mel-frames/sec for the CoVoMix hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch per GPU:
+    VoMix 2-speaker acoustic model, 32 NFE (16 midpoint steps x 2, CFG scale 0.7 => 64 network
+    forwards) on B=8 utterances of T=1000 frames (dual-channel 160-dim prompt of 400 frames)
+    followed by the HiFi-GAN generator on all 8 x 1000 generated frames and the int16 cast.
+Weights: reference-shaped random checkpoints from covomix_amd.synthetic (no pretrained weights
+exist); inputs resident in HBM before the timed region.  N > 1: one process per GPU (torchrun),
+utterances sharded (8 per rank, weak scaling), weights broadcast once over RCCL, no data-path collective.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B, T, PROMPT, NFE, COND_SCALE = 8, 1000, 400, 32, 0.7
+FLOP_PER_FRAME = 64 * 255_784_960 + 281_398_000        # 16.65 GFLOP per mel frame
+PEAK_F32_MFMA = 157.3e12                                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+class GemmTimer:
+    """HIP-event bracket around every cvx_gemm launch (events are recorded on torch's current
+    stream = the stream the kernel is launched on).  Sums algorithmic FLOPs (2*M*N*K) and durations."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = 0.0
+        self.launches = 0
+
+    def install(self, ops):
+        inner = ops.gemm
+
+        def timed(a, w, out, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = inner(a, w, out, **kw)
+            e.record()
+            k = a.shape[1] + (kw["a2"].shape[1] if kw.get("a2") is not None else 0)
+            self.pairs.append((s, e))
+            self.flops += 2.0 * a.shape[0] * w.shape[0] * k
+            self.launches += 1
+            return r
+        ops.gemm = timed
+        self._ops, self._inner = ops, inner
+
+    def remove(self):
+        self._ops.gemm = self._inner
+
+    def result(self):
+        secs = sum(s.elapsed_time(e) for s, e in self.pairs) * 1e-3
+        return self.flops, secs, self.launches
+
+
+def make_models(dev, rank, world):
+    import covomix_amd.synthetic as syn
+    from covomix_amd import dp
+    from covomix_amd.conditional_model import CoVoMixModel
+    from covomix_amd.vocoder import AttrDict, Generator
+    shapes = syn.acoustic_param_shapes()                       # VoMix: dim 1024, depth 8, 16 heads, E_in 2288
+    vshapes = syn.hifigan_param_shapes(syn.HIFIGAN_COVOMIX_CONFIG)
+    if rank == 0:
+        sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
+        vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(vshapes, seed=0).items()}
+    else:
+        sd = {k: torch.empty(v, dtype=torch.float32) for k, v in shapes.items()}
+        vsd = {k: torch.empty(v, dtype=torch.float32) for k, v in vshapes.items()}
+    cpu_sd = (sd, vsd) if rank == 0 else None
+    if world > 1:                                              # ONE start-up broadcast over RCCL/xGMI
+        sd = dp.broadcast_state_dict(sd, dev, src=0)
+        vsd = dp.broadcast_state_dict(vsd, dev, src=0)
+    sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
+    model = CoVoMixModel.from_state_dict(sd, nfe=NFE).eval().to(dev)
+    gen = Generator(AttrDict(syn.HIFIGAN_COVOMIX_CONFIG)).to(dev)
+    gen.load_state_dict({k: v.cpu() for k, v in vsd.items()})
+    gen.eval()
+    gen.remove_weight_norm()
+    return model, gen, cpu_sd
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: min(affinity mask, cgroup-v2 cpu.max quota).
+    (The GPU box exposes 256 hardware threads but a 16-CPU quota; 256 torch threads ran 80x slower.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(cpu_sd):
+    """The oracle (== the reference's PyTorch path, pinned <=1e-5 in tests/golden) on this box's host
+    cores: bounded sample = 3 CFG evaluations (6 network forwards) + 1 HiFi-GAN call at B=1, T=1000,
+    extrapolated to the 32-NFE + vocoder pipeline.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    sd, vsd = cpu_sd
+    sd = dict(sd)
+    sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    inp = syn.synthetic_inputs("vomix", 1, T, PROMPT, seed=1234)
+    tm = torch.tensor(0.25)
+    with torch.inference_mode():
+        orc.forward_with_cond_scale(sd, inp["y0"], tm, inp["phoneme_ids"], inp["cond"], COND_SCALE)   # warm-up
+        t0 = time.perf_counter()
+        n_eval = 3
+        for _ in range(n_eval):
+            orc.forward_with_cond_scale(sd, inp["y0"], tm, inp["phoneme_ids"], inp["cond"], COND_SCALE)
+        t_eval = (time.perf_counter() - t0) / n_eval
+        folded = orc.fold_weight_norm(vsd)
+        mel = inp["cond"][:, :, :80].transpose(1, 2).contiguous()
+        t0 = time.perf_counter()
+        orc.hifigan_forward(folded, syn.HIFIGAN_COVOMIX_CONFIG, mel)
+        t_voc = time.perf_counter() - t0
+    fps = T / (NFE * t_eval + t_voc)
+    return {"value": round(fps, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU restatement of the reference PyTorch path), B=1 T={T}: {n_eval} timed CFG evals "
+                      f"({t_eval:.3f} s each, x{NFE}) + 1 HiFi-GAN call ({t_voc:.3f} s), torch {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from covomix_amd import dp, ops
+    import covomix_amd.synthetic as syn
+    rank, world, local = dp.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    model, gen, cpu_sd = make_models(dev, rank, world)
+
+    inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1234 + rank)
+    ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
+    noise = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def step():
+        y0 = torch.randn(B, T, 80, device=dev, generator=noise)
+        mel = model.synthesis_sample(ids, cond, mask, COND_SCALE, y0=y0)
+        wav = gen(mel.permute(0, 2, 1).contiguous())
+        return ops.wav_to_int16(wav.squeeze(1).contiguous())
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = GemmTimer()
+    timer.install(ops)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pcm = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.remove()
+    assert pcm.shape == (B, 160 * T + 32) and pcm.dtype == torch.int16
+    frames, elapsed = dp.reduce_metric(float(B * T * args.steps), elapsed, dev)
+
+    if rank == 0:
+        value = frames / elapsed
+        flops, gemm_s, launches = timer.result()
+        achieved = flops / gemm_s / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.isfile(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("gemm_f32_kernel", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "mel-frames/sec (VoMix 32-step + HiFi-GAN, Bx1000x80)",
+            "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"VoMix 32-NFE (16 midpoint steps, CFG 0.7) + HiFi-GAN config_covomix, "
+                                   f"B={B} utterances x T={T} frames per GPU, prompt {PROMPT}",
+                       "per_gpu_batch": B, "frames": T, "nfe": NFE, "parallelism": f"dp{world} (utterance-sharded)"},
+            "path_flop_per_frame": FLOP_PER_FRAME,
+            "path_frac_of_f32_mfma_peak": round(value / world * FLOP_PER_FRAME / PEAK_F32_MFMA, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "traffic": traffic,
+                         "launches": launches, "avg_launch_ms": round(gemm_s / launches * 1e3, 4),
+                         "time_share_of_step": round(gemm_s / elapsed, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cpu_sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

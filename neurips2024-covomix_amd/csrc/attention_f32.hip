@@ -28,15 +28,19 @@ constexpr int K_LD = HD + 4;    // padded K row in LDS (floats): conflict-free d
 constexpr int V_LD = HD;
 
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int T, int H, float scale_log2e)
+                                                              int T, int H, int n_groups, int n_qt, float scale_log2e)
 {
     __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q_blk = blockIdx.x * QB;
+    // block -> (batch*head group, query tile): all query tiles of one (batch, head) get the same
+    // blockIdx % 8, i.e. (observed round-robin dispatch) the same XCD, so its K/V stay in ONE L2.
+    const int grp = (blockIdx.x / (8 * n_qt)) * 8 + (blockIdx.x & 7);
+    if (grp >= n_groups) return;
+    const int head = grp % H, b = grp / H;
+    const int q_blk = ((blockIdx.x >> 3) % n_qt) * QB;
     const int64_t row_stride = (int64_t)3 * H * HD;
     const float* qbase = qkv + (int64_t)b * T * row_stride + head * HD;
     const float* kbase = qbase + H * HD;
@@ -167,9 +171,10 @@ extern "C" int cvx_attention_f32(const float* qkv, float* out, int32_t Bt, int32
     CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0, "attention: bad shape Bt=%d T=%d H=%d", Bt, T, H);
     CVX_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attention: pointers must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;
-    dim3 grid((T + QB - 1) / QB, H, Bt);
+    const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
+    dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                       qkv, out, T, H, scale * 1.44269504088896340736f);
+                       qkv, out, T, H, n_groups, n_qt, scale * 1.44269504088896340736f);
     CVX_CHECK_LAUNCH("cvx_attention_f32");
     return CVX_OK;
 }

@@ -10,15 +10,19 @@
 //   * one ds_read_b128 feeds FOUR MFMAs: lanes 0-31 hold k = 8q..8q+3, lanes 32-63 hold
 //     k = 8q+4..8q+7 of their row, and MFMA t contracts the (8q+t, 8q+4+t) pair - the
 //     k order inside a tile is free as long as A and B use the same one;
-//   * two LDS buffers, next tile's global loads issued before the MFMAs of the current
-//     one, one barrier per K-step; 72 KB LDS -> 2 blocks per CU so the other block's
-//     waves cover the barrier;
-//   * blockIdx.x walks N: with the observed block->XCD round robin every XCD keeps its
-//     own W panels L2-resident while A row-panels stream through.
+//   * two LDS buffers; the K loop is ONE branch-free basic block per step (out-of-range
+//     rows are clamped, not predicated: their products land in accumulator rows/columns the
+//     epilogue never stores), with the next tile's global loads issued first, its LDS
+//     writes placed between the 3rd and 4th MFMA group, and one barrier per step - so the
+//     matrix pipe always has queued work while loads, address math and LDS writes retire;
+//   * XCD-aware block->tile map: an XCD owns whole M row-panels, so each A panel is
+//     fetched into exactly one L2.
 // Epilogue fuses bias, GELU/SiLU, half-split RoPE (a wave owns one whole 64-wide head, so
 // the (j, j+32) partner is the same accumulator register of the neighbouring MFMA tile)
-// and the residual add.
+// and the residual add.  K % 32 != 0 (only to_embed's 80 x-columns) takes the predicated
+// generic kernel.
 #include "cvx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,106 +30,31 @@ constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // padded row (floats)
 
-template <int TM>   // TM = MFMA tiles per wave along M (block M = TM*64)
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p)
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_mode, int& tile_m, int& tile_n)
 {
-    constexpr int BM = TM * 64;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [2][BM][LDS_LD]
-    float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int srow = tid >> 3;            // 0..31
-    const int skc = (tid & 7) * 4;        // 0..28
-
-    f32x4 ra[TM * 2], rb[4];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    auto load_tiles = [&](int k0) {
-        const float* Ap = p.A;
-        int64_t lda = p.lda;
-        int kk = k0, klim = p.K;
-        if (p.A2 != nullptr) {
-            if (k0 >= p.K1) { Ap = p.A2; lda = p.lda2; kk = k0 - p.K1; klim = p.K - p.K1; }
-            else            { klim = p.K1; }
-        }
-#pragma unroll
-        for (int i = 0; i < TM * 2; ++i) {
-            const int row = m0 + srow + 32 * i;
-            ra[i] = (row < p.M && kk + skc < klim)
-                        ? *reinterpret_cast<const f32x4*>(Ap + (int64_t)row * lda + kk + skc) : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = n0 + srow + 32 * i;
-            rb[i] = (row < p.N && k0 + skc < p.K)
-                        ? *reinterpret_cast<const f32x4*>(p.W + (int64_t)row * p.ldw + k0 + skc) : zero4;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        float* a = As + buf * BM * LDS_LD;
-        float* b = Bs + buf * BN * LDS_LD;
-#pragma unroll
-        for (int i = 0; i < TM * 2; ++i)
-            *reinterpret_cast<f32x4*>(a + (srow + 32 * i) * LDS_LD + skc) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(b + (srow + 32 * i) * LDS_LD + skc) = rb[i];
-    };
-
-    f32x16 acc[TM][2];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-    const int b_off = (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
-
-    const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-        const float* a = As + cur * BM * LDS_LD + a_off;
-        const float* b = Bs + cur * BN * LDS_LD + b_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 af[TM], bf[2];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * LDS_LD + q * 8);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_LD + q * 8);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
+    // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8: observed, used for speed only).
+    // mode 1: XCD x owns row-panels x, x+8, ... (all their N tiles): every A panel is read by one L2 only
+    // and just the (small) W matrix is read by all eight.
+    if (map_mode == 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile_m = xcd + 8 * (slot / tiles_n);
+        tile_n = slot % tiles_n;
+    } else {
+        tile_n = blockIdx.x % tiles_n;
+        tile_m = blockIdx.x / tiles_n;
     }
+}
 
-    // ---------------- epilogue ----------------
+template <int TM>
+__device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
+                                              int wm, int wn, int lane)
+{
     const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
     const int c_lo = colw + (lane & 31);
     const int c_hi = c_lo + 32;
     const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
     const float b_lo = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
     const float b_hi = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
-
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -155,19 +84,216 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p)
 }
 
 template <int TM>
+__device__ __forceinline__ void mfma_group(const float* a, const float* b, int q, f32x16 (&acc)[TM][2])
+{
+    f32x4 af[TM], bf[2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * LDS_LD + q * 8);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_LD + q * 8);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ fast path: K % 32 == 0
+template <int TM>   // TM = MFMA tiles per wave along M (block M = TM*64)
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p, int tiles_m, int tiles_n, int map_mode)
+{
+    constexpr int BM = TM * 64;
+    constexpr int NA = TM * 2;                // 16-byte A loads per thread per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int srow = tid >> 3;            // 0..31
+    const int skc = (tid & 7) * 4;        // 0..28
+
+    // per-thread streaming pointers (rows clamped into range: no predication in the K loop)
+    const float* pa[NA];
+    int64_t a_jump[NA];                   // extra element offset applied when the stream switches A -> A2
+    const float* pw[4];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = min(m0 + srow + 32 * i, p.M - 1);
+        pa[i] = p.A + (int64_t)row * p.lda + skc;
+        a_jump[i] = p.A2 ? (p.A2 + (int64_t)row * p.lda2 + skc) - (pa[i] + p.K1) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = min(n0 + srow + 32 * i, p.N - 1);
+        pw[i] = p.W + (int64_t)row * p.ldw + skc;
+    }
+    const int switch_tile = p.A2 ? p.K1 / BK : -1;   // tile index whose loads come first from A2
+
+    f32x4 ra[NA], rb[4];
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    const int b_off = (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    const int st_off = srow * LDS_LD + skc;
+
+    const int nk = p.K / BK;
+    // prologue: tile 0 -> LDS buffer 0
+    {
+        const bool sw = (0 == switch_tile);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { if (sw) pa[i] += a_jump[i]; ra[i] = *reinterpret_cast<const f32x4*>(pa[i]); pa[i] += BK; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rb[i] = *reinterpret_cast<const f32x4*>(pw[i]); pw[i] += BK; }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(As + st_off + 32 * i * LDS_LD) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Bs + st_off + 32 * i * LDS_LD) = rb[i];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* a = As + cur * BM * LDS_LD + a_off;
+        const float* b = Bs + cur * BN * LDS_LD + b_off;
+        // next tile's global loads first (clamped to the last tile on the final step: harmless re-read)
+        const bool has_next = kt + 1 < nk;
+        const int adv = has_next ? BK : 0;
+        const bool sw = (kt + 1 == switch_tile);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float* src = pa[i] + (sw ? a_jump[i] : 0) - (has_next ? 0 : BK);
+            ra[i] = *reinterpret_cast<const f32x4*>(src);
+            pa[i] = src + adv;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* src = pw[i] - (has_next ? 0 : BK);
+            rb[i] = *reinterpret_cast<const f32x4*>(src);
+            pw[i] = src + adv;
+        }
+        mfma_group<TM>(a, b, 0, acc);
+        mfma_group<TM>(a, b, 1, acc);
+        mfma_group<TM>(a, b, 2, acc);
+        // the other buffer was last read before the previous barrier: safe to refill it now
+        float* an = As + (cur ^ 1) * BM * LDS_LD + st_off;
+        float* bn = Bs + (cur ^ 1) * BN * LDS_LD + st_off;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(an + 32 * i * LDS_LD) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bn + 32 * i * LDS_LD) = rb[i];
+        mfma_group<TM>(a, b, 3, acc);
+        __syncthreads();
+    }
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------ generic path: any K % 4 == 0 (predicated loads)
+template <int TM>
+__global__ __launch_bounds__(256, 2) void gemm_f32_generic_kernel(const cvx_gemm_args p, int tiles_m, int tiles_n, int map_mode)
+{
+    constexpr int BM = TM * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int srow = tid >> 3, skc = (tid & 7) * 4;
+
+    f32x4 ra[TM * 2], rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tiles = [&](int k0) {
+        const float* Ap = p.A;
+        int64_t lda = p.lda;
+        int kk = k0, klim = p.K;
+        if (p.A2 != nullptr) {
+            if (k0 >= p.K1) { Ap = p.A2; lda = p.lda2; kk = k0 - p.K1; klim = p.K - p.K1; }
+            else            { klim = p.K1; }
+        }
+#pragma unroll
+        for (int i = 0; i < TM * 2; ++i) {
+            const int row = m0 + srow + 32 * i;
+            ra[i] = (row < p.M && kk + skc < klim)
+                        ? *reinterpret_cast<const f32x4*>(Ap + (int64_t)row * lda + kk + skc) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = n0 + srow + 32 * i;
+            rb[i] = (row < p.N && k0 + skc < p.K)
+                        ? *reinterpret_cast<const f32x4*>(p.W + (int64_t)row * p.ldw + k0 + skc) : zero4;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD;
+        float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < TM * 2; ++i) *reinterpret_cast<f32x4*>(a + (srow + 32 * i) * LDS_LD + skc) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(b + (srow + 32 * i) * LDS_LD + skc) = rb[i];
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    const int b_off = (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const float* a = As + cur * BM * LDS_LD + a_off;
+        const float* b = Bs + cur * BN * LDS_LD + b_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mfma_group<TM>(a, b, q, acc);
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int TM>
 int launch_gemm(const cvx_gemm_args& a, hipStream_t st)
 {
     constexpr int BM = TM * 64;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<TM>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool fast = (a.K % BK == 0);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fast]) {
+        const void* fn = fast ? reinterpret_cast<const void*>(gemm_f32_kernel<TM>)
+                              : reinterpret_cast<const void*>(gemm_f32_generic_kernel<TM>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cvx_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return CVX_EHIP; }
-        attr_set = true;
+        attr_set[fast] = true;
     }
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-    hipLaunchKernelGGL(gemm_f32_kernel<TM>, grid, dim3(256), lds, st, a);
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
+    dim3 grid((unsigned)(grid_m * tiles_n));
+    if (fast) hipLaunchKernelGGL(gemm_f32_kernel<TM>, grid, dim3(256), lds, st, a, tiles_m, tiles_n, map_mode);
+    else      hipLaunchKernelGGL(gemm_f32_generic_kernel<TM>, grid, dim3(256), lds, st, a, tiles_m, tiles_n, map_mode);
     CVX_CHECK_LAUNCH("cvx_gemm_bias_act_f32");
     return CVX_OK;
 }

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into profiles/pmc_summary.json.
+
+Units and corrections follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is used as reported
+(uncalibrated).  Values are averaged per launch per kernel.
+
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    m = re.search(r"(\w+_kernel)(<\d+>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def load(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            k = short(row["Kernel_Name"])
+            acc[k][0] += float(row["Counter_Value"])
+            acc[k][1] += 1
+    return acc
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        if "kernel" not in k or k.startswith("void at") or "at::native" in k:
+            continue
+        fk = f.get(k, [0.0, 0]); wk = w.get(k, [0.0, 0])
+        n = max(fk[1], wk[1], 1)
+        fetch_b = 2.0 * fk[0] * 1024 / max(fk[1], 1)
+        write_b = wk[0] * 1024 / max(wk[1], 1)
+        res[k] = {"launches": n, "fetch_bytes_per_launch_x2_corrected": round(fetch_b),
+                  "write_bytes_per_launch": round(write_b), "hbm_bytes_per_launch": round(fetch_b + write_b)}
+    # aggregate over the template instances of the dominant kernel
+    g = [v for k, v in res.items() if k.startswith("gemm_f32_kernel")]
+    if g:
+        tot_l = sum(v["launches"] for v in g)
+        res["gemm_f32_kernel"] = {
+            "launches": tot_l,
+            "hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in g) / tot_l)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
