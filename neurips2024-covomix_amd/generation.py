@@ -1,0 +1,128 @@
+"""Driver behind monologue_generation.py / dialogue_generation.py at the repo root.
+
+Keeps the reference CLI (monologue_generation.py:324-333: --t2s_ckpt --acous_ckpt --hifigan_ckpt --text_dir
+--prompt_dir --saved_dir --seed --mode) and the per-utterance flow of covosingle()/covosinx()/covomix()
+(monologue_generation.py:146-304, dialogue_generation.py:145-329) for the stages this build covers:
+token/prompt assembly -> synthesis_sample (cond_scale 0.7) -> frame selection -> HiFi-GAN -> int16 wav.
+
+Two upstream stages are "next" rows and are therefore read from files instead of computed:
+  * text2semantic (N1): `<text_dir>/<name>.semantic.npy` holds the predicted semantic tokens
+      covosingle / covosinx: int array [n];  covomix: [2, n] or flat [2n] (split at half, comix_pred :307-319)
+  * prompt mel extraction (N3): `<prompt_dir>/<name>.mel.npy` ([80, T] log-mel) next to
+      `<name>.hubert_code.npy`; dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
+New relative to the reference: utterances are sharded over ranks (torchrun) and batched by equal length.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import random
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+
+from . import assembly, dp
+from .conditional_model import CoVoMixModel
+from .vocoder import AttrDict, Generator, mel_decode_to_wav
+
+COND_SCALE = 0.7    # every shipped caller (monologue_generation.py:171,238,298)
+
+
+def build_parser() -> ArgumentParser:
+    p = ArgumentParser()
+    p.add_argument("--t2s_ckpt", type=str, default=None, help="text2semantic checkpoint (not used: tokens are read from --text_dir)")
+    p.add_argument("--acous_ckpt", type=str, default="/pretrained_models/comix.ckpt", help="acoustic model checkpoint")
+    p.add_argument("--hifigan_ckpt", type=str, default="/pretrained_models/vocoder.ckpt", help="vocoder checkpoint")
+    p.add_argument("--text_dir", type=str, default="test/test_dir", help="directory with <name>.semantic.npy")
+    p.add_argument("--prompt_dir", type=str, default="test/monologue_prompt_dir", help="directory with acoustic prompts")
+    p.add_argument("--saved_dir", type=str, default=".saved_dir", help="target directory")
+    p.add_argument("--seed", type=int, default=30, help="random seed")
+    p.add_argument("--mode", type=str, choices=["covosingle", "covosinx", "covomix"], default="covosingle")
+    p.add_argument("--max_batch", type=int, default=8, help="equal-length utterances per launch")
+    return p
+
+
+def _load_prompt(prompt_dir: str, name: str):
+    tok = torch.from_numpy(np.load(os.path.join(prompt_dir, name + ".hubert_code.npy")).astype(np.int64))
+    mel = torch.from_numpy(np.load(os.path.join(prompt_dir, name + ".mel.npy")).astype(np.float32))
+    return assembly.truncate_prompt(tok, mel)            # -> tokens [Tp], mel [Tp, 80]
+
+
+def _utterance_inputs(mode: str, dialogue: bool, text_dir: str, prompt_dir: str, name: str):
+    pred = np.load(os.path.join(text_dir, name + ".semantic.npy")).astype(np.int64)
+    if mode == "covosingle":
+        sem, mel = _load_prompt(prompt_dir, name)
+        return assembly.build_monologue_inputs(sem, torch.from_numpy(pred.reshape(-1)), mel)
+    if dialogue:
+        sa, ma = _load_prompt(prompt_dir, name + "_1")
+        sb, mb = _load_prompt(prompt_dir, name + "_2")
+    else:
+        sa, ma = _load_prompt(prompt_dir, name)
+        sb, mb = sa, ma
+    if mode == "covosinx":                                # second stream silent (:223-224)
+        pa = torch.from_numpy(pred.reshape(-1))
+        pb = torch.ones_like(pa) * assembly.SILENT_TOKEN
+    else:
+        flat = pred.reshape(-1)
+        half = flat.shape[0] // 2
+        pa, pb = torch.from_numpy(flat[:half].copy()), torch.from_numpy(flat[half:].copy())
+    return assembly.build_dialogue_inputs(sa, sb, pa, pb, ma, mb)
+
+
+def run(dialogue: bool, argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    print(args)
+    os.makedirs(args.saved_dir, exist_ok=True)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    random.seed(args.seed)
+    rank, world, local = dp.init_from_env()
+    if not torch.cuda.is_available():
+        from ._lib import CovomixHipError
+        raise CovomixHipError("generation needs an MI355X: covomix_amd has no CPU path")
+    torch.cuda.set_device(local)
+    torch.cuda.manual_seed(args.seed + rank)
+    device = torch.device("cuda", local)
+
+    config_file = os.path.join(os.path.split(args.hifigan_ckpt)[0], "vocoder_config.json")   # :368
+    with open(config_file) as f:
+        h = AttrDict(json.loads(f.read()))
+    generator = Generator(h).to(device)
+    assert os.path.isfile(args.hifigan_ckpt)
+    state_dict_g = torch.load(args.hifigan_ckpt, map_location="cpu", weights_only=False)
+    generator.load_state_dict(state_dict_g["generator"])
+    generator.eval()
+    generator.remove_weight_norm()
+    model = CoVoMixModel.load_from_checkpoint(args.acous_ckpt, base_dir="", batch_size=16, num_workers=0)
+    model.eval()
+    model = model.to(device)
+    if rank == 0:
+        with open(os.path.join(args.saved_dir, "config.txt"), "w") as f:
+            f.write("Vocoder: " + str(dict(h)) + "\n")
+            f.write("t2s_ckpt: " + str(args.t2s_ckpt) + "\n")
+            f.write("acoustic model: " + args.acous_ckpt + "\n")
+
+    names = sorted(os.path.basename(p)[: -len(".semantic.npy")] for p in glob.glob(os.path.join(args.text_dir, "*.semantic.npy")))
+    items = [_utterance_inputs(args.mode, dialogue, args.text_dir, args.prompt_dir, n) for n in names]
+    lengths = [int(it[0].shape[0]) for it in items]
+    mine = dp.shard_utterances(lengths, world)[rank]
+    done = 0
+    for batch in dp.batch_equal_length(mine, lengths, args.max_batch):
+        ids = torch.stack([items[i][0] for i in batch]).to(device)
+        cond = torch.stack([items[i][1] for i in batch]).to(device)
+        mask = torch.stack([items[i][2] for i in batch]).to(device)
+        sampled = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=COND_SCALE)
+        for j, i in enumerate(batch):
+            valid = assembly.select_generated_frames(sampled[j:j + 1], mask[j])
+            if valid.shape[1] == 0:
+                continue
+            audio = mel_decode_to_wav(generator, valid.contiguous())
+            from scipy.io.wavfile import write
+            out = os.path.join(args.saved_dir, names[i] + ".wav")
+            write(out, 8000, audio)
+            print("Saved wavfile", out)
+            done += 1
+    print(f"rank {rank}: {done} utterances")
+    return done

@@ -189,7 +189,9 @@ assert all(torch.equal(got[k], good[k]) for k in good), rank
 plan = dp.shard_utterances([100, 200, 300, 400, 500], world)
 frames, secs = dp.reduce_metric(float(sum([100, 200, 300, 400, 500][i] for i in plan[rank])), 1.0 + rank, torch.device('cpu'))
 assert frames == 1500.0 and secs == 2.0
-print('RANK_OK', rank)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print('RANK_OK', rank, flush=True)
 """)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)),
