@@ -31,5 +31,11 @@ void cvx_set_error(const char* fmt, ...);
 // ((r&3) + 8*(r>>2) + 4*(lane>>5), lane&31)   [cdna_hip_programming.md section 3]
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// 16-byte load through the GLOBAL address space.  Pointers that went through select/offset arithmetic lose
+// their provenance and hipcc falls back to flat_load (counted on lgkmcnt too, so every LDS wait would also
+// wait for HBM); this keeps them global_load_dwordx4.
+typedef const f32x4 __attribute__((address_space(1)))* cvx_gptr4;
+__device__ __forceinline__ f32x4 gload4(const float* p) { return *reinterpret_cast<cvx_gptr4>(reinterpret_cast<uintptr_t>(p)); }
+
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }

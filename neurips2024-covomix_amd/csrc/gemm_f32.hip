@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p,
     {
         const bool sw = (0 == switch_tile);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) { if (sw) pa[i] += a_jump[i]; ra[i] = *reinterpret_cast<const f32x4*>(pa[i]); pa[i] += BK; }
+        for (int i = 0; i < NA; ++i) { if (sw) pa[i] += a_jump[i]; ra[i] = gload4(pa[i]); pa[i] += BK; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { rb[i] = *reinterpret_cast<const f32x4*>(pw[i]); pw[i] += BK; }
+        for (int i = 0; i < 4; ++i) { rb[i] = gload4(pw[i]); pw[i] += BK; }
 #pragma unroll
         for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(As + st_off + 32 * i * LDS_LD) = ra[i];
 #pragma unroll
@@ -175,13 +175,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p,
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float* src = pa[i] + (sw ? a_jump[i] : 0) - (has_next ? 0 : BK);
-            ra[i] = *reinterpret_cast<const f32x4*>(src);
+            ra[i] = gload4(src);
             pa[i] = src + adv;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float* src = pw[i] - (has_next ? 0 : BK);
-            rb[i] = *reinterpret_cast<const f32x4*>(src);
+            rb[i] = gload4(src);
             pw[i] = src + adv;
         }
         mfma_group<TM>(a, b, 0, acc);
@@ -195,7 +195,140 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p,
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bn + 32 * i * LDS_LD) = rb[i];
         mfma_group<TM>(a, b, 3, acc);
+        if constexpr (TM == 2) {
+            // Issue order of this step (one scheduling region): memory instructions are spread ONE per MFMA
+            // instead of in bursts.  Measured on the probe (tools/mfma_probe.hip): a burst of 8 global loads
+            // costs 107 vs 135 TFLOP/s when the operands stream from HBM.
+            //   q0: 4 frag reads | 8 x (MFMA, global load) | 4 x (2 MFMA, q1 frag read)
+            //   q1: 4 x (4 MFMA, q2 frag read)
+            //   q2: 8 x (MFMA, LDS write of the next tile) | 4 x (2 MFMA, q3 frag read)
+            //   q3: 16 MFMA
+#define CVX_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+            CVX_SGB(0x100, 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { CVX_SGB(0x008, 1); CVX_SGB(0x020, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { CVX_SGB(0x008, 2); CVX_SGB(0x100, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { CVX_SGB(0x008, 4); CVX_SGB(0x100, 1); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { CVX_SGB(0x008, 1); CVX_SGB(0x200, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { CVX_SGB(0x008, 2); CVX_SGB(0x100, 1); }
+            CVX_SGB(0x008, 16);
+#undef CVX_SGB
+        }
         __syncthreads();
+    }
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------ LDS-DMA path: K % 32 == 0, 128 x 128 tile
+// Same tiling, but the tiles go global -> LDS directly (global_load_lds_dwordx4): no staging VGPRs and no
+// ds_write pass (the probe prices 8 ds_write_b128 per K-step at 8 % of the MFMA rate).  An LDS-DMA wave
+// instruction writes 1 KiB contiguously (wave-uniform base + lane*16 B = 8 rows x 128 B), so rows cannot be
+// padded; bank conflicts are avoided with an XOR swizzle applied on the per-lane SOURCE address and again on
+// the fragment reads:  16-byte chunk c of row r lives at chunk  c ^ ((r >> 1) & 7)  (conflict-free for the
+// ds_read_b128 lane groups, whose 16 rows then cover all 16 (row parity, chunk) slots exactly once).
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
+                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_glds_kernel(const cvx_gemm_args p, int tiles_m, int tiles_n, int map_mode)
+{
+    constexpr int TM = 2, BM = 128;
+    constexpr int TILE_F = 128 * BK;               // floats per operand tile (unpadded)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                              // [2][128][32]
+    float* Bs = smem + 2 * TILE_F;                 // [2][128][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // DMA sources: wave `wid` fills tile rows [32*wid, 32*wid+32) of A and of W, 8 rows per instruction
+    const float* pa[4];
+    int64_t a_jump[4];
+    const float* pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 32 * wid + 8 * j + (lane >> 3);          // row inside the tile
+        const int c = (lane & 7) ^ ((r >> 1) & 7);             // source chunk that lands in LDS chunk (lane & 7)
+        const int ra = min(m0 + r, p.M - 1), rw = min(n0 + r, p.N - 1);
+        pa[j] = p.A + (int64_t)ra * p.lda + 4 * c;
+        a_jump[j] = p.A2 ? (p.A2 + (int64_t)ra * p.lda2 + 4 * c) - (pa[j] + p.K1) : 0;
+        pw[j] = p.W + (int64_t)rw * p.ldw + 4 * c;
+    }
+    const int switch_tile = p.A2 ? p.K1 / BK : -1;
+    const int dma_off = (32 * wid) * BK;                        // wave-uniform float offset inside a tile
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment read offsets: row (lane & 31) of the wave's 32-row sub-tile, chunk (2q + half) ^ swizzle
+    const int i31 = lane & 31, half = lane >> 5, swz = (i31 >> 1) & 7;
+    int qoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = i31 * BK + 4 * ((2 * q + half) ^ swz);
+    const int a_row0 = wm * 64 * BK, b_row0 = wn * 64 * BK;
+
+    const int nk = p.K / BK;
+    {   // prologue: tile 0 -> buffer 0
+        const bool sw = (0 == switch_tile);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (sw) pa[j] += a_jump[j];
+            glds16(pa[j], As + dma_off + 8 * j * BK);
+            glds16(pw[j], Bs + dma_off + 8 * j * BK);
+            pa[j] += BK; pw[j] += BK;
+        }
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool has_next = kt + 1 < nk;
+        const int adv = has_next ? BK : 0;
+        const bool sw = (kt + 1 == switch_tile);
+        float* an = As + (cur ^ 1) * TILE_F + dma_off;
+        float* bn = Bs + (cur ^ 1) * TILE_F + dma_off;
+        // the NEXT tile's DMA first: it has the whole step (64 MFMAs) to land before the barrier's vmcnt(0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* sa = pa[j] + (sw ? a_jump[j] : 0) - (has_next ? 0 : BK);
+            const float* sb = pw[j] - (has_next ? 0 : BK);
+            glds16(sa, an + 8 * j * BK);
+            glds16(sb, bn + 8 * j * BK);
+            pa[j] = sa + adv; pw[j] = sb + adv;
+        }
+        const float* a = As + cur * TILE_F + a_row0;
+        const float* b = Bs + cur * TILE_F + b_row0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 af[TM], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * BK + qoff[q]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * BK + qoff[q]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();          // carries the vmcnt(0) that retires this step's LDS-DMA
     }
     gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -290,8 +423,23 @@ int launch_gemm(const cvx_gemm_args& a, hipStream_t st)
     }
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
     static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    static const int use_glds = [] { const char* e = getenv("CVX_GEMM_GLDS"); return e ? atoi(e) : 1; }();
     const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
     dim3 grid((unsigned)(grid_m * tiles_n));
+    if constexpr (TM == 2) {
+        if (fast && use_glds) {
+            const size_t lds_dma = (size_t)4 * 128 * BK * sizeof(float);
+            static bool dma_attr = false;
+            if (!dma_attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+                dma_attr = true;
+            }
+            hipLaunchKernelGGL(gemm_f32_glds_kernel, grid, dim3(256), lds_dma, st, a, tiles_m, tiles_n, map_mode);
+            CVX_CHECK_LAUNCH("cvx_gemm_bias_act_f32");
+            return CVX_OK;
+        }
+    }
     if (fast) hipLaunchKernelGGL(gemm_f32_kernel<TM>, grid, dim3(256), lds, st, a, tiles_m, tiles_n, map_mode);
     else      hipLaunchKernelGGL(gemm_f32_generic_kernel<TM>, grid, dim3(256), lds, st, a, tiles_m, tiles_n, map_mode);
     CVX_CHECK_LAUNCH("cvx_gemm_bias_act_f32");

@@ -25,10 +25,14 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ g, flo
     f32x4 af0 = {1.f, 2.f, 3.f, 4.f}, af1 = af0, bf0 = af0, bf1 = af0;
     for (int it = 0; it < iters; ++it) {
         const float* A = smem + (it & 1) * 256 * LD;
-        if (MODE & 4) {
+        if ((MODE & 4) && !(MODE & 32)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) regs[i] = *reinterpret_cast<const f32x4*>(gp + i * 32 * 1024);
             gp += 32;
+        }
+        if (MODE & 32) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { regs[i] = af0; asm volatile("" : "+v"(regs[i])); }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -39,9 +43,14 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ g, flo
                 bf1 = *reinterpret_cast<const f32x4*>(A + b_off + 32 * LD + q * 8);
             }
             if ((MODE & 4) && q == 3) {
-                float* W = smem + ((it & 1) ^ 1) * 256 * LD + (tid >> 3) * LD + (tid & 7) * 4;
+                if (MODE & 16) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(W + i * 32 * LD) = regs[i];
+                    for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(regs[i]));
+                } else {
+                    float* W = smem + ((it & 1) ^ 1) * 256 * LD + (tid >> 3) * LD + (tid & 7) * 4;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(W + i * 32 * LD) = regs[i];
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -51,6 +60,21 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ g, flo
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[t], bf1[t], acc[1][1], 0, 0, 0);
             }
             if (!(MODE & 1)) { asm volatile("" : "+v"(af0), "+v"(bf0)); }
+        }
+        if (MODE & 8) {
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+            SGB(0x100, 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SGB(0x008, 1); SGB(0x020, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 2); SGB(0x100, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 4); SGB(0x100, 1); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { SGB(0x008, 1); SGB(0x200, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { SGB(0x008, 2); SGB(0x100, 1); }
+            SGB(0x008, 16);
         }
         if (MODE & 2) __syncthreads();
     }
@@ -94,6 +118,10 @@ int main()
         run<7>("+ds_read+barrier+global(HBM stream)/ds_write", g, out, blocks, iters, gstride);
         run<7>("+ds_read+barrier+global(L2 shared)/ds_write", g, out, blocks, iters, 0);
         run<6>("barrier+global(L2 shared)/ds_write, no ds_read", g, out, blocks, iters, 0);
+        run<15>("mode 7 (L2 shared) + sched_group_barrier interleave", g, out, blocks, iters, 0);
+        run<23>("mode 7 (L2 shared) loads only, no ds_write", g, out, blocks, iters, 0);
+        run<39>("mode 7 ds_write only, no global loads", g, out, blocks, iters, 0);
+        run<15>("mode 7 (HBM stream) + sched_group_barrier interleave", g, out, blocks, iters, gstride);
     }
     return 0;
 }
