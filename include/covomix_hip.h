@@ -63,6 +63,16 @@ typedef struct {
 } cvx_gemm_args;
 int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s);
 
+/* Split-precision variant of the same contract (same nn.Linear call sites): every fp32 operand is an
+ * (fp16 hi, fp16 lo) pair, hi = fp16(x), lo = fp16(x - hi), and  a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi
+ * on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative operand error, inputs saturated to
+ * +-65504).  W_hi / W_lo are [N, a->ldw] fp16 matrices produced once by cvx_split_f16 from the fp32 weight
+ * (a->W is only validated, not read).  Extra requirements: K % 32 == 0, ldw % 8 == 0.
+ * cvx_split_f16 splits w*scale (scale = a power of two that lifts small weights out of the fp16 subnormal
+ * range); cvx_gemm_f16x3 multiplies the accumulators by acc_scale = 1/scale (exact) before the epilogue. */
+int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
+int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale, cvx_stream_t s);
+
 /* y[r,:] = x[r,:] / max(||x[r,:]||_2, eps) * scale * gamma[g,:] + beta[g,:],  g = r / rows_per_group
  * AdaptiveRMSNorm.forward (acoustic.py:198-204) with gamma/beta = the already projected
  * to_gamma/to_beta(time_emb) rows; RMSNorm.forward (:175) when beta == NULL and one group.

@@ -46,7 +46,13 @@ def _dims_from_state(sd: Dict[str, torch.Tensor]) -> dict:
 class VectorField:
     """Device-resident weights of one CoVoMix network + the launch sequence of one evaluation."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: torch.device, precision: str = "f16x3"):
+        """precision: 'f16x3' (default) runs the transformer GEMMs on the fp16 matrix pipe with every operand split
+        into (hi, lo) fp16 halves and three MFMA products - fp32-class accuracy (kernel error 5.8e-7 vs 5.1e-7 for
+        fp32 MFMA, tests/test_kernels_gpu.py) at 2x the rate; 'fp32' uses v_mfma_f32_32x32x2_f32 everywhere."""
+        if precision not in ("f16x3", "fp32"):
+            raise ValueError(f"precision must be 'f16x3' or 'fp32', got {precision!r}")
+        self.precision = precision
         sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()}
         self.device = device
         self.d = d = _dims_from_state(sd)
@@ -73,6 +79,14 @@ class VectorField:
             inv_freq = 1.0 / (10000 ** (torch.arange(0, 64, 2, device=device).float() / 64))
         self.inv_freq = inv_freq
         self._ws: Dict[tuple, dict] = {}
+        # split (fp16 hi, fp16 lo, 1/scale) copies of the big GEMM weights - load-time packing
+        self.split: Dict[str, tuple] = {}
+        if precision == "f16x3":
+            for k, v in sd.items():
+                if k.endswith(".weight") and v.ndim == 2 and v.shape[1] % 32 == 0 and (
+                        ".2.to_qkv" in k or ".2.to_out" in k or ".4.0." in k or ".4.2." in k
+                        or (k.startswith("transformer.layers.") and k.endswith(".0.weight")) or k == "to_pred.weight"):
+                    self.split[k] = ops.split_f16(v)
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, Bt: int, T: int) -> dict:
@@ -133,6 +147,7 @@ class VectorField:
         tab = ctx["table"][step]
         free: List[torch.Tensor] = list(ws["h"])
         take = free.pop
+        sp = self.split.get
 
         h0 = take()
         ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
@@ -150,23 +165,25 @@ class VectorField:
             if (p + ".0.weight") in sd:
                 s = skips.pop()
                 comb = take()
-                ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s)
+                ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"))
                 free += [h, s]
                 h, keep_input = comb, False
             else:
                 skips.append(h)
                 keep_input = True
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])
-            ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64)
+            ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                     w_split=sp(p + ".2.to_qkv.weight"))
             ops.attention(ws["qkv"], ws["att"], Bt, T, d["heads"], 64 ** -0.5)
             h_att = take() if keep_input else h
-            ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h)
+            ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"))
             h = h_att
             ops.adarmsnorm(h, g_ff, b_ff, ws["normed"])
-            ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU)
-            ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h)
+            ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
+                     w_split=sp(p + ".4.0.weight"))
+            ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h, w_split=sp(p + ".4.2.weight"))
         ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])
-        ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"])
+        ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"))
         return ws["pred"]
 
 

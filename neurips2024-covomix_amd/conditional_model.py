@@ -60,7 +60,8 @@ def parameter_order(sd_keys) -> list:
 
 class CoVoMixModel:
     def __init__(self, state_dict: Dict[str, torch.Tensor], hparams: Optional[dict] = None,
-                 ema_shadow: Optional[list] = None, nfe: int = 32, ode_method: str = "midpoint"):
+                 ema_shadow: Optional[list] = None, nfe: int = 32, ode_method: str = "midpoint",
+                 precision: Optional[str] = None):
         """state_dict: un-prefixed CoVoMix parameter names (acoustic.py:326-406)."""
         self.hparams = dict(hparams or {})
         if self.hparams.get("text2semantic"):
@@ -82,6 +83,7 @@ class CoVoMixModel:
         self._use_ema = False
         self.device = torch.device("cpu")
         self.nfe, self.ode_method = nfe, ode_method
+        self.precision = precision or os.environ.get("CVX_PRECISION", "f16x3")
         self._field: Optional[VectorField] = None
 
     # ---- construction ---------------------------------------------------------------------
@@ -132,7 +134,7 @@ class CoVoMixModel:
             if self.device.type != "cuda":
                 from ._lib import CovomixHipError
                 raise CovomixHipError("CoVoMixModel must be on a GPU (`.to('cuda')`): covomix_amd has no CPU path")
-            self._field = VectorField(self.active_state_dict(), self.device)
+            self._field = VectorField(self.active_state_dict(), self.device, precision=self.precision)
         return self._field
 
     # ---- sampling -----------------------------------------------------------------------------

@@ -1,0 +1,74 @@
+// Shared pieces of the GEMM kernels: XCD-aware block->tile map and the fused epilogue.
+#pragma once
+#include "cvx_common.h"
+
+namespace cvxg {
+
+constexpr int BN = 128;
+constexpr int BK = 32;
+
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_mode, int& tile_m, int& tile_n)
+{
+    // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8: observed, used for speed only).
+    // mode 1: XCD x owns row-panels x, x+8, ... (all their N tiles): every A panel is read by one L2 only
+    // and just the (small) W matrix is read by all eight.
+    if (map_mode == 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile_m = xcd + 8 * (slot / tiles_n);
+        tile_n = slot % tiles_n;
+    } else {
+        tile_n = blockIdx.x % tiles_n;
+        tile_m = blockIdx.x / tiles_n;
+    }
+}
+
+// acc[mi][ni]: 32x32 MFMA accumulators of a wave that owns rows [m0 + wm*TM*32, +TM*32) and the 64 columns
+// [n0 + wn*64, +64).  bias -> act -> half-split RoPE -> residual -> store.
+template <int TM>
+__device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
+                                              int wm, int wn, int lane)
+{
+    const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
+    const int c_lo = colw + (lane & 31);
+    const int c_hi = c_lo + 32;
+    const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
+    const float b_lo = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
+    const float b_hi = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * TM * 32 + mi * 32 + mfma32_row(r, lane);
+            if (row >= p.M) continue;
+            float lo = acc[mi][0][r] + b_lo;
+            float hi = acc[mi][1][r] + b_hi;
+            if (p.act == CVX_ACT_GELU) { lo = gelu_erf(lo); hi = gelu_erf(hi); }
+            else if (p.act == CVX_ACT_SILU) { lo = silu(lo); hi = silu(hi); }
+            if (do_rope) {
+                const int pos = row % p.rope_T;
+                const float c = p.rope_cos[pos * 32 + (lane & 31)];
+                const float s = p.rope_sin[pos * 32 + (lane & 31)];
+                const float nlo = lo * c - hi * s;
+                const float nhi = hi * c + lo * s;
+                lo = nlo; hi = nhi;
+            }
+            if (p.residual) {
+                if (c_lo < p.N) lo += p.residual[(int64_t)row * p.ldr + c_lo];
+                if (c_hi < p.N) hi += p.residual[(int64_t)row * p.ldr + c_hi];
+            }
+            if (c_lo < p.N) p.C[(int64_t)row * p.ldc + c_lo] = lo;
+            if (c_hi < p.N) p.C[(int64_t)row * p.ldc + c_hi] = hi;
+        }
+    }
+}
+
+// global -> LDS DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+int validate_gemm_args(const cvx_gemm_args* a);   // shared argument checks (gemm_f32.hip)
+
+}  // namespace cvxg

@@ -1,0 +1,234 @@
+// Split-precision GEMM on the 2.5 PFLOP/s matrix pipe:  C = epi([A|A2] * W^T) with every fp32 operand
+// represented as an (fp16 hi, fp16 lo) pair and three v_mfma_f32_32x32x16_f16 products per tile
+//      a*w  ~=  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi          (fp32 accumulate)
+// hi = fp16(x), lo = fp16(x - hi): 22 significand bits survive, so the dropped a_lo*w_lo term and the operand
+// truncation are ~2^-22 relative - the same class as fp32 rounding (measured in tests/test_kernels_gpu.py),
+// unlike a plain bf16/fp16 cast (2.9e-3 end-to-end, SURVEY.md section 7 hard part 1).  Three 32-cycle MFMAs
+// replace eight 64-cycle fp32 MFMAs for the same 32x32x16 block: 5.3x less matrix-pipe time.
+//
+// Same role as gemm_f32.hip (every nn.Linear of reference acoustic.py:225-246, :306-310, :516) and the same
+// 128x128x32 block tile / 4 waves / fused epilogue.  Operand paths:
+//   W : split ONCE at load time (cvx_split_f16) into two fp16 matrices; tiles arrive by LDS-DMA.
+//   A : fp32 activations, 16-byte global loads -> registers -> split on the fly -> ds_write_b64 (hi, lo).
+// LDS tiles are [128][32] fp16 (64-byte rows) with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3,
+// which makes the ds_read_b128 fragment reads conflict-free (a 256-byte bank row holds 4 rows x 4 chunks).
+#include "gemm_common.h"
+#include <stdlib.h>
+
+namespace {
+
+using namespace cvxg;
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TILE_H = 128 * BK;            // halves per operand tile (8 KiB)
+constexpr float F16_MAX = 65504.f;
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(v[e], -F16_MAX), F16_MAX);     // saturate instead of inf - inf
+        const f16 h = (f16)x;
+        hi[e] = h;
+        lo[e] = (f16)(x - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args p, const f16* __restrict__ Whi,
+                                                           const f16* __restrict__ Wlo, float acc_scale, int tiles_m, int tiles_n, int map_mode)
+{
+    constexpr int TM = 2, BM = 128;
+    extern __shared__ __attribute__((aligned(16))) f16 smem_h[];
+    // stage layout: [Ahi | Alo | Whi | Wlo], two stages
+    f16* const S0 = smem_h;
+    constexpr int STAGE = 4 * TILE_H;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- A: register staging (fp32 -> split).  thread -> (row = tid/8 + 32*i, 4 floats at k = 4*(tid%8))
+    const int srow = tid >> 3, sj = tid & 7;
+    const float* pa[4];
+    int64_t a_jump[4];
+    int a_st[4];                                // LDS half-offset of this thread's 8-byte piece
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = srow + 32 * i;
+        const int row = min(m0 + r, p.M - 1);
+        pa[i] = p.A + (int64_t)row * p.lda + 4 * sj;
+        a_jump[i] = p.A2 ? (p.A2 + (int64_t)row * p.lda2 + 4 * sj) - (pa[i] + p.K1) : 0;
+        const int chunk = (sj >> 1) ^ ((r >> 2) & 3);
+        a_st[i] = r * BK + chunk * 8 + (sj & 1) * 4;
+    }
+    // ---- W: LDS-DMA.  wave `wid` fills rows [32*wid, +32) of Whi and Wlo: 2 instructions of 16 rows each
+    const f16* pwh[2];
+    const f16* pwl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 32 * wid + 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        const int64_t off = (int64_t)min(n0 + r, p.N - 1) * p.ldw + 8 * c;
+        pwh[j] = Whi + off;
+        pwl[j] = Wlo + off;
+    }
+    const int dma_off = 32 * wid * BK;
+    const int switch_tile = p.A2 ? p.K1 / BK : -1;
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment read offsets (halves): row (lane&31), chunk (2s + g) ^ swizzle, g = lane >> 5
+    const int i31 = lane & 31, g = lane >> 5, swz = (i31 >> 2) & 3;
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = i31 * BK + 8 * ((2 * s + g) ^ swz);
+    const int a_row0 = wm * 64 * BK, b_row0 = wn * 64 * BK;
+
+    f32x4 ra[4];
+    const int nk = p.K / BK;
+    {   // prologue: tile 0 -> stage 0
+        const bool sw = (0 == switch_tile);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if (sw) pa[i] += a_jump[i]; ra[i] = gload4(pa[i]); pa[i] += BK; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(pwh[j], S0 + 2 * TILE_H + dma_off + 16 * j * BK);
+            glds16(pwl[j], S0 + 3 * TILE_H + dma_off + 16 * j * BK);
+            pwh[j] += BK; pwl[j] += BK;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f16x4 hi, lo;
+            split4(ra[i], hi, lo);
+            *reinterpret_cast<f16x4*>(S0 + a_st[i]) = hi;
+            *reinterpret_cast<f16x4*>(S0 + TILE_H + a_st[i]) = lo;
+        }
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool has_next = kt + 1 < nk;
+        const int adv = has_next ? BK : 0;
+        const bool sw = (kt + 1 == switch_tile);
+        f16* const Sc = S0 + cur * STAGE;
+        f16* const Sn = S0 + (cur ^ 1) * STAGE;
+        // next tile: W by DMA into the other stage, A into registers
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16* sh = pwh[j] - (has_next ? 0 : BK);
+            const f16* sl = pwl[j] - (has_next ? 0 : BK);
+            glds16(sh, Sn + 2 * TILE_H + dma_off + 16 * j * BK);
+            glds16(sl, Sn + 3 * TILE_H + dma_off + 16 * j * BK);
+            pwh[j] = sh + adv; pwl[j] = sl + adv;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* src = pa[i] + (sw ? a_jump[i] : 0) - (has_next ? 0 : BK);
+            ra[i] = gload4(src);
+            pa[i] = src + adv;
+        }
+        // 24 MFMAs on the current stage
+        const f16* ah = Sc + a_row0;
+        const f16* al = Sc + TILE_H + a_row0;
+        const f16* wh = Sc + 2 * TILE_H + b_row0;
+        const f16* wl = Sc + 3 * TILE_H + b_row0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 fah[TM], fal[TM], fwh[2], fwl[2];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                fah[mi] = *reinterpret_cast<const f16x8*>(ah + mi * 32 * BK + foff[s]);
+                fal[mi] = *reinterpret_cast<const f16x8*>(al + mi * 32 * BK + foff[s]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
+                fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+        // split + store the next A tile (the other stage was last read before the previous barrier)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f16x4 hi, lo;
+            split4(ra[i], hi, lo);
+            *reinterpret_cast<f16x4*>(Sn + a_st[i]) = hi;
+            *reinterpret_cast<f16x4*>(Sn + TILE_H + a_st[i]) = lo;
+        }
+        __syncthreads();
+    }
+    if (acc_scale != 1.0f) {        // undo the power-of-two weight pre-scale (exact)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
+    }
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane);
+}
+
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ w, f16* __restrict__ hi,
+                                                       f16* __restrict__ lo, int64_t n, float scale)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = fminf(fmaxf(w[i] * scale, -F16_MAX), F16_MAX);
+    const f16 h = (f16)x;
+    hi[i] = h;
+    lo[i] = (f16)(x - (float)h);
+}
+
+}  // namespace
+
+extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s)
+{
+    CVX_REQUIRE(w && hi && lo && n >= 0, "split_f16: bad arguments");
+    if (n == 0) return CVX_OK;
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale);
+    CVX_CHECK_LAUNCH("cvx_split_f16");
+    return CVX_OK;
+}
+
+extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale, cvx_stream_t s)
+{
+    const int rc = cvxg::validate_gemm_args(a);
+    if (rc != CVX_OK) return rc;
+    CVX_REQUIRE(W_hi && W_lo, "gemm_f16x3: null split weights");
+    CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
+    CVX_REQUIRE((((uintptr_t)W_hi | (uintptr_t)W_lo) & 15) == 0, "gemm_f16x3: split weights must be 16-byte aligned");
+    if (a->M == 0) return CVX_OK;
+    const int tiles_n = (a->N + BN - 1) / BN, tiles_m = (a->M + 127) / 128;
+    static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
+    const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)(grid_m * tiles_n)), dim3(256), lds, reinterpret_cast<hipStream_t>(s),
+                       *a, reinterpret_cast<const f16*>(W_hi), reinterpret_cast<const f16*>(W_lo), acc_scale, tiles_m, tiles_n, map_mode);
+    CVX_CHECK_LAUNCH("cvx_gemm_f16x3");
+    return CVX_OK;
+}

@@ -21,67 +21,13 @@
 // the (j, j+32) partner is the same accumulator register of the neighbouring MFMA tile)
 // and the residual add.  K % 32 != 0 (only to_embed's 80 x-columns) takes the predicated
 // generic kernel.
-#include "cvx_common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int BN = 128;
-constexpr int BK = 32;
+using namespace cvxg;
 constexpr int LDS_LD = BK + 4;   // padded row (floats)
-
-__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_mode, int& tile_m, int& tile_n)
-{
-    // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8: observed, used for speed only).
-    // mode 1: XCD x owns row-panels x, x+8, ... (all their N tiles): every A panel is read by one L2 only
-    // and just the (small) W matrix is read by all eight.
-    if (map_mode == 1) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        tile_m = xcd + 8 * (slot / tiles_n);
-        tile_n = slot % tiles_n;
-    } else {
-        tile_n = blockIdx.x % tiles_n;
-        tile_m = blockIdx.x / tiles_n;
-    }
-}
-
-template <int TM>
-__device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
-                                              int wm, int wn, int lane)
-{
-    const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
-    const int c_lo = colw + (lane & 31);
-    const int c_hi = c_lo + 32;
-    const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
-    const float b_lo = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
-    const float b_hi = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * TM * 32 + mi * 32 + mfma32_row(r, lane);
-            if (row >= p.M) continue;
-            float lo = acc[mi][0][r] + b_lo;
-            float hi = acc[mi][1][r] + b_hi;
-            if (p.act == CVX_ACT_GELU) { lo = gelu_erf(lo); hi = gelu_erf(hi); }
-            else if (p.act == CVX_ACT_SILU) { lo = silu(lo); hi = silu(hi); }
-            if (do_rope) {
-                const int pos = row % p.rope_T;
-                const float c = p.rope_cos[pos * 32 + (lane & 31)];
-                const float s = p.rope_sin[pos * 32 + (lane & 31)];
-                const float nlo = lo * c - hi * s;
-                const float nhi = hi * c + lo * s;
-                lo = nlo; hi = nhi;
-            }
-            if (p.residual) {
-                if (c_lo < p.N) lo += p.residual[(int64_t)row * p.ldr + c_lo];
-                if (c_hi < p.N) hi += p.residual[(int64_t)row * p.ldr + c_hi];
-            }
-            if (c_lo < p.N) p.C[(int64_t)row * p.ldc + c_lo] = lo;
-            if (c_hi < p.N) p.C[(int64_t)row * p.ldc + c_hi] = hi;
-        }
-    }
-}
 
 template <int TM>
 __device__ __forceinline__ void mfma_group(const float* a, const float* b, int q, f32x16 (&acc)[TM][2])
@@ -230,12 +176,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p,
 // padded; bank conflicts are avoided with an XOR swizzle applied on the per-lane SOURCE address and again on
 // the fragment reads:  16-byte chunk c of row r lives at chunk  c ^ ((r >> 1) & 7)  (conflict-free for the
 // ds_read_b128 lane groups, whose 16 rows then cover all 16 (row parity, chunk) slots exactly once).
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
-                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)lds_wave_base, 16, 0, 0);
-}
-
 __global__ __launch_bounds__(256, 2) void gemm_f32_glds_kernel(const cvx_gemm_args p, int tiles_m, int tiles_n, int map_mode)
 {
     constexpr int TM = 2, BM = 128;
@@ -448,11 +388,10 @@ int launch_gemm(const cvx_gemm_args& a, hipStream_t st)
 
 }  // namespace
 
-extern "C" int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s)
+int cvxg::validate_gemm_args(const cvx_gemm_args* a)
 {
     CVX_REQUIRE(a != nullptr, "gemm: null args");
     CVX_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
-    if (a->M == 0) return CVX_OK;
     CVX_REQUIRE(a->A && a->W && a->C, "gemm: null operand");
     CVX_REQUIRE(a->K % 4 == 0 && a->lda % 4 == 0 && a->ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
     CVX_REQUIRE((((uintptr_t)a->A | (uintptr_t)a->W) & 15) == 0, "gemm: A/W must be 16-byte aligned");
@@ -465,6 +404,14 @@ extern "C" int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s)
                     "gemm: bad RoPE epilogue arguments");
     }
     CVX_REQUIRE(a->act >= CVX_ACT_NONE && a->act <= CVX_ACT_SILU, "gemm: unsupported activation %d", a->act);
+    return CVX_OK;
+}
+
+extern "C" int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s)
+{
+    const int rc = cvxg::validate_gemm_args(a);
+    if (rc != CVX_OK) return rc;
+    if (a->M == 0) return CVX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     // Small-M problems (time tables, short utterances) use the 64-row tile to fill more CUs.
     const long blocks128 = (long)((a->M + 127) / 128) * ((a->N + BN - 1) / BN);

@@ -32,9 +32,11 @@ def _chk_f32(*ts):
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
-         a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0) -> torch.Tensor:
+         a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
-    inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix."""
+    inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
+    w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
+    of the fp32 one (needs K % 32 == 0; small-M problems stay on the fp32 kernel)."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -64,8 +66,32 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = cos.data_ptr(), sin.data_ptr(), cos.shape[0], rope_cols
     else:
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
+    if w_split is not None and K % 32 == 0 and M > 64:
+        hi, lo, inv_scale = w_split
+        assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == (N, K) and lo.shape == (N, K)
+        assert hi.is_contiguous() and lo.is_contiguous() and hi.is_cuda and lo.is_cuda
+        g.ldw = K
+        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), lo.data_ptr(), inv_scale, _stream()),
+                   "cvx_gemm_f16x3")
+        return out
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
     return out
+
+
+def split_f16(w: torch.Tensor):
+    """(hi, lo, 1/scale): fp16 halves of w*scale, hi = fp16(w*scale), lo = fp16(w*scale - hi), with scale the power
+    of two that brings max|w| to [2^13, 2^14) so the lo halves stay out of the fp16 subnormal range.
+    Load-time weight packing."""
+    import math
+    _chk_f32(w)
+    w = w.contiguous()
+    amax = float(w.abs().max())
+    scale = 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
+    hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    lo = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    _lib.check(_lib.load().cvx_split_f16(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(), scale, _stream()),
+               "cvx_split_f16")
+    return hi, lo, 1.0 / scale
 
 
 def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: torch.Tensor,

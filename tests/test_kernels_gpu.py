@@ -237,3 +237,50 @@ def test_hifigan_post(ops):
     ops.hifigan_post(x, w.reshape(C, 7).contiguous(), 0.05, y)
     ref = torch.tanh(F.conv1d(F.leaky_relu(x.double(), 0.01), w.double(), torch.tensor([0.05], dtype=torch.float64, device=dev()), padding=3))
     assert rel_l2(y, ref) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 1024), (1000, 3072, 1024), (130, 4096, 1024), (999, 1024, 4096), (300, 80, 1024)])
+def test_gemm_f16x3_accuracy(ops, M, N, K):
+    """Split-precision (fp16 hi/lo, 3 MFMA products) GEMM: error class of fp32, far below a plain fp16/bf16 cast."""
+    a, w = randn(M, K, seed=101) * 3.0, randn(N, K, seed=102) / math.sqrt(K)
+    b, r = randn(N, seed=103), randn(M, N, seed=104)
+    ws = ops.split_f16(w)
+    assert torch.isfinite(ws[0].float()).all() and torch.isfinite(ws[1].float()).all()
+    out = torch.full((M, N), float("nan"), device=dev())
+    ops.gemm(a, w, out, bias=b, act=1, residual=r, w_split=ws)
+    ref = F.gelu(a.double() @ w.double().T + b.double()) + r.double()
+    e3 = rel_l2(out, ref)
+    o32 = torch.empty_like(out)
+    ops.gemm(a, w, o32, bias=b, act=1, residual=r)
+    e32 = rel_l2(o32, ref)
+    half = F.gelu((a.half().double() @ w.half().double().T) + b.double()) + r.double()
+    e16 = rel_l2(half, ref)
+    print(f"f16x3 {e3:.2e}  fp32 {e32:.2e}  plain-fp16 {e16:.2e}")
+    assert e3 < 3e-6 and e3 < e16 / 50
+
+
+def test_gemm_f16x3_split_k_rope_and_range(ops):
+    M, N = 257, 384
+    x, s = randn(M, 256, seed=110), randn(M, 256, seed=111)
+    w = randn(N, 512, seed=112) / math.sqrt(512)
+    out = torch.empty(M, N, device=dev())
+    ops.gemm(x, w, out, a2=s, w_split=ops.split_f16(w))
+    assert rel_l2(out, torch.cat((x, s), -1).double() @ w.double().T) < 3e-6
+    # tiny and huge magnitudes: fp16 subnormal lo parts and saturation
+    xs = randn(M, 256, seed=113) * 1e-3
+    ws_ = randn(N, 256, seed=114) * 1e-2
+    ops.gemm(xs, ws_, out, w_split=ops.split_f16(ws_))
+    e_small = rel_l2(out, xs.double() @ ws_.double().T)
+    print("small-magnitude f16x3", e_small)
+    assert e_small < 2e-4
+    # RoPE epilogue on the split kernel
+    Bt, T, H = 2, 130, 2
+    xq = randn(Bt * T, 128, seed=115)
+    wq = randn(3 * H * 64, 128, seed=116) / math.sqrt(128)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(T).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(dev()).contiguous(), ang.sin().to(dev()).contiguous()
+    o1 = torch.empty(Bt * T, 3 * H * 64, device=dev()); o2 = torch.empty_like(o1)
+    ops.gemm(xq, wq, o1, rope=(cos, sin), rope_cols=2 * H * 64, w_split=ops.split_f16(wq))
+    ops.gemm(xq, wq, o2, rope=(cos, sin), rope_cols=2 * H * 64)
+    assert rel_l2(o1, o2) < 3e-6

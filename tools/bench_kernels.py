@@ -61,3 +61,18 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def f16x3():
+    Bt, T = 16, 1000
+    M = Bt * T
+    r = lambda *s: torch.randn(*s, device=dev)
+    for (n, k, name) in [(1024, 1024, "out-proj"), (3072, 1024, "qkv"), (4096, 1024, "ff1"), (1024, 4096, "ff2"), (1024, 2048, "skip")]:
+        a, w, c = r(M, k), r(n, k) / math.sqrt(k), torch.empty(M, n, device=dev)
+        ws = ops.split_f16(w)
+        t = timeit(lambda: ops.gemm(a, w, c, w_split=ws))
+        print(f"f16x3 {name:9s} M={M} N={n} K={k}: {t*1e3:8.3f} ms  {2*M*n*k/t/1e12:7.2f} TFLOP/s (fp32-equivalent)")
+
+
+if __name__ == "__main__" and os.environ.get("F16X3", "1") == "1":
+    f16x3()
