@@ -69,15 +69,26 @@ int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s);
  * +-65504).  W_hi / W_lo are [N, a->ldw] fp16 matrices produced once by cvx_split_f16 from the fp32 weight
  * (a->W is only validated, not read).  Extra requirements: K % 32 == 0, ldw % 8 == 0.
  * cvx_split_f16 splits w*scale (scale = a power of two that lifts small weights out of the fp16 subnormal
- * range); cvx_gemm_f16x3 multiplies the accumulators by acc_scale = 1/scale (exact) before the epilogue. */
+ * range); cvx_gemm_f16x3 multiplies the accumulators by acc_scale = 1/scale (exact) before the epilogue.
+ * `io` (may be NULL) lets activations stay in split form between kernels: A_hi/A_lo (and A2_*) give the A operand
+ * already split (then a->A / a->A2 are only validated and every tile arrives by LDS-DMA); C_hi/C_lo receive a split
+ * copy of the output for the next GEMM, and write_f32 == 0 drops the fp32 store of C altogether. */
+typedef struct {
+    const uint16_t* A_hi;  const uint16_t* A_lo;  int64_t lda_h;
+    const uint16_t* A2_hi; const uint16_t* A2_lo; int64_t lda2_h;
+    uint16_t* C_hi; uint16_t* C_lo; int64_t ldc_h;
+    int32_t write_f32;
+} cvx_gemm_split_io;
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
-int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale, cvx_stream_t s);
+int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
+                   const cvx_gemm_split_io* io, cvx_stream_t s);
 
 /* y[r,:] = x[r,:] / max(||x[r,:]||_2, eps) * scale * gamma[g,:] + beta[g,:],  g = r / rows_per_group
  * AdaptiveRMSNorm.forward (acoustic.py:198-204) with gamma/beta = the already projected
  * to_gamma/to_beta(time_emb) rows; RMSNorm.forward (:175) when beta == NULL and one group.
  * D % 4 == 0. */
 int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                       uint16_t* y_hi, uint16_t* y_lo,   /* optional fp16 (hi, lo) split copy of y; y may then be NULL */
                        int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
                        cvx_stream_t s);
 
@@ -86,8 +97,9 @@ int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, fl
  * scores.  qkv is the to_qkv output [Bt, T, 3*H*64] (q | k | v, heads contiguous
  * 64-blocks, acoustic.py:227-229) with RoPE already applied to q and k (GEMM epilogue).
  * Head dim is fixed at 64 (every shipped config, running_command/Acous_*.sh). */
-int cvx_attention_f32(const float* qkv, float* out, int32_t Bt, int32_t T, int32_t H,
-                      float scale, cvx_stream_t s);
+int cvx_attention_f32(const float* qkv, float* out,
+                      uint16_t* out_hi, uint16_t* out_lo,  /* optional fp16 (hi, lo) split copy; out may then be NULL */
+                      int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s);
 
 /* y[b,t,c] = GELU( bias[c] + sum_k w[c,k] * x[b,t+k-K/2,c] ) + x[b,t,c]
  * ConvPositionEmbed + residual (acoustic.py:141-161, :508), channels-last, K == 31. */

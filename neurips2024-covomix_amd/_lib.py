@@ -32,6 +32,15 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmSplitIO(C.Structure):
+    _fields_ = [
+        ("A_hi", C.c_void_p), ("A_lo", C.c_void_p), ("lda_h", C.c_int64),
+        ("A2_hi", C.c_void_p), ("A2_lo", C.c_void_p), ("lda2_h", C.c_int64),
+        ("C_hi", C.c_void_p), ("C_lo", C.c_void_p), ("ldc_h", C.c_int64),
+        ("write_f32", C.c_int32),
+    ]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("B", C.c_int32), ("Cin", C.c_int32), ("Lin", C.c_int32),
@@ -49,10 +58,12 @@ SIGNATURES = {
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
-    "cvx_gemm_f16x3": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
-    "cvx_adarmsnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+    "cvx_gemm_f16x3": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(GemmSplitIO),
+                                 C.c_void_p]),
+    "cvx_adarmsnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                      C.c_int64, C.c_float, C.c_float, C.c_void_p]),
-    "cvx_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "cvx_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                    C.c_void_p]),
     "cvx_dwconv31_gelu_res_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_void_p]),
     "cvx_cfg_combine_axpy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,

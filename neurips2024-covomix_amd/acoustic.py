@@ -103,6 +103,9 @@ class VectorField:
             ff=f(M, 4 * d["dim"]), base=f(M, d["dim"]), xin=f(M, d["dim_out"]), pred=f(M, d["dim_out"]),
             gathered=f(M, d["streams"] * d["dim_emb"] + d["dim_cond"]),
         )
+        if self.precision == "f16x3":      # activations that only feed GEMMs live as (fp16 hi, fp16 lo) pairs
+            h16 = lambda *s: (torch.empty(*s, dtype=torch.float16, device=dev), torch.empty(*s, dtype=torch.float16, device=dev))
+            ws["normed16"], ws["att16"], ws["ff16"] = h16(M, d["dim"]), h16(M, d["heads"] * 64), h16(M, 4 * d["dim"])
         pos = torch.arange(T, device=dev, dtype=torch.float32)
         ang = pos[:, None] * self.inv_freq[None, :]
         ws["rope"] = (ang.cos().contiguous(), ang.sin().contiguous())
@@ -148,6 +151,8 @@ class VectorField:
         free: List[torch.Tensor] = list(ws["h"])
         take = free.pop
         sp = self.split.get
+        # split activations need the f16x3 kernel on every consumer GEMM (K % 32 == 0 and more than 64 rows)
+        split_io = self.precision == "f16x3" and Bt * T > 64 and dim % 32 == 0
 
         h0 = take()
         ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
@@ -171,6 +176,21 @@ class VectorField:
             else:
                 skips.append(h)
                 keep_input = True
+            if split_io:
+                n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
+                ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16)
+                ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                         w_split=sp(p + ".2.to_qkv.weight"), a_split=n16)
+                ops.attention(ws["qkv"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
+                h_att = take() if keep_input else h
+                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), a_split=a16)
+                h = h_att
+                ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16)
+                ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
+                         w_split=sp(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False)
+                ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h,
+                         w_split=sp(p + ".4.2.weight"), a_split=f16)
+                continue
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])
             ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
                      w_split=sp(p + ".2.to_qkv.weight"))
@@ -182,8 +202,12 @@ class VectorField:
             ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
                      w_split=sp(p + ".4.0.weight"))
             ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h, w_split=sp(p + ".4.2.weight"))
-        ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])
-        ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"))
+        if split_io:
+            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["normed16"])
+            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["normed16"])
+        else:
+            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])
+            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"))
         return ws["pred"]
 
 

@@ -27,7 +27,22 @@ constexpr int KT = 32;          // keys per tile
 constexpr int K_LD = HD + 4;    // padded K row in LDS (floats): conflict-free ds_read_b128
 constexpr int V_LD = HD;
 
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, const f32x4 o)
+{
+    f16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(o[e], -65504.f), 65504.f);
+        h[e] = (_Float16)x;
+        l[e] = (_Float16)(x - (float)h[e]);
+    }
+    *reinterpret_cast<f16x4_t*>(hi) = h;
+    *reinterpret_cast<f16x4_t*>(lo) = l;
+}
+
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
                                                               int T, int H, int n_groups, int n_qt, float scale_log2e)
 {
     __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
@@ -150,31 +165,38 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_valid) {
-        float* op = out + ((int64_t)b * T + qrow) * (H * HD) + head * HD + 4 * half;
+        const int64_t o_off = ((int64_t)b * T + qrow) * (H * HD) + head * HD + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 a, c;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = o0[4 * g + e] * inv; c[e] = o1[4 * g + e] * inv; }
-            *reinterpret_cast<f32x4*>(op + 8 * g) = a;
-            *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = c;
+            if (out) {
+                *reinterpret_cast<f32x4*>(out + o_off + 8 * g) = a;
+                *reinterpret_cast<f32x4*>(out + o_off + 32 + 8 * g) = c;
+            }
+            if (out_hi) {     // split copy for the to_out GEMM's pre-split A operand
+                store_split4(out_hi + o_off + 8 * g, out_lo + o_off + 8 * g, a);
+                store_split4(out_hi + o_off + 32 + 8 * g, out_lo + o_off + 32 + 8 * g, c);
+            }
         }
     }
 }
 
 }  // namespace
 
-extern "C" int cvx_attention_f32(const float* qkv, float* out, int32_t Bt, int32_t T, int32_t H,
-                                 float scale, cvx_stream_t s)
+extern "C" int cvx_attention_f32(const float* qkv, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                 int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s)
 {
-    CVX_REQUIRE(qkv && out, "attention: null pointer");
+    CVX_REQUIRE(qkv && (out || out_hi) && ((out_hi == nullptr) == (out_lo == nullptr)), "attention: null pointer");
     CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0, "attention: bad shape Bt=%d T=%d H=%d", Bt, T, H);
     CVX_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attention: pointers must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;
     const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                       qkv, out, T, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+                       qkv, out, reinterpret_cast<_Float16*>(out_hi), reinterpret_cast<_Float16*>(out_lo),
+                       T, H, n_groups, n_qt, scale * 1.44269504088896340736f);
     CVX_CHECK_LAUNCH("cvx_attention_f32");
     return CVX_OK;
 }

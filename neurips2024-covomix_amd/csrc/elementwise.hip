@@ -32,11 +32,27 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+// split 4 floats into fp16 (hi, lo) and store 8 bytes each (for GEMMs that take their A operand pre-split)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, const f32x4 o)
+{
+    f16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(o[e], -65504.f), 65504.f);
+        h[e] = (_Float16)x;
+        l[e] = (_Float16)(x - (float)h[e]);
+    }
+    *reinterpret_cast<f16x4_t*>(hi) = h;
+    *reinterpret_cast<f16x4_t*>(lo) = l;
+}
+
 // ---------------------------------------------------------------- AdaRMSNorm
 // one wavefront per row; the row stays in registers when D <= 256*NV.
 template <int NV>
 __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                        _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
                                                         int64_t rows, int D, int64_t rows_per_group, float scale, float eps)
 {
     const int lane = threadIdx.x & 63;
@@ -46,7 +62,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
     const int64_t g = row / rows_per_group;
     const float* gr = gamma + g * D;
     const float* br = beta ? beta + g * D : nullptr;
-    float* yr = y + row * D;
+    float* yr = y ? y + row * D : nullptr;
     const int nvec = D >> 2;
 
     f32x4 v[NV];
@@ -74,7 +90,8 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += bb[e];
             }
-            *reinterpret_cast<f32x4*>(yr + 4 * j) = o;
+            if (y) *reinterpret_cast<f32x4*>(yr + 4 * j) = o;
+            if (y_hi) store_split4(y_hi + row * D + 4 * j, y_lo + row * D + 4 * j, o);
         }
     }
 }
@@ -82,6 +99,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
 // generic-D fallback: two passes over the row (second pass hits L1/L2)
 __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ y,
+                                                                _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
                                                                 int64_t rows, int D, int64_t rows_per_group, float scale, float eps)
 {
     const int lane = threadIdx.x & 63;
@@ -107,7 +125,8 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += bb[e];
         }
-        *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
+        if (y) *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
+        if (y_hi) store_split4(y_hi + row * D + 4 * j, y_lo + row * D + 4 * j, o);
     }
 }
 
@@ -210,18 +229,21 @@ __global__ __launch_bounds__(256) void wav_to_int16_kernel(const float* __restri
 }  // namespace
 
 extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                  uint16_t* y_hi_, uint16_t* y_lo_,
                                   int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
                                   cvx_stream_t s)
 {
-    CVX_REQUIRE(x && gamma && y, "adarmsnorm: null pointer");
+    CVX_REQUIRE(x && gamma && (y || y_hi_) && ((y_hi_ == nullptr) == (y_lo_ == nullptr)), "adarmsnorm: null pointer");
+    _Float16* y_hi = reinterpret_cast<_Float16*>(y_hi_);
+    _Float16* y_lo = reinterpret_cast<_Float16*>(y_lo_);
     CVX_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0 && rows_per_group > 0, "adarmsnorm: bad shape rows=%ld D=%d", (long)rows, D);
     if (rows == 0) return CVX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
-    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
-    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
-    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, rows_per_group, scale, eps);
+    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
+    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
+    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
     CVX_CHECK_LAUNCH("cvx_adarmsnorm_f32");
     return CVX_OK;
 }

@@ -24,9 +24,21 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 
 // acc[mi][ni]: 32x32 MFMA accumulators of a wave that owns rows [m0 + wm*TM*32, +TM*32) and the 64 columns
 // [n0 + wn*64, +64).  bias -> act -> half-split RoPE -> residual -> store.
+// Optional split copy of the output: (fp16 hi, fp16 lo) of the final value, row stride ldc_h (halves), for a
+// consumer GEMM that takes its A operand pre-split; write_f32 == 0 suppresses the fp32 store.
+struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32; };
+
+__device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v)
+{
+    const float x = fminf(fmaxf(v, -65504.f), 65504.f);
+    const _Float16 h = (_Float16)x;
+    so.hi[idx] = h;
+    so.lo[idx] = (_Float16)(x - (float)h);
+}
+
 template <int TM>
 __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
-                                              int wm, int wn, int lane)
+                                              int wm, int wn, int lane, const SplitOut so = SplitOut{nullptr, nullptr, 0, 1})
 {
     const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
     const int c_lo = colw + (lane & 31);
@@ -56,8 +68,14 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                 if (c_lo < p.N) lo += p.residual[(int64_t)row * p.ldr + c_lo];
                 if (c_hi < p.N) hi += p.residual[(int64_t)row * p.ldr + c_hi];
             }
-            if (c_lo < p.N) p.C[(int64_t)row * p.ldc + c_lo] = lo;
-            if (c_hi < p.N) p.C[(int64_t)row * p.ldc + c_hi] = hi;
+            if (so.write_f32) {
+                if (c_lo < p.N) p.C[(int64_t)row * p.ldc + c_lo] = lo;
+                if (c_hi < p.N) p.C[(int64_t)row * p.ldc + c_hi] = hi;
+            }
+            if (so.hi) {
+                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + c_lo, lo);
+                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + c_hi, hi);
+            }
         }
     }
 }

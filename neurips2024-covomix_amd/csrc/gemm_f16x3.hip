@@ -37,7 +37,8 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args p, const f16* __restrict__ Whi,
-                                                           const f16* __restrict__ Wlo, float acc_scale, int tiles_m, int tiles_n, int map_mode)
+                                                           const f16* __restrict__ Wlo, float acc_scale, SplitOut so,
+                                                           int tiles_m, int tiles_n, int map_mode)
 {
     constexpr int TM = 2, BM = 128;
     extern __shared__ __attribute__((aligned(16))) f16 smem_h[];
@@ -184,7 +185,134 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
     }
-    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane);
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane, so);
+}
+
+// ------------------------------------------------------------------ all-DMA variant: A arrives pre-split
+// Every operand tile (A_hi, A_lo, W_hi, W_lo: 8 KiB each) goes global -> LDS by DMA into a ring of STAGES stages;
+// tiles are requested STAGES-1 steps ahead and retired with a COUNTED vmcnt + a raw s_barrier, so loads stay in
+// flight across barriers (a 24-MFMA step is only ~770 cycles - far shorter than an L2/HBM round trip, which a
+// 2-stage scheme cannot hide).  No staging VGPRs, no split VALU work, no ds_write in the loop.
+struct PreSplitA { const f16* hi; const f16* lo; int64_t ld; const f16* hi2; const f16* lo2; int64_t ld2; };
+
+template <int STAGES>
+__global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_kernel(
+    const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
+    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
+{
+    constexpr int TM = 2, BM = 128;
+    constexpr int STAGE = 4 * TILE_H;
+    extern __shared__ __attribute__((aligned(16))) f16 smem_h[];
+    f16* const S0 = smem_h;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // DMA sources: wave `wid` fills rows [32*wid, +32) of each of the four tiles, 16 rows per instruction
+    const f16* pah[2]; const f16* pal[2]; const f16* pwh[2]; const f16* pwl[2];
+    int64_t jmp_h[2], jmp_l[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 32 * wid + 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        const int64_t ra = min(m0 + r, p.M - 1), rw = min(n0 + r, p.N - 1);
+        pah[j] = A.hi + ra * A.ld + 8 * c;
+        pal[j] = A.lo + ra * A.ld + 8 * c;
+        jmp_h[j] = A.hi2 ? (A.hi2 + ra * A.ld2 + 8 * c) - (pah[j] + p.K1) : 0;
+        jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
+        pwh[j] = Whi + rw * p.ldw + 8 * c;
+        pwl[j] = Wlo + rw * p.ldw + 8 * c;
+    }
+    const int dma_off = 32 * wid * BK;
+    const int switch_tile = A.hi2 ? p.K1 / BK : -1;
+    const int nk = p.K / BK;
+
+    // issue the 8 DMA pieces of tile t (tiles past the end re-read the last tile: keeps the vmcnt arithmetic uniform)
+    auto issue = [&](int t) {
+        f16* const S = S0 + (t % STAGES) * STAGE + dma_off;
+        const bool live = t < nk;
+        const bool sw = (t == switch_tile);
+        const int back = live ? 0 : BK, adv = live ? BK : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - back;
+            const f16* sl = pal[j] + (sw ? jmp_l[j] : 0) - back;
+            const f16* wh = pwh[j] - back;
+            const f16* wl = pwl[j] - back;
+            glds16(sh, S + 16 * j * BK);
+            glds16(sl, S + TILE_H + 16 * j * BK);
+            glds16(wh, S + 2 * TILE_H + 16 * j * BK);
+            glds16(wl, S + 3 * TILE_H + 16 * j * BK);
+            pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv;
+        }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int i31 = lane & 31, g = lane >> 5, swz = (i31 >> 2) & 3;
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = i31 * BK + 8 * ((2 * s + g) ^ swz);
+    const int a_row0 = wm * 64 * BK, b_row0 = wn * 64 * BK;
+
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t) issue(t);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most (STAGES-2) younger tiles (8 pieces each) are still outstanding
+        if constexpr (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (STAGES == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // everyone's pieces landed; stage (kt-1)%STAGES is free again
+        issue(kt + STAGES - 1);
+        const f16* Sc = S0 + (kt % STAGES) * STAGE;
+        const f16* ah = Sc + a_row0;
+        const f16* al = Sc + TILE_H + a_row0;
+        const f16* wh = Sc + 2 * TILE_H + b_row0;
+        const f16* wl = Sc + 3 * TILE_H + b_row0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 fah[TM], fal[TM], fwh[2], fwl[2];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                fah[mi] = *reinterpret_cast<const f16x8*>(ah + mi * 32 * BK + foff[s]);
+                fal[mi] = *reinterpret_cast<const f16x8*>(al + mi * 32 * BK + foff[s]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
+                fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail re-reads before LDS is released
+    if (acc_scale != 1.0f) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
+    }
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane, so);
 }
 
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ w, f16* __restrict__ hi,
@@ -210,25 +338,70 @@ extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t
     return CVX_OK;
 }
 
-extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale, cvx_stream_t s)
+template <int STAGES>
+static void launch_dma(const cvx_gemm_args& a, const PreSplitA& A, const f16* wh, const f16* wl, float acc_scale,
+                       const SplitOut& so, dim3 grid, int tiles_m, int tiles_n, int map_mode, hipStream_t st)
+{
+    const size_t lds = (size_t)STAGES * 4 * TILE_H * sizeof(f16);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma_kernel<STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_f16x3_dma_kernel<STAGES>, grid, dim3(256), lds, st, a, A, wh, wl, acc_scale, so,
+                       tiles_m, tiles_n, map_mode);
+}
+
+extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
+                              const cvx_gemm_split_io* io, cvx_stream_t s)
 {
     const int rc = cvxg::validate_gemm_args(a);
     if (rc != CVX_OK) return rc;
     CVX_REQUIRE(W_hi && W_lo, "gemm_f16x3: null split weights");
     CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
     CVX_REQUIRE((((uintptr_t)W_hi | (uintptr_t)W_lo) & 15) == 0, "gemm_f16x3: split weights must be 16-byte aligned");
+    SplitOut so{nullptr, nullptr, 0, 1};
+    PreSplitA A{nullptr, nullptr, 0, nullptr, nullptr, 0};
+    if (io) {
+        if (io->C_hi || io->C_lo) {
+            CVX_REQUIRE(io->C_hi && io->C_lo && io->ldc_h >= a->N, "gemm_f16x3: bad split output");
+            so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
+        }
+        so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
+        if (io->A_hi || io->A_lo) {
+            CVX_REQUIRE(io->A_hi && io->A_lo && io->lda_h % 8 == 0 && (((uintptr_t)io->A_hi | (uintptr_t)io->A_lo) & 15) == 0,
+                        "gemm_f16x3: bad pre-split A");
+            A.hi = reinterpret_cast<const f16*>(io->A_hi); A.lo = reinterpret_cast<const f16*>(io->A_lo); A.ld = io->lda_h;
+            if (a->A2) {
+                CVX_REQUIRE(io->A2_hi && io->A2_lo && io->lda2_h % 8 == 0 &&
+                            (((uintptr_t)io->A2_hi | (uintptr_t)io->A2_lo) & 15) == 0, "gemm_f16x3: bad pre-split A2");
+                A.hi2 = reinterpret_cast<const f16*>(io->A2_hi); A.lo2 = reinterpret_cast<const f16*>(io->A2_lo); A.ld2 = io->lda2_h;
+            }
+        }
+    }
     if (a->M == 0) return CVX_OK;
     const int tiles_n = (a->N + BN - 1) / BN, tiles_m = (a->M + 127) / 128;
     static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    static const int stages = [] { const char* e = getenv("CVX_GEMM_STAGES"); return e ? atoi(e) : 2; }();
     const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
-    const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+    dim3 grid((unsigned)(grid_m * tiles_n));
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    const f16* wh = reinterpret_cast<const f16*>(W_hi);
+    const f16* wl = reinterpret_cast<const f16*>(W_lo);
+    if (A.hi) {
+        if (stages <= 2)      launch_dma<2>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
+        else if (stages == 3) launch_dma<3>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
+        else                  launch_dma<4>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
+    } else {
+        const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL(gemm_f16x3_kernel, grid, dim3(256), lds, st, *a, wh, wl, acc_scale, so, tiles_m, tiles_n, map_mode);
     }
-    hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)(grid_m * tiles_n)), dim3(256), lds, reinterpret_cast<hipStream_t>(s),
-                       *a, reinterpret_cast<const f16*>(W_hi), reinterpret_cast<const f16*>(W_lo), acc_scale, tiles_m, tiles_n, map_mode);
     CVX_CHECK_LAUNCH("cvx_gemm_f16x3");
     return CVX_OK;
 }

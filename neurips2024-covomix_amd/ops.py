@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, GemmArgs
+from ._lib import ConvArgs, GemmArgs, GemmSplitIO
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
@@ -32,11 +32,14 @@ def _chk_f32(*ts):
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
-         a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None) -> torch.Tensor:
+         a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
+         a_split=None, a2_split=None, out_split=None, write_f32: bool = True) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
-    of the fp32 one (needs K % 32 == 0; small-M problems stay on the fp32 kernel)."""
+    of the fp32 one (needs K % 32 == 0; small-M problems stay on the fp32 kernel).
+    a_split / a2_split = (hi, lo) fp16 copies of a / a2 (then every tile arrives by LDS-DMA; `a` is only used for
+    its shape); out_split = (hi, lo) receives a split copy of the result; write_f32=False skips the fp32 store."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -71,11 +74,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == (N, K) and lo.shape == (N, K)
         assert hi.is_contiguous() and lo.is_contiguous() and hi.is_cuda and lo.is_cuda
         g.ldw = K
-        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), lo.data_ptr(), inv_scale, _stream()),
+        io = GemmSplitIO()
+        io.write_f32 = 1 if write_f32 else 0
+        if a_split is not None:
+            ah, al = a_split
+            assert ah.dtype == torch.float16 and ah.shape == a.shape and al.shape == a.shape and ah.stride(1) == 1
+            io.A_hi, io.A_lo, io.lda_h = ah.data_ptr(), al.data_ptr(), ah.stride(0)
+            if a2 is not None:
+                assert a2_split is not None, "pre-split A needs a pre-split A2 as well"
+                bh, bl = a2_split
+                assert bh.dtype == torch.float16 and bh.shape == a2.shape and bl.shape == a2.shape
+                io.A2_hi, io.A2_lo, io.lda2_h = bh.data_ptr(), bl.data_ptr(), bh.stride(0)
+        if out_split is not None:
+            oh, ol = out_split
+            assert oh.dtype == torch.float16 and oh.shape == (M, N) and ol.shape == (M, N) and oh.stride(1) == 1
+            io.C_hi, io.C_lo, io.ldc_h = oh.data_ptr(), ol.data_ptr(), oh.stride(0)
+        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), lo.data_ptr(), inv_scale, C.byref(io), _stream()),
                    "cvx_gemm_f16x3")
         return out
+    assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
     return out
+
+
+def split_act_f16(x: torch.Tensor, hi: Optional[torch.Tensor] = None, lo: Optional[torch.Tensor] = None):
+    """(hi, lo) fp16 halves of an fp32 activation tensor (unscaled) - for GEMMs that take A pre-split."""
+    _chk_f32(x)
+    assert x.is_contiguous()
+    if hi is None:
+        hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().cvx_split_f16(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), 1.0, _stream()),
+               "cvx_split_f16")
+    return hi, lo
 
 
 def split_f16(w: torch.Tensor):
@@ -94,25 +125,30 @@ def split_f16(w: torch.Tensor):
     return hi, lo, 1.0 / scale
 
 
-def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: torch.Tensor,
-               rows_per_group: Optional[int] = None, eps: float = 1e-12) -> torch.Tensor:
+def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: Optional[torch.Tensor],
+               rows_per_group: Optional[int] = None, eps: float = 1e-12, out_split=None):
+    """out_split = (hi, lo) fp16 tensors: also (or, with out=None, only) write the result as a split pair."""
     _chk_f32(x, gamma, beta, out)
-    assert x.is_contiguous() and out.is_contiguous() and gamma.stride(-1) == 1
+    assert x.is_contiguous() and (out is None or out.is_contiguous()) and gamma.stride(-1) == 1
+    oh, ol = out_split if out_split is not None else (None, None)
+    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and ol.is_contiguous() and oh.numel() == x.numel())
     D = x.shape[-1]
     rows = x.numel() // D
     rpg = rows if rows_per_group is None else rows_per_group
-    _lib.check(_lib.load().cvx_adarmsnorm_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), out.data_ptr(), rows, D, rpg,
+    _lib.check(_lib.load().cvx_adarmsnorm_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), _p(oh), _p(ol), rows, D, rpg,
                                               float(D) ** 0.5, eps, _stream()), "cvx_adarmsnorm_f32")
-    return out
+    return out if out is not None else out_split
 
 
-def attention(qkv: torch.Tensor, out: torch.Tensor, Bt: int, T: int, H: int, scale: float) -> torch.Tensor:
+def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None):
     _chk_f32(qkv, out)
-    assert qkv.is_contiguous() and out.is_contiguous()
-    assert qkv.numel() == Bt * T * 3 * H * 64 and out.numel() == Bt * T * H * 64
-    _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), out.data_ptr(), Bt, T, H, scale, _stream()),
+    assert qkv.is_contiguous() and (out is None or out.is_contiguous())
+    assert qkv.numel() == Bt * T * 3 * H * 64 and (out is None or out.numel() == Bt * T * H * 64)
+    oh, ol = out_split if out_split is not None else (None, None)
+    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and ol.is_contiguous() and oh.numel() == Bt * T * H * 64)
+    _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), _p(oh), _p(ol), Bt, T, H, scale, _stream()),
                "cvx_attention_f32")
-    return out
+    return out if out is not None else out_split
 
 
 def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor,

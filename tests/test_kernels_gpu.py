@@ -284,3 +284,33 @@ def test_gemm_f16x3_split_k_rope_and_range(ops):
     ops.gemm(xq, wq, o1, rope=(cos, sin), rope_cols=2 * H * 64, w_split=ops.split_f16(wq))
     ops.gemm(xq, wq, o2, rope=(cos, sin), rope_cols=2 * H * 64)
     assert rel_l2(o1, o2) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 1024), (1000, 3072, 1024), (999, 1024, 4096), (130, 256, 64)])
+def test_gemm_f16x3_presplit_dma_and_split_output(ops, M, N, K):
+    """A pre-split (all-DMA multi-stage kernel) and split outputs must agree with the on-the-fly split kernel."""
+    a, w = randn(M, K, seed=120) * 2.0, randn(N, K, seed=121) / math.sqrt(K)
+    b, r = randn(N, seed=122), randn(M, N, seed=123)
+    ws = ops.split_f16(w)
+    ref = F.gelu(a.double() @ w.double().T + b.double()) + r.double()
+    o1 = torch.empty(M, N, device=dev())
+    ops.gemm(a, w, o1, bias=b, act=1, residual=r, w_split=ws)
+    asp = ops.split_act_f16(a)
+    o2 = torch.full((M, N), float("nan"), device=dev())
+    oh = torch.empty(M, N, dtype=torch.float16, device=dev()); ol = torch.empty_like(oh)
+    ops.gemm(a, w, o2, bias=b, act=1, residual=r, w_split=ws, a_split=asp, out_split=(oh, ol))
+    assert rel_l2(o2, ref) < 3e-6 and rel_l2(o2, o1) < 1e-6
+    assert rel_l2(oh.float() + ol.float(), o2) < 1e-6
+    o3 = torch.full((M, N), 7.0, device=dev())
+    ops.gemm(a, w, o3, bias=b, act=1, residual=r, w_split=ws, a_split=asp, out_split=(oh, ol), write_f32=False)
+    assert bool((o3 == 7.0).all())                      # fp32 store suppressed
+    assert rel_l2(oh.float() + ol.float(), ref) < 3e-6
+
+
+def test_gemm_f16x3_presplit_concat(ops):
+    M, N = 300, 256
+    x, s = randn(M, 256, seed=130), randn(M, 256, seed=131)
+    w = randn(N, 512, seed=132) / math.sqrt(512)
+    out = torch.empty(M, N, device=dev())
+    ops.gemm(x, w, out, a2=s, w_split=ops.split_f16(w), a_split=ops.split_act_f16(x), a2_split=ops.split_act_f16(s))
+    assert rel_l2(out, torch.cat((x, s), -1).double() @ w.double().T) < 3e-6

@@ -76,3 +76,18 @@ def f16x3():
 
 if __name__ == "__main__" and os.environ.get("F16X3", "1") == "1":
     f16x3()
+
+
+def f16x3_dma():
+    Bt, T = 16, 1000
+    M = Bt * T
+    r = lambda *s: torch.randn(*s, device=dev)
+    for (n, k, name) in [(1024, 1024, "out-proj"), (3072, 1024, "qkv"), (4096, 1024, "ff1"), (1024, 4096, "ff2")]:
+        a, w, c = r(M, k), r(n, k) / math.sqrt(k), torch.empty(M, n, device=dev)
+        ws, asp = ops.split_f16(w), ops.split_act_f16(a)
+        t = timeit(lambda: ops.gemm(a, w, c, w_split=ws, a_split=asp))
+        print(f"f16x3-dma[{os.environ.get('CVX_GEMM_STAGES','4')}st] {name:9s} N={n} K={k}: {t*1e3:8.3f} ms  {2*M*n*k/t/1e12:7.2f} TFLOP/s")
+
+
+if __name__ == "__main__" and os.environ.get("F16X3", "1") == "1":
+    f16x3_dma()
