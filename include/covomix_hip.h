@@ -78,6 +78,10 @@ typedef struct {
     const uint16_t* A2_hi; const uint16_t* A2_lo; int64_t lda2_h;
     uint16_t* C_hi; uint16_t* C_lo; int64_t ldc_h;
     int32_t write_f32;
+    /* QKV mode (optional; needs the RoPE arguments, N = 3*H*64, T % 4 == 0, write_f32 = 0): the v columns are not
+     * written to C_hi/C_lo but TRANSPOSED per (sequence, head) to Vt_*[((b*H + h)*64 + d) * vt_ld + t], the layout
+     * cvx_attention_f16x3 reads its V^T tiles from. */
+    uint16_t* Vt_hi; uint16_t* Vt_lo; int64_t vt_ld;
 } cvx_gemm_split_io;
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
@@ -100,6 +104,15 @@ int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, fl
 int cvx_attention_f32(const float* qkv, float* out,
                       uint16_t* out_hi, uint16_t* out_lo,  /* optional fp16 (hi, lo) split copy; out may then be NULL */
                       int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s);
+
+/* Split-precision variant of cvx_attention_f32 (same reference computation, attend.py:108-126) on
+ * v_mfma_f32_32x32x16_f16: inputs are the (fp16 hi, fp16 lo) pairs written by cvx_gemm_f16x3 in QKV mode -
+ * qk_* [Bt*T, 2*H*64] (q | k after RoPE) and vt_* [Bt*H*64, Tp] (v transposed per (sequence, head), Tp >= T
+ * rounded up to 32, columns >= T finite) - and q.k, p.v are each computed as three fp16 products with fp32
+ * accumulation.  Output as for cvx_attention_f32 (fp32 and/or split). */
+int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                        float* out, uint16_t* out_hi, uint16_t* out_lo,
+                        int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale, cvx_stream_t s);
 
 /* y[b,t,c] = GELU( bias[c] + sum_k w[c,k] * x[b,t+k-K/2,c] ) + x[b,t,c]
  * ConvPositionEmbed + residual (acoustic.py:141-161, :508), channels-last, K == 31. */

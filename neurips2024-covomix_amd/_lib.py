@@ -38,6 +38,7 @@ class GemmSplitIO(C.Structure):
         ("A2_hi", C.c_void_p), ("A2_lo", C.c_void_p), ("lda2_h", C.c_int64),
         ("C_hi", C.c_void_p), ("C_lo", C.c_void_p), ("ldc_h", C.c_int64),
         ("write_f32", C.c_int32),
+        ("Vt_hi", C.c_void_p), ("Vt_lo", C.c_void_p), ("vt_ld", C.c_int64),
     ]
 
 
@@ -64,6 +65,8 @@ SIGNATURES = {
                                      C.c_int64, C.c_float, C.c_float, C.c_void_p]),
     "cvx_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                     C.c_void_p]),
+    "cvx_attention_f16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_dwconv31_gelu_res_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_void_p]),
     "cvx_cfg_combine_axpy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,

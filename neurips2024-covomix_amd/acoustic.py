@@ -106,6 +106,10 @@ class VectorField:
         if self.precision == "f16x3":      # activations that only feed GEMMs live as (fp16 hi, fp16 lo) pairs
             h16 = lambda *s: (torch.empty(*s, dtype=torch.float16, device=dev), torch.empty(*s, dtype=torch.float16, device=dev))
             ws["normed16"], ws["att16"], ws["ff16"] = h16(M, d["dim"]), h16(M, d["heads"] * 64), h16(M, 4 * d["dim"])
+            ws["qk16"] = h16(M, 2 * d["heads"] * 64)
+            Tp = ((T + 31) // 32) * 32           # V^T rows, zero beyond T (read by the last key tile, weight 0)
+            ws["vt16"] = (torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev),
+                          torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev))
         pos = torch.arange(T, device=dev, dtype=torch.float32)
         ang = pos[:, None] * self.inv_freq[None, :]
         ws["rope"] = (ang.cos().contiguous(), ang.sin().contiguous())
@@ -179,9 +183,15 @@ class VectorField:
             if split_io:
                 n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
                 ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16)
-                ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                         w_split=sp(p + ".2.to_qkv.weight"), a_split=n16)
-                ops.attention(ws["qkv"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
+                if T % 4 == 0:      # q | k split row-major, v split + transposed, straight into the f16x3 attention
+                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                             w_split=sp(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
+                             write_f32=False)
+                    ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
+                else:
+                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                             w_split=sp(p + ".2.to_qkv.weight"), a_split=n16)
+                    ops.attention(ws["qkv"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
                 h_att = take() if keep_input else h
                 ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), a_split=a16)
                 h = h_att

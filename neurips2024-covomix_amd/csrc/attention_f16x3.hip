@@ -1,0 +1,236 @@
+// Split-precision flash attention (gfx950): the same algorithm and register choreography as attention_f32.hip
+// (reference attend.py:108-126 without the T x T score tensor), but both contractions run on
+// v_mfma_f32_32x32x16_f16 with every operand an (fp16 hi, fp16 lo) pair and three products per tile
+//     q.k ~= k_hi*q_hi + k_hi*q_lo + k_lo*q_hi        p.v ~= v_hi*p_hi + v_hi*p_lo + v_lo*p_hi     (fp32 accumulate)
+// 24 MFMAs of 32 cycles per 32-key tile and wave instead of 64 MFMAs of 64 cycles.
+//
+// Inputs come pre-split from the to_qkv GEMM epilogue (cvx_gemm_f16x3, QKV mode):
+//   qk_hi/qk_lo [Bt*T, 2*H*64]  q | k after RoPE, row-major;
+//   vt_hi/vt_lo [Bt*H*64, Tp]   v transposed per (sequence, head): row = head dim, column = frame
+// so that every tile (K: 32 keys x 64 dims, V^T: 64 dims x 32 keys; hi and lo) is a set of contiguous rows that
+// go global -> LDS by DMA - no staging registers, no LDS writes by the waves.  LDS tiles are XOR-swizzled on
+// the DMA source address (K: chunk ^ ((row >> 1) & 7) over 128-byte rows; V^T: chunk ^ ((row >> 2) & 3) over
+// 64-byte rows) so that the fragment reads are conflict-free (K, ds_read_b128) / 2-way (V^T, ds_read_b64).
+//
+// S^T = K.Q^T keeps a query's scores in one lane pair; P is split in registers and used directly as the B
+// operand of O^T += V^T.P^T: the k-slot order of that MFMA is chosen to be exactly the key order the S^T
+// accumulator registers already have (registers 8s..8s+7 of lane half g hold keys 16s+4g+{0..3} and
+// 16s+8+4g+{0..3}), so V^T fragments are two 8-byte reads and P never moves between lanes.
+#include "cvx_common.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HD = 64, QB = 128, KT = 32;
+constexpr int TILE = KT * HD;                 // halves per operand tile (4 KiB)
+constexpr int STAGE = 4 * TILE;               // Khi | Klo | Vthi | Vtlo
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ f16x8 gload8h(const f16* p)
+{
+    typedef const f16x8 __attribute__((address_space(1)))* gp;
+    return *reinterpret_cast<gp>(reinterpret_cast<uintptr_t>(p));
+}
+
+__device__ __forceinline__ void store_split4(f16* hi, f16* lo, const f32x4 o)
+{
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(o[e], -65504.f), 65504.f);
+        h[e] = (f16)x;
+        l[e] = (f16)(x - (float)h[e]);
+    }
+    *reinterpret_cast<f16x4*>(hi) = h;
+    *reinterpret_cast<f16x4*>(lo) = l;
+}
+
+__global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
+                                                                const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
+                                                                float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
+                                                                int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) f16 smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 5, l31 = lane & 31;
+    const int grp = (blockIdx.x / (8 * n_qt)) * 8 + (blockIdx.x & 7);      // same (batch, head) -> same XCD
+    if (grp >= n_groups) return;
+    const int head = grp % H, b = grp / H;
+    const int q_blk = ((blockIdx.x >> 3) % n_qt) * QB;
+    const int64_t ldqk = (int64_t)2 * H * HD;
+
+    // ---- Q fragments (B operand of S^T): lane (q = l31, g) holds d = 16s + 8g .. +7 for s = 0..3, hi and lo
+    int qrow = q_blk + wid * 32 + l31;
+    const bool q_valid = qrow < T;
+    if (!q_valid) qrow = T - 1;
+    f16x8 qh[4], ql[4];
+    {
+        const int64_t off = ((int64_t)b * T + qrow) * ldqk + head * HD + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { qh[s] = gload8h(qk_hi + off + 16 * s); ql[s] = gload8h(qk_lo + off + 16 * s); }
+    }
+
+    // ---- DMA sources.  wave w: K rows [8w, 8w+8) (hi, lo) and V^T rows [16w, 16w+16) (hi, lo): 4 pieces per tile
+    const int k_r = 8 * wid + (lane >> 3);                                  // key row inside the tile
+    const int k_c = (lane & 7) ^ ((k_r >> 1) & 7);                          // source chunk for LDS chunk (lane & 7)
+    const int64_t k_col = (int64_t)H * HD + head * HD + 8 * k_c;
+    const int v_r = 16 * wid + (lane >> 2);                                 // head-dim row inside the tile
+    const int v_c = (lane & 3) ^ ((v_r >> 2) & 3);
+    const int64_t v_row = ((int64_t)(b * H + head) * HD + v_r) * Tp + 8 * v_c;
+    auto issue = [&](int key0, int stage) {
+        f16* S = smem + stage * STAGE;
+        const int key = min(key0 + k_r, T - 1);
+        const int64_t ko = ((int64_t)b * T + key) * ldqk + k_col;
+        glds16(qk_hi + ko, S + 8 * wid * HD);
+        glds16(qk_lo + ko, S + TILE + 8 * wid * HD);
+        const int64_t vo = v_row + key0;
+        glds16(vt_hi + vo, S + 2 * TILE + 16 * wid * KT);
+        glds16(vt_lo + vo, S + 3 * TILE + 16 * wid * KT);
+    };
+
+    // ---- fragment offsets (halves)
+    int koff[4];                                   // K rows are 64 halves; chunk (2s+g) ^ ((row>>1)&7)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = l31 * HD + 8 * ((2 * s + g) ^ ((l31 >> 1) & 7));
+    int voff[2][2];                                // V^T rows are 32 halves; chunk (2s, 2s+1) ^ ((row>>2)&3), +4g
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        voff[s][0] = l31 * KT + 8 * ((2 * s) ^ ((l31 >> 2) & 3)) + 4 * g;
+        voff[s][1] = l31 * KT + 8 * ((2 * s + 1) ^ ((l31 >> 2) & 3)) + 4 * g;
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (T + KT - 1) / KT;
+    issue(0, 0);
+    for (int it = 0; it < ntiles; ++it) {
+        const int cur = it & 1, key0 = it * KT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // tile `it` landed everywhere; stage cur^1 is free
+        if (it + 1 < ntiles) issue(key0 + KT, cur ^ 1);
+        const f16* S = smem + cur * STAGE;
+
+        // ---- S^T = K . Q^T  (3 products per 16-wide d slice)
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(S + koff[s]);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(S + TILE + koff[s]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+        }
+
+        // ---- online softmax (this lane: 16 keys of query l31; partner lane^32 holds the other 16)
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + mfma32_row(r, lane);
+            const float sv = (key < T) ? sacc[r] * scale_log2e : -1e30f;
+            sacc[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = exp2f(sacc[r] - m_new);
+            psum += pv;
+            const f16 h = (f16)pv;
+            ph[r >> 3][r & 7] = h;
+            pl[r >> 3][r & 7] = (f16)(pv - (float)h);
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T . P^T
+        const f16* Vh = S + 2 * TILE;
+        const f16* Vl = S + 3 * TILE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int base = dt * 32 * KT;
+                f16x8 vh, vl;
+                const f16x4 a0 = *reinterpret_cast<const f16x4*>(Vh + base + voff[s][0]);
+                const f16x4 a1 = *reinterpret_cast<const f16x4*>(Vh + base + voff[s][1]);
+                const f16x4 c0 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][0]);
+                const f16x4 c1 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = c0[e]; vl[4 + e] = c1[e]; }
+                if (dt == 0) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o0, 0, 0, 0);
+                } else {
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o1, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_valid) {
+        const int64_t o_off = ((int64_t)b * T + qrow) * (H * HD) + head * HD + 4 * g;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = o0[4 * gq + e] * inv; c[e] = o1[4 * gq + e] * inv; }
+            if (out) {
+                *reinterpret_cast<f32x4*>(out + o_off + 8 * gq) = a;
+                *reinterpret_cast<f32x4*>(out + o_off + 32 + 8 * gq) = c;
+            }
+            if (out_hi) {
+                store_split4(out_hi + o_off + 8 * gq, out_lo + o_off + 8 * gq, a);
+                store_split4(out_hi + o_off + 32 + 8 * gq, out_lo + o_off + 32 + 8 * gq, c);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                                   float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                   int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale, cvx_stream_t s)
+{
+    CVX_REQUIRE(qk_hi && qk_lo && vt_hi && vt_lo && (out || out_hi) && ((out_hi == nullptr) == (out_lo == nullptr)),
+                "attention_f16x3: null pointer");
+    CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0 && Tp % 8 == 0 && Tp >= ((T + KT - 1) / KT) * KT,
+                "attention_f16x3: bad shape Bt=%d T=%d Tp=%d H=%d (Tp must be a multiple of 8 and >= T rounded up to 32)", Bt, T, Tp, H);
+    CVX_REQUIRE((((uintptr_t)qk_hi | (uintptr_t)qk_lo | (uintptr_t)vt_hi | (uintptr_t)vt_lo) & 15) == 0,
+                "attention_f16x3: inputs must be 16-byte aligned");
+    if (Bt == 0) return CVX_OK;
+    const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
+    dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
+    hipLaunchKernelGGL(attention_f16x3_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
+                       reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
+                       out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
+                       T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+    CVX_CHECK_LAUNCH("cvx_attention_f16x3");
+    return CVX_OK;
+}

@@ -26,7 +26,13 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 // [n0 + wn*64, +64).  bias -> act -> half-split RoPE -> residual -> store.
 // Optional split copy of the output: (fp16 hi, fp16 lo) of the final value, row stride ldc_h (halves), for a
 // consumer GEMM that takes its A operand pre-split; write_f32 == 0 suppresses the fp32 store.
-struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32; };
+// QKV mode (vt_hi != NULL; needs the RoPE arguments: rope_T = frames per sequence, rope_cols = 2*H*64): columns
+// [0, rope_cols) (q | k, after RoPE) go to hi/lo [M, ldc_h] as usual, columns >= rope_cols (v) are written TRANSPOSED
+// per (sequence, head): vt[((b*H + h)*64 + d) * vt_ld + t] - the layout the f16x3 attention kernel DMAs its V^T
+// tiles from.
+struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
+                  _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld; };
+typedef _Float16 cvx_f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v)
 {
@@ -38,11 +44,58 @@ __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, flo
 
 template <int TM>
 __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
-                                              int wm, int wn, int lane, const SplitOut so = SplitOut{nullptr, nullptr, 0, 1})
+                                              int wm, int wn, int lane,
+                                              const SplitOut so = SplitOut{nullptr, nullptr, 0, 1, nullptr, nullptr, 0})
 {
     const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
     const int c_lo = colw + (lane & 31);
     const int c_hi = c_lo + 32;
+    if (so.vt_hi != nullptr && colw >= p.rope_cols) {
+        if (colw >= p.N) return;                   // wave entirely past the last column (N not a multiple of 128)
+        // V columns of a QKV projection: transposed split store.  Accumulator registers 4*rg .. 4*rg+3 are four
+        // consecutive rows (= frames), so they pack into one 8-byte store along t.
+        const int H = p.rope_cols / 128, T = p.rope_T;
+        const int head = (colw - p.rope_cols) / 64;
+        const float b_lo_v = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
+        const float b_hi_v = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row0 = m0 + wm * TM * 32 + mi * 32 + 8 * rg + 4 * (lane >> 5);
+                if (row0 >= p.M) continue;
+                const int b = row0 / T, t0 = row0 - b * T;
+#pragma unroll
+                for (int hsel = 0; hsel < 2; ++hsel) {
+                    const int d = (lane & 31) + 32 * hsel;
+                    const float bias = hsel ? b_hi_v : b_lo_v;
+                    cvx_f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = fminf(fmaxf(acc[mi][hsel][4 * rg + e] + bias, -65504.f), 65504.f);
+                        vh[e] = (_Float16)x;
+                        vl[e] = (_Float16)(x - (float)vh[e]);
+                    }
+                    const int64_t base = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld;
+                    if (t0 + 3 < T && row0 + 3 < p.M) {
+                        *reinterpret_cast<cvx_f16x4*>(so.vt_hi + base + t0) = vh;
+                        *reinterpret_cast<cvx_f16x4*>(so.vt_lo + base + t0) = vl;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = row0 + e;
+                            if (row >= p.M) break;
+                            const int bb = row / T, tt = row - bb * T;
+                            const int64_t idx = ((int64_t)(bb * H + head) * 64 + d) * so.vt_ld + tt;
+                            so.vt_hi[idx] = vh[e];
+                            so.vt_lo[idx] = vl[e];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
     const float b_lo = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
     const float b_hi = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;

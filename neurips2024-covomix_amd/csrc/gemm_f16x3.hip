@@ -361,14 +361,21 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     CVX_REQUIRE(W_hi && W_lo, "gemm_f16x3: null split weights");
     CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
     CVX_REQUIRE((((uintptr_t)W_hi | (uintptr_t)W_lo) & 15) == 0, "gemm_f16x3: split weights must be 16-byte aligned");
-    SplitOut so{nullptr, nullptr, 0, 1};
+    SplitOut so{nullptr, nullptr, 0, 1, nullptr, nullptr, 0};
     PreSplitA A{nullptr, nullptr, 0, nullptr, nullptr, 0};
     if (io) {
         if (io->C_hi || io->C_lo) {
-            CVX_REQUIRE(io->C_hi && io->C_lo && io->ldc_h >= a->N, "gemm_f16x3: bad split output");
+            CVX_REQUIRE(io->C_hi && io->C_lo && io->ldc_h >= ((io->Vt_hi && a->rope_cols > 0) ? a->rope_cols : a->N), "gemm_f16x3: bad split output");
             so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
         }
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
+        if (io->Vt_hi || io->Vt_lo) {
+            CVX_REQUIRE(io->Vt_hi && io->Vt_lo && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
+                        (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= a->rope_T && io->vt_ld % 8 == 0 &&
+                        a->M % a->rope_T == 0 && a->rope_T % 4 == 0 && so.write_f32 == 0,
+                        "gemm_f16x3: QKV-transpose output needs the RoPE arguments, N = 3*H*64, T %% 4 == 0, vt_ld >= T and write_f32 = 0");
+            so.vt_hi = reinterpret_cast<f16*>(io->Vt_hi); so.vt_lo = reinterpret_cast<f16*>(io->Vt_lo); so.vt_ld = io->vt_ld;
+        }
         if (io->A_hi || io->A_lo) {
             CVX_REQUIRE(io->A_hi && io->A_lo && io->lda_h % 8 == 0 && (((uintptr_t)io->A_hi | (uintptr_t)io->A_lo) & 15) == 0,
                         "gemm_f16x3: bad pre-split A");

@@ -33,7 +33,7 @@ def _chk_f32(*ts):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
-         a_split=None, a2_split=None, out_split=None, write_f32: bool = True) -> torch.Tensor:
+         a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -69,7 +69,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = cos.data_ptr(), sin.data_ptr(), cos.shape[0], rope_cols
     else:
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
-    if w_split is not None and K % 32 == 0 and M > 64:
+    if w_split is not None and K % 32 == 0 and (M > 64 or a_split is not None or out_split is not None):
         hi, lo, inv_scale = w_split
         assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == (N, K) and lo.shape == (N, K)
         assert hi.is_contiguous() and lo.is_contiguous() and hi.is_cuda and lo.is_cuda
@@ -87,8 +87,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                 io.A2_hi, io.A2_lo, io.lda2_h = bh.data_ptr(), bl.data_ptr(), bh.stride(0)
         if out_split is not None:
             oh, ol = out_split
-            assert oh.dtype == torch.float16 and oh.shape == (M, N) and ol.shape == (M, N) and oh.stride(1) == 1
+            assert oh.dtype == torch.float16 and oh.shape[0] == M and ol.shape == oh.shape and oh.stride(1) == 1
+            assert oh.shape[1] == N or (vt_split is not None and oh.shape[1] == rope_cols)
             io.C_hi, io.C_lo, io.ldc_h = oh.data_ptr(), ol.data_ptr(), oh.stride(0)
+        if vt_split is not None:          # QKV mode: v columns transposed per (sequence, head) for the f16x3 attention
+            vh, vl = vt_split
+            assert vh.dtype == torch.float16 and vh.is_contiguous() and vl.is_contiguous() and vh.shape == vl.shape
+            io.Vt_hi, io.Vt_lo, io.vt_ld = vh.data_ptr(), vl.data_ptr(), vh.shape[-1]
         _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), lo.data_ptr(), inv_scale, C.byref(io), _stream()),
                    "cvx_gemm_f16x3")
         return out
@@ -148,6 +153,22 @@ def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H
     assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and ol.is_contiguous() and oh.numel() == Bt * T * H * 64)
     _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), _p(oh), _p(ol), Bt, T, H, scale, _stream()),
                "cvx_attention_f32")
+    return out if out is not None else out_split
+
+
+def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None):
+    """Split-precision attention on the pairs written by gemm(..., out_split=qk_split, vt_split=vt_split)."""
+    qh, ql = qk_split
+    vh, vl = vt_split
+    for t in (qh, ql, vh, vl):
+        assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()
+    assert qh.shape == (Bt * T, 2 * H * 64) and vh.shape[0] == Bt * H * 64
+    Tp = vh.shape[1]
+    _chk_f32(out)
+    oh, ol = out_split if out_split is not None else (None, None)
+    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and oh.numel() == Bt * T * H * 64)
+    _lib.check(_lib.load().cvx_attention_f16x3(qh.data_ptr(), ql.data_ptr(), vh.data_ptr(), vl.data_ptr(), _p(out), _p(oh), _p(ol),
+                                               Bt, T, Tp, H, scale, _stream()), "cvx_attention_f16x3")
     return out if out is not None else out_split
 
 

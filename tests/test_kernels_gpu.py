@@ -314,3 +314,35 @@ def test_gemm_f16x3_presplit_concat(ops):
     out = torch.empty(M, N, device=dev())
     ops.gemm(x, w, out, a2=s, w_split=ops.split_f16(w), a_split=ops.split_act_f16(x), a2_split=ops.split_act_f16(s))
     assert rel_l2(out, torch.cat((x, s), -1).double() @ w.double().T) < 3e-6
+
+
+@pytest.mark.parametrize("Bt,T,H", [(2, 128, 2), (1, 36, 1), (3, 200, 2), (2, 1000, 1), (1, 132, 3)])
+def test_attention_f16x3_with_qkv_transposed_epilogue(ops, Bt, T, H):
+    """to_qkv GEMM in QKV mode (q|k split, v split + transposed) -> split-precision attention, vs fp64."""
+    dim = 128
+    x = randn(Bt * T, dim, seed=140)
+    w = randn(3 * H * 64, dim, seed=141) / math.sqrt(dim) * 1.5
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(T).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(dev()).contiguous(), ang.sin().to(dev()).contiguous()
+    M = Bt * T
+    qk = (torch.empty(M, 2 * H * 64, dtype=torch.float16, device=dev()), torch.empty(M, 2 * H * 64, dtype=torch.float16, device=dev()))
+    Tp = ((T + 31) // 32) * 32
+    vt = (torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev()), torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev()))
+    dummy = torch.empty(M, 3 * H * 64, device=dev())
+    ops.gemm(x, w, dummy, rope=(cos, sin), rope_cols=2 * H * 64, w_split=ops.split_f16(w), a_split=ops.split_act_f16(x),
+             out_split=qk, vt_split=vt, write_f32=False)
+    ref_qkv = torch.empty(M, 3 * H * 64, device=dev())
+    ops.gemm(x, w, ref_qkv, rope=(cos, sin), rope_cols=2 * H * 64)
+    assert rel_l2(qk[0].float() + qk[1].float(), ref_qkv[:, : 2 * H * 64]) < 2e-6
+    v_ref = ref_qkv[:, 2 * H * 64:].reshape(Bt, T, H, 64).permute(0, 2, 3, 1).reshape(Bt * H * 64, T)
+    assert rel_l2((vt[0].float() + vt[1].float())[:, :T], v_ref) < 2e-6
+    assert bool(((vt[0].float() + vt[1].float())[:, T:] == 0).all())
+    out = torch.full((Bt, T, H * 64), float("nan"), device=dev())
+    oh = torch.empty(Bt, T, H * 64, dtype=torch.float16, device=dev()); ol = torch.empty_like(oh)
+    ops.attention_f16x3(qk, vt, out, Bt, T, H, 0.125, out_split=(oh, ol))
+    q, k, v = ref_qkv.double().reshape(Bt, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(Bt, T, H * 64)
+    e = rel_l2(out, ref)
+    print("attention f16x3", Bt, T, H, e)
+    assert e < 5e-6 and rel_l2(oh.float() + ol.float(), out) < 1e-6

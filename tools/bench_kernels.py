@@ -91,3 +91,18 @@ def f16x3_dma():
 
 if __name__ == "__main__" and os.environ.get("F16X3", "1") == "1":
     f16x3_dma()
+
+
+def attn_f16x3():
+    Bt, T, H = 16, 1000, 16
+    M = Bt * T
+    qk = (torch.randn(M, 2 * H * 64, device=dev).half(), (torch.randn(M, 2 * H * 64, device=dev) * 1e-3).half())
+    Tp = 1024
+    vt = (torch.randn(Bt * H * 64, Tp, device=dev).half(), (torch.randn(Bt * H * 64, Tp, device=dev) * 1e-3).half())
+    oh = torch.empty(Bt, T, H * 64, dtype=torch.float16, device=dev); ol = torch.empty_like(oh)
+    t = timeit(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=(oh, ol)))
+    print(f"attention f16x3 Bt={Bt} T={T} H={H}: {t*1e3:8.3f} ms  {4*Bt*H*T*T*64/t/1e12:7.2f} TFLOP/s (fp32-equivalent)")
+
+
+if __name__ == "__main__" and os.environ.get("F16X3", "1") == "1":
+    attn_f16x3()
