@@ -123,17 +123,20 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
         const f16* S = smem + cur * STAGE;
 
         // ---- S^T = K . Q^T  (3 products per 16-wide d slice)
-        f32x16 sacc;
+        // three independent accumulators (one per product term) so that consecutive MFMAs never wait on each other
+        f32x16 sacc, sacc1, sacc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sacc1[r] = 0.f; sacc2[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f16x8 kh = *reinterpret_cast<const f16x8*>(S + koff[s]);
             const f16x8 kl = *reinterpret_cast<const f16x8*>(S + TILE + koff[s]);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+            sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc1, 0, 0, 0);
+            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc2, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r] + sacc2[r];
 
         // ---- online softmax (this lane: 16 keys of query l31; partner lane^32 holds the other 16)
         float mx = -1e30f;
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
         const f16* Vl = S + 3 * TILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            f16x8 vhh[2], vll[2];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int base = dt * 32 * KT;
@@ -177,16 +181,15 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
                 const f16x4 c1 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][1]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = c0[e]; vl[4 + e] = c1[e]; }
-                if (dt == 0) {
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o0, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o0, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o0, 0, 0, 0);
-                } else {
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o1, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o1, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o1, 0, 0, 0);
-                }
+                vhh[dt] = vh; vll[dt] = vl;
             }
+            // interleave the two O^T tiles: consecutive MFMAs alternate accumulators
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[0], ph[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[1], ph[s], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], pl[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], pl[s], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], ph[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], ph[s], o1, 0, 0, 0);
         }
     }
 

@@ -158,14 +158,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
                 fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
                 fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
             }
+            // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
+            // would wait for the previous MFMA's result every time)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
-                }
         }
         // split + store the next A tile (the other stage was last read before the previous barrier)
 #pragma unroll
@@ -293,17 +302,157 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
                 fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
                 fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
             }
+            // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
+            // would wait for the previous MFMA's result every time)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
-                }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail re-reads before LDS is released
+    if (acc_scale != 1.0f) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
+    }
+    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane, so);
+}
+
+// ------------------------------------------------------------------ 256 x 256 tile, 8 waves (all-DMA, pre-split A)
+// Twice the tile edge halves the operand bytes per MFMA: the 128 x 128 kernel moves 64 KiB per K-step and CU
+// (~10 TB/s chip-wide, near what the L2 -> LDS DMA path sustains) while its MFMA pipe is only ~39 % busy.
+// 512 threads = 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers);
+// two 64 KiB stages; one block per CU.
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
+    const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
+    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
+{
+    constexpr int TM = 4, BM = 256, BNL = 256;
+    constexpr int TILE256 = 256 * BK;                  // halves per operand tile (16 KiB)
+    constexpr int STAGE = 4 * TILE256;                 // Ahi | Alo | Whi | Wlo  (64 KiB)
+    extern __shared__ __attribute__((aligned(16))) f16 smem_h[];
+    f16* const S0 = smem_h;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BNL;
+
+    // DMA sources: wave `wid` fills rows [32*wid, +32) of each of the four tiles, 16 rows per instruction
+    const f16* pah[2]; const f16* pal[2]; const f16* pwh[2]; const f16* pwl[2];
+    int64_t jmp_h[2], jmp_l[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 32 * wid + 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        const int64_t ra = min(m0 + r, p.M - 1), rw = min(n0 + r, p.N - 1);
+        pah[j] = A.hi + ra * A.ld + 8 * c;
+        pal[j] = A.lo + ra * A.ld + 8 * c;
+        jmp_h[j] = A.hi2 ? (A.hi2 + ra * A.ld2 + 8 * c) - (pah[j] + p.K1) : 0;
+        jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
+        pwh[j] = Whi + rw * p.ldw + 8 * c;
+        pwl[j] = Wlo + rw * p.ldw + 8 * c;
+    }
+    const int dma_off = 32 * wid * BK;
+    const int switch_tile = A.hi2 ? p.K1 / BK : -1;
+    const int nk = p.K / BK;
+
+    auto issue = [&](int t) {
+        f16* const S = S0 + (t & 1) * STAGE + dma_off;
+        const bool live = t < nk;
+        const bool sw = (t == switch_tile);
+        const int back = live ? 0 : BK, adv = live ? BK : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - back;
+            const f16* sl = pal[j] + (sw ? jmp_l[j] : 0) - back;
+            const f16* wh = pwh[j] - back;
+            const f16* wl = pwl[j] - back;
+            glds16(sh, S + 16 * j * BK);
+            glds16(sl, S + TILE256 + 16 * j * BK);
+            glds16(wh, S + 2 * TILE256 + 16 * j * BK);
+            glds16(wl, S + 3 * TILE256 + 16 * j * BK);
+            pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv;
+        }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int i31 = lane & 31, g = lane >> 5, swz = (i31 >> 2) & 3;
+    int foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) foff[s] = i31 * BK + 8 * ((2 * s + g) ^ swz);
+    const int a_row0 = wm * 128 * BK, b_row0 = wn * 64 * BK;
+
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(kt + 1);
+        const f16* Sc = S0 + (kt & 1) * STAGE;
+        const f16* ah = Sc + a_row0;
+        const f16* al = Sc + TILE256 + a_row0;
+        const f16* wh = Sc + 2 * TILE256 + b_row0;
+        const f16* wl = Sc + 3 * TILE256 + b_row0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 fwh[2], fwl[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
+                fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
+            }
+            // all 12 fragments of this 16-wide k slice first (in-order LDS returns let the first MFMAs start while
+            // the later reads are still in flight), then 24 back-to-back MFMAs
+            f16x8 fah[TM], fal[TM];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                fah[mi] = *reinterpret_cast<const f16x8*>(ah + mi * 32 * BK + foff[s]);
+                fal[mi] = *reinterpret_cast<const f16x8*>(al + mi * 32 * BK + foff[s]);
+            }
+            // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
+            // would wait for the previous MFMA's result every time)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (acc_scale != 1.0f) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
@@ -390,16 +539,29 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     if (a->M == 0) return CVX_OK;
     const int tiles_n = (a->N + BN - 1) / BN, tiles_m = (a->M + 127) / 128;
     static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
-    static const int stages = [] { const char* e = getenv("CVX_GEMM_STAGES"); return e ? atoi(e) : 2; }();
     const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
     dim3 grid((unsigned)(grid_m * tiles_n));
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const f16* wh = reinterpret_cast<const f16*>(W_hi);
     const f16* wl = reinterpret_cast<const f16*>(W_lo);
-    if (A.hi) {
-        if (stages <= 2)      launch_dma<2>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
-        else if (stages == 3) launch_dma<3>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
-        else                  launch_dma<4>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
+    static const int big = [] { const char* e = getenv("CVX_GEMM_TILE256"); return e ? atoi(e) : 1; }();
+    // Measured on MI355X (tools/bench_kernels.py, M=16000): the 256x256 tile wins on every transformer shape
+    // (284-349 vs 263-312 TFLOP/s).  Deeper rings (3-4 stages, K-step 16, 256x128x3) were tried and are slower:
+    // the kernel is bound by the per-CU LDS-DMA delivery rate (~35 GB/s/CU), not by DMA latency.
+    if (A.hi && big && a->M >= 2048 && a->N >= 512) {
+        const int tn = (a->N + 255) / 256, tm = (a->M + 255) / 256;
+        const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
+        const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB
+        static bool attr256 = false;
+        if (!attr256) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma256_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            attr256 = true;
+        }
+        hipLaunchKernelGGL(gemm_f16x3_dma256_kernel, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl, acc_scale, so,
+                           tm, tn, map_mode);
+    } else if (A.hi) {
+        launch_dma<2>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);   // 2 stages, 2 blocks / CU
     } else {
         const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
         static bool attr = false;
