@@ -30,18 +30,30 @@ PEAK_F16_MFMA = 2.5e15                                  # MI355X_MICROARCH.md: d
 
 
 class GemmTimer:
-    """HIP-event bracket around every cvx_gemm launch (events are recorded on torch's current
-    stream = the stream the kernel is launched on).  Sums algorithmic FLOPs (2*M*N*K) and durations."""
+    """HIP-event bracket around every GEMM launch of the dominant kernel class (events are recorded on torch's
+    current stream = the stream the kernel is launched on).  Sums algorithmic FLOPs (2*M*N*K) and durations.
+    `dominant(a, w, kw)` says whether a launch goes to the dominant kernel (f16x3: the pre-split all-DMA 256x256
+    kernel, i.e. every per-layer transformer GEMM except the skip combiners; fp32: every GEMM)."""
 
-    def __init__(self):
+    def __init__(self, split: bool):
+        self.split = split
         self.pairs = []
         self.flops = 0.0
         self.launches = 0
+        self.other_launches = 0
+
+    def dominant(self, a, w, kw):
+        if not self.split:
+            return True
+        return kw.get("a_split") is not None and a.shape[0] >= 2048 and w.shape[0] >= 512
 
     def install(self, ops):
         inner = ops.gemm
 
         def timed(a, w, out, **kw):
+            if not self.dominant(a, w, kw):
+                self.other_launches += 1
+                return inner(a, w, out, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = inner(a, w, out, **kw)
@@ -147,7 +159,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    model, gen, cpu_sd = make_models(dev, rank, world)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # keep stdout to the single JSON line
+        model, gen, cpu_sd = make_models(dev, rank, world)
 
     inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1234 + rank)
     ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
@@ -166,7 +180,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = GemmTimer()
+    timer = GemmTimer(split=(model.precision == "f16x3"))
     timer.install(ops)
     barrier()
     t0 = time.perf_counter()
@@ -183,7 +197,7 @@ def main():
         flops, gemm_s, launches = timer.result()
         achieved = flops / gemm_s / 1e12
         split = model.precision == "f16x3"
-        kname = "gemm_f16x3_kernel" if split else "gemm_f32_kernel"
+        kname = "gemm_f16x3_dma256_kernel" if split else "gemm_f32_glds_kernel"
         peak = PEAK_F16_MFMA if split else PEAK_F32_MFMA
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")

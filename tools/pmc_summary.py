@@ -15,6 +15,9 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
+    m = re.search(r"_GLOBAL__N_1(\d\d)(\w+)", name)          # mangled: _ZN12_GLOBAL__N_1<len><name>...
+    if m:
+        return m.group(2)[: int(m.group(1))]
     m = re.search(r"(\w+_kernel)(<\d+>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
