@@ -42,6 +42,19 @@ __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, flo
     so.lo[idx] = (_Float16)(x - (float)h);
 }
 
+// 4 x 4 transpose inside every lane quad: lane q (= lane & 3) enters with v[e] = M[e][q] and leaves with v[j] = M[q][j].
+// Two butterfly stages (xor 1, xor 2); the shuffles lower to DPP quad permutes.
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int lane)
+{
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    float x = b0 ? v0 : v1, y = b0 ? v2 : v3;
+    float rx = __shfl_xor(x, 1, 64), ry = __shfl_xor(y, 1, 64);
+    const float a0 = b0 ? rx : v0, a1 = b0 ? v1 : rx, a2 = b0 ? ry : v2, a3 = b0 ? v3 : ry;
+    x = b1 ? a0 : a2; y = b1 ? a1 : a3;
+    rx = __shfl_xor(x, 2, 64); ry = __shfl_xor(y, 2, 64);
+    v0 = b1 ? rx : a0; v1 = b1 ? ry : a1; v2 = b1 ? a2 : rx; v3 = b1 ? a3 : ry;
+}
+
 template <int TM>
 __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
                                               int wm, int wn, int lane,
@@ -99,6 +112,74 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
     const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
     const float b_lo = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
     const float b_hi = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
+
+    // ---- vector path (wave-uniform choice): the MFMA layout gives a lane ONE column of 4 consecutive rows per
+    // register group; a 4x4 quad transpose turns that into 4 consecutive COLUMNS of one row, so every store /
+    // residual load is 16 bytes (8 bytes per fp16 half) instead of 4 (2): 4x fewer memory instructions.
+    const bool vec_ok = (colw + 64 <= p.N) &&
+                        (!so.write_f32 || (((uintptr_t)p.C & 15) == 0 && (p.ldc & 3) == 0)) &&
+                        (!p.residual || (((uintptr_t)p.residual & 15) == 0 && (p.ldr & 3) == 0)) &&
+                        (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0));
+    if (vec_ok) {
+        const int q = lane & 3;
+        const int c4_lo = colw + 4 * ((lane & 31) >> 2);          // this lane's 4 columns after the transpose
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row0 = m0 + wm * TM * 32 + mi * 32 + 8 * rg + 4 * (lane >> 5);
+                float lo[4], hi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = acc[mi][0][4 * rg + e] + b_lo;
+                    hi[e] = acc[mi][1][4 * rg + e] + b_hi;
+                    if (p.act == CVX_ACT_GELU) { lo[e] = gelu_erf(lo[e]); hi[e] = gelu_erf(hi[e]); }
+                    else if (p.act == CVX_ACT_SILU) { lo[e] = silu(lo[e]); hi[e] = silu(hi[e]); }
+                    if (do_rope) {
+                        const int pos = min(row0 + e, p.M - 1) % p.rope_T;
+                        const float c = p.rope_cos[pos * 32 + (lane & 31)];
+                        const float s = p.rope_sin[pos * 32 + (lane & 31)];
+                        const float nlo = lo[e] * c - hi[e] * s;
+                        const float nhi = hi[e] * c + lo[e] * s;
+                        lo[e] = nlo; hi[e] = nhi;
+                    }
+                }
+                quad_transpose(lo[0], lo[1], lo[2], lo[3], lane);
+                quad_transpose(hi[0], hi[1], hi[2], hi[3], lane);
+                const int row = row0 + q;
+                if (row >= p.M) continue;
+                f32x4 vlo = {lo[0], lo[1], lo[2], lo[3]}, vhi = {hi[0], hi[1], hi[2], hi[3]};
+                if (p.residual) {
+                    const float* rp = p.residual + (int64_t)row * p.ldr + c4_lo;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+                    const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vlo[e] += r0[e]; vhi[e] += r1[e]; }
+                }
+                if (so.write_f32) {
+                    float* cp = p.C + (int64_t)row * p.ldc + c4_lo;
+                    *reinterpret_cast<f32x4*>(cp) = vlo;
+                    *reinterpret_cast<f32x4*>(cp + 32) = vhi;
+                }
+                if (so.hi) {
+                    const int64_t o = (int64_t)row * so.ldc_h + c4_lo;
+                    cvx_f16x4 h0, l0, h1, l1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = fminf(fmaxf(vlo[e], -65504.f), 65504.f);
+                        const float x1 = fminf(fmaxf(vhi[e], -65504.f), 65504.f);
+                        h0[e] = (_Float16)x0; l0[e] = (_Float16)(x0 - (float)h0[e]);
+                        h1[e] = (_Float16)x1; l1[e] = (_Float16)(x1 - (float)h1[e]);
+                    }
+                    *reinterpret_cast<cvx_f16x4*>(so.hi + o) = h0;
+                    *reinterpret_cast<cvx_f16x4*>(so.lo + o) = l0;
+                    *reinterpret_cast<cvx_f16x4*>(so.hi + o + 32) = h1;
+                    *reinterpret_cast<cvx_f16x4*>(so.lo + o + 32) = l1;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
