@@ -113,6 +113,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
 
+    // (a stage of two key tiles - one barrier per 64 keys - was measured slower: 64 KiB of LDS drops the kernel
+    //  from 3 to 2 blocks per CU)
     const int ntiles = (T + KT - 1) / KT;
     issue(0, 0);
     for (int it = 0; it < ntiles; ++it) {
@@ -138,32 +140,38 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r] + sacc2[r];
 
-        // ---- online softmax (this lane: 16 keys of query l31; partner lane^32 holds the other 16)
-        float mx = -1e30f;
+        // ---- online softmax (this lane: 16 keys of query l31; partner lane^32 holds the other 16).
+        // The running max m_run is kept in the scaled log2 domain; scores stay raw and the scale is folded into one
+        // fma per element: p = exp2(s*c - m).  Only the last tile can contain keys >= T (wave-uniform branch), and
+        // the 32 accumulator rescales are skipped when no lane's max moved (alpha == 1 exactly - also wave-uniform).
+        if (key0 + KT > T) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + mfma32_row(r, lane);
-            const float sv = (key < T) ? sacc[r] * scale_log2e : -1e30f;
-            sacc[r] = sv;
-            mx = fmaxf(mx, sv);
+            for (int r = 0; r < 16; ++r)
+                if (key0 + mfma32_row(r, lane) >= T) sacc[r] = -1e30f;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mx = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;          // scale > 0: max commutes with it
         const float m_new = fmaxf(m_run, mx);
+        const bool moved = m_new != m_run;
         const float alpha = exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
         f16x8 ph[2], pl[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = exp2f(sacc[r] - m_new);
+            const float pv = exp2f(fmaf(sacc[r], scale_log2e, -m_new));
             psum += pv;
             const f16 h = (f16)pv;
             ph[r >> 3][r & 7] = h;
             pl[r >> 3][r & 7] = (f16)(pv - (float)h);
         }
         l_run = l_run * alpha + psum;
+        if (__any(moved)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
 
         // ---- O^T += V^T . P^T
         const f16* Vh = S + 2 * TILE;

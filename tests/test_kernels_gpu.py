@@ -346,3 +346,24 @@ def test_attention_f16x3_with_qkv_transposed_epilogue(ops, Bt, T, H):
     e = rel_l2(out, ref)
     print("attention f16x3", Bt, T, H, e)
     assert e < 5e-6 and rel_l2(oh.float() + ol.float(), out) < 1e-6
+
+
+def test_attention_f16x3_forced_rescale_and_tail(ops):
+    """Late dominant key (forces the rescale branch after tiles where the max did not move) + a ragged last tile."""
+    Bt, T, H = 1, 164, 1
+    qkv = randn(Bt * T, 192, seed=150) * 0.5
+    qkv[5, :64] = 3.0
+    qkv[140, 64:128] = 4.0
+    qkv[163, 64:128] = -4.0
+    M = Bt * T
+    ah, al = ops.split_act_f16(qkv.contiguous())
+    qk = (ah[:, :128].contiguous(), al[:, :128].contiguous())
+    Tp = 192
+    vt = (torch.zeros(64, Tp, dtype=torch.float16, device=dev()), torch.zeros(64, Tp, dtype=torch.float16, device=dev()))
+    vt[0][:, :T] = ah[:, 128:].T
+    vt[1][:, :T] = al[:, 128:].T
+    out = torch.empty(Bt, T, 64, device=dev())
+    ops.attention_f16x3(qk, vt, out, Bt, T, H, 0.125)
+    q, k, v = qkv.double().reshape(Bt, T, 3, 1, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(Bt, T, 64)
+    assert rel_l2(out, ref) < 5e-6
