@@ -107,6 +107,7 @@ class VectorField:
             h16 = lambda *s: (torch.empty(*s, dtype=torch.float16, device=dev), torch.empty(*s, dtype=torch.float16, device=dev))
             ws["normed16"], ws["att16"], ws["ff16"] = h16(M, d["dim"]), h16(M, d["heads"] * 64), h16(M, 4 * d["dim"])
             ws["qk16"] = h16(M, 2 * d["heads"] * 64)
+            ws["h16"] = [h16(M, d["dim"]) for _ in ws["h"]]      # split twins of the residual-stream buffers (skip GEMMs)
             Tp = ((T + 31) // 32) * 32           # V^T rows, zero beyond T (read by the last key tile, weight 0)
             ws["vt16"] = (torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev),
                           torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev))
@@ -163,6 +164,11 @@ class VectorField:
         h = take()
         ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T)
         free.append(h0)
+        # residual-stream tensors that later feed a skip combiner (as x or as the popped skip) also get a split
+        # twin, so that GEMM takes both operands pre-split (all-DMA kernel) instead of splitting on the fly
+        twin = {id(b): pr for b, pr in zip(ws["h"], ws["h16"])} if split_io else None
+        if split_io:
+            ops.split_act_f16(h, *twin[id(h)])
 
         skips: List[torch.Tensor] = []
         for i in range(d["depth"]):
@@ -174,7 +180,11 @@ class VectorField:
             if (p + ".0.weight") in sd:
                 s = skips.pop()
                 comb = take()
-                ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"))
+                if split_io:
+                    ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"),
+                             a_split=twin[id(h)], a2_split=twin[id(s)])
+                else:
+                    ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"))
                 free += [h, s]
                 h, keep_input = comb, False
             else:
@@ -199,7 +209,8 @@ class VectorField:
                 ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
                          w_split=sp(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False)
                 ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h,
-                         w_split=sp(p + ".4.2.weight"), a_split=f16)
+                         w_split=sp(p + ".4.2.weight"), a_split=f16,
+                         out_split=twin[id(h)] if i + 1 < d["depth"] else None)
                 continue
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])
             ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
@@ -249,25 +260,15 @@ class FlowMatchingSampler:
     def __init__(self, field: VectorField, nfe: int = 32, method: str = "midpoint"):
         self.field, self.nfe, self.method = field, nfe, method
 
-    @torch.no_grad()
-    def sample(self, *, phoneme_ids: torch.Tensor, cond: torch.Tensor, mask: Optional[torch.Tensor] = None,
-               cond_scale: float = 1.0, y0: Optional[torch.Tensor] = None) -> torch.Tensor:
-        f, d = self.field, self.field.d
-        dev = f.device
-        if cond.ndim != 3 or cond.shape[-1] != d["dim_cond"]:
-            raise AssertionError(f"cond must be [B,T,{d['dim_cond']}], got {tuple(cond.shape)}")
-        expect_ids = cond.shape[:2] + ((d["streams"],) if d["streams"] > 1 else ())
-        if tuple(phoneme_ids.shape) != tuple(expect_ids):
-            raise AssertionError(f"phoneme_ids must be {tuple(expect_ids)}, got {tuple(phoneme_ids.shape)}")
-        cond = cond.to(device=dev, dtype=torch.float32)
-        phoneme_ids = phoneme_ids.to(dev)
-        B, T, _ = cond.shape
-        if y0 is None:                       # acoustic.py:647-650 (VoMix draws 80 channels)
-            y0 = torch.randn(B, T, d["dim_out"], device=dev, dtype=torch.float32)
-        y = y0.to(device=dev, dtype=torch.float32).contiguous().clone()
-        use_null = float(cond_scale) != 1.0          # acoustic.py:423
-        times, dts = evaluation_times(self.nfe, self.method)
-        ctx = f.prepare(phoneme_ids, cond, times.to(dev), use_null)
+    # launch-bound regime (short / single utterances): the whole solve - ~2400 kernel launches for 32 NFE - is captured
+    # once per input shape into a HIP graph and replayed (env CVX_GRAPH=0 disables, CVX_GRAPH_MAX_ROWS bounds the
+    # batch size it applies to; large batches are GPU-bound and stay eager).
+    GRAPH_CACHE = 4
+
+    def _integrate(self, phoneme_ids, cond, y, times_dev, dts, s: float, use_null: bool) -> None:
+        """prepare() + the fixed-grid loop; advances `y` in place."""
+        f = self.field
+        ctx = f.prepare(phoneme_ids, cond, times_dev, use_null)
         ws, M1 = ctx["ws"], ctx["M1"]
         xin = ws["xin"]
         x_c = xin[:M1]
@@ -275,7 +276,6 @@ class FlowMatchingSampler:
         x_c.copy_(y.reshape(M1, -1))
         if use_null:
             x_n.copy_(x_c)
-        s = float(cond_scale)
         e = 0
         for dt in dts:
             if self.method == "midpoint":
@@ -286,4 +286,49 @@ class FlowMatchingSampler:
             else:
                 pred = f.evaluate(ctx, e); e += 1
                 ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
-        return y
+        return ctx
+
+    @torch.no_grad()
+    def sample(self, *, phoneme_ids: torch.Tensor, cond: torch.Tensor, mask: Optional[torch.Tensor] = None,
+               cond_scale: float = 1.0, y0: Optional[torch.Tensor] = None) -> torch.Tensor:
+        import os
+        f, d = self.field, self.field.d
+        dev = f.device
+        if cond.ndim != 3 or cond.shape[-1] != d["dim_cond"]:
+            raise AssertionError(f"cond must be [B,T,{d['dim_cond']}], got {tuple(cond.shape)}")
+        expect_ids = cond.shape[:2] + ((d["streams"],) if d["streams"] > 1 else ())
+        if tuple(phoneme_ids.shape) != tuple(expect_ids):
+            raise AssertionError(f"phoneme_ids must be {tuple(expect_ids)}, got {tuple(phoneme_ids.shape)}")
+        cond = cond.to(device=dev, dtype=torch.float32).contiguous()
+        phoneme_ids = phoneme_ids.to(device=dev, dtype=torch.int64).contiguous()
+        B, T, _ = cond.shape
+        if y0 is None:                       # acoustic.py:647-650 (VoMix draws 80 channels)
+            y0 = torch.randn(B, T, d["dim_out"], device=dev, dtype=torch.float32)
+        y = y0.to(device=dev, dtype=torch.float32).contiguous().clone()
+        use_null = float(cond_scale) != 1.0          # acoustic.py:423
+        s = float(cond_scale)
+        times, dts = evaluation_times(self.nfe, self.method)
+        rows = (2 * B if use_null else B) * T
+        if os.environ.get("CVX_GRAPH", "1") == "0" or rows > int(os.environ.get("CVX_GRAPH_MAX_ROWS", "8192")):
+            self._integrate(phoneme_ids, cond, y, times.to(dev), dts, s, use_null)
+            return y
+        key = (B, T, use_null, s, self.nfe, self.method)
+        cache = f.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            st = dict(ids=phoneme_ids.clone(), cond=cond.clone(), y=y.clone(), times=times.to(dev))
+            ctx = self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)   # eager warm-up
+            st["ws"] = ctx["ws"]             # keep this shape's workspace alive for as long as the graph is
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)
+            if len(cache) >= self.GRAPH_CACHE:
+                cache.pop(next(iter(cache)))
+            ent = cache[key] = (g, st)
+        g, st = ent
+        st["ids"].copy_(phoneme_ids)
+        st["cond"].copy_(cond)
+        st["y"].copy_(y)
+        g.replay()
+        return st["y"].clone()
