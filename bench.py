@@ -74,7 +74,7 @@ class GemmTimer:
         return self.flops, secs, self.launches
 
 
-def make_models(dev, rank, world):
+def make_models(dev, rank, world, precision=None):
     import covomix_amd.synthetic as syn
     from covomix_amd import dp
     from covomix_amd.conditional_model import CoVoMixModel
@@ -92,7 +92,7 @@ def make_models(dev, rank, world):
         sd = dp.broadcast_state_dict(sd, dev, src=0)
         vsd = dp.broadcast_state_dict(vsd, dev, src=0)
     sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
-    model = CoVoMixModel.from_state_dict(sd, nfe=NFE).eval().to(dev)
+    model = CoVoMixModel.from_state_dict(sd, nfe=NFE, precision=precision).eval().to(dev)
     gen = Generator(AttrDict(syn.HIFIGAN_COVOMIX_CONFIG)).to(dev)
     gen.load_state_dict({k: v.cpu() for k, v in vsd.items()})
     gen.eval()
@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f16x3", "f16", "fp32"], default=None,
+                    help="default f16x3 (fp32-class); f16 = opt-in single-term fp16 operands (<= 1e-3 rel-L2 budget)")
     args = ap.parse_args()
 
     from covomix_amd import dp, ops
@@ -161,7 +163,7 @@ def main():
     dev = torch.device("cuda", local)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # keep stdout to the single JSON line
-        model, gen, cpu_sd = make_models(dev, rank, world)
+        model, gen, cpu_sd = make_models(dev, rank, world, args.precision)
 
     inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1234 + rank)
     ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
@@ -180,7 +182,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = GemmTimer(split=(model.precision == "f16x3"))
+    timer = GemmTimer(split=(model.precision in ("f16x3", "f16")))
     timer.install(ops)
     barrier()
     t0 = time.perf_counter()
@@ -196,12 +198,13 @@ def main():
         value = frames / elapsed
         flops, gemm_s, launches = timer.result()
         achieved = flops / gemm_s / 1e12
-        split = model.precision == "f16x3"
+        split = model.precision in ("f16x3", "f16")
+        terms = {"f16x3": 3, "f16": 1, "fp32": 1}[model.precision]
         kname = "gemm_f16x3_dma256_kernel" if split else "gemm_f32_glds_kernel"
         peak = PEAK_F16_MFMA if split else PEAK_F32_MFMA
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.isfile(pmc):
+        if os.path.isfile(pmc) and model.precision == "f16x3":      # the committed PMC passes profile the default precision
             try:
                 traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -211,7 +214,9 @@ def main():
             "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16x3->f32 (fp32 operands split into fp16 hi/lo pairs, 3 MFMA products, fp32 accumulate)" if split else "f32",
+            "dtype": {"f16x3": "f16x3->f32 (fp32 operands split into fp16 hi/lo pairs, 3 MFMA products, fp32 accumulate)",
+                      "f16": "f16->f32 (OPT-IN reduced precision: fp16 GEMM/attention operands, fp32 accumulate/softmax/norm/residual)",
+                      "fp32": "f32"}[model.precision],
             "data": "synthetic",
             "config": {"workload": f"VoMix 32-NFE (16 midpoint steps, CFG 0.7) + HiFi-GAN config_covomix, "
                                    f"B={B} utterances x T={T} frames per GPU, prompt {PROMPT}",
@@ -221,10 +226,10 @@ def main():
             # dominant kernel.  achieved = ALGORITHMIC flops (2*M*N*K per launch) / HIP-event time of the launches;
             # the split kernel executes 3 MFMA products per algorithmic product, so its matrix-pipe work is 3x that.
             "roofline": {"bound": "mfma",
-                         "kernel": kname + (" (v_mfma_f32_32x32x16_f16 x3)" if split else " (v_mfma_f32_32x32x2_f32)"),
+                         "kernel": kname + ((" (v_mfma_f32_32x32x16_f16 x%d)" % terms) if split else " (v_mfma_f32_32x32x2_f32)"),
                          "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic,
-                         "executed_mfma_frac": round(achieved * (3 if split else 1) / (peak / 1e12), 4),
+                         "executed_mfma_frac": round(achieved * terms / (peak / 1e12), 4),
                          "vs_f32_mfma_peak": round(achieved / (PEAK_F32_MFMA / 1e12), 4),
                          "launches": launches, "avg_launch_ms": round(gemm_s / launches * 1e3, 4),
                          "time_share_of_step": round(gemm_s / elapsed, 4)},

@@ -40,7 +40,7 @@ __device__ __forceinline__ f16x8 gload8h(const f16* p)
     return *reinterpret_cast<gp>(reinterpret_cast<uintptr_t>(p));
 }
 
-__device__ __forceinline__ void store_split4(f16* hi, f16* lo, const f32x4 o)
+__device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, const f32x4 o)
 {
     f16x4 h, l;
 #pragma unroll
@@ -49,10 +49,12 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, const f32x4 o)
         h[e] = (f16)x;
         l[e] = (f16)(x - (float)h[e]);
     }
-    *reinterpret_cast<f16x4*>(hi) = h;
-    *reinterpret_cast<f16x4*>(lo) = l;
+    *reinterpret_cast<f16x4*>(hi + off) = h;
+    if (lo) *reinterpret_cast<f16x4*>(lo + off) = l;      // lo == NULL: hi halves only
 }
 
+// NT = 3: split operands, three products.  NT = 1: hi halves only (plain fp16 operands, fp32 accumulate and softmax).
+template <int NT>
 __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
                                                                 const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
     {
         const int64_t off = ((int64_t)b * T + qrow) * ldqk + head * HD + 8 * g;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { qh[s] = gload8h(qk_hi + off + 16 * s); ql[s] = gload8h(qk_lo + off + 16 * s); }
+        for (int s = 0; s < 4; ++s) {
+            qh[s] = gload8h(qk_hi + off + 16 * s);
+            if constexpr (NT == 3) ql[s] = gload8h(qk_lo + off + 16 * s);
+        }
     }
 
     // ---- DMA sources.  wave w: K rows [8w, 8w+8) (hi, lo) and V^T rows [16w, 16w+16) (hi, lo): 4 pieces per tile
@@ -91,10 +96,10 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
         const int key = min(key0 + k_r, T - 1);
         const int64_t ko = ((int64_t)b * T + key) * ldqk + k_col;
         glds16(qk_hi + ko, S + 8 * wid * HD);
-        glds16(qk_lo + ko, S + TILE + 8 * wid * HD);
+        if constexpr (NT == 3) glds16(qk_lo + ko, S + TILE + 8 * wid * HD);
         const int64_t vo = v_row + key0;
         glds16(vt_hi + vo, S + 2 * TILE + 16 * wid * KT);
-        glds16(vt_lo + vo, S + 3 * TILE + 16 * wid * KT);
+        if constexpr (NT == 3) glds16(vt_lo + vo, S + 3 * TILE + 16 * wid * KT);
     };
 
     // ---- fragment offsets (halves)
@@ -132,10 +137,15 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f16x8 kh = *reinterpret_cast<const f16x8*>(S + koff[s]);
-            const f16x8 kl = *reinterpret_cast<const f16x8*>(S + TILE + koff[s]);
-            sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc1, 0, 0, 0);
-            sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc2, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+            if constexpr (NT == 3) {
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(S + TILE + koff[s]);
+                sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc1, 0, 0, 0);
+                sacc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc2, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+            } else {                 // two accumulators (even / odd d slices) keep consecutive MFMAs independent
+                if (s & 1) sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc1, 0, 0, 0);
+                else sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r] + sacc2[r];
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
             psum += pv;
             const f16 h = (f16)pv;
             ph[r >> 3][r & 7] = h;
-            pl[r >> 3][r & 7] = (f16)(pv - (float)h);
+            if constexpr (NT == 3) pl[r >> 3][r & 7] = (f16)(pv - (float)h);
         }
         l_run = l_run * alpha + psum;
         if (__any(moved)) {
@@ -185,17 +195,24 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
                 f16x8 vh, vl;
                 const f16x4 a0 = *reinterpret_cast<const f16x4*>(Vh + base + voff[s][0]);
                 const f16x4 a1 = *reinterpret_cast<const f16x4*>(Vh + base + voff[s][1]);
-                const f16x4 c0 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][0]);
-                const f16x4 c1 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][1]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = c0[e]; vl[4 + e] = c1[e]; }
-                vhh[dt] = vh; vll[dt] = vl;
+                for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; }
+                vhh[dt] = vh;
+                if constexpr (NT == 3) {
+                    const f16x4 c0 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][0]);
+                    const f16x4 c1 = *reinterpret_cast<const f16x4*>(Vl + base + voff[s][1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vl[e] = c0[e]; vl[4 + e] = c1[e]; }
+                    vll[dt] = vl;
+                }
             }
             // interleave the two O^T tiles: consecutive MFMAs alternate accumulators
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[0], ph[s], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[1], ph[s], o1, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], pl[s], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], pl[s], o1, 0, 0, 0);
+            if constexpr (NT == 3) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[0], ph[s], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[1], ph[s], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], pl[s], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], pl[s], o1, 0, 0, 0);
+            }
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], ph[s], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], ph[s], o1, 0, 0, 0);
         }
@@ -215,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
                 *reinterpret_cast<f32x4*>(out + o_off + 32 + 8 * gq) = c;
             }
             if (out_hi) {
-                store_split4(out_hi + o_off + 8 * gq, out_lo + o_off + 8 * gq, a);
-                store_split4(out_hi + o_off + 32 + 8 * gq, out_lo + o_off + 32 + 8 * gq, c);
+                store_split4(out_hi, out_lo, o_off + 8 * gq, a);
+                store_split4(out_hi, out_lo, o_off + 32 + 8 * gq, c);
             }
         }
     }
@@ -228,7 +245,9 @@ extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo,
                                    float* out, uint16_t* out_hi, uint16_t* out_lo,
                                    int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale, cvx_stream_t s)
 {
-    CVX_REQUIRE(qk_hi && qk_lo && vt_hi && vt_lo && (out || out_hi) && ((out_hi == nullptr) == (out_lo == nullptr)),
+    const bool single = (qk_lo == nullptr);        // hi halves only: plain fp16 operands, one product
+    CVX_REQUIRE(qk_hi && vt_hi && ((qk_lo == nullptr) == (vt_lo == nullptr)) && (out || out_hi) &&
+                (out_hi || !out_lo) && (single || (out_hi == nullptr) == (out_lo == nullptr)),
                 "attention_f16x3: null pointer");
     CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0 && Tp % 8 == 0 && Tp >= ((T + KT - 1) / KT) * KT,
                 "attention_f16x3: bad shape Bt=%d T=%d Tp=%d H=%d (Tp must be a multiple of 8 and >= T rounded up to 32)", Bt, T, Tp, H);
@@ -237,11 +256,18 @@ extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo,
     if (Bt == 0) return CVX_OK;
     const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
-    hipLaunchKernelGGL(attention_f16x3_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                       reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
-                       reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
-                       out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                       T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+    if (single)
+        hipLaunchKernelGGL(attention_f16x3_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                           reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
+                           reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
+                           out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+    else
+        hipLaunchKernelGGL(attention_f16x3_kernel<3>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                           reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
+                           reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
+                           out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f);
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;
 }

@@ -28,7 +28,7 @@ constexpr int K_LD = HD + 4;    // padded K row in LDS (floats): conflict-free d
 constexpr int V_LD = HD;
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, const f32x4 o)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o)
 {
     f16x4_t h, l;
 #pragma unroll
@@ -37,8 +37,8 @@ __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, const f
         h[e] = (_Float16)x;
         l[e] = (_Float16)(x - (float)h[e]);
     }
-    *reinterpret_cast<f16x4_t*>(hi) = h;
-    *reinterpret_cast<f16x4_t*>(lo) = l;
+    *reinterpret_cast<f16x4_t*>(hi + off) = h;
+    if (lo) *reinterpret_cast<f16x4_t*>(lo + off) = l;      // lo == NULL: hi halves only
 }
 
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
                 *reinterpret_cast<f32x4*>(out + o_off + 32 + 8 * g) = c;
             }
             if (out_hi) {     // split copy for the to_out GEMM's pre-split A operand
-                store_split4(out_hi + o_off + 8 * g, out_lo + o_off + 8 * g, a);
-                store_split4(out_hi + o_off + 32 + 8 * g, out_lo + o_off + 32 + 8 * g, c);
+                store_split4(out_hi, out_lo, o_off + 8 * g, a);
+                store_split4(out_hi, out_lo, o_off + 32 + 8 * g, c);
             }
         }
     }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
 extern "C" int cvx_attention_f32(const float* qkv, float* out, uint16_t* out_hi, uint16_t* out_lo,
                                  int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s)
 {
-    CVX_REQUIRE(qkv && (out || out_hi) && ((out_hi == nullptr) == (out_lo == nullptr)), "attention: null pointer");
+    CVX_REQUIRE(qkv && (out || out_hi) && (out_hi || !out_lo), "attention: null pointer");      // out_lo == NULL: hi halves only
     CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0, "attention: bad shape Bt=%d T=%d H=%d", Bt, T, H);
     CVX_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attention: pointers must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;

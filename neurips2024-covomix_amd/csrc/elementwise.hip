@@ -34,7 +34,7 @@ __device__ __forceinline__ float wave_sum(float v)
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 // split 4 floats into fp16 (hi, lo) and store 8 bytes each (for GEMMs that take their A operand pre-split)
-__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, const f32x4 o)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o)
 {
     f16x4_t h, l;
 #pragma unroll
@@ -43,8 +43,8 @@ __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, const f
         h[e] = (_Float16)x;
         l[e] = (_Float16)(x - (float)h[e]);
     }
-    *reinterpret_cast<f16x4_t*>(hi) = h;
-    *reinterpret_cast<f16x4_t*>(lo) = l;
+    *reinterpret_cast<f16x4_t*>(hi + off) = h;
+    if (lo) *reinterpret_cast<f16x4_t*>(lo + off) = l;      // lo == NULL: hi halves only
 }
 
 // ---------------------------------------------------------------- AdaRMSNorm
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
                 for (int e = 0; e < 4; ++e) o[e] += bb[e];
             }
             if (y) *reinterpret_cast<f32x4*>(yr + 4 * j) = o;
-            if (y_hi) store_split4(y_hi + row * D + 4 * j, y_lo + row * D + 4 * j, o);
+            if (y_hi) store_split4(y_hi, y_lo, row * D + 4 * j, o);
         }
     }
 }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
             for (int e = 0; e < 4; ++e) o[e] += bb[e];
         }
         if (y) *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
-        if (y_hi) store_split4(y_hi + row * D + 4 * j, y_lo + row * D + 4 * j, o);
+        if (y_hi) store_split4(y_hi, y_lo, row * D + 4 * j, o);
     }
 }
 
@@ -233,7 +233,7 @@ extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const floa
                                   int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
                                   cvx_stream_t s)
 {
-    CVX_REQUIRE(x && gamma && (y || y_hi_) && ((y_hi_ == nullptr) == (y_lo_ == nullptr)), "adarmsnorm: null pointer");
+    CVX_REQUIRE(x && gamma && (y || y_hi_) && (y_hi_ || !y_lo_), "adarmsnorm: null pointer");     // y_lo == NULL: hi halves only
     _Float16* y_hi = reinterpret_cast<_Float16*>(y_hi_);
     _Float16* y_lo = reinterpret_cast<_Float16*>(y_lo_);
     CVX_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0 && rows_per_group > 0, "adarmsnorm: bad shape rows=%ld D=%d", (long)rows, D);

@@ -25,7 +25,8 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 // acc[mi][ni]: 32x32 MFMA accumulators of a wave that owns rows [m0 + wm*TM*32, +TM*32) and the 64 columns
 // [n0 + wn*64, +64).  bias -> act -> half-split RoPE -> residual -> store.
 // Optional split copy of the output: (fp16 hi, fp16 lo) of the final value, row stride ldc_h (halves), for a
-// consumer GEMM that takes its A operand pre-split; write_f32 == 0 suppresses the fp32 store.
+// consumer GEMM that takes its A operand pre-split; write_f32 == 0 suppresses the fp32 store.  lo == NULL (and
+// vt_lo == NULL) writes the hi halves only - the single-term fp16 mode.
 // QKV mode (vt_hi != NULL; needs the RoPE arguments: rope_T = frames per sequence, rope_cols = 2*H*64): columns
 // [0, rope_cols) (q | k, after RoPE) go to hi/lo [M, ldc_h] as usual, columns >= rope_cols (v) are written TRANSPOSED
 // per (sequence, head): vt[((b*H + h)*64 + d) * vt_ld + t] - the layout the f16x3 attention kernel DMAs its V^T
@@ -39,7 +40,7 @@ __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, flo
     const float x = fminf(fmaxf(v, -65504.f), 65504.f);
     const _Float16 h = (_Float16)x;
     so.hi[idx] = h;
-    so.lo[idx] = (_Float16)(x - (float)h);
+    if (so.lo) so.lo[idx] = (_Float16)(x - (float)h);      // lo == NULL: single-term fp16 consumer
 }
 
 // 4 x 4 transpose inside every lane quad: lane q (= lane & 3) enters with v[e] = M[e][q] and leaves with v[j] = M[q][j].
@@ -92,7 +93,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                     const int64_t base = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld;
                     if (t0 + 3 < T && row0 + 3 < p.M) {
                         *reinterpret_cast<cvx_f16x4*>(so.vt_hi + base + t0) = vh;
-                        *reinterpret_cast<cvx_f16x4*>(so.vt_lo + base + t0) = vl;
+                        if (so.vt_lo) *reinterpret_cast<cvx_f16x4*>(so.vt_lo + base + t0) = vl;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                             const int bb = row / T, tt = row - bb * T;
                             const int64_t idx = ((int64_t)(bb * H + head) * 64 + d) * so.vt_ld + tt;
                             so.vt_hi[idx] = vh[e];
-                            so.vt_lo[idx] = vl[e];
+                            if (so.vt_lo) so.vt_lo[idx] = vl[e];
                         }
                     }
                 }
@@ -172,9 +173,11 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                         h1[e] = (_Float16)x1; l1[e] = (_Float16)(x1 - (float)h1[e]);
                     }
                     *reinterpret_cast<cvx_f16x4*>(so.hi + o) = h0;
-                    *reinterpret_cast<cvx_f16x4*>(so.lo + o) = l0;
                     *reinterpret_cast<cvx_f16x4*>(so.hi + o + 32) = h1;
-                    *reinterpret_cast<cvx_f16x4*>(so.lo + o + 32) = l1;
+                    if (so.lo) {
+                        *reinterpret_cast<cvx_f16x4*>(so.lo + o) = l0;
+                        *reinterpret_cast<cvx_f16x4*>(so.lo + o + 32) = l1;
+                    }
                 }
             }
         }

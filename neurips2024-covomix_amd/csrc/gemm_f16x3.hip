@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 // 2-stage scheme cannot hide).  No staging VGPRs, no split VALU work, no ds_write in the loop.
 struct PreSplitA { const f16* hi; const f16* lo; int64_t ld; const f16* hi2; const f16* lo2; int64_t ld2; };
 
-template <int STAGES>
+template <int STAGES, int NT>
 __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
     float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
@@ -230,22 +230,27 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
         const int c = (lane & 3) ^ ((r >> 2) & 3);
         const int64_t ra = min(m0 + r, p.M - 1), rw = min(n0 + r, p.N - 1);
         pah[j] = A.hi + ra * A.ld + 8 * c;
-        pal[j] = A.lo + ra * A.ld + 8 * c;
         jmp_h[j] = A.hi2 ? (A.hi2 + ra * A.ld2 + 8 * c) - (pah[j] + p.K1) : 0;
-        jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
         pwh[j] = Whi + rw * p.ldw + 8 * c;
-        pwl[j] = Wlo + rw * p.ldw + 8 * c;
+        if constexpr (NT == 1) {      // the "lo" slots carry the NEXT 32 k of the same fp16 operands
+            pal[j] = pah[j] + BK; jmp_l[j] = jmp_h[j]; pwl[j] = pwh[j] + BK;
+        } else {
+            pal[j] = A.lo + ra * A.ld + 8 * c;
+            jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
+            pwl[j] = Wlo + rw * p.ldw + 8 * c;
+        }
     }
+    constexpr int KSTEP = (NT == 1) ? 2 * BK : BK;      // k consumed per stage
     const int dma_off = 32 * wid * BK;
-    const int switch_tile = A.hi2 ? p.K1 / BK : -1;
-    const int nk = p.K / BK;
+    const int switch_tile = A.hi2 ? p.K1 / KSTEP : -1;
+    const int nk = p.K / KSTEP;
 
     // issue the 8 DMA pieces of tile t (tiles past the end re-read the last tile: keeps the vmcnt arithmetic uniform)
     auto issue = [&](int t) {
         f16* const S = S0 + (t % STAGES) * STAGE + dma_off;
         const bool live = t < nk;
         const bool sw = (t == switch_tile);
-        const int back = live ? 0 : BK, adv = live ? BK : 0;
+        const int back = live ? 0 : KSTEP, adv = live ? KSTEP : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - back;
@@ -304,6 +309,18 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
             }
             // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
             // would wait for the previous MFMA's result every time)
+            if constexpr (NT == 1) {     // plain fp16: slot "lo" is the next 32 k, one product each
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail re-reads before LDS is released
@@ -338,6 +356,7 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
 // (~10 TB/s chip-wide, near what the L2 -> LDS DMA path sustains) while its MFMA pipe is only ~39 % busy.
 // 512 threads = 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers);
 // two 64 KiB stages; one block per CU.
+template <int NT>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
     float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
@@ -364,21 +383,26 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
         const int c = (lane & 3) ^ ((r >> 2) & 3);
         const int64_t ra = min(m0 + r, p.M - 1), rw = min(n0 + r, p.N - 1);
         pah[j] = A.hi + ra * A.ld + 8 * c;
-        pal[j] = A.lo + ra * A.ld + 8 * c;
         jmp_h[j] = A.hi2 ? (A.hi2 + ra * A.ld2 + 8 * c) - (pah[j] + p.K1) : 0;
-        jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
         pwh[j] = Whi + rw * p.ldw + 8 * c;
-        pwl[j] = Wlo + rw * p.ldw + 8 * c;
+        if constexpr (NT == 1) {      // the "lo" slots carry the NEXT 32 k of the same fp16 operands
+            pal[j] = pah[j] + BK; jmp_l[j] = jmp_h[j]; pwl[j] = pwh[j] + BK;
+        } else {
+            pal[j] = A.lo + ra * A.ld + 8 * c;
+            jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
+            pwl[j] = Wlo + rw * p.ldw + 8 * c;
+        }
     }
+    constexpr int KSTEP = (NT == 1) ? 2 * BK : BK;      // k consumed per stage
     const int dma_off = 32 * wid * BK;
-    const int switch_tile = A.hi2 ? p.K1 / BK : -1;
-    const int nk = p.K / BK;
+    const int switch_tile = A.hi2 ? p.K1 / KSTEP : -1;
+    const int nk = p.K / KSTEP;
 
     auto issue = [&](int t) {
         f16* const S = S0 + (t & 1) * STAGE + dma_off;
         const bool live = t < nk;
         const bool sw = (t == switch_tile);
-        const int back = live ? 0 : BK, adv = live ? BK : 0;
+        const int back = live ? 0 : KSTEP, adv = live ? KSTEP : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - back;
@@ -435,6 +459,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
             }
             // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
             // would wait for the previous MFMA's result every time)
+            if constexpr (NT == 1) {     // plain fp16: slot "lo" is the next 32 k, one product each
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -450,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -472,14 +509,14 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     const float x = fminf(fmaxf(w[i] * scale, -F16_MAX), F16_MAX);
     const f16 h = (f16)x;
     hi[i] = h;
-    lo[i] = (f16)(x - (float)h);
+    if (lo) lo[i] = (f16)(x - (float)h);
 }
 
 }  // namespace
 
 extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s)
 {
-    CVX_REQUIRE(w && hi && lo && n >= 0, "split_f16: bad arguments");
+    CVX_REQUIRE(w && hi && n >= 0, "split_f16: bad arguments");      // lo == NULL: plain fp16 cast (saturating)
     if (n == 0) return CVX_OK;
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                        w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale);
@@ -487,18 +524,18 @@ extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t
     return CVX_OK;
 }
 
-template <int STAGES>
+template <int STAGES, int NT>
 static void launch_dma(const cvx_gemm_args& a, const PreSplitA& A, const f16* wh, const f16* wl, float acc_scale,
                        const SplitOut& so, dim3 grid, int tiles_m, int tiles_n, int map_mode, hipStream_t st)
 {
     const size_t lds = (size_t)STAGES * 4 * TILE_H * sizeof(f16);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma_kernel<STAGES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<STAGES, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm_f16x3_dma_kernel<STAGES>, grid, dim3(256), lds, st, a, A, wh, wl, acc_scale, so,
+    hipLaunchKernelGGL((gemm_f16x3_dma_kernel<STAGES, NT>), grid, dim3(256), lds, st, a, A, wh, wl, acc_scale, so,
                        tiles_m, tiles_n, map_mode);
 }
 
@@ -507,30 +544,34 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
 {
     const int rc = cvxg::validate_gemm_args(a);
     if (rc != CVX_OK) return rc;
-    CVX_REQUIRE(W_hi && W_lo, "gemm_f16x3: null split weights");
+    CVX_REQUIRE(W_hi, "gemm_f16x3: null split weights");
+    const bool single = (W_lo == nullptr);      // plain fp16 operands (hi halves only), one MFMA product
     CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
     CVX_REQUIRE((((uintptr_t)W_hi | (uintptr_t)W_lo) & 15) == 0, "gemm_f16x3: split weights must be 16-byte aligned");
+    if (single)
+        CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
+                    "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
     SplitOut so{nullptr, nullptr, 0, 1, nullptr, nullptr, 0};
     PreSplitA A{nullptr, nullptr, 0, nullptr, nullptr, 0};
     if (io) {
         if (io->C_hi || io->C_lo) {
-            CVX_REQUIRE(io->C_hi && io->C_lo && io->ldc_h >= ((io->Vt_hi && a->rope_cols > 0) ? a->rope_cols : a->N), "gemm_f16x3: bad split output");
+            CVX_REQUIRE(io->C_hi && (io->C_lo || single) && io->ldc_h >= ((io->Vt_hi && a->rope_cols > 0) ? a->rope_cols : a->N), "gemm_f16x3: bad split output");
             so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
         }
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
         if (io->Vt_hi || io->Vt_lo) {
-            CVX_REQUIRE(io->Vt_hi && io->Vt_lo && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
+            CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
                         (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= a->rope_T && io->vt_ld % 8 == 0 &&
                         a->M % a->rope_T == 0 && a->rope_T % 4 == 0 && so.write_f32 == 0,
                         "gemm_f16x3: QKV-transpose output needs the RoPE arguments, N = 3*H*64, T %% 4 == 0, vt_ld >= T and write_f32 = 0");
             so.vt_hi = reinterpret_cast<f16*>(io->Vt_hi); so.vt_lo = reinterpret_cast<f16*>(io->Vt_lo); so.vt_ld = io->vt_ld;
         }
         if (io->A_hi || io->A_lo) {
-            CVX_REQUIRE(io->A_hi && io->A_lo && io->lda_h % 8 == 0 && (((uintptr_t)io->A_hi | (uintptr_t)io->A_lo) & 15) == 0,
+            CVX_REQUIRE(io->A_hi && (io->A_lo || single) && io->lda_h % 8 == 0 && (((uintptr_t)io->A_hi | (uintptr_t)io->A_lo) & 15) == 0,
                         "gemm_f16x3: bad pre-split A");
             A.hi = reinterpret_cast<const f16*>(io->A_hi); A.lo = reinterpret_cast<const f16*>(io->A_lo); A.ld = io->lda_h;
             if (a->A2) {
-                CVX_REQUIRE(io->A2_hi && io->A2_lo && io->lda2_h % 8 == 0 &&
+                CVX_REQUIRE(io->A2_hi && (io->A2_lo || single) && io->lda2_h % 8 == 0 &&
                             (((uintptr_t)io->A2_hi | (uintptr_t)io->A2_lo) & 15) == 0, "gemm_f16x3: bad pre-split A2");
                 A.hi2 = reinterpret_cast<const f16*>(io->A2_hi); A.lo2 = reinterpret_cast<const f16*>(io->A2_lo); A.ld2 = io->lda2_h;
             }
@@ -554,14 +595,21 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB
         static bool attr256 = false;
         if (!attr256) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma256_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma256_kernel<3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma256_kernel<1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
             attr256 = true;
         }
-        hipLaunchKernelGGL(gemm_f16x3_dma256_kernel, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl, acc_scale, so,
-                           tm, tn, map_mode);
+        if (single)
+            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<1>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
+                               acc_scale, so, tm, tn, map_mode);
+        else
+            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<3>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
+                               acc_scale, so, tm, tn, map_mode);
     } else if (A.hi) {
-        launch_dma<2>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);   // 2 stages, 2 blocks / CU
+        if (single) launch_dma<2, 1>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
+        else launch_dma<2, 3>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);   // 2 stages, 2 blocks / CU
     } else {
         const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
         static bool attr = false;

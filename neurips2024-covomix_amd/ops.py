@@ -39,7 +39,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
     of the fp32 one (needs K % 32 == 0; small-M problems stay on the fp32 kernel).
     a_split / a2_split = (hi, lo) fp16 copies of a / a2 (then every tile arrives by LDS-DMA; `a` is only used for
-    its shape); out_split = (hi, lo) receives a split copy of the result; write_f32=False skips the fp32 store."""
+    its shape); out_split = (hi, lo) receives a split copy of the result; write_f32=False skips the fp32 store.
+    Any `lo` may be None: w_split = (hi, None, 1/scale) selects the single-term fp16 kernel (plain fp16 operands,
+    fp32 accumulate; needs a_split and K % 64 == 0), whose inputs / outputs only carry the hi halves."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -71,30 +73,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
     if w_split is not None and K % 32 == 0 and (M > 64 or a_split is not None or out_split is not None):
         hi, lo, inv_scale = w_split
-        assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == (N, K) and lo.shape == (N, K)
-        assert hi.is_contiguous() and lo.is_contiguous() and hi.is_cuda and lo.is_cuda
+        assert hi.dtype == torch.float16 and hi.shape == (N, K) and hi.is_contiguous() and hi.is_cuda
+        assert lo is None or (lo.dtype == torch.float16 and lo.shape == (N, K) and lo.is_contiguous() and lo.is_cuda)
         g.ldw = K
         io = GemmSplitIO()
         io.write_f32 = 1 if write_f32 else 0
         if a_split is not None:
             ah, al = a_split
-            assert ah.dtype == torch.float16 and ah.shape == a.shape and al.shape == a.shape and ah.stride(1) == 1
-            io.A_hi, io.A_lo, io.lda_h = ah.data_ptr(), al.data_ptr(), ah.stride(0)
+            assert ah.dtype == torch.float16 and ah.shape == a.shape and (al is None or al.shape == a.shape) and ah.stride(1) == 1
+            io.A_hi, io.A_lo, io.lda_h = ah.data_ptr(), _p(al), ah.stride(0)
             if a2 is not None:
                 assert a2_split is not None, "pre-split A needs a pre-split A2 as well"
                 bh, bl = a2_split
-                assert bh.dtype == torch.float16 and bh.shape == a2.shape and bl.shape == a2.shape
-                io.A2_hi, io.A2_lo, io.lda2_h = bh.data_ptr(), bl.data_ptr(), bh.stride(0)
+                assert bh.dtype == torch.float16 and bh.shape == a2.shape and (bl is None or bl.shape == a2.shape)
+                io.A2_hi, io.A2_lo, io.lda2_h = bh.data_ptr(), _p(bl), bh.stride(0)
         if out_split is not None:
             oh, ol = out_split
-            assert oh.dtype == torch.float16 and oh.shape[0] == M and ol.shape == oh.shape and oh.stride(1) == 1
+            assert oh.dtype == torch.float16 and oh.shape[0] == M and (ol is None or ol.shape == oh.shape) and oh.stride(1) == 1
             assert oh.shape[1] == N or (vt_split is not None and oh.shape[1] == rope_cols)
-            io.C_hi, io.C_lo, io.ldc_h = oh.data_ptr(), ol.data_ptr(), oh.stride(0)
+            io.C_hi, io.C_lo, io.ldc_h = oh.data_ptr(), _p(ol), oh.stride(0)
         if vt_split is not None:          # QKV mode: v columns transposed per (sequence, head) for the f16x3 attention
             vh, vl = vt_split
-            assert vh.dtype == torch.float16 and vh.is_contiguous() and vl.is_contiguous() and vh.shape == vl.shape
-            io.Vt_hi, io.Vt_lo, io.vt_ld = vh.data_ptr(), vl.data_ptr(), vh.shape[-1]
-        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), lo.data_ptr(), inv_scale, C.byref(io), _stream()),
+            assert vh.dtype == torch.float16 and vh.is_contiguous() and (vl is None or (vl.is_contiguous() and vh.shape == vl.shape))
+            io.Vt_hi, io.Vt_lo, io.vt_ld = vh.data_ptr(), _p(vl), vh.shape[-1]
+        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), _p(lo), inv_scale, C.byref(io), _stream()),
                    "cvx_gemm_f16x3")
         return out
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
@@ -103,29 +105,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
 
 
 def split_act_f16(x: torch.Tensor, hi: Optional[torch.Tensor] = None, lo: Optional[torch.Tensor] = None):
-    """(hi, lo) fp16 halves of an fp32 activation tensor (unscaled) - for GEMMs that take A pre-split."""
+    """(hi, lo) fp16 halves of an fp32 activation tensor (unscaled) - for GEMMs that take A pre-split.
+    With `hi` given and lo=None only the (saturating) fp16 cast is written."""
     _chk_f32(x)
     assert x.is_contiguous()
     if hi is None:
         hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    _lib.check(_lib.load().cvx_split_f16(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), 1.0, _stream()),
+    _lib.check(_lib.load().cvx_split_f16(x.data_ptr(), hi.data_ptr(), _p(lo), x.numel(), 1.0, _stream()),
                "cvx_split_f16")
     return hi, lo
 
 
-def split_f16(w: torch.Tensor):
+def split_f16(w: torch.Tensor, with_lo: bool = True):
     """(hi, lo, 1/scale): fp16 halves of w*scale, hi = fp16(w*scale), lo = fp16(w*scale - hi), with scale the power
     of two that brings max|w| to [2^13, 2^14) so the lo halves stay out of the fp16 subnormal range.
-    Load-time weight packing."""
+    Load-time weight packing.  with_lo=False: (hi, None, 1/scale) for the single-term fp16 mode."""
     import math
     _chk_f32(w)
     w = w.contiguous()
     amax = float(w.abs().max())
     scale = 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
     hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
-    lo = torch.empty(w.shape, dtype=torch.float16, device=w.device)
-    _lib.check(_lib.load().cvx_split_f16(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), w.numel(), scale, _stream()),
+    lo = torch.empty(w.shape, dtype=torch.float16, device=w.device) if with_lo else None
+    _lib.check(_lib.load().cvx_split_f16(w.data_ptr(), hi.data_ptr(), _p(lo), w.numel(), scale, _stream()),
                "cvx_split_f16")
     return hi, lo, 1.0 / scale
 
@@ -136,7 +139,7 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     _chk_f32(x, gamma, beta, out)
     assert x.is_contiguous() and (out is None or out.is_contiguous()) and gamma.stride(-1) == 1
     oh, ol = out_split if out_split is not None else (None, None)
-    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and ol.is_contiguous() and oh.numel() == x.numel())
+    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and (ol is None or ol.is_contiguous()) and oh.numel() == x.numel())
     D = x.shape[-1]
     rows = x.numel() // D
     rpg = rows if rows_per_group is None else rows_per_group
@@ -150,24 +153,26 @@ def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H
     assert qkv.is_contiguous() and (out is None or out.is_contiguous())
     assert qkv.numel() == Bt * T * 3 * H * 64 and (out is None or out.numel() == Bt * T * H * 64)
     oh, ol = out_split if out_split is not None else (None, None)
-    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and ol.is_contiguous() and oh.numel() == Bt * T * H * 64)
+    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and (ol is None or ol.is_contiguous()) and oh.numel() == Bt * T * H * 64)
     _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), _p(oh), _p(ol), Bt, T, H, scale, _stream()),
                "cvx_attention_f32")
     return out if out is not None else out_split
 
 
 def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None):
-    """Split-precision attention on the pairs written by gemm(..., out_split=qk_split, vt_split=vt_split)."""
+    """Split-precision attention on the pairs written by gemm(..., out_split=qk_split, vt_split=vt_split).
+    (hi, None) pairs select the single-term fp16 kernel."""
     qh, ql = qk_split
     vh, vl = vt_split
+    assert (ql is None) == (vl is None)
     for t in (qh, ql, vh, vl):
-        assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()
+        assert t is None or (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous())
     assert qh.shape == (Bt * T, 2 * H * 64) and vh.shape[0] == Bt * H * 64
     Tp = vh.shape[1]
     _chk_f32(out)
     oh, ol = out_split if out_split is not None else (None, None)
     assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and oh.numel() == Bt * T * H * 64)
-    _lib.check(_lib.load().cvx_attention_f16x3(qh.data_ptr(), ql.data_ptr(), vh.data_ptr(), vl.data_ptr(), _p(out), _p(oh), _p(ol),
+    _lib.check(_lib.load().cvx_attention_f16x3(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), _p(oh), _p(ol),
                                                Bt, T, Tp, H, scale, _stream()), "cvx_attention_f16x3")
     return out if out is not None else out_split
 

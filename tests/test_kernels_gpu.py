@@ -367,3 +367,79 @@ def test_attention_f16x3_forced_rescale_and_tail(ops):
     q, k, v = qkv.double().reshape(Bt, T, 3, 1, 64).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(Bt, T, 64)
     assert rel_l2(out, ref) < 5e-6
+
+
+# ---------------------------------------------------------------- single-term fp16 mode (precision="f16", opt-in)
+F16_TOL = 1e-3        # plain fp16 operands (11-bit significand), fp32 accumulate: measured 2-4e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024), (2500, 512, 4096), (300, 256, 512), (999, 80, 1024)])
+def test_gemm_f16_single_term(ops, M, N, K):
+    """W_lo == NULL: hi halves only, K consumed 64 per stage (256x256 tile for big shapes, 128x128 otherwise).
+    The result must equal the product of the fp16-ROUNDED operands to fp32 accuracy, and the unrounded product
+    to fp16 accuracy."""
+    a, w = randn(M, K, seed=200) * 2.0, randn(N, K, seed=201) / math.sqrt(K)
+    b, r = randn(N, seed=202), randn(M, N, seed=203)
+    wh, wl, inv = ops.split_f16(w, with_lo=False)
+    assert wl is None
+    ah = torch.empty(M, K, dtype=torch.float16, device=dev())
+    ops.split_act_f16(a, ah, None)
+    assert torch.equal(ah, a.half())
+    out = torch.full((M, N), float("nan"), device=dev())
+    oh = torch.empty(M, N, dtype=torch.float16, device=dev())
+    ops.gemm(a, w, out, bias=b, act=1, residual=r, w_split=(wh, None, inv), a_split=(ah, None), out_split=(oh, None))
+    rounded = F.gelu(ah.double() @ (wh.double() * inv).T + b.double()) + r.double()
+    exact = F.gelu(a.double() @ w.double().T + b.double()) + r.double()
+    assert rel_l2(out, rounded) < 3e-6
+    e = rel_l2(out, exact)
+    print("f16 single-term gemm", (M, N, K), e)
+    assert e < F16_TOL
+    assert torch.equal(oh, out.half())
+
+
+def test_gemm_f16_single_term_concat(ops):
+    M, N = 2304, 512
+    x, s = randn(M, 256, seed=210), randn(M, 192, seed=211)
+    w = randn(N, 448, seed=212) / math.sqrt(448)
+    wh, _, inv = ops.split_f16(w, with_lo=False)
+    out = torch.empty(M, N, device=dev())
+    ops.gemm(x, w, out, a2=s, w_split=(wh, None, inv), a_split=(x.half(), None), a2_split=(s.half(), None))
+    ref = torch.cat((x.half(), s.half()), -1).double() @ (wh.double() * inv).T
+    assert rel_l2(out, ref) < 3e-6
+
+
+def test_gemm_f16_single_term_rejects_bad_k(ops):
+    import covomix_amd._lib as L
+    a, w = randn(128, 96), randn(128, 96)
+    wh, _, inv = ops.split_f16(w, with_lo=False)
+    with pytest.raises(L.CovomixHipError):              # K = 96 is not a multiple of 64
+        ops.gemm(a, w, torch.empty(128, 128, device=dev()), w_split=(wh, None, inv), a_split=(a.half(), None))
+
+
+@pytest.mark.parametrize("Bt,T,H", [(2, 128, 2), (1, 36, 1), (2, 1000, 1)])
+def test_attention_f16_single_term(ops, Bt, T, H):
+    """QKV GEMM (single-term, q|k hi + v^T hi) -> single-term attention, against fp64 attention."""
+    dim = 128
+    x = randn(Bt * T, dim, seed=220)
+    w = randn(3 * H * 64, dim, seed=221) / math.sqrt(dim)
+    inv_f = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(T).float()[:, None] * inv_f[None, :]
+    cos, sin = ang.cos().to(dev()).contiguous(), ang.sin().to(dev()).contiguous()
+    Tp = ((T + 31) // 32) * 32
+    qk = (torch.empty(Bt * T, 2 * H * 64, dtype=torch.float16, device=dev()), None)
+    vt = (torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev()), None)
+    wh, _, inv = ops.split_f16(w, with_lo=False)
+    dummy = torch.empty(Bt * T, 3 * H * 64, device=dev())
+    ops.gemm(x, w, dummy, rope=(cos, sin), rope_cols=2 * H * 64, w_split=(wh, None, inv), a_split=(x.half(), None),
+             out_split=qk, vt_split=vt, write_f32=False)
+    ref_qkv = torch.empty(Bt * T, 3 * H * 64, device=dev())
+    ops.gemm(x, w, ref_qkv, rope=(cos, sin), rope_cols=2 * H * 64)
+    q, k, v = [t.reshape(Bt, T, H, 64).permute(0, 2, 1, 3).double() for t in ref_qkv.reshape(Bt, T, 3, H * 64).unbind(2)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(Bt * T, H * 64)
+    out = torch.empty(Bt * T, H * 64, device=dev())
+    oh = torch.empty(Bt * T, H * 64, dtype=torch.float16, device=dev())
+    ops.attention_f16x3(qk, vt, out, Bt, T, H, 0.125, out_split=(oh, None))
+    e = rel_l2(out, ref)
+    print("f16 single-term attention", (Bt, T, H), e)
+    assert e < 2e-3
+    assert torch.equal(oh, out.half())

@@ -166,3 +166,25 @@ def test_full_size_properties():
     outp = model.synthesis_sample(args[0][perm.cuda()], args[1][perm.cuda()], args[2][perm.cuda()], 0.7,
                                   y0=inp["y0"][perm])
     assert rel_l2(outp, out[perm.cuda()]) < 1e-5
+
+
+# ---------------------------------------------------------------- opt-in precision="f16" (single-term fp16 operands)
+F16_ROLL_TOL = 1e-3          # BASELINE.json north_star budget: <= 1e-3 rel-L2 on the final mel
+
+
+@pytest.mark.parametrize("name", ["vomix_full", "vosingle_full", "vomix_small"])
+def test_f16_precision_rollout_within_north_star_budget(name):
+    """precision='f16' is NOT fp32-class (the default f16x3 is); it must stay inside the 1e-3 rel-L2 budget the
+    north star states, measured against the REFERENCE golden rollout."""
+    from covomix_amd.conditional_model import CoVoMixModel
+    kind, kw = CASES[name]
+    g = np.load(os.path.join(GOLDEN, f"acoustic_{name}.npz"))
+    model = CoVoMixModel.from_state_dict(_state(kind, **kw), precision="f16").eval().to("cuda:0")
+    model.nfe = int(g["rollout_nfe"])
+    ids = torch.from_numpy(g["phoneme_ids"][:1]).cuda()
+    cond = torch.from_numpy(g["cond"][:1]).cuda()
+    mask = torch.from_numpy(g["mask"][:1]).cuda()
+    out = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=0.7, y0=torch.from_numpy(g["y0"][:1]))
+    e = rel_l2(out, torch.from_numpy(g["rollout"]))
+    print(name, "f16 rollout", int(g["rollout_nfe"]), e)
+    assert e < F16_ROLL_TOL
