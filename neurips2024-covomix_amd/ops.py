@@ -73,9 +73,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
     if w_split is not None and K % 32 == 0 and (M > 64 or a_split is not None or out_split is not None):
         hi, lo, inv_scale = w_split
-        assert hi.dtype == torch.float16 and hi.shape == (N, K) and hi.is_contiguous() and hi.is_cuda
-        assert lo is None or (lo.dtype == torch.float16 and lo.shape == (N, K) and lo.is_contiguous() and lo.is_cuda)
-        g.ldw = K
+        assert hi.dtype == torch.float16 and hi.shape == (N, K) and hi.stride(1) == 1 and hi.is_cuda
+        assert lo is None or (lo.dtype == torch.float16 and lo.shape == (N, K) and lo.stride() == hi.stride() and lo.is_cuda)
+        g.ldw = hi.stride(0)                       # rows may be padded (row stride > K)
         io = GemmSplitIO()
         io.write_f32 = 1 if write_f32 else 0
         if a_split is not None:
