@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import zlib
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Optional, Dict, Tuple
 
 import numpy as np
 
@@ -118,6 +118,13 @@ def _rule(name: str, shape) -> Tuple[float, float]:
         return 0.1, 1.0
     if name == "sinu_pos_emb.0.weights" or name == "to_phoneme_emb.weight":
         return 1.0, 0.0
+    # ---- text2semantic (N1)
+    if name in ("semantic_token_emb.weight", "token_emb.text.weight"):
+        return 0.1, 0.0                      # tied logits: std(logit) ~ 0.1 * sqrt(dim) ~ 2.3
+    if name.startswith("start_token.") or name.endswith(".null_kv"):
+        return 1.0, 0.0
+    if name.endswith(".gamma"):
+        return 0.1, 1.0
     # ---- vocoder (weight-norm parametrisation)
     if name.endswith(".weight_g"):
         g = 0.3 if name.startswith("conv_post") else 1.2
@@ -139,6 +146,59 @@ def synth_array(name: str, shape, seed: int = 0) -> np.ndarray:
 
 def synth_state_dict(shapes: Shapes, seed: int = 0) -> "Dict[str, np.ndarray]":
     return OrderedDict((k, synth_array(k, v, seed)) for k, v in shapes.items())
+
+
+def t2s_param_shapes(two_output: bool = False, dim: int = 512, dim_target: Optional[int] = None, source_depth: int = 4,
+                     target_depth: int = 4, heads: int = 8, num_text: int = 30530, num_semantic: int = 501) -> Shapes:
+    """Parameters of the reference TextToSemantic in nn.Module.parameters() order (text2semantic.py:405-600;
+    running_command/T2S_CoSingle.sh: dim 512; T2S_CoMix.sh: two_output, target dim 1024).  The rotary `freqs`
+    parameter is shared by the layers of one transformer and appears once (under layers.0.0)."""
+    dim_t = dim_target or dim
+    inner = heads * 64
+    emb = dim_t // 2 if two_output else dim_t
+    sh: Shapes = OrderedDict()
+    sh["semantic_token_emb.weight"] = (num_semantic + 1, emb)
+    sh["token_emb.text.weight"] = (num_text + 1, dim)
+    sh["start_token.speech"] = (dim_t,)
+    sh["start_token.text"] = (dim,)
+
+    def attn(p, d, d_ctx, first, null):
+        if first:
+            sh[p + ".rotary_emb.freqs"] = (32,)
+        if null:
+            sh[p + ".null_kv"] = (2, heads, 1, 64)
+        sh[p + ".norm.gamma"] = (d,)
+        sh[p + ".to_q.0.weight"] = (inner, d)
+        sh[p + ".to_kv.0.weight"] = (2 * inner, d_ctx)
+        sh[p + ".to_out.weight"] = (d, inner)
+
+    def ff(p, d):
+        di = int(d * 4 * 2 / 3)
+        sh[p + ".0.gamma"] = (d,)
+        sh[p + ".1.weight"] = (2 * di, d)
+        sh[p + ".1.bias"] = (2 * di,)
+        sh[p + ".4.weight"] = (d, di)
+        sh[p + ".4.bias"] = (d,)
+
+    for i in range(source_depth):
+        attn(f"source_transformer.layers.{i}.0", dim, dim, i == 0, False)
+        ff(f"source_transformer.layers.{i}.2", dim)
+    sh["source_transformer.final_norm.gamma"] = (dim,)
+    for i in range(target_depth):
+        attn(f"target_transformer.layers.{i}.0", dim_t, dim_t, i == 0, False)
+        attn(f"target_transformer.layers.{i}.1", dim_t, dim, False, True)
+        ff(f"target_transformer.layers.{i}.2", dim_t)
+    sh["target_transformer.final_norm.gamma"] = (dim_t,)
+    return sh
+
+
+def t2s_state_dict(shapes: Shapes, seed: int = 0) -> "Dict[str, np.ndarray]":
+    """Recipe weights with the two rotary `freqs` parameters set to their real (non-learned) values."""
+    sd = synth_state_dict(shapes, seed)
+    for k in sd:
+        if k.endswith("rotary_emb.freqs"):
+            sd[k] = np.asarray(rotary_inv_freq(64), dtype=np.float32)
+    return sd
 
 
 def rotary_inv_freq(dim_head: int = 64, theta: float = 10000.0) -> np.ndarray:
