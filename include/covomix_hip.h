@@ -175,6 +175,54 @@ int cvx_hifigan_post_f32(const float* x, const float* w, float bias, float* y,
  * numpy astype('int16') semantics for in-range values (C truncation toward zero). */
 int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * text2semantic autoregressive decode - SURVEY.md section 8f row N1 ("next" row, built after the hot path).
+ *
+ * cvx_t2s_decode_steps enqueues n_steps token steps of the sampling loop of TextToSemantic.generate
+ * (covomix/covomix_model/text2semantic.py:748-820) at batch 1 with a KV cache: per decoder layer
+ * Attention.forward for the causal self-attention (:225-270, rotary_embedding_torch.py:146-157) and the
+ * cross-attention over [learned null k/v | encoder context] (:253-262), the GEGLU FeedForward (:154-167), then
+ * final RMSNorm (:143-151), tied logits (:545), top_k (:126-132) + gumbel_sample (:105-113) from the caller's
+ * U(0,1) draws, eos bookkeeping (:803-818) and the embedding of the sampled ids as the next input.
+ * No host synchronisation: the position lives in state[0] on the device, so a captured graph replays.
+ *
+ * Host packing contract (neurips2024-covomix_amd/t2s.py):
+ *   wqkv_s [3*inner, dim] = to_q | to_k | to_v rows; inside every 64-row head of to_q and to_k the rows are
+ *       permuted (0,2,..,62,1,3,..,63) so the reference's interleaved rotary pairs become half-split pairs;
+ *   kv_c   [n_ctx, 2, inner]: row 0 = null_kv, rows 1.. = to_kv(encoder output), computed once per utterance;
+ *   w2     [dim, ff_inner_pad]: the K dimension zero-padded to a multiple of 4;
+ *   rope_cos / rope_sin [max_len, 32]: cos / sin(position * freqs[i]);
+ *   uniforms [max_len, streams, vocab]; tokens [streams, max_len] int64;
+ *   state int32[4]: [0] position (= tokens produced so far), [1] 1 once an eos was sampled in any stream,
+ *       [2] number of steps at that moment, [3] context rows (null row included) used when n_ctx == 0, so that one
+ *       captured graph serves utterances of different text length; x must hold start_token and state[0..2]
+ *       zeros before the first step.
+ * The caller must not ask for more than max_len steps in total (extra steps are ignored on the device).
+ */
+typedef struct {
+    const float *gamma_s, *wqkv_s, *wo_s;        /* self-attention: norm.gamma, packed to_q|to_kv, to_out [dim, inner] */
+    const float *gamma_c, *wq_c, *wo_c;          /* cross-attention */
+    const float *kv_c;
+    const float *gamma_f, *w1, *b1, *w2, *b2;    /* FeedForward: RMSNorm gamma, Linear(dim, 2F)+b, Linear(F, dim)+b */
+    float *k_cache, *v_cache;                    /* [max_len, inner] */
+} cvx_t2s_layer;
+
+typedef struct {
+    int32_t dim, inner, heads, ff_inner, ff_inner_pad, depth, streams, vocab, dim_emb, n_ctx, max_len, top_k;
+    float temperature;
+    const cvx_t2s_layer* layers;                 /* HOST array of `depth` entries */
+    const float *final_gamma, *emb, *rope_cos, *rope_sin, *uniforms;
+    float *x, *q, *att, *h, *logits;             /* [dim], [inner], [inner], [ff_inner_pad], [streams, vocab] */
+    int64_t* tokens;
+    int32_t* state;
+} cvx_t2s_decoder;
+
+int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream_t stream);
+
+/* out[r, c] = h[r, c] * gelu(h[r, F + c]) for c < F, 0 for F <= c < ld_out   (GEGLU, text2semantic.py:154-157;
+ * the encoder's feed-forward; ld_out >= F pads the K dimension of the following GEMM). */
+int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F, int64_t ld_out, cvx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

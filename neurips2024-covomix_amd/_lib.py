@@ -53,9 +53,24 @@ class ConvArgs(C.Structure):
     ]
 
 
+class T2SLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c",
+                                          "gamma_f", "w1", "b1", "w2", "b2", "k_cache", "v_cache")]
+
+
+class T2SDecoder(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "inner", "heads", "ff_inner", "ff_inner_pad", "depth", "streams", "vocab",
+                                         "dim_emb", "n_ctx", "max_len", "top_k")] + \
+               [("temperature", C.c_float), ("layers", C.POINTER(T2SLayer))] + \
+               [(n, C.c_void_p) for n in ("final_gamma", "emb", "rope_cos", "rope_sin", "uniforms",
+                                          "x", "q", "att", "h", "logits", "tokens", "state")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/covomix_hip.h
 SIGNATURES = {
     "cvx_version": (C.c_int, []),
+    "cvx_t2s_decode_steps": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p]),
+    "cvx_geglu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),

@@ -1,0 +1,376 @@
+// text2semantic autoregressive decode: one token step of the reference's
+// TextToSemantic.generate sampling loop (covomix/covomix_model/text2semantic.py:748-820) with a KV cache.
+//
+// B = 1, one new position per step: every projection is a matrix-VECTOR product, so the step is bound by streaming
+// the decoder weights (CoSingle 67 MB, CoMix 184 MB of fp32 per token) - an HBM/MALL-bound path, not an MFMA one.
+// Kernels (all fp32, fp32 accumulate):
+//   gemv_kernel<MODE>   block = 4 waves, every wave owns TWO output rows (the pairs are chosen so that the epilogue
+//                       has both members of a RoPE pair / a GEGLU (value, gate) pair in one wave); the input vector is
+//                       staged in LDS once per block, optionally RMS-normalised (F.normalize * sqrt(D) * gamma,
+//                       text2semantic.py:143-151) on the way; rows stream with 16-byte loads + a wave reduction.
+//   attn_kernel         one block per head over the cached keys (self: roped keys [0, pos]; cross: learned null k/v +
+//                       the encoder context, text2semantic.py:253-262); 16 lanes per key for coalesced 256-byte rows.
+//   sample_kernel       top-k (k = ceil(0.1 * V), :126-132) + Gumbel argmax (:105-113) from caller-supplied U(0,1)
+//                       draws, eos bookkeeping (:803-818), and the embedding of the sampled ids = next step's input.
+// The reference rotates ALL cached keys again every step with rotary_embedding_torch's interleaved pairs
+// (rotary_embedding_torch.py:146-157); rotating a key once at its own position when it enters the cache is the same
+// arithmetic.  Interleaved pairs (2i, 2i+1) become half-split pairs (i, i+32) by permuting the rows of to_q / to_k
+// inside every head at load time (q.k is invariant under a common permutation) - done by the host packer.
+// Positions: the device counter state[0]; every kernel reads it, so a captured HIP graph of N steps replays as is.
+#include "cvx_common.h"
+
+namespace {
+
+constexpr int T2S_MAX_KEYS = 4096;
+constexpr int T2S_MAX_DIM = 4096;     // floats of the staged input vector (16 KiB of LDS)
+
+enum { MODE_QKV = 0, MODE_PLAIN = 1, MODE_RES = 2, MODE_GEGLU = 3, MODE_LOGITS = 4 };
+
+struct GemvArgs {
+    const float* W;          // [N, ldw]
+    int64_t ldw;
+    const float* x;          // input vector [K]
+    const float* gamma;      // RMSNorm weight over x (NULL: x is used as is)
+    const float* bias;       // [N] or NULL
+    float* y;                // output
+    int N, K;
+    // MODE_QKV: rows [0, inner) q, [inner, 2 inner) k, [2 inner, 3 inner) v; RoPE on q/k at position *pos
+    int inner;
+    const float* rope_cos;   // [max_len, 32]
+    const float* rope_sin;
+    float* k_cache;          // [max_len, inner]
+    float* v_cache;
+    const int* state;        // state[0] = pos
+    int max_len;             // positions >= max_len are clamped (the host never asks for them; keeps a stray call in bounds)
+    // MODE_GEGLU: rows j (value) and j + F (gate), F = N / 2; y[j] for j < F, zero fill up to y_pad
+    int y_pad;
+    // MODE_LOGITS: `streams` independent slices of the normalised vector: y[s*N + n] = W[n,:] . xn[s*K .. (s+1)*K)
+    int streams;
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float xs[T2S_MAX_DIM];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length
+
+    // ---- stage (and normalise) the input vector
+    float ss = 0.f;
+    for (int k = tid; k < Kin; k += 256) {
+        const float v = a.x[k];
+        ss += v * v;
+        xs[k] = a.gamma ? v * a.gamma[k] : v;
+    }
+    float inv = 1.f;
+    if (a.gamma) {
+        ss = wave_sum(ss);
+        if (lane == 0) red[wid] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        inv = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);          // F.normalize(eps = 1e-12) * sqrt(dim)
+    } else {
+        __syncthreads();
+    }
+
+    // ---- the two rows of this wave
+    const int pair = blockIdx.x * 4 + wid;
+    int r0, r1, sidx = 0;
+    bool valid;
+    if (MODE == MODE_QKV) {
+        // pair p -> head-local (h, i): rows base + h*64 + i and + 32 for i in [0, 32); 3*inner/2 pairs in total
+        const int per = a.inner / 2;
+        const int sec = pair / per, q = pair - sec * per;             // 0 q, 1 k, 2 v
+        r0 = sec * a.inner + (q >> 5) * 64 + (q & 31);
+        r1 = r0 + 32;
+        valid = pair < 3 * per;
+    } else if (MODE == MODE_GEGLU) {
+        const int F = a.N / 2;
+        r0 = pair; r1 = pair + F;
+        valid = pair < F;
+    } else if (MODE == MODE_LOGITS) {
+        const int per = (a.N + 1) / 2;
+        sidx = pair / per;
+        r0 = 2 * (pair - sidx * per); r1 = r0 + 1;
+        valid = sidx < a.streams;
+    } else {
+        r0 = 2 * pair; r1 = r0 + 1;
+        valid = r0 < a.N;
+    }
+    if (!valid) {
+        if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
+            const int F = a.N / 2;
+            if (pair >= F && pair < a.y_pad && lane == 0) a.y[pair] = 0.f;
+        }
+        return;
+    }
+    const bool has1 = r1 < a.N;
+    const float* w0 = a.W + (int64_t)r0 * a.ldw;
+    const float* w1 = a.W + (int64_t)(has1 ? r1 : r0) * a.ldw;
+    const float* xv = xs + ((MODE == MODE_LOGITS) ? sidx * a.K : 0);
+    float s0 = 0.f, s1 = 0.f;
+    const int K4 = a.K & ~3;
+    for (int k = 4 * lane; k < K4; k += 256) {
+        const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + k);
+        const f32x4 a0 = gload4(w0 + k);
+        const f32x4 a1 = gload4(w1 + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0 = fmaf(a0[e], xw[e], s0); s1 = fmaf(a1[e], xw[e], s1); }
+    }
+    for (int k = K4 + lane; k < a.K; k += 64) { s0 = fmaf(w0[k], xv[k], s0); s1 = fmaf(w1[k], xv[k], s1); }
+    s0 = wave_sum(s0) * inv;
+    s1 = wave_sum(s1) * inv;
+    if (lane != 0) return;
+    if (a.bias) { s0 += a.bias[r0]; if (has1) s1 += a.bias[r1]; }
+
+    if (MODE == MODE_QKV) {
+        const int pos = min(a.state[0], a.max_len - 1);
+        const int sec = r0 / a.inner, c0 = r0 - sec * a.inner;        // column inside q / k / v
+        if (sec < 2) {                                                // half-split RoPE on the (i, i+32) pair
+            const float c = a.rope_cos[pos * 32 + (c0 & 31)], s = a.rope_sin[pos * 32 + (c0 & 31)];
+            const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
+            s0 = n0; s1 = n1;
+        }
+        float* dst = sec == 0 ? a.y : (sec == 1 ? a.k_cache + (int64_t)pos * a.inner : a.v_cache + (int64_t)pos * a.inner);
+        dst[c0] = s0;
+        dst[c0 + 32] = s1;
+    } else if (MODE == MODE_RES) {
+        a.y[r0] += s0;
+        if (has1) a.y[r1] += s1;
+    } else if (MODE == MODE_GEGLU) {
+        a.y[r0] = s0 * gelu_erf(s1);                                  // F.gelu(gate) * x, text2semantic.py:154-157
+    } else if (MODE == MODE_LOGITS) {
+        a.y[sidx * a.N + r0] = s0;
+        if (has1) a.y[sidx * a.N + r1] = s1;
+    } else {
+        a.y[r0] = s0;
+        if (has1) a.y[r1] = s1;
+    }
+}
+
+// ---------------------------------------------------------------- attention of ONE query over n cached keys
+struct AttnArgs {
+    const float* q;          // [heads*64]
+    const float* k;          // key j of head h at k + j*stride + h*64
+    const float* v;
+    int64_t stride;
+    float* out;              // [heads*64]
+    const int* state;
+    int n_fixed;             // >= 0: that many keys; -1: state[0] + 1 (self-attention); -2: state[3] (context length)
+    float scale;
+    int max_len;
+};
+
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
+{
+    __shared__ float sc[T2S_MAX_KEYS];
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float part[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x;
+    const int n = a.n_fixed >= 0 ? a.n_fixed : (a.n_fixed == -1 ? min(a.state[0] + 1, a.max_len) : min(a.state[3], T2S_MAX_KEYS));
+    const int sub = tid & 15, grp = tid >> 4;              // 16 lanes per key, 16 keys per pass
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + h * 64 + 4 * sub);
+    float mx = -3.0e38f;
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        const int j = j0 + grp;
+        float d = 0.f;
+        if (j < n) {
+            const f32x4 k4 = gload4(a.k + (int64_t)j * a.stride + h * 64 + 4 * sub);
+            d = k4[0] * q4[0] + k4[1] * q4[1] + k4[2] * q4[2] + k4[3] * q4[3];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        d *= a.scale;
+        if (j < n) { if (sub == 0) sc[j] = d; mx = fmaxf(mx, d); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = grp; j < n; j += 16) {
+        const f32x4 v4 = gload4(a.v + (int64_t)j * a.stride + h * 64 + 4 * sub);
+        const float p = sc[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, v4[e], acc[e]);
+    }
+    *reinterpret_cast<f32x4*>(&part[grp][4 * sub]) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float o = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o += part[g][tid];
+        a.out[h * 64 + tid] = o / sum;
+    }
+}
+
+// ---------------------------------------------------------------- top-k + Gumbel argmax, eos bookkeeping, next input
+struct SampleArgs {
+    const float* logits;     // [streams, V]
+    const float* uniforms;   // [max_len, streams, V]
+    const float* emb;        // [V, dim_emb]
+    float* x;                // [streams * dim_emb]  next step's input (residual stream)
+    int64_t* tokens;         // [streams, max_len]
+    int* state;              // [0] pos  [1] done  [2] length at the first eos
+    int V, dim_emb, streams, max_len, top_k, eos_id;
+    float inv_temp;
+};
+
+__global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
+{
+    __shared__ float lg[1024];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int chosen;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pos = a.state[0];
+    if (pos >= a.max_len) return;
+    bool eos = false;
+    for (int s = 0; s < a.streams; ++s) {
+        if (tid < a.V) lg[tid] = a.logits[s * a.V + tid];
+        __syncthreads();
+        float val = -INFINITY;
+        if (tid < a.V) {
+            const float me = lg[tid];
+            int cnt = 0;
+            for (int j = 0; j < a.V; ++j) cnt += (lg[j] > me) ? 1 : 0;
+            if (cnt < a.top_k) {
+                const float u = a.uniforms[((int64_t)pos * a.streams + s) * a.V + tid];
+                const float g = -logf(fmaxf(-logf(fmaxf(u, 1e-20f)), 1e-20f));
+                val = me * a.inv_temp + g;
+            }
+        }
+        // argmax, lowest index on ties (torch.argmax)
+        int idx = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(val, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+        }
+        if (lane == 0) { bv[wid] = val; bi[wid] = idx; }
+        __syncthreads();
+        if (tid == 0) {
+            float best = bv[0]; int b = bi[0];
+            for (int w = 1; w < 16; ++w)
+                if (bv[w] > best || (bv[w] == best && bi[w] < b)) { best = bv[w]; b = bi[w]; }
+            chosen = b;
+            a.tokens[(int64_t)s * a.max_len + pos] = b;
+        }
+        __syncthreads();
+        const int tok = chosen;
+        eos = eos || (tok == a.eos_id);
+        for (int d = tid; d < a.dim_emb; d += 1024) a.x[s * a.dim_emb + d] = a.emb[(int64_t)tok * a.dim_emb + d];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (eos && a.state[1] == 0) { a.state[1] = 1; a.state[2] = pos + 1; }
+        a.state[0] = pos + 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h, float* __restrict__ out, int64_t rows,
+                                                   int F, int64_t ld_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ld_out) return;
+    const int64_t r = i / ld_out;
+    const int c = (int)(i - r * ld_out);
+    out[i] = c < F ? h[r * 2 * F + c] * gelu_erf(h[r * 2 * F + F + c]) : 0.f;
+}
+
+template <int MODE>
+void launch_gemv(const GemvArgs& g, int pairs, hipStream_t st)
+{
+    hipLaunchKernelGGL(gemv_kernel<MODE>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, g);
+}
+
+}  // namespace
+
+extern "C" int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F, int64_t ld_out, cvx_stream_t s)
+{
+    CVX_REQUIRE(h && out && rows >= 0 && F > 0 && ld_out >= F, "geglu: bad arguments");
+    if (rows == 0) return CVX_OK;
+    const int64_t n = rows * ld_out;
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       h, out, rows, F, ld_out);
+    CVX_CHECK_LAUNCH("cvx_geglu_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, cvx_stream_t s)
+{
+    CVX_REQUIRE(d && d->layers && n_steps >= 0, "t2s_decode: null decoder");
+    CVX_REQUIRE(d->dim > 0 && d->dim % 4 == 0 && d->dim <= T2S_MAX_DIM && d->inner == d->heads * 64 && d->depth > 0 &&
+                d->streams >= 1 && d->streams <= 2 && d->dim_emb * d->streams == d->dim && d->vocab > 0 && d->vocab <= 1024 &&
+                d->ff_inner > 0 && d->ff_inner_pad >= d->ff_inner && d->ff_inner_pad % 4 == 0 && d->ff_inner_pad <= T2S_MAX_DIM &&
+                d->n_ctx >= 0 && d->n_ctx <= T2S_MAX_KEYS && d->max_len > 0 && d->max_len <= T2S_MAX_KEYS &&
+                d->top_k > 0 && d->top_k <= d->vocab && d->temperature >= 0.f,
+                "t2s_decode: bad dimensions (dim=%d inner=%d heads=%d streams=%d dim_emb=%d vocab=%d ff=%d/%d n_ctx=%d max_len=%d)",
+                d->dim, d->inner, d->heads, d->streams, d->dim_emb, d->vocab, d->ff_inner, d->ff_inner_pad, d->n_ctx, d->max_len);
+    CVX_REQUIRE(d->final_gamma && d->emb && d->rope_cos && d->rope_sin && d->uniforms && d->x && d->q && d->att && d->h &&
+                d->logits && d->tokens && d->state, "t2s_decode: null buffer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    const float scale = 0.125f;        // dim_head ** -0.5
+    for (int step = 0; step < n_steps; ++step) {
+        for (int l = 0; l < d->depth; ++l) {
+            const cvx_t2s_layer& L = d->layers[l];
+            CVX_REQUIRE(L.gamma_s && L.wqkv_s && L.wo_s && L.gamma_c && L.wq_c && L.wo_c && L.kv_c && L.gamma_f && L.w1 && L.b1 &&
+                        L.w2 && L.b2 && L.k_cache && L.v_cache, "t2s_decode: null pointer in layer %d", l);
+            GemvArgs g{};
+            // self-attention: q | k | v with RoPE; k, v appended to the cache at position pos
+            g.W = L.wqkv_s; g.ldw = d->dim; g.x = d->x; g.gamma = L.gamma_s; g.y = d->q; g.N = 3 * d->inner; g.K = d->dim;
+            g.inner = d->inner; g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.k_cache = L.k_cache; g.v_cache = L.v_cache;
+            g.state = d->state; g.max_len = d->max_len;
+            launch_gemv<MODE_QKV>(g, 3 * d->inner / 2, st);
+            AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, d->att, d->state, -1, scale, d->max_len};
+            hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads), dim3(256), 0, st, at);
+            g = GemvArgs{};
+            g.W = L.wo_s; g.ldw = d->inner; g.x = d->att; g.y = d->x; g.N = d->dim; g.K = d->inner;
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, st);
+            // cross-attention over [null kv | encoder context]
+            g = GemvArgs{};
+            g.W = L.wq_c; g.ldw = d->dim; g.x = d->x; g.gamma = L.gamma_c; g.y = d->q; g.N = d->inner; g.K = d->dim;
+            launch_gemv<MODE_PLAIN>(g, d->inner / 2, st);
+            AttnArgs ac{d->q, L.kv_c, L.kv_c + d->inner, 2 * (int64_t)d->inner, d->att, d->state, d->n_ctx > 0 ? d->n_ctx : -2, scale, d->max_len};
+            hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads), dim3(256), 0, st, ac);
+            g = GemvArgs{};
+            g.W = L.wo_c; g.ldw = d->inner; g.x = d->att; g.y = d->x; g.N = d->dim; g.K = d->inner;
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, st);
+            // GEGLU feed-forward
+            g = GemvArgs{};
+            g.W = L.w1; g.ldw = d->dim; g.x = d->x; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d->h; g.N = 2 * d->ff_inner; g.K = d->dim;
+            g.y_pad = d->ff_inner_pad;
+            launch_gemv<MODE_GEGLU>(g, d->ff_inner_pad, st);
+            g = GemvArgs{};
+            g.W = L.w2; g.ldw = d->ff_inner_pad; g.x = d->h; g.bias = L.b2; g.y = d->x; g.N = d->dim; g.K = d->ff_inner_pad;
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, st);
+        }
+        GemvArgs g{};
+        g.W = d->emb; g.ldw = d->dim_emb; g.x = d->x; g.gamma = d->final_gamma; g.y = d->logits; g.N = d->vocab; g.K = d->dim_emb;
+        g.streams = d->streams;
+        launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), st);
+        SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, d->vocab, d->dim_emb, d->streams, d->max_len,
+                      d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f)};
+        hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, st, sa);
+    }
+    CVX_CHECK_LAUNCH("cvx_t2s_decode_steps");
+    return CVX_OK;
+}

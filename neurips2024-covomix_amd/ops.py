@@ -177,6 +177,14 @@ def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T:
     return out if out is not None else out_split
 
 
+def geglu(h: torch.Tensor, out: torch.Tensor, F: int) -> torch.Tensor:
+    """out[r, c] = h[r, c] * gelu(h[r, F + c]) for c < F, zeros in the padding columns (text2semantic.py:154-157)."""
+    _chk_f32(h, out)
+    assert h.is_contiguous() and out.is_contiguous() and h.shape[-1] == 2 * F and out.shape[-1] >= F and h.shape[0] == out.shape[0]
+    _lib.check(_lib.load().cvx_geglu_f32(h.data_ptr(), out.data_ptr(), h.shape[0], F, out.shape[-1], _stream()), "cvx_geglu_f32")
+    return out
+
+
 def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor,
                       Bt: int, T: int) -> torch.Tensor:
     _chk_f32(x, w, bias, out)

@@ -1,0 +1,251 @@
+"""text2semantic (CoSingle / CoMix) on the GPU - SURVEY.md section 8f row N1.
+
+Host mirror of the reference's `TextToSemantic.generate` sampling branch + `TextToSemanticWrapper.sample`
+(covomix/covomix_model/text2semantic.py:662-848, :1237-1251), the call `CoVoMixModel.synthesis_sample_text2semantic`
+forwards to (covomix/conditional_model.py:313-321).  Only what the generation scripts reach is built: cond_scale == 1
+(the reference asserts on anything else with its default cond_drop_prob = 0), no beam / speculative decoding, batch 1.
+
+  encoder  (source transformer, once per utterance): the full-sequence kernels of the acoustic path - fp32 GEMM with
+           the RoPE epilogue, flash attention, RMSNorm - plus a GEGLU kernel;
+  decoder  (one token per step): csrc/t2s_decode.hip through cvx_t2s_decode_steps, 34 launches per step, replayed
+           from a HIP graph of CHUNK steps; the host only looks at the eos flag between chunks.
+
+The reference's rotary embedding rotates interleaved pairs (2i, 2i+1) (rotary_embedding_torch.py:25-41); the kernels
+rotate half-split pairs (i, i+32).  Permuting the rows of to_q and to_k inside every head (the same permutation on
+both, so q.k is unchanged) maps one onto the other - done once here at load time.
+"""
+import ctypes as C
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+
+PAD_ID = -1                    # semantic_pad_id (conditional_model.py:126)
+TOP_K_THRES = 0.1              # top_k default (text2semantic.py:126)
+CHUNK = 16                     # token steps per graph replay / host check
+
+
+def _dims(sd: Dict[str, torch.Tensor]) -> dict:
+    dim = sd["token_emb.text.weight"].shape[1]
+    dim_t = sd["start_token.speech"].shape[0]
+    emb = sd["semantic_token_emb.weight"].shape[1]
+    heads = sd["target_transformer.layers.0.1.null_kv"].shape[1]
+    if sd["target_transformer.layers.0.1.null_kv"].shape[-1] != 64:
+        raise ValueError("only dim_head == 64 is supported (reference default)")
+    if emb not in (dim_t, dim_t // 2):
+        raise ValueError("semantic embedding width must be the target width (one output) or half of it (two outputs)")
+    depth = lambda pre: len({k.split(".")[2] for k in sd if k.startswith(pre + ".layers.")})
+    ff = lambda pre: sd[pre + ".layers.0.2.4.weight"].shape[1]
+    return dict(dim=dim, dim_target=dim_t, dim_emb=emb, streams=dim_t // emb, heads=heads, inner=heads * 64,
+                source_depth=depth("source_transformer"), target_depth=depth("target_transformer"),
+                vocab=sd["semantic_token_emb.weight"].shape[0], ff_src=ff("source_transformer"), ff_tgt=ff("target_transformer"),
+                text_eos=sd["token_emb.text.weight"].shape[0] - 1)
+
+
+def _half_split_rows(w: torch.Tensor, heads: int) -> torch.Tensor:
+    """Rows of a [heads*64, K] projection reordered (0,2,..,62,1,3,..,63) inside every head."""
+    perm = torch.cat((torch.arange(0, 64, 2), torch.arange(1, 64, 2))).to(w.device)
+    return w.reshape(heads, 64, -1)[:, perm, :].reshape(heads * 64, -1).contiguous()
+
+
+def _pad_cols(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    k = w.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return w.contiguous()
+    out = torch.zeros(w.shape[0], kp, dtype=w.dtype, device=w.device)
+    out[:, :k] = w
+    return out
+
+
+class TextToSemanticDecoder:
+    """Device-resident packed weights of one TextToSemantic network + encode / generate."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: torch.device, max_length: int = 2048, max_source: int = 1024):
+        sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()}
+        self.device = device
+        self.d = d = _dims(sd)
+        self.max_length, self.max_source = int(max_length), int(max_source)
+        H, I = d["heads"], d["inner"]
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+
+        def attn_pack(p, self_attn):
+            wq, wkv = sd[p + ".to_q.0.weight"], sd[p + ".to_kv.0.weight"]
+            wk, wv = wkv[:I], wkv[I:]
+            if self_attn:
+                return torch.cat((_half_split_rows(wq, H), _half_split_rows(wk, H), wv), dim=0).contiguous()
+            return wq.contiguous(), wkv.contiguous()
+
+        self.emb_text = sd["token_emb.text.weight"]
+        self.emb = sd["semantic_token_emb.weight"]
+        self.start = sd["start_token.speech"]
+        # ---- encoder
+        self.enc = []
+        for i in range(d["source_depth"]):
+            p = f"source_transformer.layers.{i}"
+            self.enc.append(dict(gamma_a=sd[p + ".0.norm.gamma"], wqkv=attn_pack(p + ".0", True), wo=sd[p + ".0.to_out.weight"],
+                                 gamma_f=sd[p + ".2.0.gamma"], w1=sd[p + ".2.1.weight"], b1=sd[p + ".2.1.bias"],
+                                 w2=_pad_cols(sd[p + ".2.4.weight"]), b2=sd[p + ".2.4.bias"]))
+        self.enc_final = sd["source_transformer.final_norm.gamma"]
+        self.freqs_src = sd["source_transformer.layers.0.0.rotary_emb.freqs"]
+        # ---- decoder
+        self.Fp = (d["ff_tgt"] + 3) // 4 * 4
+        self.dec = []
+        for i in range(d["target_depth"]):
+            p = f"target_transformer.layers.{i}"
+            wq_c, wkv_c = attn_pack(p + ".1", False)
+            nkv = sd[p + ".1.null_kv"]                                    # [2, H, 1, 64]
+            self.dec.append(dict(gamma_s=sd[p + ".0.norm.gamma"], wqkv_s=attn_pack(p + ".0", True), wo_s=sd[p + ".0.to_out.weight"],
+                                 gamma_c=sd[p + ".1.norm.gamma"], wq_c=wq_c, wkv_c=wkv_c, wo_c=sd[p + ".1.to_out.weight"],
+                                 null=torch.cat((nkv[0].reshape(I), nkv[1].reshape(I))).contiguous(),
+                                 gamma_f=sd[p + ".2.0.gamma"], w1=sd[p + ".2.1.weight"], b1=sd[p + ".2.1.bias"],
+                                 w2=_pad_cols(sd[p + ".2.4.weight"]), b2=sd[p + ".2.4.bias"],
+                                 kv_c=f32(self.max_source + 2, 2 * I), k_cache=f32(self.max_length, I), v_cache=f32(self.max_length, I)))
+        self.dec_final = sd["target_transformer.final_norm.gamma"]
+        pos = torch.arange(self.max_length, device=device, dtype=torch.float32)
+        ang = pos[:, None] * sd["target_transformer.layers.0.0.rotary_emb.freqs"][None, :]
+        self.rope = (ang.cos().contiguous(), ang.sin().contiguous())
+        S, V = d["streams"], d["vocab"]
+        self.top_k = math.ceil(TOP_K_THRES * V)
+        self.buf = dict(x=f32(d["dim_target"]), q=f32(I), att=f32(I), h=f32(self.Fp), logits=f32(S, V),
+                        uniforms=f32(self.max_length, S, V),
+                        tokens=torch.zeros(S, self.max_length, dtype=torch.int64, device=device),
+                        state=torch.zeros(4, dtype=torch.int32, device=device))
+        self._layers = (_lib.T2SLayer * d["target_depth"])()
+        for i, L in enumerate(self.dec):
+            for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
+                         "k_cache", "v_cache"):
+                setattr(self._layers[i], name, L[name].data_ptr())
+        self._graphs: Dict[float, torch.cuda.CUDAGraph] = {}
+
+    # ------------------------------------------------------------------ encoder (text2semantic.py:716-741)
+    def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
+        d = self.d
+        ids = source_ids.reshape(-1).to(self.device, torch.int64)
+        if bool((ids == 0).any()):
+            raise NotImplementedError("padded text batches (id 0) are not supported: one un-padded utterance per call")
+        if ids.numel() + 1 > self.max_source:
+            raise ValueError(f"text of {ids.numel()} tokens exceeds max_source = {self.max_source}")
+        src = torch.cat((ids, torch.tensor([d["text_eos"]], device=self.device)))          # set_eos_id, no padding
+        n, H, I, D = src.numel(), d["heads"], d["inner"], d["dim"]
+        x = self.emb_text.index_select(0, src).contiguous()
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        normed, qkv, att = f(n, D), f(n, 3 * I), f(n, I)
+        F_ = d["ff_src"]
+        Fp = (F_ + 3) // 4 * 4
+        h2, hg = f(n, 2 * F_), f(n, Fp)
+        pos = torch.arange(n, device=self.device, dtype=torch.float32)
+        ang = pos[:, None] * self.freqs_src[None, :]
+        rope = (ang.cos().contiguous(), ang.sin().contiguous())
+        for L in self.enc:
+            ops.adarmsnorm(x, L["gamma_a"], None, normed)
+            ops.gemm(normed, L["wqkv"], qkv, rope=rope, rope_cols=2 * I)
+            ops.attention(qkv, att, 1, n, H, 64 ** -0.5)
+            ops.gemm(att, L["wo"], x, residual=x)
+            ops.adarmsnorm(x, L["gamma_f"], None, normed)
+            ops.gemm(normed, L["w1"], h2, bias=L["b1"])
+            ops.geglu(h2, hg, F_)
+            ops.gemm(hg, L["w2"], x, bias=L["b2"], residual=x)
+        enc = f(n, D)
+        ops.adarmsnorm(x, self.enc_final, None, enc)
+        return enc
+
+    # ------------------------------------------------------------------ decoder
+    def _descriptor(self, temperature: float) -> "_lib.T2SDecoder":
+        d, b = self.d, self.buf
+        dec = _lib.T2SDecoder()
+        dec.dim, dec.inner, dec.heads = d["dim_target"], d["inner"], d["heads"]
+        dec.ff_inner, dec.ff_inner_pad, dec.depth = d["ff_tgt"], self.Fp, d["target_depth"]
+        dec.streams, dec.vocab, dec.dim_emb = d["streams"], d["vocab"], d["dim_emb"]
+        dec.n_ctx, dec.max_len, dec.top_k, dec.temperature = 0, self.max_length, self.top_k, float(temperature)
+        dec.layers = C.cast(self._layers, C.POINTER(_lib.T2SLayer))
+        dec.final_gamma, dec.emb = self.dec_final.data_ptr(), self.emb.data_ptr()
+        dec.rope_cos, dec.rope_sin = self.rope[0].data_ptr(), self.rope[1].data_ptr()
+        for n in ("uniforms", "x", "q", "att", "h", "logits", "tokens", "state"):
+            setattr(dec, n, b[n].data_ptr())
+        return dec
+
+    def _run_chunk(self, temperature: float) -> None:
+        """CHUNK token steps on the current stream (graph replay when enabled)."""
+        def launch():
+            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature)), CHUNK,
+                                                        torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+        if os.environ.get("CVX_GRAPH", "1") != "1":
+            launch()
+            return
+        g = self._graphs.get(temperature)
+        if g is None:
+            saved = {k: v.clone() for k, v in self.buf.items()}
+            caches = [(L["k_cache"].clone(), L["v_cache"].clone()) for L in self.dec]
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                launch()                                   # warm-up outside capture (module load, attributes)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch()
+            for k, v in saved.items():                     # capture does not execute, the warm-up did: restore
+                self.buf[k].copy_(v)
+            for L, (kc, vc) in zip(self.dec, caches):
+                L["k_cache"].copy_(kc); L["v_cache"].copy_(vc)
+            self._graphs = {temperature: g}
+        g.replay()
+
+    @torch.inference_mode()
+    def generate(self, source_ids: torch.Tensor, uniforms: Optional[torch.Tensor] = None, max_length: Optional[int] = None,
+                 temperature: float = 1.0, generator: Optional[torch.Generator] = None, return_streams: bool = False,
+                 collect_logits: bool = False):
+        """== TextToSemanticWrapper.sample(grapheme_token_ids): flat int64 tensor, stream 1 then stream 2 (two-output
+        models), each cut after its eos.  uniforms [steps, streams, vocab] (or [steps, streams, 1, vocab]) replaces
+        the random draws of gumbel_noise (text2semantic.py:108-110); default: torch.rand from `generator`.
+        collect_logits (tests): step one token at a time without a graph and also return the pre-filter logits
+        [steps, streams, vocab]."""
+        d, b = self.d, self.buf
+        S, V = d["streams"], d["vocab"]
+        max_len = min(int(max_length or self.max_length), self.max_length)
+        if source_ids.ndim == 2 and source_ids.shape[0] != 1:
+            raise NotImplementedError("one utterance per call (the generation scripts run batch 1)")
+        enc = self.encode(source_ids)
+        n = enc.shape[0]
+        I = d["inner"]
+        for L in self.dec:                                              # context k/v once: [null | to_kv(enc)]
+            L["kv_c"][0].copy_(L["null"])
+            ops.gemm(enc, L["wkv_c"], L["kv_c"][1:n + 1])
+        if uniforms is None:
+            b["uniforms"][:max_len].copy_(torch.rand(max_len, S, V, device=self.device, generator=generator))
+        else:
+            u = uniforms.to(self.device, torch.float32).reshape(uniforms.shape[0], S, V)
+            max_len = min(max_len, u.shape[0])
+            b["uniforms"][:max_len].copy_(u[:max_len])
+        b["x"].copy_(self.start)
+        b["state"].copy_(torch.tensor([0, 0, 0, n + 1], dtype=torch.int32))
+        steps = 0
+        logits = []
+        while steps < max_len:
+            if collect_logits:
+                _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(float(temperature))), 1,
+                                                            torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+                logits.append(b["logits"].clone())
+                steps += 1
+            else:
+                self._run_chunk(float(temperature))
+                steps += CHUNK
+            st = b["state"].tolist()                                     # the only host sync: once per CHUNK tokens
+            if st[1]:
+                break
+        st = b["state"].tolist()
+        length = min(st[2] if st[1] and st[2] <= max_len else max_len, max_len)
+        streams = b["tokens"][:, :length].clone()
+        eos = V - 1
+        after = (streams == eos).cumsum(dim=-1) > 0                      # mask_after_eos (text2semantic.py:73-76)
+        after = torch.nn.functional.pad(after, (1, -1), value=False)
+        flat = streams.masked_fill(after, PAD_ID).reshape(-1)
+        out = flat[flat != PAD_ID]
+        if collect_logits:
+            return out, streams, torch.stack(logits)[:length]
+        return (out, streams) if return_streams else out
