@@ -7,9 +7,12 @@ Mirrors the inference surface of the reference LightningModule
     model.eval()                  # swaps in the EMA shadow weights (conditional_model.py:203-217)
     model = model.to(device)
     mel = model.synthesis_sample(phoneme_ids=..., cond=..., mask=..., cond_scale=0.7)   # :295-302
+    tok = t2s_model.synthesis_sample_text2semantic(grapheme_token_ids)                  # :313-321 (text2semantic ckpt)
 
 Checkpoint layout accepted (what Lightning's ModelCheckpoint + on_save_checkpoint write, :150,:200-201):
-    ckpt['state_dict']        keys 'cfm_wrapper.CoVoMix.<param>'
+    ckpt['state_dict']        keys 'cfm_wrapper.CoVoMix.<param>' (acoustic) or 'cfm_wrapper.model.<param>' (text2semantic:
+                              TextToSemanticWrapper.model, text2semantic.py:1205-1213; tied / shared tensors appear
+                              under several names - token_emb.speech.*, to_logits.*, per-layer rotary_emb.freqs)
     ckpt['hyper_parameters']  dict (may reference classes such as covomix.data_module.SpecsDataModule
                               that do not exist here -> unpickled as inert stubs)
     ckpt['ema']               torch_ema state: {'decay','num_updates','shadow_params': [...], 'collected_params'}
@@ -30,6 +33,7 @@ import torch
 from .acoustic import FlowMatchingSampler, VectorField
 
 _PREFIX = "cfm_wrapper.CoVoMix."
+_PREFIX_T2S = "cfm_wrapper.model."
 
 
 class _StubUnpickler(pickle.Unpickler):
@@ -58,20 +62,29 @@ def parameter_order(sd_keys) -> list:
     return [k for k in sd_keys if not k.endswith("rotary_emb.inv_freq")]
 
 
+def t2s_parameter_order(sd_keys) -> list:
+    """nn.Module.parameters() order of the reference TextToSemantic: state_dict order minus the aliases of tied /
+    shared parameters (to_logits.* and token_emb.speech.* are the embedding tables, text2semantic.py:524-552; one
+    RotaryEmbedding per transformer is shared by its layers, :291-299)."""
+    return [k for k in sd_keys if not (k.startswith("token_emb.speech.") or k.startswith("to_logits.")
+                                       or (k.endswith("rotary_emb.freqs") and ".layers.0.0." not in k))]
+
+
 class CoVoMixModel:
     def __init__(self, state_dict: Dict[str, torch.Tensor], hparams: Optional[dict] = None,
                  ema_shadow: Optional[list] = None, nfe: int = 32, ode_method: str = "midpoint",
                  precision: Optional[str] = None):
         """state_dict: un-prefixed CoVoMix parameter names (acoustic.py:326-406)."""
         self.hparams = dict(hparams or {})
-        if self.hparams.get("text2semantic"):
-            raise NotImplementedError("text2semantic checkpoints are outside this build's hot path (SURVEY.md section 8f N1)")
+        self.is_text2semantic = "token_emb.text.weight" in state_dict
+        if bool(self.hparams.get("text2semantic", self.is_text2semantic)) != self.is_text2semantic:
+            raise ValueError("hyper_parameters['text2semantic'] disagrees with the parameter names of the state_dict")
         if self.hparams.get("twocondition_twooutput"):
             raise NotImplementedError("twocondition_twooutput is not supported (SURVEY.md section 8f N2)")
         self._raw = OrderedDict((k, v.detach().cpu()) for k, v in state_dict.items())
         self._ema = None
         if ema_shadow is not None:
-            names = parameter_order(self._raw.keys())
+            names = (t2s_parameter_order if self.is_text2semantic else parameter_order)(self._raw.keys())
             if len(names) != len(ema_shadow):
                 raise ValueError(f"EMA has {len(ema_shadow)} shadow params, model has {len(names)} parameters")
             self._ema = OrderedDict(self._raw)
@@ -85,6 +98,7 @@ class CoVoMixModel:
         self.nfe, self.ode_method = nfe, ode_method
         self.precision = precision or os.environ.get("CVX_PRECISION", "f16x3")
         self._field: Optional[VectorField] = None
+        self._t2s = None
 
     # ---- construction ---------------------------------------------------------------------
     @classmethod
@@ -92,8 +106,10 @@ class CoVoMixModel:
         assert os.path.isfile(checkpoint_path), checkpoint_path      # mirrors monologue_generation.py:46
         ckpt = _torch_load(checkpoint_path)
         sd = OrderedDict((k[len(_PREFIX):], v) for k, v in ckpt["state_dict"].items() if k.startswith(_PREFIX))
+        if not sd:                                                   # text2semantic checkpoint (CoSingle / CoMix)
+            sd = OrderedDict((k[len(_PREFIX_T2S):], v) for k, v in ckpt["state_dict"].items() if k.startswith(_PREFIX_T2S))
         if not sd:
-            raise KeyError(f"no '{_PREFIX}*' entries in checkpoint state_dict")
+            raise KeyError(f"no '{_PREFIX}*' or '{_PREFIX_T2S}*' entries in checkpoint state_dict")
         ema = ckpt.get("ema")
         shadow = None
         if ema is not None:
@@ -114,6 +130,7 @@ class CoVoMixModel:
         if use != self._use_ema:
             self._use_ema = use
             self._field = None
+            self._t2s = None
         return self
 
     def eval(self, no_ema: bool = False):
@@ -124,12 +141,15 @@ class CoVoMixModel:
         if device != self.device:
             self.device = device
             self._field = None
+            self._t2s = None
         return self
 
     def active_state_dict(self) -> Dict[str, torch.Tensor]:
         return self._ema if (self._use_ema and self._ema is not None) else self._raw
 
     def _get_field(self) -> VectorField:
+        if self.is_text2semantic:
+            raise TypeError("this checkpoint is a text2semantic model: use synthesis_sample_text2semantic")
         if self._field is None:
             if self.device.type != "cuda":
                 from ._lib import CovomixHipError
@@ -147,5 +167,26 @@ class CoVoMixModel:
         out = sampler.sample(phoneme_ids=phoneme_ids, cond=cond, mask=mask, cond_scale=cond_scale, y0=y0)
         return out.to(cond.device) if cond.device != out.device else out
 
-    def synthesis_sample_text2semantic(self, *a, **k):
-        raise NotImplementedError("text2semantic AR decoding is a 'next' row (SURVEY.md section 8f N1), not built yet")
+    @torch.no_grad()
+    def synthesis_sample_text2semantic(self, grapheme_token_ids, temprature=1.0, cond_scale=1.0, beam_search_decode=False,
+                                       prompt_mel=None, uniforms=None, generator=None, max_length=None):
+        """reference conditional_model.py:313-321 -> TextToSemanticWrapper.sample (text2semantic.py:1237-1251): the
+        sampled semantic tokens as one flat int64 tensor (two-output models: stream 1 then stream 2) on the input's
+        device.  (`temprature` is the reference's spelling.)  `uniforms` / `generator` (optional) fix the U(0,1) draws
+        behind the Gumbel noise; parity is defined given them."""
+        if not self.is_text2semantic:
+            raise TypeError("this checkpoint is an acoustic model: use synthesis_sample")
+        assert cond_scale >= 1., "cond_scale >= 1 (text2semantic.py:690)"
+        assert not cond_scale > 1, ("you need to train with conditional drop probability greater than 0 to use classifier "
+                                    "free guidance at inference (text2semantic.py:691; the reference builds the model with 0)")
+        if beam_search_decode:
+            raise NotImplementedError("beam search decoding is not built (the generation scripts sample)")
+        if self._t2s is None:
+            if self.device.type != "cuda":
+                from ._lib import CovomixHipError
+                raise CovomixHipError("CoVoMixModel must be on a GPU (`.to('cuda')`): covomix_amd has no CPU path")
+            from .t2s import TextToSemanticDecoder
+            self._t2s = TextToSemanticDecoder(self.active_state_dict(), self.device)
+        ids = grapheme_token_ids
+        out = self._t2s.generate(ids, uniforms=uniforms, max_length=max_length, temperature=float(temprature), generator=generator)
+        return out.to(ids.device) if ids.device != out.device else out

@@ -5,9 +5,12 @@ Keeps the reference CLI (monologue_generation.py:324-333: --t2s_ckpt --acous_ckp
 (monologue_generation.py:146-304, dialogue_generation.py:145-329) for the stages this build covers:
 token/prompt assembly -> synthesis_sample (cond_scale 0.7) -> frame selection -> HiFi-GAN -> int16 wav.
 
-Two upstream stages are "next" rows and are therefore read from files instead of computed:
-  * text2semantic (N1): `<text_dir>/<name>.semantic.npy` holds the predicted semantic tokens
-      covosingle / covosinx: int array [n];  covomix: [2, n] or flat [2n] (split at half, comix_pred :307-319)
+Upstream stages:
+  * text2semantic (N1, built: t2s.py): with --t2s_ckpt, `<text_dir>/<name>.text_ids.npy` (the BERT token ids of the
+      cleaned text, what tokenizer(...).input_ids holds in cosingle_pred / comix_pred, :179-186, :307-319) or
+      `<name>.txt` (needs the bert-base-uncased vocabulary in the local transformers cache - a third-party asset
+      this repo does not ship) is decoded on the GPU; otherwise `<text_dir>/<name>.semantic.npy` holds already
+      predicted tokens (covosingle / covosinx: int array [n]; covomix: [2, n] or flat [2n], split at half).
   * prompt mel extraction (N3): `<prompt_dir>/<name>.mel.npy` ([80, T] log-mel) next to
       `<name>.hubert_code.npy`; dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
 New relative to the reference: utterances are sharded over ranks (torchrun) and batched by equal length.
@@ -32,7 +35,8 @@ COND_SCALE = 0.7    # every shipped caller (monologue_generation.py:171,238,298)
 
 def build_parser() -> ArgumentParser:
     p = ArgumentParser()
-    p.add_argument("--t2s_ckpt", type=str, default=None, help="text2semantic checkpoint (not used: tokens are read from --text_dir)")
+    p.add_argument("--t2s_ckpt", type=str, default=None, help="text2semantic checkpoint (CoSingle / CoMix); without it "
+                   "<name>.semantic.npy files are read from --text_dir")
     p.add_argument("--acous_ckpt", type=str, default="/pretrained_models/comix.ckpt", help="acoustic model checkpoint")
     p.add_argument("--hifigan_ckpt", type=str, default="/pretrained_models/vocoder.ckpt", help="vocoder checkpoint")
     p.add_argument("--text_dir", type=str, default="test/test_dir", help="directory with <name>.semantic.npy")
@@ -50,8 +54,44 @@ def _load_prompt(prompt_dir: str, name: str):
     return assembly.truncate_prompt(tok, mel)            # -> tokens [Tp], mel [Tp, 80]
 
 
-def _utterance_inputs(mode: str, dialogue: bool, text_dir: str, prompt_dir: str, name: str):
-    pred = np.load(os.path.join(text_dir, name + ".semantic.npy")).astype(np.int64)
+def remove_punctuation(text: str) -> str:
+    """monologue_generation.py:108-114."""
+    punctuation = '''!()-{};:'"\\,<>./?@#$%^&*_~'''
+    text = text.lower()
+    for x in text:
+        if x in punctuation:
+            text = text.replace(x, "")
+    return text
+
+
+_TOKENIZER = None
+
+
+def _text_ids(text_dir: str, name: str) -> torch.Tensor:
+    """[1, n] BERT ids of the utterance text (load_text2semantic_model, monologue_generation.py:92-104)."""
+    npy = os.path.join(text_dir, name + ".text_ids.npy")
+    if os.path.isfile(npy):
+        return torch.from_numpy(np.load(npy).astype(np.int64)).reshape(1, -1)
+    global _TOKENIZER
+    if _TOKENIZER is None:
+        from transformers import BertTokenizer
+        tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+        for t in ("[laughter]", "[spkchange]", "[spka]", "[spkb]", "[partialoverlap]", "[backchannel]"):
+            tok.add_tokens([t])
+        _TOKENIZER = tok
+    with open(os.path.join(text_dir, name + ".txt"), "r", encoding="utf-8") as f:
+        txt = remove_punctuation(f.read()).lower()
+    return _TOKENIZER([txt], padding=True, truncation=True, return_tensors="pt").input_ids
+
+
+def _predicted_tokens(text_dir: str, name: str, t2s, device) -> np.ndarray:
+    sem = os.path.join(text_dir, name + ".semantic.npy")
+    if t2s is None or os.path.isfile(sem):
+        return np.load(sem).astype(np.int64)
+    return t2s.synthesis_sample_text2semantic(_text_ids(text_dir, name).to(device)).cpu().numpy().astype(np.int64)
+
+
+def _utterance_inputs(mode: str, dialogue: bool, text_dir: str, prompt_dir: str, name: str, pred: np.ndarray):
     if mode == "covosingle":
         sem, mel = _load_prompt(prompt_dir, name)
         return assembly.build_monologue_inputs(sem, torch.from_numpy(pred.reshape(-1)), mel)
@@ -104,8 +144,17 @@ def run(dialogue: bool, argv=None) -> int:
             f.write("t2s_ckpt: " + str(args.t2s_ckpt) + "\n")
             f.write("acoustic model: " + args.acous_ckpt + "\n")
 
-    names = sorted(os.path.basename(p)[: -len(".semantic.npy")] for p in glob.glob(os.path.join(args.text_dir, "*.semantic.npy")))
-    items = [_utterance_inputs(args.mode, dialogue, args.text_dir, args.prompt_dir, n) for n in names]
+    t2s = None
+    if args.t2s_ckpt and os.path.isfile(args.t2s_ckpt):
+        t2s = CoVoMixModel.load_from_checkpoint(args.t2s_ckpt, base_dir="", batch_size=16, num_workers=0)   # :93-96
+        t2s.eval()
+        t2s = t2s.to(device)
+    stems = set()
+    for ext in (".semantic.npy",) + ((".text_ids.npy", ".txt") if t2s is not None else ()):
+        stems |= {os.path.basename(p)[: -len(ext)] for p in glob.glob(os.path.join(args.text_dir, "*" + ext))}
+    names = sorted(stems)
+    items = [_utterance_inputs(args.mode, dialogue, args.text_dir, args.prompt_dir, n,
+                               _predicted_tokens(args.text_dir, n, t2s, device)) for n in names]
     lengths = [int(it[0].shape[0]) for it in items]
     mine = dp.shard_utterances(lengths, world)[rank]
     done = 0

@@ -196,7 +196,8 @@ class TextToSemanticDecoder:
             self._graphs = {temperature: g}
         g.replay()
 
-    @torch.inference_mode()
+    @torch.no_grad()          # (not inference_mode: tensors torch creates lazily during the first graph capture,
+                              #  e.g. the generator's graph-safe state, would become inference tensors)
     def generate(self, source_ids: torch.Tensor, uniforms: Optional[torch.Tensor] = None, max_length: Optional[int] = None,
                  temperature: float = 1.0, generator: Optional[torch.Generator] = None, return_streams: bool = False,
                  collect_logits: bool = False):

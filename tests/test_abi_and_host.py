@@ -199,3 +199,40 @@ print('RANK_OK', rank, flush=True)
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+def test_text2semantic_checkpoint_layout_and_ema_order(tmp_path):
+    """A text2semantic .ckpt as Lightning writes it for TextToSemanticWrapper: prefix cfm_wrapper.model., tied / shared
+    tensors under several names, EMA shadow params in parameters() order (aliases excluded)."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel, t2s_parameter_order
+    shapes = syn.t2s_param_shapes(two_output=True, dim=64, dim_target=128, source_depth=2, target_depth=2, heads=1, num_text=50)
+    sd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(shapes, seed=0).items()}
+    ema = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(shapes, seed=3).items()}
+    full = {}
+    for k, v in sd.items():                                     # state_dict order of the reference module
+        full["cfm_wrapper.model." + k] = v
+        if k == "semantic_token_emb.weight":
+            full["cfm_wrapper.model.token_emb.speech.weight"] = v
+        if k == "start_token.text":
+            full["cfm_wrapper.model.to_logits.speech.weight"] = sd["semantic_token_emb.weight"]
+            full["cfm_wrapper.model.to_logits.text.weight"] = sd["token_emb.text.weight"]
+        if k.endswith(".0.norm.gamma") and ".layers.0.0." not in k:
+            pre = k[: -len("norm.gamma")]
+            full["cfm_wrapper.model." + pre + "rotary_emb.freqs"] = sd[k.split(".layers.")[0] + ".layers.0.0.rotary_emb.freqs"]
+    names = t2s_parameter_order([k[len("cfm_wrapper.model."):] for k in full])
+    assert names == list(shapes.keys())                         # == reference named_parameters() order (make_golden_t2s.py)
+    p = str(tmp_path / "t2s.ckpt")
+    torch.save({"state_dict": full, "hyper_parameters": {"text2semantic": True, "text2semantic_two_output": True},
+                "ema": {"decay": 0.999, "num_updates": 1, "shadow_params": [ema[k] for k in shapes], "collected_params": None}}, p)
+    m = CoVoMixModel.load_from_checkpoint(p).eval()
+    assert m.is_text2semantic
+    assert torch.equal(m.active_state_dict()["start_token.speech"], ema["start_token.speech"])
+    assert torch.equal(m.eval(no_ema=True).active_state_dict()["start_token.speech"], sd["start_token.speech"])
+    with pytest.raises(TypeError):
+        m.synthesis_sample(None, None, None, 0.7)
+    with pytest.raises(AssertionError):
+        m.synthesis_sample_text2semantic(torch.tensor([[1, 2]]), cond_scale=3.0)
+    from covomix_amd._lib import CovomixHipError
+    with pytest.raises(CovomixHipError):                        # no CPU fallback
+        m.synthesis_sample_text2semantic(torch.tensor([[1, 2]]))

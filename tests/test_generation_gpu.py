@@ -77,3 +77,65 @@ def test_cli_end_to_end(tmp_path, mode, dialogue, monkeypatch):
             assert sr == 8000 and pcm.dtype == np.int16 and pcm.shape == ref_pcm.shape == (160 * (T - 30) + 32,)
             err = np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32))
             assert err.max() <= 64 and (err > 2).mean() < 0.01, (err.max(), (err > 2).mean())
+
+
+def test_cli_full_pipeline_with_text2semantic(tmp_path, monkeypatch):
+    """BASELINE config 5 in miniature: text ids -> CoMix text2semantic (GPU) -> token assembly -> VoMix -> HiFi-GAN.
+    The semantic tokens that reach the acoustic model must be BIT-EXACT the oracle's (same uniform draws), including
+    the split of the two streams at half (comix_pred) and the 157-padding / 501-clamp of the assembly."""
+    import t2s_oracle as torc
+    import covomix_amd.synthetic as syn
+    from covomix_amd import assembly, generation
+    tmp = str(tmp_path)
+    _write_fixture(tmp, "vomix")
+    shapes = syn.t2s_param_shapes(two_output=True, dim=64, dim_target=128, source_depth=2, target_depth=2, heads=1, num_text=200)
+    tsd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(shapes, seed=0).items()}
+    torch.save({"state_dict": {"cfm_wrapper.model." + k: v for k, v in tsd.items()},
+                "hyper_parameters": {"text2semantic": True, "text2semantic_two_output": True}}, os.path.join(tmp, "t2s.ckpt"))
+    tdir, pdir, sdir = (os.path.join(tmp, d) for d in ("text", "prompt", "out"))
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(1)
+    names = ["dlg_a", "dlg_b"]
+    text = {}
+    for n in names:
+        for suf in ("_1", "_2"):
+            np.save(os.path.join(pdir, f"{n}{suf}.hubert_code.npy"), g.randint(0, 510, size=20))
+            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), (g.randn(80, 20) * 2 - 6).astype(np.float32))
+        text[n] = g.randint(1, 199, size=(1, 9)).astype(np.int64)
+        np.save(os.path.join(tdir, f"{n}.text_ids.npy"), text[n])
+    uni = torch.from_numpy(g.uniform(1e-6, 1 - 1e-6, size=(24, 2, 502)).astype(np.float32))
+    real_t2s = generation.CoVoMixModel.synthesis_sample_text2semantic
+    seen_ids = []
+
+    def spy_t2s(self, ids, **kw):
+        return real_t2s(self, ids, uniforms=uni, max_length=24)
+    real_syn = generation.CoVoMixModel.synthesis_sample
+
+    def spy_syn(self, phoneme_ids, cond, mask, cond_scale, y0=None):
+        seen_ids.append(phoneme_ids.cpu())
+        return real_syn(self, phoneme_ids, cond, mask, cond_scale, y0=y0)
+    monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample_text2semantic", spy_t2s)
+    monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample", spy_syn)
+    with pytest.warns(UserWarning, match="EMA"):                 # the t2s fixture has no EMA block
+        n = generation.run(True, ["--t2s_ckpt", os.path.join(tmp, "t2s.ckpt"), "--acous_ckpt", os.path.join(tmp, "acous.ckpt"),
+                                  "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir,
+                                  "--prompt_dir", pdir, "--saved_dir", sdir, "--mode", "covomix", "--seed", "30"])
+    assert n == 2
+    want = {}
+    for nm in names:
+        o = torc.generate(tsd, torch.from_numpy(text[nm]), uni[:, :, None, :], max_length=24)
+        flat = o["tokens"]
+        half = flat.shape[0] // 2
+        sa = torch.from_numpy(np.load(os.path.join(pdir, nm + "_1.hubert_code.npy")).astype(np.int64))
+        sb = torch.from_numpy(np.load(os.path.join(pdir, nm + "_2.hubert_code.npy")).astype(np.int64))
+        ma = torch.from_numpy(np.load(os.path.join(pdir, nm + "_1.mel.npy")))
+        mb = torch.from_numpy(np.load(os.path.join(pdir, nm + "_2.mel.npy")))
+        sa, ma = assembly.truncate_prompt(sa, ma)
+        sb, mb = assembly.truncate_prompt(sb, mb)
+        want[nm] = assembly.build_dialogue_inputs(sa, sb, flat[:half], flat[half:], ma, mb)[0]
+    got = [row for batch in seen_ids for row in batch]
+    assert len(got) == 2
+    for w in want.values():
+        assert any(g_.shape == w.shape and torch.equal(g_, w) for g_ in got)
+    for nm in names:
+        assert os.path.isfile(os.path.join(sdir, nm + ".wav"))
