@@ -63,24 +63,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length
 
-    // ---- stage (and normalise) the input vector
-    float ss = 0.f;
-    for (int k = tid; k < Kin; k += 256) {
-        const float v = a.x[k];
-        ss += v * v;
-        xs[k] = a.gamma ? v * a.gamma[k] : v;
-    }
-    float inv = 1.f;
-    if (a.gamma) {
-        ss = wave_sum(ss);
-        if (lane == 0) red[wid] = ss;
-        __syncthreads();
-        const float tot = red[0] + red[1] + red[2] + red[3];
-        inv = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);          // F.normalize(eps = 1e-12) * sqrt(dim)
-    } else {
-        __syncthreads();
-    }
-
     // ---- the two rows of this wave
     const int pair = blockIdx.x * 4 + wid;
     int r0, r1, sidx = 0;
@@ -105,6 +87,38 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         r0 = 2 * pair; r1 = r0 + 1;
         valid = r0 < a.N;
     }
+    const bool has1 = valid && r1 < a.N;
+    const float* w0 = a.W + (int64_t)(valid ? r0 : 0) * a.ldw;
+    const float* w1 = a.W + (int64_t)(has1 ? r1 : (valid ? r0 : 0)) * a.ldw;
+    const int K4 = a.K & ~3;
+
+    // ---- weights first: they do not depend on the input vector, so their HBM / MALL round trip overlaps the
+    // staging of x below (the step is a chain of 34 dependent launches; every microsecond of latency counts)
+    constexpr int PF = 4;                                  // 4 x 256 floats per row in flight (K <= 1024 entirely)
+    f32x4 pa[PF], pb[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int k = 4 * lane + 256 * i;
+        if (k < K4) { pa[i] = gload4(w0 + k); pb[i] = gload4(w1 + k); }
+    }
+
+    // ---- stage (and normalise) the input vector
+    float ss = 0.f;
+    for (int k = tid; k < Kin; k += 256) {
+        const float v = a.x[k];
+        ss += v * v;
+        xs[k] = a.gamma ? v * a.gamma[k] : v;
+    }
+    float inv = 1.f;
+    if (a.gamma) {
+        ss = wave_sum(ss);
+        if (lane == 0) red[wid] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        inv = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);          // F.normalize(eps = 1e-12) * sqrt(dim)
+    } else {
+        __syncthreads();
+    }
     if (!valid) {
         if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
             const int F = a.N / 2;
@@ -112,13 +126,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         }
         return;
     }
-    const bool has1 = r1 < a.N;
-    const float* w0 = a.W + (int64_t)r0 * a.ldw;
-    const float* w1 = a.W + (int64_t)(has1 ? r1 : r0) * a.ldw;
     const float* xv = xs + ((MODE == MODE_LOGITS) ? sidx * a.K : 0);
     float s0 = 0.f, s1 = 0.f;
-    const int K4 = a.K & ~3;
-    for (int k = 4 * lane; k < K4; k += 256) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int k = 4 * lane + 256 * i;
+        if (k < K4) {
+            const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s0 = fmaf(pa[i][e], xw[e], s0); s1 = fmaf(pb[i][e], xw[e], s1); }
+        }
+    }
+    for (int k = 4 * lane + 256 * PF; k < K4; k += 256) {
         const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + k);
         const f32x4 a0 = gload4(w0 + k);
         const f32x4 a1 = gload4(w1 + k);

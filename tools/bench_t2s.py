@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Dev: text2semantic decode rate (tokens/s, us/token) for the CoSingle / CoMix configurations with recipe weights:
+encoder once, then N token steps through the graph-replayed decode loop (eos ignored so that the step count is fixed).
+Also prints the weight bytes a token step has to stream (the HBM/MALL roofline of a batch-1 decode)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import covomix_amd.synthetic as syn
+from covomix_amd.t2s import TextToSemanticDecoder, CHUNK
+dev = torch.device("cuda:0")
+N = int(os.environ.get("TOKENS", "512"))
+for name, kw in [("cosingle", dict(two_output=False, dim=512, dim_target=512)), ("comix", dict(two_output=True, dim=512, dim_target=1024))]:
+    sd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(syn.t2s_param_shapes(**kw), seed=0).items()}
+    m = TextToSemanticDecoder(sd, dev, max_length=2048)
+    src = torch.randint(1, 30000, (1, 48))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.generate(src, max_length=CHUNK)                       # encoder + graph capture + one chunk
+    torch.cuda.synchronize(); t_first = time.perf_counter() - t0
+    t0 = time.perf_counter(); enc = m.encode(src); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
+    m.buf["x"].copy_(m.start); m.buf["state"].copy_(torch.tensor([0, 0, 0, enc.shape[0] + 1], dtype=torch.int32))
+    m.buf["uniforms"].uniform_(1e-6, 1 - 1e-6)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(N // CHUNK):
+        m._run_chunk(1.0)
+        m.buf["state"].tolist()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    wbytes = sum(L[k].numel() * 4 for L in m.dec for k in ("wqkv_s", "wo_s", "wq_c", "wo_c", "w1", "w2")) + m.emb.numel() * 4
+    print(f"{name}: first call {t_first*1e3:.1f} ms (capture), encoder {t_enc*1e3:.2f} ms, {N} tokens in {dt*1e3:.1f} ms = "
+          f"{dt/N*1e6:.1f} us/token = {N/dt:.0f} tokens/s; weights/token {wbytes/1e6:.1f} MB -> {wbytes/(dt/N)/1e12:.2f} TB/s")
