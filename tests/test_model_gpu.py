@@ -188,3 +188,44 @@ def test_f16_precision_rollout_within_north_star_budget(name):
     e = rel_l2(out, torch.from_numpy(g["rollout"]))
     print(name, "f16 rollout", int(g["rollout_nfe"]), e)
     assert e < F16_ROLL_TOL
+
+
+# ---------------------------------------------------------------- edge shapes (ragged tiles, tiny and long sequences)
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16"])
+@pytest.mark.parametrize("kind,B,T,prompt", [("vomix", 1, 1, 0), ("vomix", 2, 3, 1), ("vosingle", 1, 33, 10),
+                                             ("vomix", 1, 130, 130), ("vosingle", 2, 257, 0)])
+def test_edge_shapes_vs_oracle(kind, B, T, prompt, precision):
+    """T = 1 (one key), T % 4 != 0 (the transposed-V epilogue is not usable: fp32-attention fallback), T % 32 != 0
+    (masked last key tile), prompt = T (nothing to generate) and prompt = 0, at B = 1 and 2 - against the CPU oracle."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _state(kind, dim=128, dim_emb=64, depth=4, heads=2)
+    model = CoVoMixModel.from_state_dict(sd, nfe=4, precision=precision).eval().to("cuda:0")
+    inp = syn.synthetic_inputs(kind, B, T, prompt, seed=5)
+    for s in (0.7, 1.0):                                       # s == 1.0 skips the null branch (acoustic.py:421-423)
+        out = model.synthesis_sample(inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda(), s, y0=inp["y0"])
+        ref = orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], s, nfe=4)
+        assert out.shape == ref.shape == (B, T, 80)
+        e = rel_l2(out, ref)
+        assert e < (F16_ROLL_TOL if precision == "f16" else ROLL_TOL), (kind, B, T, prompt, precision, s, e)
+
+
+def test_long_sequence_and_argument_errors():
+    """T = 2500 (79 key tiles, 10 query blocks per head) against the oracle on a narrow model, and the reference's
+    own argument checks (acoustic.py:441-443 cond width; midpoint needs an even NFE)."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _state("vosingle", dim=128, dim_emb=64, depth=4, heads=2)
+    model = CoVoMixModel.from_state_dict(sd, nfe=2).eval().to("cuda:0")
+    inp = syn.synthetic_inputs("vosingle", 1, 2500, 700, seed=6)
+    out = model.synthesis_sample(inp["phoneme_ids"].cuda(), inp["cond"].cuda(), None, 0.7, y0=inp["y0"])
+    torch.set_num_threads(8)
+    ref = orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2)
+    assert rel_l2(out, ref) < ROLL_TOL
+    with pytest.raises((AssertionError, ValueError)):
+        model.synthesis_sample(inp["phoneme_ids"].cuda(), inp["cond"][..., :40].cuda(), None, 0.7)
+    model.nfe = 3
+    with pytest.raises((AssertionError, ValueError)):
+        model.synthesis_sample(inp["phoneme_ids"][:, :8].cuda(), inp["cond"][:, :8].cuda(), None, 0.7)
