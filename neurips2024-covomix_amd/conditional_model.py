@@ -79,8 +79,6 @@ class CoVoMixModel:
         self.is_text2semantic = "token_emb.text.weight" in state_dict
         if bool(self.hparams.get("text2semantic", self.is_text2semantic)) != self.is_text2semantic:
             raise ValueError("hyper_parameters['text2semantic'] disagrees with the parameter names of the state_dict")
-        if self.hparams.get("twocondition_twooutput"):
-            raise NotImplementedError("twocondition_twooutput is not supported (SURVEY.md section 8f N2)")
         self._raw = OrderedDict((k, v.detach().cpu()) for k, v in state_dict.items())
         self._ema = None
         if ema_shadow is not None:

@@ -63,14 +63,17 @@ def main():
     report = {}
 
     def build_ref(kind, **kw):
-        two = kind == "vomix"
+        two = kind in ("vomix", "vomix2out")
+        two_out = kind == "vomix2out"            # twocondition_twooutput (acoustic.py:375-376): state and output 160 wide
         dim = kw.get("dim", 1024)
         shapes = syn.acoustic_param_shapes(dim=dim, dim_cond=160 if two else 80,
                                            dim_emb=kw.get("dim_emb", 1024), depth=kw.get("depth", 8),
-                                           heads=kw.get("heads", 16), streams=2 if two else 1)
+                                           heads=kw.get("heads", 16), streams=2 if two else 1,
+                                           dim_out=160 if two_out else 80)
         ref = CoVoMix(dim=dim, dim_in=160 if two else 80, dim_phoneme_emb=kw.get("dim_emb", 1024),
                       num_phoneme_tokens=502, depth=kw.get("depth", 8), dim_head=64,
-                      heads=kw.get("heads", 16), twocondition_oneoutput=two)
+                      heads=kw.get("heads", 16), twocondition_oneoutput=two and not two_out,
+                      twocondition_twooutput=two_out)
         names = [n for n, _ in ref.named_parameters()]
         assert names == list(shapes.keys()), "parameter order/name mismatch vs reference"
         for n, p in ref.named_parameters():
@@ -84,8 +87,10 @@ def main():
 
     def acoustic_cases(tag, kind, b, t, prompt, nfe_roll, **kw):
         ref, sd = build_ref(kind, **kw)
-        inp = syn.synthetic_inputs(kind, b, t, prompt, seed=1234)
+        inp = syn.synthetic_inputs("vomix" if kind == "vomix2out" else kind, b, t, prompt, seed=1234)
         ids, cond, y0 = inp["phoneme_ids"], inp["cond"], inp["y0"]
+        if kind == "vomix2out":                  # y0 = randn_like(cond) (acoustic.py:647-648)
+            y0 = torch.randn(b, t, 160, generator=torch.Generator().manual_seed(4321))
         tm = torch.tensor(0.28125)
         save = dict(phoneme_ids=ids.numpy(), cond=cond.numpy(), y0=y0.numpy(), times=tm.numpy(),
                     mask=inp["mask"].numpy())
@@ -120,10 +125,22 @@ def main():
         print(tag, errs, flush=True)
 
     # full-width VoMix / VoSingle (F-full) and a reduced-width genericity case (F-small)
-    acoustic_cases("vomix_full", "vomix", b=2, t=48, prompt=20, nfe_roll=32)
-    acoustic_cases("vosingle_full", "vosingle", b=2, t=37, prompt=15, nfe_roll=8)
-    acoustic_cases("vomix_small", "vomix", b=3, t=200, prompt=80, nfe_roll=32,
-                   dim=128, dim_emb=64, depth=4, heads=2)
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None     # regenerate one acoustic case
+    if only in (None, "vomix_full"):
+        acoustic_cases("vomix_full", "vomix", b=2, t=48, prompt=20, nfe_roll=32)
+    if only in (None, "vosingle_full"):
+        acoustic_cases("vosingle_full", "vosingle", b=2, t=37, prompt=15, nfe_roll=8)
+    if only in (None, "vomix_small"):
+        acoustic_cases("vomix_small", "vomix", b=3, t=200, prompt=80, nfe_roll=32,
+                       dim=128, dim_emb=64, depth=4, heads=2)
+    if only in (None, "vomix2out_small"):        # row N2: twocondition_twooutput
+        acoustic_cases("vomix2out_small", "vomix2out", b=2, t=100, prompt=40, nfe_roll=16,
+                       dim=128, dim_emb=64, depth=4, heads=2)
+    if only is not None:
+        old = json.load(open(os.path.join(OUT, "REPORT.json")))
+        old.update(report)
+        json.dump(old, open(os.path.join(OUT, "REPORT.json"), "w"), indent=1)
+        return
 
     # ---------------- G5: HiFi-GAN -----------------
     with open(os.path.join(REF, "hifi-gan", "config_covomix.json")) as f:

@@ -18,10 +18,11 @@ ROLL_TOL = 2e-4
 
 def _state(kind, **kw):
     import covomix_amd.synthetic as syn
-    two = kind == "vomix"
+    two = kind in ("vomix", "vomix2out")
     shapes = syn.acoustic_param_shapes(dim=kw.get("dim", 1024), dim_cond=160 if two else 80,
                                        dim_emb=kw.get("dim_emb", 1024), depth=kw.get("depth", 8),
-                                       heads=kw.get("heads", 16), streams=2 if two else 1)
+                                       heads=kw.get("heads", 16), streams=2 if two else 1,
+                                       dim_out=160 if kind == "vomix2out" else 80)
     sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
     sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
     return sd
@@ -31,6 +32,7 @@ CASES = {
     "vomix_full": ("vomix", {}),
     "vosingle_full": ("vosingle", {}),
     "vomix_small": ("vomix", dict(dim=128, dim_emb=64, depth=4, heads=2)),
+    "vomix2out_small": ("vomix2out", dict(dim=128, dim_emb=64, depth=4, heads=2)),    # twocondition_twooutput (row N2)
 }
 
 
@@ -94,7 +96,7 @@ def test_rollout_vs_reference_golden(case):
     mask = torch.from_numpy(g["mask"][:1]).cuda()
     y0 = torch.from_numpy(g["y0"][:1])
     out = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=0.7, y0=y0)
-    assert out.shape == (1, ids.shape[1], 80) and out.is_cuda
+    assert out.shape == (1, ids.shape[1], g["y0"].shape[-1]) and out.is_cuda
     e = rel_l2(out, torch.from_numpy(g["rollout"]))
     print(name, "rollout", nfe, e)
     assert e < ROLL_TOL

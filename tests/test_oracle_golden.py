@@ -13,10 +13,11 @@ import covomix_amd.synthetic as syn
 
 
 def _state(kind, **kw):
-    two = kind == "vomix"
+    two = kind in ("vomix", "vomix2out")
     shapes = syn.acoustic_param_shapes(dim=kw.get("dim", 1024), dim_cond=160 if two else 80,
                                        dim_emb=kw.get("dim_emb", 1024), depth=kw.get("depth", 8),
-                                       heads=kw.get("heads", 16), streams=2 if two else 1)
+                                       heads=kw.get("heads", 16), streams=2 if two else 1,
+                                       dim_out=160 if kind == "vomix2out" else 80)
     sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
     sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
     return sd
@@ -37,9 +38,11 @@ def test_recipe_is_deterministic():
     assert abs(float(a[0, 0]) - float(syn.synth_array("transformer.layers.3.2.to_qkv.weight", (8, 4), seed=1)[0, 0])) > 0
 
 
-def test_oracle_small_vs_reference_golden():
-    sd = _state("vomix", dim=128, dim_emb=64, depth=4, heads=2)
-    g = np.load(os.path.join(GOLDEN, "acoustic_vomix_small.npz"))
+@pytest.mark.parametrize("name,kind", [("vomix_small", "vomix"), ("vomix2out_small", "vomix2out")])
+def test_oracle_small_vs_reference_golden(name, kind):
+    """vomix2out = twocondition_twooutput (acoustic.py:375-376): 160-wide state and output."""
+    sd = _state(kind, dim=128, dim_emb=64, depth=4, heads=2)
+    g = np.load(os.path.join(GOLDEN, f"acoustic_{name}.npz"))
     ids, cond, y0 = (torch.from_numpy(g[k]) for k in ("phoneme_ids", "cond", "y0"))
     t = torch.tensor(float(g["times"]))
     assert rel_l2(orc.acoustic_forward(sd, y0, t, ids, cond, False), torch.from_numpy(g["fwd_cond"])) < 1e-5
