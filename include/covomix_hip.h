@@ -171,6 +171,44 @@ int     cvx_hifigan_pack_weight_f32(const float* w, int32_t Cout, int32_t Cin, i
 int cvx_hifigan_post_f32(const float* x, const float* w, float bias, float* y,
                          int32_t B, int32_t Cin, int32_t L, float slope, cvx_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * ResBlock1 convolutions (covomix/vocoder/models.py:11-48, 97 % of the vocoder's FLOPs) on the fp16 matrix pipe
+ * with split-precision operands (three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate - same scheme and
+ * accuracy class as cvx_gemm_f16x3).  Stride-1 "same" convolution, pad = (ksize-1)*dil/2 (utils.py:34-35).
+ *
+ * All tensors here are CHANNELS-LAST with zero halos: [B][Lp][Cp], position l of batch b at row b*Lp + halo_l + l,
+ * rows outside [halo_l, halo_l + L) and channels >= C must hold zeros (the kernels keep them zero);
+ * halo_l >= pad, Lp >= halo_l + roundup(L, 256) + 64, Cp = channels rounded up to a multiple of 32.
+ *   z_hi/z_lo : input = leaky_relu of the previous value, as (fp16 hi, fp16 lo) pairs, [B][Lp][Cp_in]
+ *   w_hi/w_lo : weights pre-scaled by 1/acc_scale and split, packed [Cp_in/32][ksize][Np][32 ci]
+ *   v = acc*acc_scale + bias[co] (+ res);   out_x = (v (+ accum)) * out_scale   [fp32, optional]
+ *   out_zhi/out_zlo = split(leaky_relu(v, z_slope))                             [optional: the next conv's input]
+ * Np (padded output channels) must be 32, 64, 128 or 256; (ksize-1)*dil even and <= 50.
+ */
+typedef struct {
+    const uint16_t *z_hi, *z_lo;
+    int32_t B, L, Lp, Cp_in, halo_l;
+    const uint16_t *w_hi, *w_lo;
+    float acc_scale;
+    const float* bias;
+    int32_t Np, ksize, dil;
+    const float* res;
+    const float* accum;
+    float* out_x;
+    float out_scale;
+    uint16_t *out_zhi, *out_zlo;
+    float z_slope;
+} cvx_conv16_args;
+int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s);
+
+/* Layout converters between the channel-major fp32 tensors of cvx_hifigan_conv1d_f32 ([B][C][L]) and the
+ * channels-last buffers above: to_channels_last writes the fp32 copy (x_cl, optional) and / or the split pair of
+ * leaky_relu(x, slope) (z_hi/z_lo, optional); from_channels_last the reverse of the fp32 copy. */
+int cvx_hifigan_to_channels_last(const float* x, float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int32_t B, int32_t C,
+                                 int32_t L, int32_t Lp, int32_t Cp, int32_t halo_l, float slope, cvx_stream_t s);
+int cvx_hifigan_from_channels_last(const float* x_cl, float* x, int32_t B, int32_t C, int32_t L, int32_t Lp,
+                                   int32_t Cp, int32_t halo_l, cvx_stream_t s);
+
 /* pcm[i] = (int16) trunc( wav[i] * 32768 )   mel_decode_to_wav tail (monologue_generation.py:55-57),
  * numpy astype('int16') semantics for in-range values (C truncation toward zero). */
 int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s);

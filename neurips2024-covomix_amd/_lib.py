@@ -53,6 +53,17 @@ class ConvArgs(C.Structure):
     ]
 
 
+class Conv16Args(C.Structure):
+    _fields_ = [
+        ("z_hi", C.c_void_p), ("z_lo", C.c_void_p),
+        ("B", C.c_int32), ("L", C.c_int32), ("Lp", C.c_int32), ("Cp_in", C.c_int32), ("halo_l", C.c_int32),
+        ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("bias", C.c_void_p),
+        ("Np", C.c_int32), ("ksize", C.c_int32), ("dil", C.c_int32),
+        ("res", C.c_void_p), ("accum", C.c_void_p), ("out_x", C.c_void_p), ("out_scale", C.c_float),
+        ("out_zhi", C.c_void_p), ("out_zlo", C.c_void_p), ("z_slope", C.c_float),
+    ]
+
+
 class T2SLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c",
                                           "gamma_f", "w1", "b1", "w2", "b2", "k_cache", "v_cache")]
@@ -69,6 +80,11 @@ class T2SDecoder(C.Structure):
 # name -> (restype, argtypes); must list every symbol of include/covomix_hip.h
 SIGNATURES = {
     "cvx_version": (C.c_int, []),
+    "cvx_hifigan_conv1d_f16x3": (C.c_int, [C.POINTER(Conv16Args), C.c_void_p]),
+    "cvx_hifigan_to_channels_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "cvx_hifigan_from_channels_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_int32, C.c_void_p]),
     "cvx_t2s_decode_steps": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p]),
     "cvx_geglu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),

@@ -1,0 +1,341 @@
+// HiFi-GAN ResBlock convolutions on the fp16 matrix pipe with split-precision operands (gfx950).
+//
+// Reference: covomix/vocoder/models.py:11-48 (ResBlock1: 3 x [lrelu -> Conv1d(k, dil) -> lrelu -> Conv1d(k, 1) -> +x]),
+// :104-110 (xs = sum of the resblocks / num_kernels).  97 % of the vocoder's FLOPs are these 72 stride-1 "same"
+// convolutions; hifigan_f32.hip runs them (and everything else) on v_mfma_f32_32x32x2_f32 at 47-62 TFLOP/s.  Here
+// they use the scheme of gemm_f16x3.hip: every fp32 value is an (fp16 hi, fp16 lo) pair and each product is three
+// v_mfma_f32_32x32x16_f16 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulate) - fp32-class accuracy.
+//
+// Layout: activations are CHANNELS-LAST, [B][Lp][Cp] with Cp = C rounded up to 32 and HALO_L zero rows in front of
+// position 0 (and zero rows behind position L-1), so "same" padding and ragged tiles need no predication: an
+// activation tile is a set of contiguous 64-byte rows that go global -> LDS by DMA.
+// Implicit GEMM:  out[l, co] = sum_{c, kk}  z[l + kk*dil - pad, c] * W[co, c, kk]
+//   M = positions (A operand = activations), N = output channels (B operand = weights), K = 32 input channels per
+//   chunk x taps.  Block = 256 positions x all output channels (Np = 32/64/128/256), 8 waves.
+//   A tile: the 256 + (k-1)*dil rows of one channel chunk, staged ONCE per chunk and shared by all taps (a tap is a
+//           row offset of the fragment reads) - double buffered across chunks;
+//   W stage: TS = 256/Np taps of one chunk ([tap][co][32 ci], 64-byte rows), double buffered; one barrier per stage.
+// Both use the GEMM's XOR swizzle (16-byte chunk ^ ((row >> 2) & 3)) on the DMA source and on the ds_read_b128.
+// Epilogue (rows = positions, so a lane quad transposes 4x4 blocks and stores 4 consecutive channels): bias, ResBlock
+// residual, the running xs accumulate / scale, an fp32 store of the new residual stream and / or the split fp16 store
+// of leaky_relu(value) = the next convolution's input - no separate activation pass exists.
+#include "gemm_common.h"
+
+namespace {
+
+using namespace cvxg;
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CK = 32;                 // input channels per chunk (one 64-byte row)
+constexpr int TMB = 256;               // positions per block
+constexpr int A_ROWS = 320;            // TMB + halo (<= 50) rounded up to the 16-row DMA piece
+constexpr int A_TILE = A_ROWS * CK;    // halves of one (hi or lo) activation tile: 20 KiB
+constexpr int W_TILE = 256 * CK;       // halves of one (hi or lo) weight stage (TS taps x Np rows = 256 rows): 16 KiB
+constexpr int LDS_HALVES = 2 * 2 * A_TILE + 2 * 2 * W_TILE;      // 144 KiB
+
+struct Conv16Args {
+    const f16* z_hi; const f16* z_lo;  // [B][Lp][Cp_in]
+    const f16* w_hi; const f16* w_lo;  // [chunk][tap][Np][32]
+    const float* bias;                 // [Np]
+    const float* res;                  // fp32 [B][Lp][Np] or NULL
+    const float* accum;                // fp32 [B][Lp][Np] or NULL
+    float* out_x;                      // fp32 [B][Lp][Np] or NULL
+    f16* out_zhi; f16* out_zlo;        // [B][Lp][Np] or NULL
+    int L, Lp, Cp_in, Np, ksize, dil, pad, halo_l;
+    float acc_scale, out_scale, z_slope;
+};
+
+template <int TMI, int TNI, int WN>
+__global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
+{
+    constexpr int WM = 8 / WN;
+    constexpr int NP = WN * TNI * 32;
+    constexpr int TS = 256 / NP;                         // taps per weight stage
+    static_assert(WM * TMI * 32 == TMB, "block tile must be 256 positions");
+    extern __shared__ __attribute__((aligned(16))) f16 smem_c[];
+    f16* const As = smem_c;                              // [2 buffers][hi | lo][A_ROWS][32]
+    f16* const Ws = smem_c + 4 * A_TILE;                 // [2 stages][hi | lo][256][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l0 = blockIdx.x * TMB;
+    const int b = blockIdx.y;
+    const int n_chunks = p.Cp_in / CK;
+    const int n_groups = (p.ksize + TS - 1) / TS;
+    const int steps = n_chunks * n_groups;
+
+    // ---- DMA addressing: a piece = 16 rows x 64 bytes; lane -> (row = lane >> 2, 16-byte chunk = lane & 3, swizzled)
+    const int prow = lane >> 2;
+    const int64_t a_row0 = (int64_t)b * p.Lp + p.halo_l + l0 - p.pad;            // global row of tile row 0 (>= 0)
+    auto issue_a = [&](int chunk) {
+        f16* dst = As + (chunk & 1) * 2 * A_TILE;
+        for (int pc = wid; pc < A_ROWS / 16; pc += 8) {
+            const int r = 16 * pc + prow;
+            const int c4 = (lane & 3) ^ ((r >> 2) & 3);
+            const int64_t src = (a_row0 + r) * p.Cp_in + chunk * CK + 8 * c4;
+            glds16(p.z_hi + src, dst + 16 * pc * CK);
+            glds16(p.z_lo + src, dst + A_TILE + 16 * pc * CK);
+        }
+    };
+    auto issue_w = [&](int st) {
+        const int chunk = st / n_groups, grp = st - chunk * n_groups;
+        const int t0 = grp * TS, nt = min(TS, p.ksize - t0);
+        f16* dst = Ws + (st & 1) * 2 * W_TILE;
+        const int64_t base = ((int64_t)chunk * p.ksize + t0) * NP * CK;
+        for (int pc = wid; pc < nt * NP / 16; pc += 8) {
+            const int r = 16 * pc + prow;
+            const int c4 = (lane & 3) ^ ((r >> 2) & 3);
+            const int64_t src = base + (int64_t)r * CK + 8 * c4;
+            glds16(p.w_hi + src, dst + 16 * pc * CK);
+            glds16(p.w_lo + src, dst + W_TILE + 16 * pc * CK);
+        }
+    };
+
+    f32x16 acc[TMI][TNI];
+#pragma unroll
+    for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int i31 = lane & 31, g = lane >> 5;
+    const int wswz = (i31 >> 2) & 3;
+    int woff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) woff[s] = (wn * TNI * 32 + i31) * CK + 8 * ((2 * s + g) ^ wswz);
+    const int arow_base = wm * TMI * 32 + i31;
+
+    issue_a(0);
+    issue_w(0);
+    for (int st = 0; st < steps; ++st) {
+        const int chunk = st / n_groups, grp = st - chunk * n_groups;
+        const int t0 = grp * TS, nt = min(TS, p.ksize - t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // stage st (and its activation tile) landed; the other buffers are free
+        if (st + 1 < steps) {
+            issue_w(st + 1);
+            if (grp == 0 && chunk + 1 < n_chunks) issue_a(chunk + 1);
+        }
+        const f16* Ah = As + (chunk & 1) * 2 * A_TILE;
+        const f16* Al = Ah + A_TILE;
+        const f16* Wh = Ws + (st & 1) * 2 * W_TILE;
+        const f16* Wl = Wh + W_TILE;
+        for (int tl = 0; tl < nt; ++tl) {
+            const int arow = arow_base + (t0 + tl) * p.dil;            // tile row of output row i31 for this tap
+            const int aswz = (arow >> 2) & 3;
+            const f16* wth = Wh + tl * NP * CK;
+            const f16* wtl = Wl + tl * NP * CK;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int aoff = arow * CK + 8 * ((2 * s + g) ^ aswz);
+                f16x8 fah[TMI], fal[TMI], fwh[TNI], fwl[TNI];
+#pragma unroll
+                for (int ni = 0; ni < TNI; ++ni) {
+                    fwh[ni] = *reinterpret_cast<const f16x8*>(wth + ni * 32 * CK + woff[s]);
+                    fwl[ni] = *reinterpret_cast<const f16x8*>(wtl + ni * 32 * CK + woff[s]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < TMI; ++mi) {
+                    fah[mi] = *reinterpret_cast<const f16x8*>(Ah + mi * 32 * CK + aoff);
+                    fal[mi] = *reinterpret_cast<const f16x8*>(Al + mi * 32 * CK + aoff);
+                }
+#pragma unroll
+                for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue.  acc register 4*rg + e of lane (i31, g): position 8*rg + 4*g + e, channel i31.  After the quad
+    // transpose lane q = lane & 3 holds position 8*rg + 4*g + q and the 4 channels 4*(i31 >> 2) .. +3.
+    const int q = lane & 3;
+    const int c4 = 4 * (i31 >> 2);
+#pragma unroll
+    for (int mi = 0; mi < TMI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) {
+            const int co = wn * TNI * 32 + ni * 32 + c4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v0 = acc[mi][ni][4 * rg + 0], v1 = acc[mi][ni][4 * rg + 1];
+                float v2 = acc[mi][ni][4 * rg + 2], v3 = acc[mi][ni][4 * rg + 3];
+                quad_transpose(v0, v1, v2, v3, lane);
+                const int l = l0 + wm * TMI * 32 + mi * 32 + 8 * rg + 4 * g + q;
+                if (l >= p.L) continue;
+                const int64_t o = ((int64_t)b * p.Lp + p.halo_l + l) * NP + co;
+                f32x4 v = {v0 * p.acc_scale + bv[0], v1 * p.acc_scale + bv[1], v2 * p.acc_scale + bv[2], v3 * p.acc_scale + bv[3]};
+                if (p.res) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                }
+                if (p.out_x) {
+                    f32x4 w = v;
+                    if (p.accum) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.accum + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] += a4[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] *= p.out_scale;
+                    *reinterpret_cast<f32x4*>(p.out_x + o) = w;
+                }
+                if (p.out_zhi) {
+                    cvx_f16x4 zh, zl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float z = v[e] > 0.f ? v[e] : v[e] * p.z_slope;
+                        z = fminf(fmaxf(z, -65504.f), 65504.f);
+                        zh[e] = (_Float16)z;
+                        zl[e] = (_Float16)(z - (float)zh[e]);
+                    }
+                    *reinterpret_cast<cvx_f16x4*>(p.out_zhi + o) = zh;
+                    *reinterpret_cast<cvx_f16x4*>(p.out_zlo + o) = zl;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- layout converters (HBM-bound transposes)
+// channel-major fp32 [B][C][L]  ->  channels-last [B][Lp][Cp]: fp32 copy (optional) + split fp16 of leaky_relu(x)
+__global__ __launch_bounds__(256) void cm_to_cl_kernel(const float* __restrict__ x, float* __restrict__ x_cl,
+                                                      f16* __restrict__ z_hi, f16* __restrict__ z_lo,
+                                                      int C, int L, int Lp, int Cp, int halo_l, float slope)
+{
+    __shared__ float tile[32][65];
+    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    {
+        const int j = tid & 63, cs = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + cs + 4 * i, l = l0 + j;
+            tile[cs + 4 * i][j] = (c < C && l < L) ? x[((int64_t)b * C + c) * L + l] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int c = tid & 31, js = tid >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = js + 8 * i, l = l0 + j;
+        if (l >= L) continue;
+        const float v = tile[c][j];
+        const int64_t o = ((int64_t)b * Lp + halo_l + l) * Cp + c0 + c;
+        if (x_cl) x_cl[o] = v;
+        if (z_hi) {
+            float z = v > 0.f ? v : v * slope;
+            z = fminf(fmaxf(z, -65504.f), 65504.f);
+            const f16 h = (f16)z;
+            z_hi[o] = h;
+            z_lo[o] = (f16)(z - (float)h);
+        }
+    }
+}
+
+// channels-last fp32 [B][Lp][Cp]  ->  channel-major fp32 [B][C][L]
+__global__ __launch_bounds__(256) void cl_to_cm_kernel(const float* __restrict__ x_cl, float* __restrict__ x, int C, int L,
+                                                      int Lp, int Cp, int halo_l)
+{
+    __shared__ float tile[64][33];
+    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    {
+        const int c = tid & 31, js = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = js + 8 * i, l = l0 + j;
+            tile[j][c] = (l < L) ? x_cl[((int64_t)b * Lp + halo_l + l) * Cp + c0 + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int j = tid & 63, cs = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c0 + cs + 4 * i, l = l0 + j;
+        if (c < C && l < L) x[((int64_t)b * C + c) * L + l] = tile[j][cs + 4 * i];
+    }
+}
+
+template <int TMI, int TNI, int WN>
+void launch_conv16(const Conv16Args& a, int B, hipStream_t st)
+{
+    static bool attr = false;
+    const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((unsigned)((a.L + TMB - 1) / TMB), (unsigned)B);
+    hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN>), grid, dim3(512), lds, st, a);
+}
+
+}  // namespace
+
+extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->z_hi && a->z_lo && a->w_hi && a->w_lo && a->bias, "conv1d_f16x3: null pointer");
+    CVX_REQUIRE(a->B >= 0 && a->L > 0 && a->Cp_in > 0 && a->Cp_in % 32 == 0 &&
+                (a->Np == 32 || a->Np == 64 || a->Np == 128 || a->Np == 256),
+                "conv1d_f16x3: bad shape (L=%d Cp_in=%d Np=%d): channels are padded to 32 and Np is 32/64/128/256", a->L, a->Cp_in, a->Np);
+    CVX_REQUIRE(a->ksize > 0 && a->dil > 0 && (a->ksize - 1) * a->dil <= A_ROWS - TMB - 14 && (a->ksize - 1) * a->dil % 2 == 0,
+                "conv1d_f16x3: (ksize-1)*dil = %d must be even and <= 50", (a->ksize - 1) * a->dil);
+    const int pad = (a->ksize - 1) * a->dil / 2;                       // "same" convolution (get_padding, utils.py:34-35)
+    CVX_REQUIRE(a->halo_l >= pad && a->Lp >= a->halo_l + ((a->L + TMB - 1) / TMB) * TMB + (A_ROWS - TMB),
+                "conv1d_f16x3: buffers need %d zero rows in front and Lp >= halo_l + roundup(L, 256) + 64 (halo_l=%d Lp=%d)", pad, a->halo_l, a->Lp);
+    CVX_REQUIRE((a->out_zhi == nullptr) == (a->out_zlo == nullptr) && (a->out_x || a->out_zhi) && (!a->accum || a->out_x),
+                "conv1d_f16x3: bad output combination");
+    if (a->B == 0) return CVX_OK;
+    Conv16Args k{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
+                 reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
+                 reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
+                 a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope};
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    if (a->Np == 256) launch_conv16<4, 2, 4>(k, a->B, st);
+    else if (a->Np == 128) launch_conv16<2, 2, 2>(k, a->B, st);
+    else if (a->Np == 64) launch_conv16<1, 2, 1>(k, a->B, st);
+    else launch_conv16<1, 1, 1>(k, a->B, st);
+    CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_f16x3");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_to_channels_last(const float* x, float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int32_t B, int32_t C,
+                                            int32_t L, int32_t Lp, int32_t Cp, int32_t halo_l, float slope, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && (x_cl || z_hi) && ((z_hi == nullptr) == (z_lo == nullptr)) && B >= 0 && C > 0 && L > 0 && Cp >= C && Cp % 32 == 0 &&
+                halo_l >= 0 && Lp >= halo_l + L, "to_channels_last: bad arguments");
+    if (B == 0) return CVX_OK;
+    dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
+    hipLaunchKernelGGL(cm_to_cl_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, x_cl,
+                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope);
+    CVX_CHECK_LAUNCH("cvx_hifigan_to_channels_last");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_from_channels_last(const float* x_cl, float* x, int32_t B, int32_t C, int32_t L, int32_t Lp,
+                                              int32_t Cp, int32_t halo_l, cvx_stream_t s)
+{
+    CVX_REQUIRE(x_cl && x && B >= 0 && C > 0 && L > 0 && Cp >= C && Cp % 32 == 0 && halo_l >= 0 && Lp >= halo_l + L,
+                "from_channels_last: bad arguments");
+    if (B == 0) return CVX_OK;
+    dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
+    hipLaunchKernelGGL(cl_to_cm_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x_cl, x, C, L, Lp, Cp, halo_l);
+    CVX_CHECK_LAUNCH("cvx_hifigan_from_channels_last");
+    return CVX_OK;
+}

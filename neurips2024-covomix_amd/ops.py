@@ -260,6 +260,74 @@ def hifigan_pack_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
     return wp
 
 
+HIFI_HALO_L = 32        # zero rows in front of position 0 of every channels-last vocoder buffer (>= largest pad, 25)
+
+
+def hifigan_cl_rows(L: int) -> int:
+    """Rows per batch item of a channels-last vocoder buffer for L valid positions."""
+    return HIFI_HALO_L + (L + 255) // 256 * 256 + 64
+
+
+def hifigan_pack_weight_f16x3(w: torch.Tensor):
+    """Conv1d weight [Cout, Cin, k] (fp32, on the GPU) -> (w_hi, w_lo, 1/scale, Np, Cp_in): pre-scaled split pair
+    packed [Cp_in/32][k][Np][32] for cvx_hifigan_conv1d_f16x3.  Load-time plumbing."""
+    cout, cin, k = w.shape
+    tile = lambda c: 32 if c <= 32 else 64 if c <= 64 else 128 if c <= 128 else 256
+    assert cout <= 256 and cin <= 256, "conv1d_f16x3 supports up to 256 channels"
+    np_, cp = tile(cout), tile(cin)          # a stage's buffers are as wide as its output tile, for inputs too
+    full = torch.zeros(np_, cp, k, dtype=torch.float32, device=w.device)
+    full[:cout, :cin] = w
+    packed = full.reshape(np_, cp // 32, 32, k).permute(1, 3, 0, 2).contiguous()      # [chunk][tap][co][ci]
+    hi, lo, inv = split_f16(packed)
+    return hi, lo, inv, np_, cp
+
+
+def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, res=None, accum=None, out_x=None,
+                         out_scale: float = 1.0, out_z=None, z_slope: float = 0.1) -> None:
+    """z = (hi, lo) channels-last [B, Lp, Cp_in]; wpk from hifigan_pack_weight_f16x3; bias [Np] (zero padded)."""
+    zh, zl = z
+    w_hi, w_lo, inv, np_, cp = wpk
+    assert zh.dtype == torch.float16 and zh.is_contiguous() and zl.is_contiguous() and zh.shape == zl.shape
+    assert zh.shape[0] == B and zh.shape[2] == cp and bias.numel() == np_
+    a = _lib.Conv16Args()
+    a.z_hi, a.z_lo = zh.data_ptr(), zl.data_ptr()
+    a.B, a.L, a.Lp, a.Cp_in, a.halo_l = B, L, zh.shape[1], cp, HIFI_HALO_L
+    a.w_hi, a.w_lo, a.acc_scale, a.bias = w_hi.data_ptr(), w_lo.data_ptr(), inv, bias.data_ptr()
+    a.Np, a.ksize, a.dil = np_, ksize, dil
+    for t in (res, accum, out_x):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (B, zh.shape[1], np_))
+    a.res, a.accum, a.out_x, a.out_scale = _p(res), _p(accum), _p(out_x), out_scale
+    if out_z is not None:
+        oh, ol = out_z
+        assert oh.dtype == torch.float16 and oh.is_contiguous() and ol.is_contiguous() and tuple(oh.shape) == (B, zh.shape[1], np_)
+        a.out_zhi, a.out_zlo = oh.data_ptr(), ol.data_ptr()
+    else:
+        a.out_zhi, a.out_zlo = None, None
+    a.z_slope = z_slope
+    _lib.check(_lib.load().cvx_hifigan_conv1d_f16x3(C.byref(a), _stream()), "cvx_hifigan_conv1d_f16x3")
+
+
+def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, slope: float) -> None:
+    """x [B, C, L] fp32 channel-major -> x_cl [B, Lp, Cp] fp32 and / or z = split(leaky_relu(x)) [B, Lp, Cp]."""
+    _chk_f32(x, x_cl)
+    B, Cc, L = x.shape
+    ref = x_cl if x_cl is not None else z[0]
+    Lp, Cp = ref.shape[1], ref.shape[2]
+    assert x.is_contiguous() and ref.is_contiguous() and ref.shape[0] == B
+    zh, zl = z if z is not None else (None, None)
+    _lib.check(_lib.load().cvx_hifigan_to_channels_last(x.data_ptr(), _p(x_cl), _p(zh), _p(zl), B, Cc, L, Lp, Cp, HIFI_HALO_L,
+                                                        slope, _stream()), "cvx_hifigan_to_channels_last")
+
+
+def hifigan_from_channels_last(x_cl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _chk_f32(x_cl, x)
+    B, Cc, L = x.shape
+    assert x.is_contiguous() and x_cl.is_contiguous() and x_cl.shape[0] == B
+    _lib.check(_lib.load().cvx_hifigan_from_channels_last(x_cl.data_ptr(), x.data_ptr(), B, Cc, L, x_cl.shape[1], x_cl.shape[2],
+                                                          HIFI_HALO_L, _stream()), "cvx_hifigan_from_channels_last")
+    return x
+
+
 def hifigan_post(x: torch.Tensor, w: torch.Tensor, bias: float, out: torch.Tensor, slope: float = 0.01) -> torch.Tensor:
     _chk_f32(x, w, out)
     B, Cin, L = x.shape

@@ -12,9 +12,17 @@ covomix/vocoder/env.py:5-8 (AttrDict) of the reference:
 Only resblock == '1' (what config_covomix.json selects) is implemented.  Each conv launch
 fuses the preceding leaky_relu, bias, the ResBlock residual add and the running
 `xs += resblock(x)` / `xs / num_kernels` of Generator.forward (models.py:104-110).
+
+precision (constructor argument or env CVX_VOCODER_PRECISION):
+  'f16x3' (default)  the 72 ResBlock convolutions (97 % of the FLOPs) run on the fp16 matrix pipe with split-precision
+                     operands (cvx_hifigan_conv1d_f16x3, channels-last activations with zero halos); conv_pre, the four
+                     ConvTranspose1d upsamplers and conv_post stay on the fp32 kernels, with a layout converter on
+                     either side of every ResBlock stage;
+  'fp32'             everything on v_mfma_f32_32x32x2_f32 (cvx_hifigan_conv1d_f32).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -52,13 +60,17 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 class _Conv:
-    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn")
+    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn", "w16", "bias16")
 
 
 class Generator:
-    def __init__(self, h):
+    def __init__(self, h, precision: Optional[str] = None):
         if str(h["resblock"]) != "1":
             raise NotImplementedError("only ResBlock1 (resblock == '1') is supported, as in config_covomix.json")
+        self.precision = precision or os.environ.get("CVX_VOCODER_PRECISION", "f16x3")
+        if self.precision not in ("f16x3", "fp32"):
+            raise ValueError(f"vocoder precision must be 'f16x3' or 'fp32', got {self.precision!r}")
+        self._cl: Dict[tuple, dict] = {}
         self.h = h
         self.num_kernels = len(h["resblock_kernel_sizes"])
         self.num_upsamples = len(h["upsample_rates"])
@@ -109,6 +121,12 @@ class Generator:
         c.dil, c.up = dil, up
         c.wp = ops.hifigan_pack_weight(w, transposed).to(self.device)
         c.bias = sd[name + ".bias"].float().to(self.device).contiguous()
+        c.w16 = c.bias16 = None
+        if (self.precision == "f16x3" and not transposed and up == 1 and name.startswith("resblocks.") and c.cout <= 256
+                and (c.k - 1) * dil <= 50 and (c.k - 1) * dil % 2 == 0):
+            c.w16 = ops.hifigan_pack_weight_f16x3(w.to(self.device))
+            c.bias16 = torch.zeros(c.w16[3], dtype=torch.float32, device=self.device)
+            c.bias16[: c.cout] = c.bias
         return c
 
     def _pack(self):
@@ -158,6 +176,9 @@ class Generator:
         x = self._run(pk["pre"], x)
         for i in range(self.num_upsamples):
             x = self._run(pk["ups"][i], x, in_slope=LRELU_SLOPE)            # leaky_relu + ConvTranspose1d
+            if all(c.w16 is not None for block in pk["res"][i] for pair in block for c in pair):
+                x = self._resblocks_f16x3(pk["res"][i], x)
+                continue
             t = torch.empty_like(x)
             r = torch.empty_like(x)
             xs = torch.empty_like(x)
@@ -179,6 +200,48 @@ class Generator:
         return y.squeeze(0) if unbatched else y
 
     forward = __call__
+
+    # ---- ResBlock stage on the split-precision kernel ---------------------------------------
+    def _cl_buffers(self, B: int, C: int, L: int) -> dict:
+        """Channels-last buffers of one stage, zero-initialised ONCE (the kernels only ever write valid rows, and
+        write zeros into the padded channels), cached per shape."""
+        key = (B, C, L)
+        buf = self._cl.get(key)
+        if buf is None:
+            Lp, Cp = ops.hifigan_cl_rows(L), (C + 31) // 32 * 32
+            np_ = 32 if C <= 32 else 64 if C <= 64 else 128 if C <= 128 else 256
+            assert np_ == Cp or Cp < np_          # Cp (input padding, x32) <= Np (output tile); use Np for both
+            Cp = np_
+            f32 = lambda: torch.zeros(B, Lp, Cp, dtype=torch.float32, device=self.device)
+            f16 = lambda: (torch.zeros(B, Lp, Cp, dtype=torch.float16, device=self.device),
+                           torch.zeros(B, Lp, Cp, dtype=torch.float16, device=self.device))
+            buf = dict(x0=f32(), r0=f32(), r1=f32(), xs=f32(), z0=f16(), t=f16(), rz0=f16(), rz1=f16())
+            if len(self._cl) >= 8:
+                self._cl.clear()
+            self._cl[key] = buf
+        return buf
+
+    def _resblocks_f16x3(self, blocks, x: torch.Tensor) -> torch.Tensor:
+        """xs = sum_j ResBlock1_j(x) / num_kernels  (models.py:104-110, :35-42) for one upsampling stage."""
+        B, C, L = x.shape
+        buf = self._cl_buffers(B, C, L)
+        ops.hifigan_to_channels_last(x, buf["x0"], buf["z0"], LRELU_SLOPE)
+        nblk = len(blocks)
+        for j, block in enumerate(blocks):
+            cur_x, cur_z = buf["x0"], buf["z0"]
+            for m, (c1, c2) in enumerate(block):
+                ops.hifigan_conv1d_f16x3(cur_z, c1.w16, c1.bias16, B, L, ksize=c1.k, dil=c1.dil, out_z=buf["t"], z_slope=LRELU_SLOPE)
+                if m + 1 < len(block):
+                    ox, oz = (buf["r0"], buf["rz0"]) if m % 2 == 0 else (buf["r1"], buf["rz1"])
+                    ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x, out_x=ox,
+                                             out_z=oz, z_slope=LRELU_SLOPE)
+                    cur_x, cur_z = ox, oz
+                else:                                                    # last pair: fold into xs
+                    ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x,
+                                             accum=buf["xs"] if j > 0 else None, out_x=buf["xs"],
+                                             out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0)
+        out = torch.empty_like(x)
+        return ops.hifigan_from_channels_last(buf["xs"], out)
 
 
 def mel_decode_to_wav(generator: Generator, mel: torch.Tensor):
