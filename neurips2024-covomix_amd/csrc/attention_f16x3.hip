@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
 
     // (a stage of two key tiles - one barrier per 64 keys - was measured slower: 64 KiB of LDS drops the kernel
     //  from 3 to 2 blocks per CU)
+    // (a 3-stage ring - tiles requested two ahead - measured the same: the loop is not DMA-latency bound)
     const int ntiles = (T + KT - 1) / KT;
     issue(0, 0);
     for (int it = 0; it < ntiles; ++it) {
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;          // scale > 0: max commutes with it
         const float m_new = fmaxf(m_run, mx);
         const bool moved = m_new != m_run;
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
         f16x8 ph[2], pl[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = exp2f(fmaf(sacc[r], scale_log2e, -m_new));
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -m_new));
             psum += pv;
             const f16 h = (f16)pv;
             ph[r >> 3][r & 7] = h;
