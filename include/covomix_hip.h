@@ -227,11 +227,14 @@ int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s);
  * Host packing contract (neurips2024-covomix_amd/t2s.py):
  *   wqkv_s [3*inner, dim] = to_q | to_k | to_v rows; inside every 64-row head of to_q and to_k the rows are
  *       permuted (0,2,..,62,1,3,..,63) so the reference's interleaved rotary pairs become half-split pairs;
- *   kv_c   [n_ctx, 2, inner]: row 0 = null_kv, rows 1.. = to_kv(encoder output), computed once per utterance;
+ *   kv_c   [batch, ctx_rows, 2, inner]: row 0 = null_kv, rows 1.. = to_kv(encoder output), computed once per utterance;
+ *   k_cache / v_cache [batch, max_len, inner]; every per-utterance buffer below is [batch, ...];
  *   w2     [dim, ff_inner_pad]: the K dimension zero-padded to a multiple of 4;
  *   rope_cos / rope_sin [max_len, 32]: cos / sin(position * freqs[i]);
- *   uniforms [max_len, streams, vocab]; tokens [streams, max_len] int64;
- *   state int32[4]: [0] position (= tokens produced so far), [1] 1 once an eos was sampled in any stream,
+ *   uniforms [max_len, batch, streams, vocab]; tokens [batch, streams, max_len] int64;
+ *   batch (1..8) utterances advance together; a weight row is read once per step for all of them, and the
+ *   arithmetic per utterance does not depend on the batch size (results are bit-identical to batch 1);
+ *   state int32[batch][4]: [0] position (= tokens produced so far), [1] 1 once an eos was sampled in any stream,
  *       [2] number of steps at that moment, [3] context rows (null row included) used when n_ctx == 0, so that one
  *       captured graph serves utterances of different text length; x must hold start_token and state[0..2]
  *       zeros before the first step.
@@ -247,10 +250,11 @@ typedef struct {
 
 typedef struct {
     int32_t dim, inner, heads, ff_inner, ff_inner_pad, depth, streams, vocab, dim_emb, n_ctx, max_len, top_k;
+    int32_t batch, ctx_rows;                     /* utterances decoded together (1..8); kv_c rows allocated per utterance */
     float temperature;
     const cvx_t2s_layer* layers;                 /* HOST array of `depth` entries */
     const float *final_gamma, *emb, *rope_cos, *rope_sin, *uniforms;
-    float *x, *q, *att, *h, *logits;             /* [dim], [inner], [inner], [ff_inner_pad], [streams, vocab] */
+    float *x, *q, *att, *h, *logits;             /* per utterance: [dim], [inner], [inner], [ff_inner_pad], [streams, vocab] */
     int64_t* tokens;
     int32_t* state;
 } cvx_t2s_decoder;

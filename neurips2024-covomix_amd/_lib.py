@@ -71,7 +71,7 @@ class T2SLayer(C.Structure):
 
 class T2SDecoder(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "inner", "heads", "ff_inner", "ff_inner_pad", "depth", "streams", "vocab",
-                                         "dim_emb", "n_ctx", "max_len", "top_k")] + \
+                                         "dim_emb", "n_ctx", "max_len", "top_k", "batch", "ctx_rows")] + \
                [("temperature", C.c_float), ("layers", C.POINTER(T2SLayer))] + \
                [(n, C.c_void_p) for n in ("final_gamma", "emb", "rope_cos", "rope_sin", "uniforms",
                                           "x", "q", "att", "h", "logits", "tokens", "state")]

@@ -171,7 +171,8 @@ class CoVoMixModel:
         """reference conditional_model.py:313-321 -> TextToSemanticWrapper.sample (text2semantic.py:1237-1251): the
         sampled semantic tokens as one flat int64 tensor (two-output models: stream 1 then stream 2) on the input's
         device.  (`temprature` is the reference's spelling.)  `uniforms` / `generator` (optional) fix the U(0,1) draws
-        behind the Gumbel noise; parity is defined given them."""
+        behind the Gumbel noise; parity is defined given them.  A LIST of id tensors (up to 8) is decoded as one batch and
+        returns a list (the reference decodes utterances one by one; the tokens are the same)."""
         if not self.is_text2semantic:
             raise TypeError("this checkpoint is an acoustic model: use synthesis_sample")
         assert cond_scale >= 1., "cond_scale >= 1 (text2semantic.py:690)"
@@ -186,5 +187,8 @@ class CoVoMixModel:
             from .t2s import TextToSemanticDecoder
             self._t2s = TextToSemanticDecoder(self.active_state_dict(), self.device)
         ids = grapheme_token_ids
+        if isinstance(ids, (list, tuple)):          # extension: several utterances decoded together (bit-identical tokens)
+            res = self._t2s.generate_batch(list(ids), uniforms, max_length, float(temprature), generator)
+            return [r[0].to(i.device) for r, i in zip(res, ids)]
         out = self._t2s.generate(ids, uniforms=uniforms, max_length=max_length, temperature=float(temprature), generator=generator)
         return out.to(ids.device) if ids.device != out.device else out

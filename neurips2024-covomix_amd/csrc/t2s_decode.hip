@@ -1,8 +1,11 @@
 // text2semantic autoregressive decode: one token step of the reference's
 // TextToSemantic.generate sampling loop (covomix/covomix_model/text2semantic.py:748-820) with a KV cache.
 //
-// B = 1, one new position per step: every projection is a matrix-VECTOR product, so the step is bound by streaming
-// the decoder weights (CoSingle 67 MB, CoMix 184 MB of fp32 per token) - an HBM/MALL-bound path, not an MFMA one.
+// One new position per step: every projection is a matrix-VECTOR product, so the step is bound by streaming the
+// decoder weights (CoSingle 60 MB, CoMix 186 MB of fp32 per token step) - an HBM/MALL-bound path, not an MFMA one.
+// BATCH: up to 8 utterances advance together (same position, own context / cache / eos): a weight row is read once
+// and multiplied with every utterance's vector, so the step costs about the same as for one utterance.  The arithmetic
+// per utterance (summation order included) does not depend on the batch size: results are bit-identical to batch 1.
 // Kernels (all fp32, fp32 accumulate):
 //   gemv_kernel<MODE>   block = 4 waves, every wave owns TWO output rows (the pairs are chosen so that the epilogue
 //                       has both members of a RoPE pair / a GEGLU (value, gate) pair in one wave); the input vector is
@@ -29,11 +32,13 @@ enum { MODE_QKV = 0, MODE_PLAIN = 1, MODE_RES = 2, MODE_GEGLU = 3, MODE_LOGITS =
 struct GemvArgs {
     const float* W;          // [N, ldw]
     int64_t ldw;
-    const float* x;          // input vector [K]
+    const float* x;          // input vectors [batch][x_stride], K used
     const float* gamma;      // RMSNorm weight over x (NULL: x is used as is)
     const float* bias;       // [N] or NULL
-    float* y;                // output
+    float* y;                // output [batch][y_stride]
     int N, K;
+    int x_stride, y_stride;
+    int64_t cache_stride;    // floats between the k/v caches of two utterances
     // MODE_QKV: rows [0, inner) q, [inner, 2 inner) k, [2 inner, 3 inner) v; RoPE on q/k at position *pos
     int inner;
     const float* rope_cos;   // [max_len, 32]
@@ -55,13 +60,13 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <int MODE>
+template <int MODE, int BQ>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float xs[T2S_MAX_DIM];
-    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float xs[];         // [BQ][Kin] (Kin a multiple of 4)
+    __shared__ float red[BQ][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length
+    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per utterance
 
     // ---- the two rows of this wave
     const int pair = blockIdx.x * 4 + wid;
@@ -102,87 +107,116 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         if (k < K4) { pa[i] = gload4(w0 + k); pb[i] = gload4(w1 + k); }
     }
 
-    // ---- stage (and normalise) the input vector
-    float ss = 0.f;
+    // ---- stage (and normalise) the input vectors (k outer, utterances inner: the loads of one k are independent)
+    float inv[BQ], ss[BQ];
+#pragma unroll
+    for (int b = 0; b < BQ; ++b) ss[b] = 0.f;
     for (int k = tid; k < Kin; k += 256) {
-        const float v = a.x[k];
-        ss += v * v;
-        xs[k] = a.gamma ? v * a.gamma[k] : v;
+        const float gk = a.gamma ? a.gamma[k] : 1.f;
+        float v[BQ];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) v[b] = a.x[(int64_t)b * a.x_stride + k];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) { ss[b] = fmaf(v[b], v[b], ss[b]); xs[b * Kin + k] = v[b] * gk; }
     }
-    float inv = 1.f;
     if (a.gamma) {
-        ss = wave_sum(ss);
-        if (lane == 0) red[wid] = ss;
-        __syncthreads();
-        const float tot = red[0] + red[1] + red[2] + red[3];
-        inv = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);          // F.normalize(eps = 1e-12) * sqrt(dim)
-    } else {
-        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) ss[b] = wave_sum(ss[b]);
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) red[b][wid] = ss[b];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < BQ; ++b) {
+        inv[b] = 1.f;
+        if (a.gamma) {
+            const float tot = red[b][0] + red[b][1] + red[b][2] + red[b][3];
+            inv[b] = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize(eps = 1e-12) * sqrt(dim)
+        }
     }
     if (!valid) {
         if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
             const int F = a.N / 2;
-            if (pair >= F && pair < a.y_pad && lane == 0) a.y[pair] = 0.f;
+            if (pair >= F && pair < a.y_pad && lane == 0)
+                for (int b = 0; b < BQ; ++b) a.y[(int64_t)b * a.y_stride + pair] = 0.f;
         }
         return;
     }
     const float* xv = xs + ((MODE == MODE_LOGITS) ? sidx * a.K : 0);
-    float s0 = 0.f, s1 = 0.f;
+    float acc0[BQ], acc1[BQ];
+#pragma unroll
+    for (int b = 0; b < BQ; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
         const int k = 4 * lane + 256 * i;
         if (k < K4) {
-            const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s0 = fmaf(pa[i][e], xw[e], s0); s1 = fmaf(pb[i][e], xw[e], s1); }
+            for (int b = 0; b < BQ; ++b) {
+                const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc0[b] = fmaf(pa[i][e], xw[e], acc0[b]); acc1[b] = fmaf(pb[i][e], xw[e], acc1[b]); }
+            }
         }
     }
     for (int k = 4 * lane + 256 * PF; k < K4; k += 256) {
-        const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + k);
         const f32x4 a0 = gload4(w0 + k);
         const f32x4 a1 = gload4(w1 + k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s0 = fmaf(a0[e], xw[e], s0); s1 = fmaf(a1[e], xw[e], s1); }
+        for (int b = 0; b < BQ; ++b) {
+            const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[b] = fmaf(a0[e], xw[e], acc0[b]); acc1[b] = fmaf(a1[e], xw[e], acc1[b]); }
+        }
     }
-    for (int k = K4 + lane; k < a.K; k += 64) { s0 = fmaf(w0[k], xv[k], s0); s1 = fmaf(w1[k], xv[k], s1); }
-    s0 = wave_sum(s0) * inv;
-    s1 = wave_sum(s1) * inv;
+    for (int k = K4 + lane; k < a.K; k += 64) {
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) { acc0[b] = fmaf(w0[k], xv[b * Kin + k], acc0[b]); acc1[b] = fmaf(w1[k], xv[b * Kin + k], acc1[b]); }
+    }
+#pragma unroll
+    for (int b = 0; b < BQ; ++b) { acc0[b] = wave_sum(acc0[b]) * inv[b]; acc1[b] = wave_sum(acc1[b]) * inv[b]; }
     if (lane != 0) return;
+    const int pos = (MODE == MODE_QKV) ? min(a.state[0], a.max_len - 1) : 0;
+#pragma unroll
+    for (int b = 0; b < BQ; ++b) {
+    float s0 = acc0[b], s1 = acc1[b];
+    float* const yb = a.y + (int64_t)b * a.y_stride;
     if (a.bias) { s0 += a.bias[r0]; if (has1) s1 += a.bias[r1]; }
 
     if (MODE == MODE_QKV) {
-        const int pos = min(a.state[0], a.max_len - 1);
         const int sec = r0 / a.inner, c0 = r0 - sec * a.inner;        // column inside q / k / v
         if (sec < 2) {                                                // half-split RoPE on the (i, i+32) pair
             const float c = a.rope_cos[pos * 32 + (c0 & 31)], s = a.rope_sin[pos * 32 + (c0 & 31)];
             const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
             s0 = n0; s1 = n1;
         }
-        float* dst = sec == 0 ? a.y : (sec == 1 ? a.k_cache + (int64_t)pos * a.inner : a.v_cache + (int64_t)pos * a.inner);
+        float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + b * a.cache_stride + (int64_t)pos * a.inner;
         dst[c0] = s0;
         dst[c0 + 32] = s1;
     } else if (MODE == MODE_RES) {
-        a.y[r0] += s0;
-        if (has1) a.y[r1] += s1;
+        yb[r0] += s0;
+        if (has1) yb[r1] += s1;
     } else if (MODE == MODE_GEGLU) {
-        a.y[r0] = s0 * gelu_erf(s1);                                  // F.gelu(gate) * x, text2semantic.py:154-157
+        yb[r0] = s0 * gelu_erf(s1);                                   // F.gelu(gate) * x, text2semantic.py:154-157
     } else if (MODE == MODE_LOGITS) {
-        a.y[sidx * a.N + r0] = s0;
-        if (has1) a.y[sidx * a.N + r1] = s1;
+        yb[sidx * a.N + r0] = s0;
+        if (has1) yb[sidx * a.N + r1] = s1;
     } else {
-        a.y[r0] = s0;
-        if (has1) a.y[r1] = s1;
+        yb[r0] = s0;
+        if (has1) yb[r1] = s1;
+    }
     }
 }
 
 // ---------------------------------------------------------------- attention of ONE query over n cached keys
 struct AttnArgs {
-    const float* q;          // [heads*64]
-    const float* k;          // key j of head h at k + j*stride + h*64
+    const float* q;          // [batch][heads*64]
+    const float* k;          // key j of head h of utterance b at k + b*batch_stride + j*stride + h*64
     const float* v;
-    int64_t stride;
-    float* out;              // [heads*64]
-    const int* state;
+    int64_t stride, batch_stride;
+    float* out;              // [batch][heads*64]
+    const int* state;        // [batch][4]
     int n_fixed;             // >= 0: that many keys; -1: state[0] + 1 (self-attention); -2: state[3] (context length)
     float scale;
     int max_len;
@@ -194,16 +228,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) float part[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int h = blockIdx.x;
-    const int n = a.n_fixed >= 0 ? a.n_fixed : (a.n_fixed == -1 ? min(a.state[0] + 1, a.max_len) : min(a.state[3], T2S_MAX_KEYS));
+    const int h = blockIdx.x, b = blockIdx.y, HD64 = gridDim.x * 64;
+    const int n = a.n_fixed >= 0 ? a.n_fixed
+                                 : (a.n_fixed == -1 ? min(a.state[0] + 1, a.max_len) : min(a.state[4 * b + 3], T2S_MAX_KEYS));
+    const float* const kb = a.k + b * a.batch_stride;
+    const float* const vb = a.v + b * a.batch_stride;
     const int sub = tid & 15, grp = tid >> 4;              // 16 lanes per key, 16 keys per pass
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + h * 64 + 4 * sub);
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + (int64_t)b * HD64 + h * 64 + 4 * sub);
     float mx = -3.0e38f;
     for (int j0 = 0; j0 < n; j0 += 16) {
         const int j = j0 + grp;
         float d = 0.f;
         if (j < n) {
-            const f32x4 k4 = gload4(a.k + (int64_t)j * a.stride + h * 64 + 4 * sub);
+            const f32x4 k4 = gload4(kb + (int64_t)j * a.stride + h * 64 + 4 * sub);
             d = k4[0] * q4[0] + k4[1] * q4[1] + k4[2] * q4[2] + k4[3] * q4[3];
         }
 #pragma unroll
@@ -225,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
     sum = red[0] + red[1] + red[2] + red[3];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int j = grp; j < n; j += 16) {
-        const f32x4 v4 = gload4(a.v + (int64_t)j * a.stride + h * 64 + 4 * sub);
+        const f32x4 v4 = gload4(vb + (int64_t)j * a.stride + h * 64 + 4 * sub);
         const float p = sc[j];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, v4[e], acc[e]);
@@ -236,18 +273,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
         float o = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) o += part[g][tid];
-        a.out[h * 64 + tid] = o / sum;
+        a.out[(int64_t)b * HD64 + h * 64 + tid] = o / sum;
     }
 }
 
 // ---------------------------------------------------------------- top-k + Gumbel argmax, eos bookkeeping, next input
 struct SampleArgs {
-    const float* logits;     // [streams, V]
-    const float* uniforms;   // [max_len, streams, V]
+    const float* logits;     // [batch][streams, V]
+    const float* uniforms;   // [max_len][batch][streams, V]
     const float* emb;        // [V, dim_emb]
-    float* x;                // [streams * dim_emb]  next step's input (residual stream)
-    int64_t* tokens;         // [streams, max_len]
-    int* state;              // [0] pos  [1] done  [2] length at the first eos
+    float* x;                // [batch][streams * dim_emb]  next step's input (residual stream)
+    int64_t* tokens;         // [batch][streams, max_len]
+    int* state;              // [batch][4]: [0] pos  [1] done  [2] length at the first eos  [3] context rows
+    int batch;
     int V, dim_emb, streams, max_len, top_k, eos_id;
     float inv_temp;
 };
@@ -259,11 +297,13 @@ __global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
     __shared__ int bi[16];
     __shared__ int chosen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int pos = a.state[0];
+    const int b = blockIdx.x;
+    int* const state = a.state + 4 * b;
+    const int pos = state[0];
     if (pos >= a.max_len) return;
     bool eos = false;
     for (int s = 0; s < a.streams; ++s) {
-        if (tid < a.V) lg[tid] = a.logits[s * a.V + tid];
+        if (tid < a.V) lg[tid] = a.logits[((int64_t)b * a.streams + s) * a.V + tid];
         __syncthreads();
         float val = -INFINITY;
         if (tid < a.V) {
@@ -271,7 +311,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
             int cnt = 0;
             for (int j = 0; j < a.V; ++j) cnt += (lg[j] > me) ? 1 : 0;
             if (cnt < a.top_k) {
-                const float u = a.uniforms[((int64_t)pos * a.streams + s) * a.V + tid];
+                const float u = a.uniforms[(((int64_t)pos * a.batch + b) * a.streams + s) * a.V + tid];
                 const float g = -logf(fmaxf(-logf(fmaxf(u, 1e-20f)), 1e-20f));
                 val = me * a.inv_temp + g;
             }
@@ -287,21 +327,22 @@ __global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
         if (lane == 0) { bv[wid] = val; bi[wid] = idx; }
         __syncthreads();
         if (tid == 0) {
-            float best = bv[0]; int b = bi[0];
+            float best = bv[0]; int bt = bi[0];
             for (int w = 1; w < 16; ++w)
-                if (bv[w] > best || (bv[w] == best && bi[w] < b)) { best = bv[w]; b = bi[w]; }
-            chosen = b;
-            a.tokens[(int64_t)s * a.max_len + pos] = b;
+                if (bv[w] > best || (bv[w] == best && bi[w] < bt)) { best = bv[w]; bt = bi[w]; }
+            chosen = bt;
+            a.tokens[((int64_t)b * a.streams + s) * a.max_len + pos] = bt;
         }
         __syncthreads();
         const int tok = chosen;
         eos = eos || (tok == a.eos_id);
-        for (int d = tid; d < a.dim_emb; d += 1024) a.x[s * a.dim_emb + d] = a.emb[(int64_t)tok * a.dim_emb + d];
+        for (int d = tid; d < a.dim_emb; d += 1024)
+            a.x[((int64_t)b * a.streams + s) * a.dim_emb + d] = a.emb[(int64_t)tok * a.dim_emb + d];
         __syncthreads();
     }
     if (tid == 0) {
-        if (eos && a.state[1] == 0) { a.state[1] = 1; a.state[2] = pos + 1; }
-        a.state[0] = pos + 1;
+        if (eos && state[1] == 0) { state[1] = 1; state[2] = pos + 1; }
+        state[0] = pos + 1;
     }
 }
 
@@ -315,10 +356,26 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h,
     out[i] = c < F ? h[r * 2 * F + c] * gelu_erf(h[r * 2 * F + F + c]) : 0.f;
 }
 
-template <int MODE>
-void launch_gemv(const GemvArgs& g, int pairs, hipStream_t st)
+template <int MODE, int BQ>
+void launch_gemv_b(const GemvArgs& g, int pairs, hipStream_t st)
 {
-    hipLaunchKernelGGL(gemv_kernel<MODE>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, g);
+    const int Kin = (MODE == MODE_LOGITS) ? g.K * g.streams : g.K;
+    const size_t lds = sizeof(float) * (size_t)BQ * Kin;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL((gemv_kernel<MODE, BQ>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), lds, st, g);
+}
+
+template <int MODE>
+void launch_gemv(const GemvArgs& g, int pairs, int batch, hipStream_t st)
+{
+    if (batch <= 1) launch_gemv_b<MODE, 1>(g, pairs, st);
+    else if (batch <= 2) launch_gemv_b<MODE, 2>(g, pairs, st);
+    else if (batch <= 4) launch_gemv_b<MODE, 4>(g, pairs, st);
+    else launch_gemv_b<MODE, 8>(g, pairs, st);
 }
 
 }  // namespace
@@ -341,13 +398,17 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
                 d->streams >= 1 && d->streams <= 2 && d->dim_emb * d->streams == d->dim && d->vocab > 0 && d->vocab <= 1024 &&
                 d->ff_inner > 0 && d->ff_inner_pad >= d->ff_inner && d->ff_inner_pad % 4 == 0 && d->ff_inner_pad <= T2S_MAX_DIM &&
                 d->n_ctx >= 0 && d->n_ctx <= T2S_MAX_KEYS && d->max_len > 0 && d->max_len <= T2S_MAX_KEYS &&
-                d->top_k > 0 && d->top_k <= d->vocab && d->temperature >= 0.f,
-                "t2s_decode: bad dimensions (dim=%d inner=%d heads=%d streams=%d dim_emb=%d vocab=%d ff=%d/%d n_ctx=%d max_len=%d)",
-                d->dim, d->inner, d->heads, d->streams, d->dim_emb, d->vocab, d->ff_inner, d->ff_inner_pad, d->n_ctx, d->max_len);
+                d->top_k > 0 && d->top_k <= d->vocab && d->temperature >= 0.f && d->batch >= 1 && d->batch <= 8 &&
+                d->ctx_rows > 0 && d->ctx_rows <= T2S_MAX_KEYS && d->n_ctx <= d->ctx_rows,
+                "t2s_decode: bad dimensions (dim=%d inner=%d heads=%d streams=%d dim_emb=%d vocab=%d ff=%d/%d n_ctx=%d/%d max_len=%d batch=%d)",
+                d->dim, d->inner, d->heads, d->streams, d->dim_emb, d->vocab, d->ff_inner, d->ff_inner_pad, d->n_ctx, d->ctx_rows,
+                d->max_len, d->batch);
     CVX_REQUIRE(d->final_gamma && d->emb && d->rope_cos && d->rope_sin && d->uniforms && d->x && d->q && d->att && d->h &&
                 d->logits && d->tokens && d->state, "t2s_decode: null buffer");
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const float scale = 0.125f;        // dim_head ** -0.5
+    const int nb = d->batch;
+    const int64_t cache_stride = (int64_t)d->max_len * d->inner;
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < d->depth; ++l) {
             const cvx_t2s_layer& L = d->layers[l];
@@ -355,40 +416,44 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
                         L.w2 && L.b2 && L.k_cache && L.v_cache, "t2s_decode: null pointer in layer %d", l);
             GemvArgs g{};
             // self-attention: q | k | v with RoPE; k, v appended to the cache at position pos
-            g.W = L.wqkv_s; g.ldw = d->dim; g.x = d->x; g.gamma = L.gamma_s; g.y = d->q; g.N = 3 * d->inner; g.K = d->dim;
+            g.W = L.wqkv_s; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_s; g.y = d->q; g.y_stride = d->inner;
+            g.N = 3 * d->inner; g.K = d->dim;
             g.inner = d->inner; g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.k_cache = L.k_cache; g.v_cache = L.v_cache;
-            g.state = d->state; g.max_len = d->max_len;
-            launch_gemv<MODE_QKV>(g, 3 * d->inner / 2, st);
-            AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, d->att, d->state, -1, scale, d->max_len};
-            hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads), dim3(256), 0, st, at);
+            g.cache_stride = cache_stride; g.state = d->state; g.max_len = d->max_len;
+            launch_gemv<MODE_QKV>(g, 3 * d->inner / 2, nb, st);
+            AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, cache_stride, d->att, d->state, -1, scale, d->max_len};
+            hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, at);
             g = GemvArgs{};
-            g.W = L.wo_s; g.ldw = d->inner; g.x = d->att; g.y = d->x; g.N = d->dim; g.K = d->inner;
-            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, st);
+            g.W = L.wo_s; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, st);
             // cross-attention over [null kv | encoder context]
             g = GemvArgs{};
-            g.W = L.wq_c; g.ldw = d->dim; g.x = d->x; g.gamma = L.gamma_c; g.y = d->q; g.N = d->inner; g.K = d->dim;
-            launch_gemv<MODE_PLAIN>(g, d->inner / 2, st);
-            AttnArgs ac{d->q, L.kv_c, L.kv_c + d->inner, 2 * (int64_t)d->inner, d->att, d->state, d->n_ctx > 0 ? d->n_ctx : -2, scale, d->max_len};
-            hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads), dim3(256), 0, st, ac);
+            g.W = L.wq_c; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_c; g.y = d->q; g.y_stride = d->inner;
+            g.N = d->inner; g.K = d->dim;
+            launch_gemv<MODE_PLAIN>(g, d->inner / 2, nb, st);
+            AttnArgs ac{d->q, L.kv_c, L.kv_c + d->inner, 2 * (int64_t)d->inner, (int64_t)d->ctx_rows * 2 * d->inner, d->att, d->state,
+                        d->n_ctx > 0 ? d->n_ctx : -2, scale, d->max_len};
+            hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, ac);
             g = GemvArgs{};
-            g.W = L.wo_c; g.ldw = d->inner; g.x = d->att; g.y = d->x; g.N = d->dim; g.K = d->inner;
-            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, st);
+            g.W = L.wo_c; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, st);
             // GEGLU feed-forward
             g = GemvArgs{};
-            g.W = L.w1; g.ldw = d->dim; g.x = d->x; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d->h; g.N = 2 * d->ff_inner; g.K = d->dim;
-            g.y_pad = d->ff_inner_pad;
-            launch_gemv<MODE_GEGLU>(g, d->ff_inner_pad, st);
+            g.W = L.w1; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d->h;
+            g.y_stride = d->ff_inner_pad; g.N = 2 * d->ff_inner; g.K = d->dim; g.y_pad = d->ff_inner_pad;
+            launch_gemv<MODE_GEGLU>(g, d->ff_inner_pad, nb, st);
             g = GemvArgs{};
-            g.W = L.w2; g.ldw = d->ff_inner_pad; g.x = d->h; g.bias = L.b2; g.y = d->x; g.N = d->dim; g.K = d->ff_inner_pad;
-            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, st);
+            g.W = L.w2; g.ldw = d->ff_inner_pad; g.x = d->h; g.x_stride = d->ff_inner_pad; g.bias = L.b2; g.y = d->x; g.y_stride = d->dim;
+            g.N = d->dim; g.K = d->ff_inner_pad;
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, st);
         }
         GemvArgs g{};
-        g.W = d->emb; g.ldw = d->dim_emb; g.x = d->x; g.gamma = d->final_gamma; g.y = d->logits; g.N = d->vocab; g.K = d->dim_emb;
-        g.streams = d->streams;
-        launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), st);
-        SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, d->vocab, d->dim_emb, d->streams, d->max_len,
+        g.W = d->emb; g.ldw = d->dim_emb; g.x = d->x; g.x_stride = d->dim; g.gamma = d->final_gamma; g.y = d->logits;
+        g.y_stride = d->streams * d->vocab; g.N = d->vocab; g.K = d->dim_emb; g.streams = d->streams;
+        launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), nb, st);
+        SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, nb, d->vocab, d->dim_emb, d->streams, d->max_len,
                       d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f)};
-        hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, st, sa);
+        hipLaunchKernelGGL(sample_kernel, dim3((unsigned)nb), dim3(1024), 0, st, sa);
     }
     CVX_CHECK_LAUNCH("cvx_t2s_decode_steps");
     return CVX_OK;

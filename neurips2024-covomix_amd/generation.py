@@ -84,11 +84,22 @@ def _text_ids(text_dir: str, name: str) -> torch.Tensor:
     return _TOKENIZER([txt], padding=True, truncation=True, return_tensors="pt").input_ids
 
 
-def _predicted_tokens(text_dir: str, name: str, t2s, device) -> np.ndarray:
-    sem = os.path.join(text_dir, name + ".semantic.npy")
-    if t2s is None or os.path.isfile(sem):
-        return np.load(sem).astype(np.int64)
-    return t2s.synthesis_sample_text2semantic(_text_ids(text_dir, name).to(device)).cpu().numpy().astype(np.int64)
+def _predicted_tokens(text_dir: str, names, t2s, device, batch: int = 8) -> dict:
+    """name -> predicted semantic tokens: read from <name>.semantic.npy when present, otherwise text2semantic on the GPU,
+    `batch` utterances per decode batch (the tokens do not depend on the batching)."""
+    out, todo = {}, []
+    for n in names:
+        sem = os.path.join(text_dir, n + ".semantic.npy")
+        if t2s is None or os.path.isfile(sem):
+            out[n] = np.load(sem).astype(np.int64)
+        else:
+            todo.append(n)
+    for i in range(0, len(todo), batch):
+        group = todo[i:i + batch]
+        toks = t2s.synthesis_sample_text2semantic([_text_ids(text_dir, n).to(device) for n in group])
+        for n, t in zip(group, toks):
+            out[n] = t.cpu().numpy().astype(np.int64)
+    return out
 
 
 def _utterance_inputs(mode: str, dialogue: bool, text_dir: str, prompt_dir: str, name: str, pred: np.ndarray):
@@ -153,8 +164,8 @@ def run(dialogue: bool, argv=None) -> int:
     for ext in (".semantic.npy",) + ((".text_ids.npy", ".txt") if t2s is not None else ()):
         stems |= {os.path.basename(p)[: -len(ext)] for p in glob.glob(os.path.join(args.text_dir, "*" + ext))}
     names = sorted(stems)
-    items = [_utterance_inputs(args.mode, dialogue, args.text_dir, args.prompt_dir, n,
-                               _predicted_tokens(args.text_dir, n, t2s, device)) for n in names]
+    pred = _predicted_tokens(args.text_dir, names, t2s, device)
+    items = [_utterance_inputs(args.mode, dialogue, args.text_dir, args.prompt_dir, n, pred[n]) for n in names]
     lengths = [int(it[0].shape[0]) for it in items]
     mine = dp.shard_utterances(lengths, world)[rank]
     done = 0

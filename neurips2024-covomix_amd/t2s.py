@@ -8,7 +8,10 @@ forwards to (covomix/conditional_model.py:313-321).  Only what the generation sc
   encoder  (source transformer, once per utterance): the full-sequence kernels of the acoustic path - fp32 GEMM with
            the RoPE epilogue, flash attention, RMSNorm - plus a GEGLU kernel;
   decoder  (one token per step): csrc/t2s_decode.hip through cvx_t2s_decode_steps, 34 launches per step, replayed
-           from a HIP graph of CHUNK steps; the host only looks at the eos flag between chunks.
+           from a HIP graph of CHUNK steps; the host only looks at the eos flags between chunks.  `generate_batch`
+           advances up to MAX_BATCH utterances together (the reference decodes them one by one): a token step is
+           bound by streaming the decoder weights, which a batch shares, and the per-utterance arithmetic does not
+           depend on the batch size - the tokens are bit-identical to the one-by-one decode.
 
 The reference's rotary embedding rotates interleaved pairs (2i, 2i+1) (rotary_embedding_torch.py:25-41); the kernels
 rotate half-split pairs (i, i+32).  Permuting the rows of to_q and to_k inside every head (the same permutation on
@@ -26,6 +29,7 @@ from . import _lib, ops
 PAD_ID = -1                    # semantic_pad_id (conditional_model.py:126)
 TOP_K_THRES = 0.1              # top_k default (text2semantic.py:126)
 CHUNK = 16                     # token steps per graph replay / host check
+MAX_BATCH = 8                  # utterances per decode step (kernel limit)
 
 
 def _dims(sd: Dict[str, torch.Tensor]) -> dict:
@@ -103,23 +107,24 @@ class TextToSemanticDecoder:
                                  null=torch.cat((nkv[0].reshape(I), nkv[1].reshape(I))).contiguous(),
                                  gamma_f=sd[p + ".2.0.gamma"], w1=sd[p + ".2.1.weight"], b1=sd[p + ".2.1.bias"],
                                  w2=_pad_cols(sd[p + ".2.4.weight"]), b2=sd[p + ".2.4.bias"],
-                                 kv_c=f32(self.max_source + 2, 2 * I), k_cache=f32(self.max_length, I), v_cache=f32(self.max_length, I)))
+                                 kv_c=f32(MAX_BATCH, self.max_source + 2, 2 * I), k_cache=f32(MAX_BATCH, self.max_length, I),
+                                 v_cache=f32(MAX_BATCH, self.max_length, I)))
         self.dec_final = sd["target_transformer.final_norm.gamma"]
         pos = torch.arange(self.max_length, device=device, dtype=torch.float32)
         ang = pos[:, None] * sd["target_transformer.layers.0.0.rotary_emb.freqs"][None, :]
         self.rope = (ang.cos().contiguous(), ang.sin().contiguous())
         S, V = d["streams"], d["vocab"]
         self.top_k = math.ceil(TOP_K_THRES * V)
-        self.buf = dict(x=f32(d["dim_target"]), q=f32(I), att=f32(I), h=f32(self.Fp), logits=f32(S, V),
-                        uniforms=f32(self.max_length, S, V),
-                        tokens=torch.zeros(S, self.max_length, dtype=torch.int64, device=device),
-                        state=torch.zeros(4, dtype=torch.int32, device=device))
+        self.buf = dict(x=f32(MAX_BATCH, d["dim_target"]), q=f32(MAX_BATCH, I), att=f32(MAX_BATCH, I), h=f32(MAX_BATCH, self.Fp),
+                        logits=f32(MAX_BATCH, S, V), uniforms=f32(self.max_length * MAX_BATCH * S * V),
+                        tokens=torch.zeros(MAX_BATCH, S, self.max_length, dtype=torch.int64, device=device),
+                        state=torch.zeros(MAX_BATCH, 4, dtype=torch.int32, device=device))
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
             for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
                          "k_cache", "v_cache"):
                 setattr(self._layers[i], name, L[name].data_ptr())
-        self._graphs: Dict[float, torch.cuda.CUDAGraph] = {}
+        self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
 
     # ------------------------------------------------------------------ encoder (text2semantic.py:716-741)
     def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
@@ -154,9 +159,10 @@ class TextToSemanticDecoder:
         return enc
 
     # ------------------------------------------------------------------ decoder
-    def _descriptor(self, temperature: float) -> "_lib.T2SDecoder":
+    def _descriptor(self, temperature: float, batch: int = 1) -> "_lib.T2SDecoder":
         d, b = self.d, self.buf
         dec = _lib.T2SDecoder()
+        dec.batch, dec.ctx_rows = batch, self.max_source + 2
         dec.dim, dec.inner, dec.heads = d["dim_target"], d["inner"], d["heads"]
         dec.ff_inner, dec.ff_inner_pad, dec.depth = d["ff_tgt"], self.Fp, d["target_depth"]
         dec.streams, dec.vocab, dec.dim_emb = d["streams"], d["vocab"], d["dim_emb"]
@@ -168,15 +174,15 @@ class TextToSemanticDecoder:
             setattr(dec, n, b[n].data_ptr())
         return dec
 
-    def _run_chunk(self, temperature: float) -> None:
+    def _run_chunk(self, temperature: float, batch: int = 1) -> None:
         """CHUNK token steps on the current stream (graph replay when enabled)."""
         def launch():
-            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature)), CHUNK,
+            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch)), CHUNK,
                                                         torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
         if os.environ.get("CVX_GRAPH", "1") != "1":
             launch()
             return
-        g = self._graphs.get(temperature)
+        g = self._graphs.get((temperature, batch))
         if g is None:
             saved = {k: v.clone() for k, v in self.buf.items()}
             caches = [(L["k_cache"].clone(), L["v_cache"].clone()) for L in self.dec]
@@ -193,11 +199,73 @@ class TextToSemanticDecoder:
                 self.buf[k].copy_(v)
             for L, (kc, vc) in zip(self.dec, caches):
                 L["k_cache"].copy_(kc); L["v_cache"].copy_(vc)
-            self._graphs = {temperature: g}
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            self._graphs[(temperature, batch)] = g
         g.replay()
 
     @torch.no_grad()          # (not inference_mode: tensors torch creates lazily during the first graph capture,
                               #  e.g. the generator's graph-safe state, would become inference tensors)
+    def generate_batch(self, sources, uniforms=None, max_length: Optional[int] = None, temperature: float = 1.0,
+                       generator: Optional[torch.Generator] = None, collect_logits: bool = False):
+        """Decode up to MAX_BATCH utterances together.  sources: list of [n] / [1, n] id tensors; uniforms: optional list
+        of [steps, streams, vocab] tensors (one per utterance).  Returns a list of (flat tokens, streams[, logits])
+        tuples, each exactly what `generate` returns for that utterance alone."""
+        d, b = self.d, self.buf
+        S, V, nb = d["streams"], d["vocab"], len(sources)
+        if not 1 <= nb <= MAX_BATCH:
+            raise ValueError(f"1..{MAX_BATCH} utterances per decode batch, got {nb}")
+        max_len = min(int(max_length or self.max_length), self.max_length)
+        if uniforms is not None:
+            us = [u.to(self.device, torch.float32).reshape(u.shape[0], S, V) for u in uniforms]
+            max_len = min([max_len] + [u.shape[0] for u in us])
+        ctx = []
+        for i, src in enumerate(sources):
+            if src.ndim == 2 and src.shape[0] != 1:
+                raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
+            enc = self.encode(src)
+            n = enc.shape[0]
+            ctx.append(n + 1)
+            for L in self.dec:                                          # context k/v once: [null | to_kv(enc)]
+                L["kv_c"][i, 0].copy_(L["null"])
+                ops.gemm(enc, L["wkv_c"], L["kv_c"][i, 1:n + 1])
+        uview = b["uniforms"][: max_len * nb * S * V].view(max_len, nb, S, V)
+        if uniforms is None:
+            uview.copy_(torch.rand(max_len, nb, S, V, device=self.device, generator=generator))
+        else:
+            for i, u in enumerate(us):
+                uview[:, i].copy_(u[:max_len])
+        b["x"][:nb].copy_(self.start[None, :].expand(nb, -1))
+        b["state"].copy_(torch.tensor([[0, 0, 0, ctx[i] if i < nb else 1] for i in range(MAX_BATCH)], dtype=torch.int32))
+        steps = 0
+        logits = []
+        while steps < max_len:
+            if collect_logits:
+                _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(float(temperature), nb)), 1,
+                                                            torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+                logits.append(b["logits"][:nb].clone())
+                steps += 1
+            else:
+                self._run_chunk(float(temperature), nb)
+                steps += CHUNK
+            st = b["state"][:nb].tolist()                               # the only host sync: once per CHUNK tokens
+            if all(row[1] for row in st):
+                break
+        st = b["state"][:nb].tolist()
+        eos = V - 1
+        out = []
+        for i in range(nb):
+            length = min(st[i][2] if st[i][1] and st[i][2] <= max_len else max_len, max_len)
+            streams = b["tokens"][i, :, :length].clone()
+            after = (streams == eos).cumsum(dim=-1) > 0                  # mask_after_eos (text2semantic.py:73-76)
+            after = torch.nn.functional.pad(after, (1, -1), value=False)
+            flat = streams.masked_fill(after, PAD_ID).reshape(-1)
+            item = (flat[flat != PAD_ID], streams)
+            if collect_logits:
+                item = item + (torch.stack([lg[i] for lg in logits])[:length],)
+            out.append(item)
+        return out
+
     def generate(self, source_ids: torch.Tensor, uniforms: Optional[torch.Tensor] = None, max_length: Optional[int] = None,
                  temperature: float = 1.0, generator: Optional[torch.Generator] = None, return_streams: bool = False,
                  collect_logits: bool = False):
@@ -206,47 +274,10 @@ class TextToSemanticDecoder:
         the random draws of gumbel_noise (text2semantic.py:108-110); default: torch.rand from `generator`.
         collect_logits (tests): step one token at a time without a graph and also return the pre-filter logits
         [steps, streams, vocab]."""
-        d, b = self.d, self.buf
-        S, V = d["streams"], d["vocab"]
-        max_len = min(int(max_length or self.max_length), self.max_length)
         if source_ids.ndim == 2 and source_ids.shape[0] != 1:
-            raise NotImplementedError("one utterance per call (the generation scripts run batch 1)")
-        enc = self.encode(source_ids)
-        n = enc.shape[0]
-        I = d["inner"]
-        for L in self.dec:                                              # context k/v once: [null | to_kv(enc)]
-            L["kv_c"][0].copy_(L["null"])
-            ops.gemm(enc, L["wkv_c"], L["kv_c"][1:n + 1])
-        if uniforms is None:
-            b["uniforms"][:max_len].copy_(torch.rand(max_len, S, V, device=self.device, generator=generator))
-        else:
-            u = uniforms.to(self.device, torch.float32).reshape(uniforms.shape[0], S, V)
-            max_len = min(max_len, u.shape[0])
-            b["uniforms"][:max_len].copy_(u[:max_len])
-        b["x"].copy_(self.start)
-        b["state"].copy_(torch.tensor([0, 0, 0, n + 1], dtype=torch.int32))
-        steps = 0
-        logits = []
-        while steps < max_len:
-            if collect_logits:
-                _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(float(temperature))), 1,
-                                                            torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
-                logits.append(b["logits"].clone())
-                steps += 1
-            else:
-                self._run_chunk(float(temperature))
-                steps += CHUNK
-            st = b["state"].tolist()                                     # the only host sync: once per CHUNK tokens
-            if st[1]:
-                break
-        st = b["state"].tolist()
-        length = min(st[2] if st[1] and st[2] <= max_len else max_len, max_len)
-        streams = b["tokens"][:, :length].clone()
-        eos = V - 1
-        after = (streams == eos).cumsum(dim=-1) > 0                      # mask_after_eos (text2semantic.py:73-76)
-        after = torch.nn.functional.pad(after, (1, -1), value=False)
-        flat = streams.masked_fill(after, PAD_ID).reshape(-1)
-        out = flat[flat != PAD_ID]
+            raise NotImplementedError("one utterance per call (the generation scripts run batch 1); see generate_batch")
+        res = self.generate_batch([source_ids], None if uniforms is None else [uniforms], max_length, temperature, generator,
+                                  collect_logits)[0]
         if collect_logits:
-            return out, streams, torch.stack(logits)[:length]
-        return (out, streams) if return_streams else out
+            return res
+        return res if return_streams else res[0]

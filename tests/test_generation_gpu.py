@@ -107,8 +107,9 @@ def test_cli_full_pipeline_with_text2semantic(tmp_path, monkeypatch):
     real_t2s = generation.CoVoMixModel.synthesis_sample_text2semantic
     seen_ids = []
 
-    def spy_t2s(self, ids, **kw):
-        return real_t2s(self, ids, uniforms=uni, max_length=24)
+    def spy_t2s(self, ids, **kw):                     # the driver hands over a LIST: both utterances decode as one batch
+        assert isinstance(ids, list) and len(ids) == 2
+        return real_t2s(self, ids, uniforms=[uni] * len(ids), max_length=24)
     real_syn = generation.CoVoMixModel.synthesis_sample
 
     def spy_syn(self, phoneme_ids, cond, mask, cond_scale, y0=None):

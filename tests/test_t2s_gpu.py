@@ -109,3 +109,29 @@ def test_facade_synthesis_sample_text2semantic():
     assert out.device == src.device and torch.equal(out, torch.from_numpy(g["tokens"]))
     half = out.shape[0] // 2                                   # comix_pred (monologue_generation.py:307-319) splits the halves
     assert torch.equal(out[:half], torch.from_numpy(g["streams"])[0, 0]) and torch.equal(out[half:], torch.from_numpy(g["streams"])[0, 1])
+
+
+def test_batched_decode_is_bit_identical_to_one_by_one(case):
+    """generate_batch advances several utterances together (shared weight streaming); every utterance must get exactly
+    the tokens AND logits it gets alone - here the golden utterance next to shorter / longer texts, in slot 0 and 2."""
+    name, g, model = case
+    src, uni = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
+    S, V = uni.shape[1], uni.shape[-1]
+    gen = torch.Generator().manual_seed(11)
+    other = [src[:, :5], torch.cat((src, src[:, :7]), dim=1), src[:, 2:9]]
+    other_u = [torch.rand(uni.shape[0], S, V, generator=gen) for _ in other]
+    alone = [model.generate(o, uniforms=u, return_streams=True) for o, u in zip(other, other_u)]
+    for slot in (0, 2):
+        sources = list(other); unis = list(other_u)
+        sources.insert(slot, src); unis.insert(slot, uni)
+        res = model.generate_batch(sources, unis, collect_logits=True)
+        assert torch.equal(res[slot][0].cpu(), torch.from_numpy(g["tokens"]))
+        assert rel_l2(res[slot][2], torch.from_numpy(g["logits"])[:, :, 0, :]) < TOL
+        ref = list(alone); ref.insert(slot, None)
+        for i, r in enumerate(res):
+            if i != slot:
+                assert torch.equal(r[0], ref[i][0]) and torch.equal(r[1], ref[i][1])
+    # graph path, full batch of 8
+    res8 = model.generate_batch([src] * 8, [uni] * 8)
+    for r in res8:
+        assert torch.equal(r[0].cpu(), torch.from_numpy(g["tokens"]))

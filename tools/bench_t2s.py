@@ -18,11 +18,19 @@ for name, kw in [("cosingle", dict(two_output=False, dim=512, dim_target=512)), 
     t0 = time.perf_counter(); enc = m.encode(src); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
     m.buf["x"].copy_(m.start); m.buf["state"].copy_(torch.tensor([0, 0, 0, enc.shape[0] + 1], dtype=torch.int32))
     m.buf["uniforms"].uniform_(1e-6, 1 - 1e-6)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(N // CHUNK):
-        m._run_chunk(1.0)
-        m.buf["state"].tolist()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
     wbytes = sum(L[k].numel() * 4 for L in m.dec for k in ("wqkv_s", "wo_s", "wq_c", "wo_c", "w1", "w2")) + m.emb.numel() * 4
-    print(f"{name}: first call {t_first*1e3:.1f} ms (capture), encoder {t_enc*1e3:.2f} ms, {N} tokens in {dt*1e3:.1f} ms = "
-          f"{dt/N*1e6:.1f} us/token = {N/dt:.0f} tokens/s; weights/token {wbytes/1e6:.1f} MB -> {wbytes/(dt/N)/1e12:.2f} TB/s")
+    print(f"{name}: first call {t_first*1e3:.1f} ms (capture), encoder {t_enc*1e3:.2f} ms, weights per token step {wbytes/1e6:.1f} MB")
+    for nb in (1, 2, 4, 8):                                   # utterances decoded together
+        for i in range(nb):
+            for L in m.dec:
+                L["kv_c"][i, : enc.shape[0] + 1].copy_(m.dec[0]["kv_c"][0, : enc.shape[0] + 1])
+        m.buf["x"][:nb].copy_(m.start[None, :].expand(nb, -1))
+        m.buf["state"].copy_(torch.tensor([[0, 0, 0, enc.shape[0] + 1]] * 8, dtype=torch.int32))
+        m._run_chunk(1.0, nb)                                 # capture for this batch size
+        m.buf["state"].copy_(torch.tensor([[0, 0, 0, enc.shape[0] + 1]] * 8, dtype=torch.int32))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(N // CHUNK):
+            m._run_chunk(1.0, nb)
+            m.buf["state"].tolist()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"   batch {nb}: {dt/N*1e6:7.1f} us/step = {nb*N/dt:7.0f} tokens/s; weight streaming {wbytes/(dt/N)/1e12:.2f} TB/s")
