@@ -79,7 +79,8 @@ typedef struct {
     uint16_t* C_hi; uint16_t* C_lo; int64_t ldc_h;
     int32_t write_f32;
     /* QKV mode (optional; needs the RoPE arguments, N = 3*H*64, T % 4 == 0, write_f32 = 0): the v columns are not
-     * written to C_hi/C_lo but TRANSPOSED per (sequence, head) to Vt_*[((b*H + h)*64 + d) * vt_ld + t], the layout
+     * written to C_hi/C_lo but TRANSPOSED per (sequence, head) to Vt_*[((b*H + h)*64 + d) * vt_ld + slot(t)] (slot swaps bits 2 and 3
+     * of t: four-frame groups in the order 0, 2, 1, 3 inside every 16 frames), the layout
      * cvx_attention_f16x3 reads its V^T tiles from. */
     uint16_t* Vt_hi; uint16_t* Vt_lo; int64_t vt_ld;
 } cvx_gemm_split_io;

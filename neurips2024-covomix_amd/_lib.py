@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the kernels share with torch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcovomix_hip.so")
+LIB_PATH = os.environ.get("CVX_LIB_PATH") or os.path.join(_HERE, "libcovomix_hip.so")      # CVX_LIB_PATH: dev A/B builds
 
 _f32p = C.POINTER(C.c_float)
 

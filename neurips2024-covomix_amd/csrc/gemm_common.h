@@ -29,11 +29,15 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 // vt_lo == NULL) writes the hi halves only - the single-term fp16 mode.
 // QKV mode (vt_hi != NULL; needs the RoPE arguments: rope_T = frames per sequence, rope_cols = 2*H*64): columns
 // [0, rope_cols) (q | k, after RoPE) go to hi/lo [M, ldc_h] as usual, columns >= rope_cols (v) are written TRANSPOSED
-// per (sequence, head): vt[((b*H + h)*64 + d) * vt_ld + t] - the layout the f16x3 attention kernel DMAs its V^T
-// tiles from.
+// per (sequence, head): vt[((b*H + h)*64 + d) * vt_ld + slot(t)] - the layout the f16x3 attention kernel DMAs its
+// V^T tiles from.  slot(t) swaps bits 2 and 3 of t: inside every block of 16 frames the four-frame groups are stored
+// in the order 0, 2, 1, 3, so that the eight keys one lane of the attention kernel's O^T += V^T.P^T MFMA needs
+// (keys 16s+4g+{0..3} and 16s+8+4g+{0..3}, the order its P registers already have) are ONE 16-byte LDS read.
 struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
                   _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld; };
 typedef _Float16 cvx_f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int vt_slot(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
 __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v)
 {
@@ -92,15 +96,15 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                     }
                     const int64_t base = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld;
                     if (t0 + 3 < T && row0 + 3 < p.M) {
-                        *reinterpret_cast<cvx_f16x4*>(so.vt_hi + base + t0) = vh;
-                        if (so.vt_lo) *reinterpret_cast<cvx_f16x4*>(so.vt_lo + base + t0) = vl;
+                        *reinterpret_cast<cvx_f16x4*>(so.vt_hi + base + vt_slot(t0)) = vh;
+                        if (so.vt_lo) *reinterpret_cast<cvx_f16x4*>(so.vt_lo + base + vt_slot(t0)) = vl;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int row = row0 + e;
                             if (row >= p.M) break;
                             const int bb = row / T, tt = row - bb * T;
-                            const int64_t idx = ((int64_t)(bb * H + head) * 64 + d) * so.vt_ld + tt;
+                            const int64_t idx = ((int64_t)(bb * H + head) * 64 + d) * so.vt_ld + vt_slot(tt);
                             so.vt_hi[idx] = vh[e];
                             if (so.vt_lo) so.vt_lo[idx] = vl[e];
                         }

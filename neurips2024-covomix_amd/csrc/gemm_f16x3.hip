@@ -561,9 +561,9 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
         if (io->Vt_hi || io->Vt_lo) {
             CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
-                        (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= a->rope_T && io->vt_ld % 8 == 0 &&
+                        (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= ((a->rope_T + 15) / 16) * 16 && io->vt_ld % 8 == 0 &&
                         a->M % a->rope_T == 0 && a->rope_T % 4 == 0 && so.write_f32 == 0,
-                        "gemm_f16x3: QKV-transpose output needs the RoPE arguments, N = 3*H*64, T %% 4 == 0, vt_ld >= T and write_f32 = 0");
+                        "gemm_f16x3: QKV-transpose output needs the RoPE arguments, N = 3*H*64, T %% 4 == 0, vt_ld >= T rounded up to 16 and write_f32 = 0");
             so.vt_hi = reinterpret_cast<f16*>(io->Vt_hi); so.vt_lo = reinterpret_cast<f16*>(io->Vt_lo); so.vt_ld = io->vt_ld;
         }
         if (io->A_hi || io->A_lo) {

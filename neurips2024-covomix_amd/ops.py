@@ -159,6 +159,13 @@ def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H
     return out if out is not None else out_split
 
 
+def vt_frame_slots(T: int, device=None) -> torch.Tensor:
+    """Column of frame t in the V^T buffers of the f16x3 attention: bits 2 and 3 of t swapped (four-frame groups in the
+    order 0, 2, 1, 3 inside every 16 frames) - what the to_qkv epilogue writes and the attention kernel reads."""
+    t = torch.arange(T, device=device)
+    return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+
+
 def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None):
     """Split-precision attention on the pairs written by gemm(..., out_split=qk_split, vt_split=vt_split).
     (hi, None) pairs select the single-term fp16 kernel."""

@@ -336,8 +336,10 @@ def test_attention_f16x3_with_qkv_transposed_epilogue(ops, Bt, T, H):
     ops.gemm(x, w, ref_qkv, rope=(cos, sin), rope_cols=2 * H * 64)
     assert rel_l2(qk[0].float() + qk[1].float(), ref_qkv[:, : 2 * H * 64]) < 2e-6
     v_ref = ref_qkv[:, 2 * H * 64:].reshape(Bt, T, H, 64).permute(0, 2, 3, 1).reshape(Bt * H * 64, T)
-    assert rel_l2((vt[0].float() + vt[1].float())[:, :T], v_ref) < 2e-6
-    assert bool(((vt[0].float() + vt[1].float())[:, T:] == 0).all())
+    slots = ops.vt_frame_slots(T, dev())                      # frame t lives in column slot(t)
+    free = torch.ones(Tp, dtype=torch.bool, device=dev()); free[slots] = False
+    assert rel_l2((vt[0].float() + vt[1].float())[:, slots], v_ref) < 2e-6
+    assert bool(((vt[0].float() + vt[1].float())[:, free] == 0).all())
     out = torch.full((Bt, T, H * 64), float("nan"), device=dev())
     oh = torch.empty(Bt, T, H * 64, dtype=torch.float16, device=dev()); ol = torch.empty_like(oh)
     ops.attention_f16x3(qk, vt, out, Bt, T, H, 0.125, out_split=(oh, ol))
@@ -360,8 +362,9 @@ def test_attention_f16x3_forced_rescale_and_tail(ops):
     qk = (ah[:, :128].contiguous(), al[:, :128].contiguous())
     Tp = 192
     vt = (torch.zeros(64, Tp, dtype=torch.float16, device=dev()), torch.zeros(64, Tp, dtype=torch.float16, device=dev()))
-    vt[0][:, :T] = ah[:, 128:].T
-    vt[1][:, :T] = al[:, 128:].T
+    slots = ops.vt_frame_slots(T, dev())
+    vt[0][:, slots] = ah[:, 128:].T
+    vt[1][:, slots] = al[:, 128:].T
     out = torch.empty(Bt, T, 64, device=dev())
     ops.attention_f16x3(qk, vt, out, Bt, T, H, 0.125)
     q, k, v = qkv.double().reshape(Bt, T, 3, 1, 64).permute(2, 0, 3, 1, 4)
