@@ -446,3 +446,53 @@ def test_attention_f16_single_term(ops, Bt, T, H):
     print("f16 single-term attention", (Bt, T, H), e)
     assert e < 2e-3
     assert torch.equal(oh, out.half())
+
+
+# ---------------------------------------------------------------- HiFi-GAN ResBlock convolution on the split-fp16 pipe
+@pytest.mark.parametrize("C,k,dil,L,B", [(250, 11, 5, 700, 2), (125, 7, 3, 1030, 1), (62, 3, 1, 2049, 2), (31, 11, 1, 515, 3),
+                                         (16, 7, 5, 256, 1), (250, 3, 1, 255, 1)])
+def test_hifigan_conv1d_f16x3_vs_torch(ops, C, k, dil, L, B):
+    """cvx_hifigan_conv1d_f16x3 (channels-last, zero halos) against torch conv1d in fp64 for every tile configuration
+    (Np = 256 / 128 / 64 / 32), ragged L, all epilogue outputs: new residual stream, running accumulate and scale, and the
+    split leaky_relu copy for the next convolution; padding rows / channels must stay zero."""
+    g = torch.Generator().manual_seed(300 + C + k)
+    x = torch.randn(B, C, L, generator=g).to(dev())
+    w = (torch.randn(C, C, k, generator=g) / math.sqrt(C * k)).to(dev())
+    b = (torch.randn(C, generator=g) * 0.1).to(dev())
+    res = torch.randn(B, C, L, generator=g).to(dev())
+    acc = torch.randn(B, C, L, generator=g).to(dev())
+    wpk = ops.hifigan_pack_weight_f16x3(w)
+    Np, Lp = wpk[3], ops.hifigan_cl_rows(L)
+    bias = torch.zeros(Np, device=dev()); bias[:C] = b
+    z = (torch.zeros(B, Lp, Np, dtype=torch.float16, device=dev()), torch.zeros(B, Lp, Np, dtype=torch.float16, device=dev()))
+    f32 = lambda: torch.zeros(B, Lp, Np, device=dev())
+    res_cl, acc_cl, out_x = f32(), f32(), f32()
+    out_z = (torch.zeros_like(z[0]), torch.zeros_like(z[0]))
+    ops.hifigan_to_channels_last(x, None, z, 0.1)                       # z = split(leaky_relu(x))
+    ops.hifigan_to_channels_last(res, res_cl, None, 1.0)
+    ops.hifigan_to_channels_last(acc, acc_cl, None, 1.0)
+    ops.hifigan_conv1d_f16x3(z, wpk, bias, B, L, ksize=k, dil=dil, res=res_cl, accum=acc_cl, out_x=out_x, out_scale=1.0 / 3,
+                             out_z=out_z, z_slope=0.1)
+    pad = (k * dil - dil) // 2
+    v = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=dil, padding=pad) + res.double()
+    want_x = (v + acc.double()) / 3
+    want_z = F.leaky_relu(v, 0.1)
+    got = torch.empty(B, C, L, device=dev())
+    ops.hifigan_from_channels_last(out_x, got)
+    assert rel_l2(got, want_x) < 2e-6
+    H = ops.HIFI_HALO_L
+    zsum = (out_z[0].float() + out_z[1].float())
+    assert rel_l2(zsum[:, H:H + L, :C].transpose(1, 2), want_z) < 2e-6
+    for t in (out_x, zsum):                                             # halos and padded channels stay zero
+        assert float(t[:, :H].abs().max()) == 0 and float(t[:, H + L:].abs().max()) == 0
+        if Np > C:
+            assert float(t[:, :, C:].abs().max()) == 0
+
+
+def test_hifigan_conv1d_f16x3_rejects_bad_args(ops):
+    import covomix_amd._lib as L
+    w = torch.randn(32, 32, 4, device=dev())                            # (k-1)*dil odd: not a "same" convolution
+    wpk = ops.hifigan_pack_weight_f16x3(w)
+    z = (torch.zeros(1, ops.hifigan_cl_rows(64), 32, dtype=torch.float16, device=dev()),) * 2
+    with pytest.raises(L.CovomixHipError):
+        ops.hifigan_conv1d_f16x3(z, wpk, torch.zeros(32, device=dev()), 1, 64, ksize=4, dil=1, out_x=torch.zeros(1, z[0].shape[1], 32, device=dev()))

@@ -231,3 +231,24 @@ def test_long_sequence_and_argument_errors():
     model.nfe = 3
     with pytest.raises((AssertionError, ValueError)):
         model.synthesis_sample(inp["phoneme_ids"][:, :8].cuda(), inp["cond"][:, :8].cuda(), None, 0.7)
+
+
+def test_vocoder_full_size_properties_and_precisions():
+    """config_covomix generator at BASELINE size (T = 1000 frames): the split-precision path against the all-fp32 path
+    (same kernels as round 0, pinned by the goldens at T = 50), batched == unbatched, batch-permutation equivariance."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd.vocoder import AttrDict, Generator
+    h = AttrDict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    gens = {}
+    for prec in ("f16x3", "fp32"):
+        g = Generator(h, precision=prec).to("cuda:0")
+        g.load_state_dict(vsd); g.eval(); g.remove_weight_norm()
+        gens[prec] = g
+    mel = (torch.randn(3, 80, 1000, generator=torch.Generator().manual_seed(5)) * 2 - 6).clamp(-11.52, 2.0).cuda()
+    y16, y32 = gens["f16x3"](mel), gens["fp32"](mel)
+    assert y16.shape == (3, 1, 160032) and torch.isfinite(y16).all()
+    assert rel_l2(y16, y32) < 3e-6
+    assert rel_l2(gens["f16x3"](mel[1]), y16[1]) < 1e-6
+    perm = torch.tensor([2, 0, 1]).cuda()
+    assert rel_l2(gens["f16x3"](mel[perm]), y16[perm]) < 1e-6
