@@ -7,19 +7,6 @@ namespace cvxg {
 constexpr int BN = 128;
 constexpr int BK = 32;
 
-__device__ __forceinline__ void tile_of_vblock(int vb, int tiles_m, int tiles_n, int map_mode, int& tile_m, int& tile_n)
-{
-    // same map for a VIRTUAL block id (persistent kernels: vb = blockIdx.x + round * gridDim.x, gridDim.x % 8 == 0)
-    if (map_mode == 1) {
-        const int xcd = vb & 7, slot = vb >> 3;
-        tile_m = xcd + 8 * (slot / tiles_n);
-        tile_n = slot % tiles_n;
-    } else {
-        tile_n = vb % tiles_n;
-        tile_m = vb / tiles_n;
-    }
-}
-
 __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_mode, int& tile_m, int& tile_n)
 {
     // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8: observed, used for speed only).

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
 template <int NT>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
-    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode, int total_vb)
+    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
 {
     constexpr int TM = 4, BM = 256, BNL = 256;
     constexpr int TILE256 = 256 * BK;                  // halves per operand tile (16 KiB)
@@ -369,13 +369,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
-    // PERSISTENT over output tiles: a block walks the virtual block ids blockIdx.x, + gridDim.x, ... (the launcher caps
-    // the grid at one block per CU).  The epilogue's stores are only ISSUED before the next tile's DMA and MFMAs start,
-    // so they drain to HBM under the next mainloop instead of holding the CU until the block retires.
-    for (int vb = blockIdx.x; vb < total_vb; vb += gridDim.x) {
     int tile_m, tile_n;
-    tile_of_vblock(vb, tiles_m, tiles_n, map_mode, tile_m, tile_n);
-    if (tile_m >= tiles_m) continue;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
     const int m0 = tile_m * BM, n0 = tile_n * BNL;
 
     // DMA sources: wave `wid` fills rows [32*wid, +32) of each of the four tiles, 16 rows per instruction
@@ -503,8 +499,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
     }
     gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane, so);
-    __builtin_amdgcn_s_barrier();          // nobody reads the last stage any more: the next tile may refill stage 0
-    }
 }
 
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ w, f16* __restrict__ hi,
@@ -607,15 +601,12 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
             attr256 = true;
         }
-        static const int persist = [] { const char* e = getenv("CVX_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
-        const int total_vb = gm * tn;
-        const int grid256 = (persist && total_vb > persist) ? persist : total_vb;      // persist = blocks (multiple of 8)
         if (single)
-            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<1>, dim3((unsigned)grid256), dim3(512), lds256, st, *a, A, wh, wl,
-                               acc_scale, so, tm, tn, map_mode, total_vb);
+            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<1>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
+                               acc_scale, so, tm, tn, map_mode);
         else
-            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<3>, dim3((unsigned)grid256), dim3(512), lds256, st, *a, A, wh, wl,
-                               acc_scale, so, tm, tn, map_mode, total_vb);
+            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<3>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
+                               acc_scale, so, tm, tn, map_mode);
     } else if (A.hi) {
         if (single) launch_dma<2, 1>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
         else launch_dma<2, 3>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);   // 2 stages, 2 blocks / CU
