@@ -83,6 +83,11 @@ typedef struct {
      * of t: four-frame groups in the order 0, 2, 1, 3 inside every 16 frames), the layout
      * cvx_attention_f16x3 reads its V^T tiles from. */
     uint16_t* Vt_hi; uint16_t* Vt_lo; int64_t vt_ld;
+    /* Optional caller-owned scratch (fp32, at least 4*M*N floats) for small problems: with few output tiles and a long
+     * K the K range is cut into up to 4 slices computed by different blocks, the partial sums go to `workspace` and a
+     * second kernel adds them in a fixed order (deterministic) and applies the epilogue.  NULL = never split K.
+     * Not available together with the RoPE / QKV-transpose epilogues. */
+    float* workspace; int64_t workspace_floats;
 } cvx_gemm_split_io;
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,

@@ -39,6 +39,7 @@ class GemmSplitIO(C.Structure):
         ("C_hi", C.c_void_p), ("C_lo", C.c_void_p), ("ldc_h", C.c_int64),
         ("write_f32", C.c_int32),
         ("Vt_hi", C.c_void_p), ("Vt_lo", C.c_void_p), ("vt_ld", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
     ]
 
 
@@ -139,7 +140,15 @@ def load() -> C.CDLL:
     return lib
 
 
+_DEBUG_SYNC = os.environ.get("CVX_DEBUG_SYNC") == "1"      # dev: synchronise after every call so a GPU fault names its kernel
+
+
 def check(rc: int, what: str = "") -> None:
+    if _DEBUG_SYNC:
+        import sys
+        import torch
+        print("[cvx]", what, file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if rc != 0:
         msg = load().cvx_last_error_string()
         raise CovomixHipError(f"{what or 'covomix_hip'} failed (rc={rc}): {msg.decode() if msg else ''}")

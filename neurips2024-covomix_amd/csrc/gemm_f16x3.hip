@@ -204,11 +204,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 // 2-stage scheme cannot hide).  No staging VGPRs, no split VALU work, no ds_write in the loop.
 struct PreSplitA { const f16* hi; const f16* lo; int64_t ld; const f16* hi2; const f16* lo2; int64_t ld2; };
 
+// Split-K (ksplit > 1, small problems only): blockIdx.y selects a K slice of k_per columns; the block writes its raw
+// partial sums (fp32, no epilogue) to `partial` [ksplit][M][N] and splitk_reduce_kernel finishes the job.
 template <int STAGES, int NT>
 __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_kernel(
-    const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
-    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
+    const cvx_gemm_args p_in, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
+    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode, int k_per, float* __restrict__ partial)
 {
+    cvx_gemm_args p = p_in;
+    const int k_begin = k_per > 0 ? (int)blockIdx.y * k_per : 0;
+    if (k_per > 0) {            // this block: columns [k_begin, k_begin + k_per) of [A | A2] and of W, plain fp32 store
+        p.K = k_per;
+        p.C = partial + (int64_t)blockIdx.y * p.M * p.N; p.ldc = p.N;
+        p.bias = nullptr; p.residual = nullptr; p.act = CVX_ACT_NONE; p.rope_cos = nullptr;
+        so = SplitOut{nullptr, nullptr, 0, 1, nullptr, nullptr, 0};
+    }
     constexpr int TM = 2, BM = 128;
     constexpr int STAGE = 4 * TILE_H;
     extern __shared__ __attribute__((aligned(16))) f16 smem_h[];
@@ -242,14 +252,23 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
     }
     constexpr int KSTEP = (NT == 1) ? 2 * BK : BK;      // k consumed per stage
     const int dma_off = 32 * wid * BK;
-    const int switch_tile = A.hi2 ? p.K1 / KSTEP : -1;
+    if (k_begin > 0) {                                  // K slice: start at column k_begin of [A | A2] and of W
+        const bool in2 = A.hi2 && k_begin >= p.K1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pah[j] += k_begin + (in2 ? jmp_h[j] : 0);
+            pal[j] += k_begin + (in2 ? jmp_l[j] : 0);
+            pwh[j] += k_begin; pwl[j] += k_begin;
+        }
+    }
+    const int switch_tile = (A.hi2 && k_begin < p.K1) ? (p.K1 - k_begin) / KSTEP : -1;
     const int nk = p.K / KSTEP;
 
     // issue the 8 DMA pieces of tile t (tiles past the end re-read the last tile: keeps the vmcnt arithmetic uniform)
     auto issue = [&](int t) {
         f16* const S = S0 + (t % STAGES) * STAGE + dma_off;
         const bool live = t < nk;
-        const bool sw = (t == switch_tile);
+        const bool sw = live && (t == switch_tile);      // (a K slice may END exactly at the A | A2 boundary)
         const int back = live ? 0 : KSTEP, adv = live ? KSTEP : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
             glds16(sl, S + TILE_H + 16 * j * BK);
             glds16(wh, S + 2 * TILE_H + 16 * j * BK);
             glds16(wl, S + 3 * TILE_H + 16 * j * BK);
-            pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv;
+            if (live) { pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv; }   // a dummy re-read moves nothing
         }
     };
 
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
     auto issue = [&](int t) {
         f16* const S = S0 + (t & 1) * STAGE + dma_off;
         const bool live = t < nk;
-        const bool sw = (t == switch_tile);
+        const bool sw = live && (t == switch_tile);      // (a K slice may END exactly at the A | A2 boundary)
         const int back = live ? 0 : KSTEP, adv = live ? KSTEP : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
             glds16(sl, S + TILE256 + 16 * j * BK);
             glds16(wh, S + 2 * TILE256 + 16 * j * BK);
             glds16(wl, S + 3 * TILE256 + 16 * j * BK);
-            pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv;
+            if (live) { pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv; }   // a dummy re-read moves nothing
         }
     };
 
@@ -524,9 +543,38 @@ extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t
     return CVX_OK;
 }
 
+// out = epilogue( sum_s partial[s] ) in a fixed order: bias -> act -> residual -> fp32 and / or split store
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, const cvx_gemm_args p, SplitOut so)
+{
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t total = (int64_t)p.M * p.N;
+    if (i4 >= total) return;
+    const int row = (int)(i4 / p.N), col = (int)(i4 - (int64_t)row * p.N);          // N % 4 == 0: the 4 columns share a row
+    f32x4 v = *reinterpret_cast<const f32x4*>(partial + i4);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(partial + (int64_t)s * total + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (p.bias ? p.bias[col + e] : 0.f);
+        if (p.act == CVX_ACT_GELU) x = gelu_erf(x);
+        else if (p.act == CVX_ACT_SILU) x = silu(x);
+        if (p.residual) x += p.residual[(int64_t)row * p.ldr + col + e];
+        v[e] = x;
+    }
+    if (so.write_f32) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
+    if (so.hi) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + col + e, v[e]);
+    }
+}
+
 template <int STAGES, int NT>
 static void launch_dma(const cvx_gemm_args& a, const PreSplitA& A, const f16* wh, const f16* wl, float acc_scale,
-                       const SplitOut& so, dim3 grid, int tiles_m, int tiles_n, int map_mode, hipStream_t st)
+                       const SplitOut& so, dim3 grid, int tiles_m, int tiles_n, int map_mode, hipStream_t st,
+                       int k_per = 0, float* partial = nullptr)
 {
     const size_t lds = (size_t)STAGES * 4 * TILE_H * sizeof(f16);
     static bool attr = false;
@@ -536,7 +584,7 @@ static void launch_dma(const cvx_gemm_args& a, const PreSplitA& A, const f16* wh
         attr = true;
     }
     hipLaunchKernelGGL((gemm_f16x3_dma_kernel<STAGES, NT>), grid, dim3(256), lds, st, a, A, wh, wl, acc_scale, so,
-                       tiles_m, tiles_n, map_mode);
+                       tiles_m, tiles_n, map_mode, k_per, partial);
 }
 
 extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
@@ -608,8 +656,35 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
             hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<3>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
     } else if (A.hi) {
-        if (single) launch_dma<2, 1>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);
-        else launch_dma<2, 3>(*a, A, wh, wl, acc_scale, so, grid, tiles_m, tiles_n, map_mode, st);   // 2 stages, 2 blocks / CU
+        // Small problems (one utterance: M ~ 1000) leave most CUs with at most one block of 4 waves and nothing to hide
+        // the DMA / LDS round trips behind.  Two remedies (measured on BASELINE config 2, tools/bench_c2.py):
+        //   * split K into up to 4 slices on separate blocks when the caller provides a workspace and the grid is small
+        //     (partials in fp32, summed in a fixed order by splitk_reduce_kernel, which also applies the epilogue);
+        //   * a 4-stage DMA ring when the whole grid fits the chip at one block per CU.
+        // Large grids keep the 2-stage kernel at two blocks per CU.
+        static const int splitk_on = [] { const char* e = getenv("CVX_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
+        static const int small_stages = [] { const char* e = getenv("CVX_GEMM_SMALL_STAGES"); return e ? atoi(e) : 4; }();
+        int ksplit = 1;
+        if (splitk_on && io && io->workspace && !a->rope_cos && !so.vt_hi && (int)grid.x <= 128 && a->N % 4 == 0 && a->ldc % 4 == 0) {
+            for (int cand = 4; cand >= 2; cand >>= 1) {
+                const int kp = a->K / cand;
+                if (a->K % cand == 0 && kp % 64 == 0 && kp >= 512 && (!a->A2 || a->K1 % kp == 0) &&
+                    io->workspace_floats >= (int64_t)cand * a->M * a->N) { ksplit = cand; break; }
+            }
+        }
+        const int k_per = ksplit > 1 ? a->K / ksplit : 0;
+        float* part = ksplit > 1 ? io->workspace : nullptr;
+        dim3 g2(grid.x, (unsigned)ksplit);
+        const bool deep = (int)(grid.x * ksplit) <= 256 && small_stages == 4;
+        if (deep) {
+            if (single) launch_dma<4, 1>(*a, A, wh, wl, acc_scale, so, g2, tiles_m, tiles_n, map_mode, st, k_per, part);
+            else launch_dma<4, 3>(*a, A, wh, wl, acc_scale, so, g2, tiles_m, tiles_n, map_mode, st, k_per, part);
+        } else if (single) launch_dma<2, 1>(*a, A, wh, wl, acc_scale, so, g2, tiles_m, tiles_n, map_mode, st, k_per, part);
+        else launch_dma<2, 3>(*a, A, wh, wl, acc_scale, so, g2, tiles_m, tiles_n, map_mode, st, k_per, part);   // 2 stages, 2 blocks / CU
+        if (ksplit > 1) {
+            const int64_t quads = ((int64_t)a->M * a->N + 3) / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, part, ksplit, *a, so);
+        }
     } else {
         const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
         static bool attr = false;

@@ -31,6 +31,19 @@ def _chk_f32(*ts):
             raise TypeError(f"expected float32, got {t.dtype}")
 
 
+_SPLITK_WS: dict = {}
+
+
+def _splitk_workspace(device) -> torch.Tensor:
+    """Caller-owned scratch of cvx_gemm_f16x3's split-K path: 4 x 2048 x 4096 floats, allocated once per device and
+    never re-allocated (its address is baked into captured HIP graphs)."""
+    ws = _SPLITK_WS.get(device)
+    if ws is None:
+        ws = torch.empty(4 * 2048 * 4096, dtype=torch.float32, device=device)
+        _SPLITK_WS[device] = ws
+    return ws
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
          a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None) -> torch.Tensor:
@@ -78,6 +91,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.ldw = hi.stride(0)                       # rows may be padded (row stride > K)
         io = GemmSplitIO()
         io.write_f32 = 1 if write_f32 else 0
+        if a_split is not None and M <= 2048 and rope is None:          # small problems may split K (see the header)
+            ws = _splitk_workspace(a.device)
+            io.workspace, io.workspace_floats = ws.data_ptr(), ws.numel()
         if a_split is not None:
             ah, al = a_split
             assert ah.dtype == torch.float16 and ah.shape == a.shape and (al is None or al.shape == a.shape) and ah.stride(1) == 1
@@ -96,6 +112,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
             vh, vl = vt_split
             assert vh.dtype == torch.float16 and vh.is_contiguous() and (vl is None or (vl.is_contiguous() and vh.shape == vl.shape))
             io.Vt_hi, io.Vt_lo, io.vt_ld = vh.data_ptr(), _p(vl), vh.shape[-1]
+        if _lib._DEBUG_SYNC:
+            import sys
+            print(f"[cvx] gemm_f16x3 M={M} N={N} K={K} k1={g.K1} lo={lo is not None} a_split={a_split is not None} rope={rope is not None} "
+                  f"out_split={out_split is not None} vt={vt_split is not None} ws={bool(io.workspace)}", file=sys.stderr, flush=True)
         _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), _p(lo), inv_scale, C.byref(io), _stream()),
                    "cvx_gemm_f16x3")
         return out

@@ -496,3 +496,40 @@ def test_hifigan_conv1d_f16x3_rejects_bad_args(ops):
     z = (torch.zeros(1, ops.hifigan_cl_rows(64), 32, dtype=torch.float16, device=dev()),) * 2
     with pytest.raises(L.CovomixHipError):
         ops.hifigan_conv1d_f16x3(z, wpk, torch.zeros(32, device=dev()), 1, 64, ksize=4, dil=1, out_x=torch.zeros(1, z[0].shape[1], 32, device=dev()))
+
+
+# ---------------------------------------------------------------- split-K path of the small-problem GEMM
+@pytest.mark.parametrize("terms", [3, 1])
+@pytest.mark.parametrize("M,N,K,K1", [(1000, 1024, 4096, 0), (1000, 1024, 2048, 1024), (500, 1024, 1024, 0), (77, 256, 2048, 0)])
+def test_gemm_split_k_small_problem(ops, M, N, K, K1, terms):
+    """Few output tiles + long K: K is cut into 2-4 slices on separate blocks, partials are added in a fixed order and the
+    epilogue (bias, GELU, residual in place, split output) runs in the reduce kernel.  Against fp64, deterministic."""
+    g = torch.Generator().manual_seed(400 + M + K)
+    a = torch.randn(M, K, generator=g).to(dev())
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    r = torch.randn(M, N, generator=g).to(dev())
+    ws = ops.split_f16(w, with_lo=(terms == 3))
+    ah, al = ops.split_act_f16(a)
+    if terms == 1:
+        al = None
+    kw = {}
+    if K1:
+        kw = dict(a2=a[:, K1:].contiguous(), a2_split=(ah[:, K1:].contiguous(), None if al is None else al[:, K1:].contiguous()))
+        a_in, asp = a[:, :K1].contiguous(), (ah[:, :K1].contiguous(), None if al is None else al[:, :K1].contiguous())
+    else:
+        a_in, asp = a, (ah, al)
+    src = ah.double() + (al.double() if al is not None else 0)
+    wd = (ws[0].double() + (ws[1].double() if ws[1] is not None else 0)) * ws[2]
+    ref = F.gelu(src @ wd.T + b.double()) + r.double()
+    outs = []
+    for _ in range(2):
+        c = r.clone()                                                   # residual in place
+        oh = torch.empty(M, N, dtype=torch.float16, device=dev())
+        ol = torch.empty_like(oh) if terms == 3 else None
+        ops.gemm(a_in, w, c, bias=b, act=1, residual=c, w_split=ws, a_split=asp, out_split=(oh, ol), **kw)
+        outs.append(c)
+        assert rel_l2(c, ref) < 3e-6
+        got = oh.float() + (ol.float() if ol is not None else 0)
+        assert rel_l2(got, c) < (1e-6 if terms == 3 else 1e-3)
+    assert torch.equal(outs[0], outs[1])

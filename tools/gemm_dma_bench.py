@@ -13,7 +13,7 @@ def timeit(fn, iters=20, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-M = 16000
+M = int(os.environ.get("M", "16000"))
 tot = {3: 0.0, 1: 0.0}
 only = os.environ.get("SHAPES")            # e.g. SHAPES=ff2 TERMS=3 for a PMC run on one kernel
 for (N, K, name, cnt) in [(3072, 1024, "qkv", 8), (1024, 1024, "out", 8), (4096, 1024, "ff1", 8), (1024, 4096, "ff2", 8), (1024, 2048, "skip", 4)]:
