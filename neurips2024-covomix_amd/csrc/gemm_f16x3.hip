@@ -664,8 +664,9 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         // Large grids keep the 2-stage kernel at two blocks per CU.
         static const int splitk_on = [] { const char* e = getenv("CVX_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
         static const int small_stages = [] { const char* e = getenv("CVX_GEMM_SMALL_STAGES"); return e ? atoi(e) : 4; }();
+        static const int splitk_max_grid = [] { const char* e = getenv("CVX_GEMM_SPLITK_GRID"); return e ? atoi(e) : 128; }();
         int ksplit = 1;
-        if (splitk_on && io && io->workspace && !a->rope_cos && !so.vt_hi && (int)grid.x <= 128 && a->N % 4 == 0 && a->ldc % 4 == 0) {
+        if (splitk_on && io && io->workspace && !a->rope_cos && !so.vt_hi && (int)grid.x <= splitk_max_grid && a->N % 4 == 0 && a->ldc % 4 == 0) {
             for (int cand = 4; cand >= 2; cand >>= 1) {
                 const int kp = a->K / cand;
                 if (a->K % cand == 0 && kp % 64 == 0 && kp >= 512 && (!a->A2 || a->K1 % kp == 0) &&
