@@ -215,6 +215,17 @@ int cvx_hifigan_to_channels_last(const float* x, float* x_cl, uint16_t* z_hi, ui
 int cvx_hifigan_from_channels_last(const float* x_cl, float* x, int32_t B, int32_t C, int32_t L, int32_t Lp,
                                    int32_t Cp, int32_t halo_l, cvx_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * Prompt mel extraction - SURVEY.md section 8f row N3 (data_preparation/generate_mel.py:49-72 as called by
+ * monologue_generation.py:62-74): the 480-point windowed DFT of every frame and the mel projection are two calls of
+ * cvx_gemm_bias_act_f32 (A = the reflect-padded signal viewed as overlapping rows, lda = hop = 160; W = the
+ * hann-windowed cos | sin basis [482, 480]; then the [80, 244] mel basis); these two are the steps in between:
+ *   mag[t, k] = sqrt(re[t,k]^2 + im[t,k]^2 + 1e-9)  for k < nb (= 241), 0 for nb <= k < nbp      spec = [T, 2*nb] (re | im)
+ *   y[m, t]   = log(max(x[t, m], 1e-5))                                                         x = [T, n_mels]
+ */
+int cvx_mel_magnitude_f32(const float* spec, float* mag, int64_t T, int32_t nb, int32_t nbp, cvx_stream_t s);
+int cvx_mel_log_transpose_f32(const float* x, float* y, int64_t T, int32_t n_mels, cvx_stream_t s);
+
 /* pcm[i] = (int16) trunc( wav[i] * 32768 )   mel_decode_to_wav tail (monologue_generation.py:55-57),
  * numpy astype('int16') semantics for in-range values (C truncation toward zero). */
 int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s);

@@ -86,6 +86,8 @@ SIGNATURES = {
                                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_hifigan_from_channels_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, C.c_void_p]),
+    "cvx_mel_magnitude_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "cvx_mel_log_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "cvx_t2s_decode_steps": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p]),
     "cvx_geglu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),

@@ -226,7 +226,54 @@ __global__ __launch_bounds__(256) void wav_to_int16_kernel(const float* __restri
     pcm[i] = (int16_t)(int32_t)v;     // trunc toward zero, wrap like numpy astype on x86
 }
 
+// ---------------------------------------------------------------- prompt mel extraction (row N3) epilogues
+// spec [T, 2*nb] = (re | im) of the windowed DFT  ->  mag [T, nbp] = sqrt(re^2 + im^2 + 1e-9), zero in the padding
+__global__ __launch_bounds__(256) void mel_magnitude_kernel(const float* __restrict__ spec, float* __restrict__ mag,
+                                                           int64_t T, int nb, int nbp)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * nbp) return;
+    const int64_t t = i / nbp;
+    const int k = (int)(i - t * nbp);
+    float v = 0.f;
+    if (k < nb) {
+        const float re = spec[t * 2 * nb + k], im = spec[t * 2 * nb + nb + k];
+        v = sqrtf(re * re + im * im + 1e-9f);
+    }
+    mag[i] = v;
+}
+
+// x [T, n_mels] -> y [n_mels, T] = log(max(x, 1e-5))
+__global__ __launch_bounds__(256) void mel_log_transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t T, int n_mels)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * n_mels) return;
+    const int m = (int)(i / T);
+    const int64_t t = i - (int64_t)m * T;
+    y[i] = logf(fmaxf(x[t * n_mels + m], 1e-5f));
+}
+
 }  // namespace
+
+extern "C" int cvx_mel_magnitude_f32(const float* spec, float* mag, int64_t T, int32_t nb, int32_t nbp, cvx_stream_t s)
+{
+    CVX_REQUIRE(spec && mag && T >= 0 && nb > 0 && nbp >= nb, "mel_magnitude: bad arguments");
+    if (T == 0) return CVX_OK;
+    hipLaunchKernelGGL(mel_magnitude_kernel, dim3((unsigned)((T * nbp + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       spec, mag, T, nb, nbp);
+    CVX_CHECK_LAUNCH("cvx_mel_magnitude_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_mel_log_transpose_f32(const float* x, float* y, int64_t T, int32_t n_mels, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && y && T >= 0 && n_mels > 0, "mel_log_transpose: bad arguments");
+    if (T == 0) return CVX_OK;
+    hipLaunchKernelGGL(mel_log_transpose_kernel, dim3((unsigned)((T * n_mels + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(s), x, y, T, n_mels);
+    CVX_CHECK_LAUNCH("cvx_mel_log_transpose_f32");
+    return CVX_OK;
+}
 
 extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
                                   uint16_t* y_hi_, uint16_t* y_lo_,

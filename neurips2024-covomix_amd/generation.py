@@ -11,8 +11,9 @@ Upstream stages:
       `<name>.txt` (needs the bert-base-uncased vocabulary in the local transformers cache - a third-party asset
       this repo does not ship) is decoded on the GPU; otherwise `<text_dir>/<name>.semantic.npy` holds already
       predicted tokens (covosingle / covosinx: int array [n]; covomix: [2, n] or flat [2n], split at half).
-  * prompt mel extraction (N3): `<prompt_dir>/<name>.mel.npy` ([80, T] log-mel) next to
-      `<name>.hubert_code.npy`; dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
+  * prompt mel extraction (N3, built: mel.py): `<prompt_dir>/<name>.mel.npy` ([80, T] log-mel) if present, else the
+      log-mel of `<prompt_dir>/<name>.wav` (8 kHz) computed on the GPU; next to `<name>.hubert_code.npy` (the HuBERT
+      tokeniser, N4, is not built); dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
 New relative to the reference: utterances are sharded over ranks (torchrun) and batched by equal length.
 """
 from __future__ import annotations
@@ -50,7 +51,12 @@ def build_parser() -> ArgumentParser:
 
 def _load_prompt(prompt_dir: str, name: str):
     tok = torch.from_numpy(np.load(os.path.join(prompt_dir, name + ".hubert_code.npy")).astype(np.int64))
-    mel = torch.from_numpy(np.load(os.path.join(prompt_dir, name + ".mel.npy")).astype(np.float32))
+    npy = os.path.join(prompt_dir, name + ".mel.npy")
+    if os.path.isfile(npy):
+        mel = torch.from_numpy(np.load(npy).astype(np.float32))
+    else:                                                  # extract_mel(prompt wav), monologue_generation.py:62-74 (row N3)
+        from .mel import extract_mel
+        mel = extract_mel(os.path.join(prompt_dir, name + ".wav"))
     return assembly.truncate_prompt(tok, mel)            # -> tokens [Tp], mel [Tp, 80]
 
 
