@@ -88,6 +88,10 @@ typedef struct {
      * second kernel adds them in a fixed order (deterministic) and applies the epilogue.  NULL = never split K.
      * Not available together with the RoPE / QKV-transpose epilogues. */
     float* workspace; int64_t workspace_floats;
+    /* Non-zero: the split weight is ONE interleaved matrix [N][K/32][hi 32 | lo 32] (W_lo == W_hi + 32 halves,
+     * a->ldw >= 2K halves), so that a K-step of a row is a whole 128-byte cache line.  Large-problem kernel only
+     * (pre-split A, M >= 2048, N >= 512). */
+    int32_t w_interleaved;
 } cvx_gemm_split_io;
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,

@@ -40,6 +40,7 @@ class GemmSplitIO(C.Structure):
         ("write_f32", C.c_int32),
         ("Vt_hi", C.c_void_p), ("Vt_lo", C.c_void_p), ("vt_ld", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+        ("w_interleaved", C.c_int32),
     ]
 
 

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -89,6 +91,12 @@ class VectorField:
                         ".2.to_qkv" in k or ".2.to_out" in k or ".4.0." in k or ".4.2." in k
                         or (k.startswith("transformer.layers.") and k.endswith(".0.weight")) or k == "to_pred.weight"):
                     self.split[k] = ops.split_f16(v, with_lo=(precision == "f16x3"))
+        # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
+        self.split_il: Dict[str, tuple] = {}
+        if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
+            for k, v in self.split.items():
+                if v[0].shape[0] >= 512:
+                    self.split_il[k] = ops.split_f16_interleaved(v)
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, Bt: int, T: int) -> dict:
@@ -161,6 +169,7 @@ class VectorField:
         take = free.pop
         # split activations need the f16x3 kernel on every consumer GEMM (K % 32 == 0 and more than 64 rows; the
         # single-term mode consumes 64 k per stage).  'f16' without split I/O falls back to the fp32 kernels.
+        il = self.split_il.get
         if self.precision == "f16":
             split_io = Bt * T > 64 and dim % 64 == 0
             sp = self.split.get if split_io else (lambda k: None)
@@ -190,7 +199,7 @@ class VectorField:
                 s = skips.pop()
                 comb = take()
                 if split_io:
-                    ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"),
+                    ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
                              a_split=twin[id(h)], a2_split=twin[id(s)])
                 else:
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"))
@@ -204,21 +213,21 @@ class VectorField:
                 ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16)
                 if T % 4 == 0:      # q | k split row-major, v split + transposed, straight into the f16x3 attention
                     ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                             w_split=sp(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
+                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
                              write_f32=False)
                     ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
                 else:
                     ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                             w_split=sp(p + ".2.to_qkv.weight"), a_split=n16)
+                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16)
                     ops.attention(ws["qkv"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
                 h_att = take() if keep_input else h
-                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), a_split=a16)
+                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"), a_split=a16)
                 h = h_att
                 ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16)
                 ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
-                         w_split=sp(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False)
+                         w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False)
                 ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h,
-                         w_split=sp(p + ".4.2.weight"), a_split=f16,
+                         w_split=sp(p + ".4.2.weight"), w_il=il(p + ".4.2.weight"), a_split=f16,
                          out_split=twin[id(h)] if i + 1 < d["depth"] else None)
                 continue
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])

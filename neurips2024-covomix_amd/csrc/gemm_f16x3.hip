@@ -375,7 +375,11 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
 // (~10 TB/s chip-wide, near what the L2 -> LDS DMA path sustains) while its MFMA pipe is only ~39 % busy.
 // 512 threads = 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers);
 // two 64 KiB stages; one block per CU.
-template <int NT>
+// WIL: the weights arrive INTERLEAVED, [N][K/32][hi 32 | lo 32] (ldw = 2K): one K-step of one row is a whole 128-byte
+// cache line, fetched by one DMA piece of 8 rows x 128 bytes (separate hi / lo matrices give 16 rows x 64 bytes = half
+// lines, which costs 6-10 % of the K-step when both operands do it).  The W tile in LDS is then [256 rows][128 bytes]
+// with the 16-byte chunk XOR-swizzled by (row >> 1) & 7.
+template <int NT, bool WIL>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
     float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
@@ -411,6 +415,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
             jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
             pwl[j] = Wlo + rw * p.ldw + 8 * c;
         }
+        if constexpr (WIL) {          // four pieces of 8 rows x 128 bytes: rows 32*wid + 8*q + (lane >> 3), q = 2j, 2j+1
+            const int r0 = 32 * wid + 8 * (2 * j) + (lane >> 3), r1 = r0 + 8;
+            const int64_t rw0 = min(n0 + r0, p.N - 1), rw1 = min(n0 + r1, p.N - 1);
+            pwh[j] = Whi + rw0 * p.ldw + 8 * ((lane & 7) ^ ((r0 >> 1) & 7));
+            pwl[j] = Whi + rw1 * p.ldw + 8 * ((lane & 7) ^ ((r1 >> 1) & 7));
+        }
     }
     constexpr int KSTEP = (NT == 1) ? 2 * BK : BK;      // k consumed per stage
     const int dma_off = 32 * wid * BK;
@@ -426,13 +436,20 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
         for (int j = 0; j < 2; ++j) {
             const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - back;
             const f16* sl = pal[j] + (sw ? jmp_l[j] : 0) - back;
-            const f16* wh = pwh[j] - back;
-            const f16* wl = pwl[j] - back;
+            const int wback = WIL ? 2 * back : back, wadv = WIL ? 2 * adv : adv;     // interleaved rows hold 64 halves per K-step
+            const f16* wh = pwh[j] - wback;
+            const f16* wl = pwl[j] - wback;
             glds16(sh, S + 16 * j * BK);
             glds16(sl, S + TILE256 + 16 * j * BK);
-            glds16(wh, S + 2 * TILE256 + 16 * j * BK);
-            glds16(wl, S + 3 * TILE256 + 16 * j * BK);
-            if (live) { pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + adv; pwl[j] = wl + adv; }   // a dummy re-read moves nothing
+            if constexpr (WIL) {
+                f16* const Wd = S0 + (t & 1) * STAGE + 2 * TILE256 + (32 * wid + 16 * j) * 2 * BK;
+                glds16(wh, Wd);
+                glds16(wl, Wd + 8 * 2 * BK);
+            } else {
+                glds16(wh, S + 2 * TILE256 + 16 * j * BK);
+                glds16(wl, S + 3 * TILE256 + 16 * j * BK);
+            }
+            if (live) { pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + wadv; pwl[j] = wl + wadv; }   // a dummy re-read moves nothing
         }
     };
 
@@ -449,6 +466,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
 #pragma unroll
     for (int s = 0; s < 2; ++s) foff[s] = i31 * BK + 8 * ((2 * s + g) ^ swz);
     const int a_row0 = wm * 128 * BK, b_row0 = wn * 64 * BK;
+    int wofh[2], wofl[2];                               // WIL: fragment offsets inside the [256][64 halves] W tile
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int sw8 = (i31 >> 1) & 7;
+        wofh[s] = (wn * 64 + i31) * 2 * BK + 8 * ((2 * s + g) ^ sw8);
+        wofl[s] = (wn * 64 + i31) * 2 * BK + 8 * ((4 + 2 * s + g) ^ sw8);
+    }
 
     issue(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -465,8 +489,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
             f16x8 fwh[2], fwl[2];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
-                fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
+                if constexpr (WIL) {
+                    fwh[ni] = *reinterpret_cast<const f16x8*>(Sc + 2 * TILE256 + ni * 32 * 2 * BK + wofh[s]);
+                    fwl[ni] = *reinterpret_cast<const f16x8*>(Sc + 2 * TILE256 + ni * 32 * 2 * BK + wofl[s]);
+                } else {
+                    fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
+                    fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
+                }
             }
             // all 12 fragments of this 16-wide k slice first (in-order LDS returns let the first MFMAs start while
             // the later reads are still in flight), then 24 back-to-back MFMAs
@@ -596,6 +625,10 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     const bool single = (W_lo == nullptr);      // plain fp16 operands (hi halves only), one MFMA product
     CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
     CVX_REQUIRE((((uintptr_t)W_hi | (uintptr_t)W_lo) & 15) == 0, "gemm_f16x3: split weights must be 16-byte aligned");
+    const bool w_il = io && io->w_interleaved != 0;          // [N][K/32][hi 32 | lo 32]: W_lo == W_hi + 32, ldw == 2K
+    if (w_il)
+        CVX_REQUIRE(!single && W_lo == W_hi + 32 && a->ldw >= 2 * (int64_t)a->K && io->A_hi && a->M >= 2048 && a->N >= 512,
+                    "gemm_f16x3: interleaved weights need W_lo == W_hi + 32, ldw >= 2K, a pre-split A and the large-problem kernel");
     if (single)
         CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
                     "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
@@ -643,17 +676,23 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB
         static bool attr256 = false;
         if (!attr256) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma256_kernel<3>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_dma256_kernel<1>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<1, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
             attr256 = true;
         }
+        const dim3 g256((unsigned)(gm * tn));
         if (single)
-            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<1>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
+                               acc_scale, so, tm, tn, map_mode);
+        else if (w_il)
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
         else
-            hipLaunchKernelGGL(gemm_f16x3_dma256_kernel<3>, dim3((unsigned)(gm * tn)), dim3(512), lds256, st, *a, A, wh, wl,
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
     } else if (A.hi) {
         // Small problems (one utterance: M ~ 1000) leave most CUs with at most one block of 4 waves and nothing to hide

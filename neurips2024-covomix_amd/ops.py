@@ -46,7 +46,7 @@ def _splitk_workspace(device) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
-         a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None) -> torch.Tensor:
+         a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -84,6 +84,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = cos.data_ptr(), sin.data_ptr(), cos.shape[0], rope_cols
     else:
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
+    if w_il is not None and a_split is not None and M >= 2048 and N >= 512 and w_split is not None and w_split[1] is not None:
+        il, inv_il = w_il                      # interleaved [N, 2K] copy of the same split weight (split_f16_interleaved)
+        assert il.dtype == torch.float16 and il.shape == (N, 2 * K) and il.is_contiguous() and il.is_cuda
+        use_il = True
+    else:
+        use_il = False
     if w_split is not None and K % 32 == 0 and (M > 64 or a_split is not None or out_split is not None):
         hi, lo, inv_scale = w_split
         assert hi.dtype == torch.float16 and hi.shape == (N, K) and hi.stride(1) == 1 and hi.is_cuda
@@ -116,7 +122,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
             import sys
             print(f"[cvx] gemm_f16x3 M={M} N={N} K={K} k1={g.K1} lo={lo is not None} a_split={a_split is not None} rope={rope is not None} "
                   f"out_split={out_split is not None} vt={vt_split is not None} ws={bool(io.workspace)}", file=sys.stderr, flush=True)
-        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), hi.data_ptr(), _p(lo), inv_scale, C.byref(io), _stream()),
+        w_hi_ptr, w_lo_ptr = hi.data_ptr(), _p(lo)
+        if use_il:
+            io.w_interleaved, g.ldw = 1, 2 * K
+            w_hi_ptr, w_lo_ptr, inv_scale = il.data_ptr(), il.data_ptr() + 64, inv_il
+        _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), w_hi_ptr, w_lo_ptr, inv_scale, C.byref(io), _stream()),
                    "cvx_gemm_f16x3")
         return out
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
@@ -151,6 +161,16 @@ def split_f16(w: torch.Tensor, with_lo: bool = True):
     _lib.check(_lib.load().cvx_split_f16(w.data_ptr(), hi.data_ptr(), _p(lo), w.numel(), scale, _stream()),
                "cvx_split_f16")
     return hi, lo, 1.0 / scale
+
+
+def split_f16_interleaved(w_split):
+    """(hi, lo, 1/scale) from split_f16 -> (il [N, 2K], 1/scale) with il[n] = [hi 0:32 | lo 0:32 | hi 32:64 | lo 32:64 | ...]:
+    a K-step of one row becomes one 128-byte cache line for the large-problem GEMM's DMA.  Load-time packing."""
+    hi, lo, inv = w_split
+    N, K = hi.shape
+    assert K % 32 == 0 and lo is not None
+    il = torch.stack((hi.view(N, K // 32, 32), lo.view(N, K // 32, 32)), dim=2).reshape(N, 2 * K).contiguous()
+    return il, inv
 
 
 def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: Optional[torch.Tensor],

@@ -533,3 +533,29 @@ def test_gemm_split_k_small_problem(ops, M, N, K, K1, terms):
         got = oh.float() + (ol.float() if ol is not None else 0)
         assert rel_l2(got, c) < (1e-6 if terms == 3 else 1e-3)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,K1", [(2048, 512, 1024, 0), (4100, 1024, 4096, 0), (2300, 3072, 1024, 0), (2048, 1024, 2048, 1024)])
+def test_gemm_f16x3_interleaved_weights(ops, M, N, K, K1):
+    """Large-problem kernel with the weight stored interleaved ([hi 32 | lo 32] per K-step): must equal the separate
+    hi / lo layout bit for bit (same products in the same order) and fp64 to fp32 accuracy."""
+    g = torch.Generator().manual_seed(500 + N + K)
+    a = torch.randn(M, K, generator=g).to(dev())
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev())
+    b = torch.randn(N, generator=g).to(dev())
+    ws = ops.split_f16(w)
+    il = ops.split_f16_interleaved(ws)
+    assert il[0].shape == (N, 2 * K)
+    assert torch.equal(il[0][:, 64:96], ws[0][:, 32:64]) and torch.equal(il[0][:, 32:64], ws[1][:, :32])
+    ah, al = ops.split_act_f16(a)
+    kw = {}
+    if K1:
+        kw = dict(a2=a[:, K1:].contiguous(), a2_split=(ah[:, K1:].contiguous(), al[:, K1:].contiguous()))
+        a_in, asp = a[:, :K1].contiguous(), (ah[:, :K1].contiguous(), al[:, :K1].contiguous())
+    else:
+        a_in, asp = a, (ah, al)
+    c0, c1 = torch.empty(M, N, device=dev()), torch.empty(M, N, device=dev())
+    ops.gemm(a_in, w, c0, bias=b, w_split=ws, a_split=asp, **kw)
+    ops.gemm(a_in, w, c1, bias=b, w_split=ws, a_split=asp, w_il=il, **kw)
+    assert torch.equal(c0, c1)
+    assert rel_l2(c1, a.double() @ w.double().T + b.double()) < 3e-6

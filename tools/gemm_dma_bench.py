@@ -36,7 +36,8 @@ for (N, K, name, cnt) in [(3072, 1024, "qkv", 8), (1024, 1024, "out", 8), (4096,
             ws = (padded(ws[0]), padded(ws[1]), ws[2])
             ah, al = padded(ah), padded(al)
         asp = (ah, al if terms == 3 else None)
-        t = timeit(lambda: ops.gemm(a, w, c, w_split=ws, a_split=asp))
+        il = ops.split_f16_interleaved(ws) if (terms == 3 and os.environ.get("WIL") == "1" and not pad) else None
+        t = timeit(lambda: ops.gemm(a, w, c, w_split=ws, a_split=asp, w_il=il))
         if ref is None:
             ref = (ah.double() + al.double()) @ w.double().T if N * K <= 1024 * 1024 else None
         err = float((c.double() - ref).norm() / ref.norm()) if ref is not None else float("nan")
