@@ -117,9 +117,15 @@ class VectorField:
             lo_too = self.precision == "f16x3"          # 'f16': (hi, None)
             h16 = lambda *s: (torch.empty(*s, dtype=torch.float16, device=dev),
                               torch.empty(*s, dtype=torch.float16, device=dev) if lo_too else None)
-            ws["normed16"], ws["att16"], ws["ff16"] = h16(M, d["dim"]), h16(M, d["heads"] * 64), h16(M, 4 * d["dim"])
+            # GEMM A operands: for the large-problem kernel (M >= 2048, interleaved weights available) as INTERLEAVED pairs
+            # ([hi 32 | lo 32] per K-step: whole cache lines for the DMA), otherwise as two separate fp16 tensors
+            a16 = h16
+            if lo_too and M >= 2048 and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
+                a16 = lambda rows, cols: ops.SplitIL(rows, cols, dev)
+            ws["normed16"], ws["att16"], ws["ff16"] = a16(M, d["dim"]), a16(M, d["heads"] * 64), a16(M, 4 * d["dim"])
+            ws["pred16"] = h16(M, d["dim"])                      # final norm -> to_pred (N = 80: small-N kernel, plain pair)
             ws["qk16"] = h16(M, 2 * d["heads"] * 64)
-            ws["h16"] = [h16(M, d["dim"]) for _ in ws["h"]]      # split twins of the residual-stream buffers (skip GEMMs)
+            ws["h16"] = [a16(M, d["dim"]) for _ in ws["h"]]      # split twins of the residual-stream buffers (skip GEMMs)
             Tp = ((T + 31) // 32) * 32           # V^T rows, zero beyond T (read by the last key tile, weight 0)
             ws["vt16"] = (torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev),
                           torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev) if lo_too else None)
@@ -186,7 +192,8 @@ class VectorField:
         # twin, so that GEMM takes both operands pre-split (all-DMA kernel) instead of splitting on the fly
         twin = {id(b): pr for b, pr in zip(ws["h"], ws["h16"])} if split_io else None
         if split_io:
-            ops.split_act_f16(h, *twin[id(h)])
+            tw = twin[id(h)]
+            ops.split_act_f16(h, tw) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw)
 
         skips: List[torch.Tensor] = []
         for i in range(d["depth"]):
@@ -242,8 +249,8 @@ class VectorField:
                      w_split=sp(p + ".4.0.weight"))
             ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h, w_split=sp(p + ".4.2.weight"))
         if split_io:
-            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["normed16"])
-            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["normed16"])
+            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"])
+            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"])
         else:
             ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])
             ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"))

@@ -44,6 +44,9 @@ __device__ __forceinline__ f16x8 gload8h(const f16* p)
 
 __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, const f32x4 o)
 {
+    // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
+    // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
+    if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
     f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -30,6 +30,9 @@ constexpr int V_LD = HD;
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o)
 {
+    // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
+    // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
+    if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
     f16x4_t h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

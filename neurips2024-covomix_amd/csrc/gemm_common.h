@@ -39,6 +39,9 @@ typedef _Float16 cvx_f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int vt_slot(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
+// column -> position inside a row of an INTERLEAVED split pair ([hi 32 | lo 32] per block of 32 columns; lo == hi + 32)
+__device__ __forceinline__ int il_col(int c) { return ((c >> 5) << 6) | (c & 31); }
+
 __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v)
 {
     const float x = fminf(fmaxf(v, -65504.f), 65504.f);
@@ -167,7 +170,9 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                     *reinterpret_cast<f32x4*>(cp + 32) = vhi;
                 }
                 if (so.hi) {
-                    const int64_t o = (int64_t)row * so.ldc_h + c4_lo;
+                    const bool il = so.lo == so.hi + 32;
+                    const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c4_lo) : c4_lo);
+                    const int64_t o32 = il ? 64 : 32;              // the partner columns c4_lo + 32 are the next block
                     cvx_f16x4 h0, l0, h1, l1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -177,10 +182,10 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                         h1[e] = (_Float16)x1; l1[e] = (_Float16)(x1 - (float)h1[e]);
                     }
                     *reinterpret_cast<cvx_f16x4*>(so.hi + o) = h0;
-                    *reinterpret_cast<cvx_f16x4*>(so.hi + o + 32) = h1;
+                    *reinterpret_cast<cvx_f16x4*>(so.hi + o + o32) = h1;
                     if (so.lo) {
                         *reinterpret_cast<cvx_f16x4*>(so.lo + o) = l0;
-                        *reinterpret_cast<cvx_f16x4*>(so.lo + o + 32) = l1;
+                        *reinterpret_cast<cvx_f16x4*>(so.lo + o + o32) = l1;
                     }
                 }
             }
@@ -214,8 +219,9 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                 if (c_hi < p.N) p.C[(int64_t)row * p.ldc + c_hi] = hi;
             }
             if (so.hi) {
-                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + c_lo, lo);
-                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + c_hi, hi);
+                const bool il = so.lo == so.hi + 32;
+                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_lo) : c_lo), lo);
+                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_hi) : c_hi), hi);
             }
         }
     }

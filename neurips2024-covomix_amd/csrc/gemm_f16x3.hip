@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
 // cache line, fetched by one DMA piece of 8 rows x 128 bytes (separate hi / lo matrices give 16 rows x 64 bytes = half
 // lines, which costs 6-10 % of the K-step when both operands do it).  The W tile in LDS is then [256 rows][128 bytes]
 // with the 16-byte chunk XOR-swizzled by (row >> 1) & 7.
-template <int NT, bool WIL>
+// AIL: the same for the activations (A and A2 interleaved, lda = 2K, A_lo == A_hi + 32): A tile in LDS [256][128 bytes].
+template <int NT, bool WIL, bool AIL>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
     float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
@@ -415,6 +416,15 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
             jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
             pwl[j] = Wlo + rw * p.ldw + 8 * c;
         }
+        if constexpr (AIL) {          // as WIL below, for A (and A2): pah = piece 2j, pal = piece 2j+1
+            const int r0 = 32 * wid + 8 * (2 * j) + (lane >> 3), r1 = r0 + 8;
+            const int64_t ra0 = min(m0 + r0, p.M - 1), ra1 = min(m0 + r1, p.M - 1);
+            const int c0 = (lane & 7) ^ ((r0 >> 1) & 7), c1 = (lane & 7) ^ ((r1 >> 1) & 7);
+            pah[j] = A.hi + ra0 * A.ld + 8 * c0;
+            pal[j] = A.hi + ra1 * A.ld + 8 * c1;
+            jmp_h[j] = A.hi2 ? (A.hi2 + ra0 * A.ld2 + 8 * c0) - (pah[j] + 2 * p.K1) : 0;
+            jmp_l[j] = A.hi2 ? (A.hi2 + ra1 * A.ld2 + 8 * c1) - (pal[j] + 2 * p.K1) : 0;
+        }
         if constexpr (WIL) {          // four pieces of 8 rows x 128 bytes: rows 32*wid + 8*q + (lane >> 3), q = 2j, 2j+1
             const int r0 = 32 * wid + 8 * (2 * j) + (lane >> 3), r1 = r0 + 8;
             const int64_t rw0 = min(n0 + r0, p.N - 1), rw1 = min(n0 + r1, p.N - 1);
@@ -434,13 +444,20 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
         const int back = live ? 0 : KSTEP, adv = live ? KSTEP : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - back;
-            const f16* sl = pal[j] + (sw ? jmp_l[j] : 0) - back;
-            const int wback = WIL ? 2 * back : back, wadv = WIL ? 2 * adv : adv;     // interleaved rows hold 64 halves per K-step
+            const int aback = AIL ? 2 * back : back, aadv = AIL ? 2 * adv : adv;     // interleaved rows hold 64 halves per K-step
+            const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - aback;
+            const f16* sl = pal[j] + (sw ? jmp_l[j] : 0) - aback;
+            const int wback = WIL ? 2 * back : back, wadv = WIL ? 2 * adv : adv;
             const f16* wh = pwh[j] - wback;
             const f16* wl = pwl[j] - wback;
-            glds16(sh, S + 16 * j * BK);
-            glds16(sl, S + TILE256 + 16 * j * BK);
+            if constexpr (AIL) {
+                f16* const Ad = S0 + (t & 1) * STAGE + (32 * wid + 16 * j) * 2 * BK;
+                glds16(sh, Ad);
+                glds16(sl, Ad + 8 * 2 * BK);
+            } else {
+                glds16(sh, S + 16 * j * BK);
+                glds16(sl, S + TILE256 + 16 * j * BK);
+            }
             if constexpr (WIL) {
                 f16* const Wd = S0 + (t & 1) * STAGE + 2 * TILE256 + (32 * wid + 16 * j) * 2 * BK;
                 glds16(wh, Wd);
@@ -449,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
                 glds16(wh, S + 2 * TILE256 + 16 * j * BK);
                 glds16(wl, S + 3 * TILE256 + 16 * j * BK);
             }
-            if (live) { pah[j] = sh + adv; pal[j] = sl + adv; pwh[j] = wh + wadv; pwl[j] = wl + wadv; }   // a dummy re-read moves nothing
+            if (live) { pah[j] = sh + aadv; pal[j] = sl + aadv; pwh[j] = wh + wadv; pwl[j] = wl + wadv; }   // a dummy re-read moves nothing
         }
     };
 
@@ -466,12 +483,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
 #pragma unroll
     for (int s = 0; s < 2; ++s) foff[s] = i31 * BK + 8 * ((2 * s + g) ^ swz);
     const int a_row0 = wm * 128 * BK, b_row0 = wn * 64 * BK;
-    int wofh[2], wofl[2];                               // WIL: fragment offsets inside the [256][64 halves] W tile
+    int wofh[2], wofl[2], aofh[2], aofl[2];             // WIL / AIL: fragment offsets inside a [256][64 halves] tile
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int sw8 = (i31 >> 1) & 7;
         wofh[s] = (wn * 64 + i31) * 2 * BK + 8 * ((2 * s + g) ^ sw8);
         wofl[s] = (wn * 64 + i31) * 2 * BK + 8 * ((4 + 2 * s + g) ^ sw8);
+        aofh[s] = (wm * 128 + i31) * 2 * BK + 8 * ((2 * s + g) ^ sw8);
+        aofl[s] = (wm * 128 + i31) * 2 * BK + 8 * ((4 + 2 * s + g) ^ sw8);
     }
 
     issue(0);
@@ -502,8 +521,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
             f16x8 fah[TM], fal[TM];
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
-                fah[mi] = *reinterpret_cast<const f16x8*>(ah + mi * 32 * BK + foff[s]);
-                fal[mi] = *reinterpret_cast<const f16x8*>(al + mi * 32 * BK + foff[s]);
+                if constexpr (AIL) {
+                    fah[mi] = *reinterpret_cast<const f16x8*>(Sc + mi * 32 * 2 * BK + aofh[s]);
+                    fal[mi] = *reinterpret_cast<const f16x8*>(Sc + mi * 32 * 2 * BK + aofl[s]);
+                } else {
+                    fah[mi] = *reinterpret_cast<const f16x8*>(ah + mi * 32 * BK + foff[s]);
+                    fal[mi] = *reinterpret_cast<const f16x8*>(al + mi * 32 * BK + foff[s]);
+                }
             }
             // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
             // would wait for the previous MFMA's result every time)
@@ -556,8 +580,9 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     if (i >= n) return;
     const float x = fminf(fmaxf(w[i] * scale, -F16_MAX), F16_MAX);
     const f16 h = (f16)x;
-    hi[i] = h;
-    if (lo) lo[i] = (f16)(x - (float)h);
+    const int64_t o = (lo == hi + 32) ? (((i >> 5) << 6) | (i & 31)) : i;      // interleaved pair: [hi 32 | lo 32] blocks
+    hi[o] = h;
+    if (lo) lo[o] = (f16)(x - (float)h);
 }
 
 }  // namespace
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (so.write_f32) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
     if (so.hi) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + col + e, v[e]);
+        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + ((so.lo == so.hi + 32) ? il_col(col + e) : col + e), v[e]);
     }
 }
 
@@ -629,6 +654,13 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     if (w_il)
         CVX_REQUIRE(!single && W_lo == W_hi + 32 && a->ldw >= 2 * (int64_t)a->K && io->A_hi && a->M >= 2048 && a->N >= 512,
                     "gemm_f16x3: interleaved weights need W_lo == W_hi + 32, ldw >= 2K, a pre-split A and the large-problem kernel");
+    // interleaved activations: A_lo == A_hi + 32 (and A2_lo == A2_hi + 32), lda_h >= 2K - only together with interleaved
+    // weights on the large-problem kernel
+    const bool a_il = io && io->A_hi && io->A_lo == io->A_hi + 32;
+    if (a_il)
+        CVX_REQUIRE(w_il && io->lda_h >= 2 * (int64_t)(a->A2 ? a->K1 : a->K) &&
+                    (!a->A2 || (io->A2_lo == io->A2_hi + 32 && io->lda2_h >= 2 * (int64_t)(a->K - a->K1))),
+                    "gemm_f16x3: interleaved A needs interleaved weights, lda_h >= 2K and an interleaved A2");
     if (single)
         CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
                     "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
@@ -676,23 +708,28 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB
         static bool attr256 = false;
         if (!attr256) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, false, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<1, false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<1, false, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
             attr256 = true;
         }
         const dim3 g256((unsigned)(gm * tn));
         if (single)
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
+                               acc_scale, so, tm, tn, map_mode);
+        else if (w_il && a_il)
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true, true>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
         else if (w_il)
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true>), g256, dim3(512), lds256, st, *a, A, wh, wl,
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
         else
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
+            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
     } else if (A.hi) {
         // Small problems (one utterance: M ~ 1000) leave most CUs with at most one block of 4 waves and nothing to hide

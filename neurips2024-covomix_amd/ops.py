@@ -31,6 +31,36 @@ def _chk_f32(*ts):
             raise TypeError(f"expected float32, got {t.dtype}")
 
 
+class SplitIL:
+    """INTERLEAVED split pair of a [rows, cols] fp32 tensor: one fp16 buffer [rows, 2*cols] laid out [hi 32 | lo 32] per
+    block of 32 columns, so that a K-step of one row is one 128-byte cache line for the large-problem GEMM's DMA.  The C ABI
+    recognises it by lo == hi + 32 halves.  Accepted wherever a (hi, lo) tuple of split ACTIVATIONS is (GEMM A / A2 operands
+    and split outputs, norm and attention outputs); only the large-problem kernel (M >= 2048, N >= 512, interleaved weights)
+    can consume it."""
+
+    def __init__(self, rows: int, cols: int, device):
+        assert cols % 32 == 0
+        self.rows, self.cols = rows, cols
+        self.buf = torch.empty(rows, 2 * cols, dtype=torch.float16, device=device)
+
+    def dense(self):
+        """(hi, lo) as ordinary [rows, cols] tensors (copies; tests)."""
+        b = self.buf.view(self.rows, self.cols // 32, 2, 32)
+        return b[:, :, 0].reshape(self.rows, self.cols), b[:, :, 1].reshape(self.rows, self.cols)
+
+
+def _pair(x, rows=None, cols=None):
+    """(hi_ptr, lo_ptr, ld) of a split pair: a (hi, lo) tuple (lo may be None) or a SplitIL."""
+    if isinstance(x, SplitIL):
+        assert (rows is None or x.rows == rows) and (cols is None or x.cols == cols), "SplitIL shape mismatch"
+        return x.buf.data_ptr(), x.buf.data_ptr() + 64, 2 * x.cols
+    hi, lo = x
+    assert hi.dtype == torch.float16 and hi.stride(-1) == 1 and hi.is_cuda
+    assert (rows is None or hi.shape[0] == rows) and (cols is None or hi.shape[-1] == cols)
+    assert lo is None or (lo.dtype == torch.float16 and lo.shape == hi.shape and lo.stride() == hi.stride())
+    return hi.data_ptr(), _p(lo), hi.stride(0) if hi.ndim == 2 else hi.shape[-1]
+
+
 _SPLITK_WS: dict = {}
 
 
@@ -84,6 +114,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = cos.data_ptr(), sin.data_ptr(), cos.shape[0], rope_cols
     else:
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
+    if isinstance(a_split, SplitIL):
+        assert w_il is not None and M >= 2048 and N >= 512, "an interleaved A operand needs interleaved weights and the large-problem kernel"
     if w_il is not None and a_split is not None and M >= 2048 and N >= 512 and w_split is not None and w_split[1] is not None:
         il, inv_il = w_il                      # interleaved [N, 2K] copy of the same split weight (split_f16_interleaved)
         assert il.dtype == torch.float16 and il.shape == (N, 2 * K) and il.is_contiguous() and il.is_cuda
@@ -101,19 +133,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
             ws = _splitk_workspace(a.device)
             io.workspace, io.workspace_floats = ws.data_ptr(), ws.numel()
         if a_split is not None:
-            ah, al = a_split
-            assert ah.dtype == torch.float16 and ah.shape == a.shape and (al is None or al.shape == a.shape) and ah.stride(1) == 1
-            io.A_hi, io.A_lo, io.lda_h = ah.data_ptr(), _p(al), ah.stride(0)
+            io.A_hi, io.A_lo, io.lda_h = _pair(a_split, M, k1)
             if a2 is not None:
                 assert a2_split is not None, "pre-split A needs a pre-split A2 as well"
-                bh, bl = a2_split
-                assert bh.dtype == torch.float16 and bh.shape == a2.shape and (bl is None or bl.shape == a2.shape)
-                io.A2_hi, io.A2_lo, io.lda2_h = bh.data_ptr(), _p(bl), bh.stride(0)
+                assert isinstance(a2_split, SplitIL) == isinstance(a_split, SplitIL)
+                io.A2_hi, io.A2_lo, io.lda2_h = _pair(a2_split, M, K - k1)
         if out_split is not None:
-            oh, ol = out_split
-            assert oh.dtype == torch.float16 and oh.shape[0] == M and (ol is None or ol.shape == oh.shape) and oh.stride(1) == 1
-            assert oh.shape[1] == N or (vt_split is not None and oh.shape[1] == rope_cols)
-            io.C_hi, io.C_lo, io.ldc_h = oh.data_ptr(), _p(ol), oh.stride(0)
+            io.C_hi, io.C_lo, io.ldc_h = _pair(out_split, M, rope_cols if vt_split is not None else N)
         if vt_split is not None:          # QKV mode: v columns transposed per (sequence, head) for the f16x3 attention
             vh, vl = vt_split
             assert vh.dtype == torch.float16 and vh.is_contiguous() and (vl is None or (vl.is_contiguous() and vh.shape == vl.shape))
@@ -134,11 +160,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     return out
 
 
-def split_act_f16(x: torch.Tensor, hi: Optional[torch.Tensor] = None, lo: Optional[torch.Tensor] = None):
+def split_act_f16(x: torch.Tensor, hi=None, lo: Optional[torch.Tensor] = None):
     """(hi, lo) fp16 halves of an fp32 activation tensor (unscaled) - for GEMMs that take A pre-split.
-    With `hi` given and lo=None only the (saturating) fp16 cast is written."""
+    With `hi` given and lo=None only the (saturating) fp16 cast is written; hi may be a SplitIL (interleaved pair)."""
     _chk_f32(x)
     assert x.is_contiguous()
+    if isinstance(hi, SplitIL):
+        h, l, _ = _pair(hi, x.shape[0], x.shape[1])
+        _lib.check(_lib.load().cvx_split_f16(x.data_ptr(), h, l, x.numel(), 1.0, _stream()), "cvx_split_f16")
+        return hi
     if hi is None:
         hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
@@ -178,12 +208,14 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     """out_split = (hi, lo) fp16 tensors: also (or, with out=None, only) write the result as a split pair."""
     _chk_f32(x, gamma, beta, out)
     assert x.is_contiguous() and (out is None or out.is_contiguous()) and gamma.stride(-1) == 1
-    oh, ol = out_split if out_split is not None else (None, None)
-    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and (ol is None or ol.is_contiguous()) and oh.numel() == x.numel())
     D = x.shape[-1]
     rows = x.numel() // D
+    oh, ol = (None, None)
+    if out_split is not None:
+        oh, ol, ld = _pair(out_split, rows if isinstance(out_split, SplitIL) else None, D)
+        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == x.numel())
     rpg = rows if rows_per_group is None else rows_per_group
-    _lib.check(_lib.load().cvx_adarmsnorm_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), _p(oh), _p(ol), rows, D, rpg,
+    _lib.check(_lib.load().cvx_adarmsnorm_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), oh, ol, rows, D, rpg,
                                               float(D) ** 0.5, eps, _stream()), "cvx_adarmsnorm_f32")
     return out if out is not None else out_split
 
@@ -192,9 +224,11 @@ def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H
     _chk_f32(qkv, out)
     assert qkv.is_contiguous() and (out is None or out.is_contiguous())
     assert qkv.numel() == Bt * T * 3 * H * 64 and (out is None or out.numel() == Bt * T * H * 64)
-    oh, ol = out_split if out_split is not None else (None, None)
-    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and (ol is None or ol.is_contiguous()) and oh.numel() == Bt * T * H * 64)
-    _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), _p(oh), _p(ol), Bt, T, H, scale, _stream()),
+    oh, ol = (None, None)
+    if out_split is not None:
+        oh, ol, _ = _pair(out_split, Bt * T if isinstance(out_split, SplitIL) else None, H * 64)
+        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == Bt * T * H * 64)
+    _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), oh, ol, Bt, T, H, scale, _stream()),
                "cvx_attention_f32")
     return out if out is not None else out_split
 
@@ -217,9 +251,11 @@ def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T:
     assert qh.shape == (Bt * T, 2 * H * 64) and vh.shape[0] == Bt * H * 64
     Tp = vh.shape[1]
     _chk_f32(out)
-    oh, ol = out_split if out_split is not None else (None, None)
-    assert oh is None or (oh.dtype == torch.float16 and oh.is_contiguous() and oh.numel() == Bt * T * H * 64)
-    _lib.check(_lib.load().cvx_attention_f16x3(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), _p(oh), _p(ol),
+    oh, ol = (None, None)
+    if out_split is not None:
+        oh, ol, _ = _pair(out_split, Bt * T if isinstance(out_split, SplitIL) else None, H * 64)
+        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == Bt * T * H * 64)
+    _lib.check(_lib.load().cvx_attention_f16x3(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), oh, ol,
                                                Bt, T, Tp, H, scale, _stream()), "cvx_attention_f16x3")
     return out if out is not None else out_split
 

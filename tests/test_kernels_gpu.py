@@ -559,3 +559,52 @@ def test_gemm_f16x3_interleaved_weights(ops, M, N, K, K1):
     ops.gemm(a_in, w, c1, bias=b, w_split=ws, a_split=asp, w_il=il, **kw)
     assert torch.equal(c0, c1)
     assert rel_l2(c1, a.double() @ w.double().T + b.double()) < 3e-6
+
+
+def test_interleaved_activation_pairs_end_to_end(ops):
+    """SplitIL (one buffer, [hi 32 | lo 32] per 32 columns) through every producer and the large-problem GEMM: each
+    producer must write exactly the values of the two-tensor form, and the GEMM must give bit-identical results."""
+    M, D, H = 2100, 1024, 16
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(M, D, generator=g).to(dev())
+    gam, bet = torch.randn(D, generator=g).to(dev()), torch.randn(D, generator=g).to(dev())
+    # norm
+    sep = (torch.empty(M, D, dtype=torch.float16, device=dev()), torch.empty(M, D, dtype=torch.float16, device=dev()))
+    il = ops.SplitIL(M, D, dev())
+    ops.adarmsnorm(x, gam, bet, None, out_split=sep)
+    ops.adarmsnorm(x, gam, bet, None, out_split=il)
+    assert all(torch.equal(a, b) for a, b in zip(il.dense(), sep))
+    # plain split
+    il2 = ops.SplitIL(M, D, dev())
+    ops.split_act_f16(x, il2)
+    assert all(torch.equal(a, b) for a, b in zip(il2.dense(), ops.split_act_f16(x)))
+    # GEMM: interleaved A (and A2) + interleaved W + interleaved split output, against the separate form
+    w = (torch.randn(1024, 2 * D, generator=g) / 45).to(dev())
+    ws = ops.split_f16(w)
+    wil = ops.split_f16_interleaved(ws)
+    b = torch.randn(1024, generator=g).to(dev())
+    c0, c1 = torch.empty(M, 1024, device=dev()), torch.empty(M, 1024, device=dev())
+    o_sep = (torch.empty(M, 1024, dtype=torch.float16, device=dev()), torch.empty(M, 1024, dtype=torch.float16, device=dev()))
+    o_il = ops.SplitIL(M, 1024, dev())
+    ops.gemm(x, w, c0, bias=b, act=1, a2=x, w_split=ws, w_il=wil, a_split=sep, a2_split=ops.split_act_f16(x), out_split=o_sep)
+    ops.gemm(x, w, c1, bias=b, act=1, a2=x, w_split=ws, w_il=wil, a_split=il, a2_split=il2, out_split=o_il)
+    assert torch.equal(c0, c1)
+    assert all(torch.equal(a, b_) for a, b_ in zip(o_il.dense(), o_sep))
+    # attention output (both attention kernels)
+    Bt, T = 2, 1050
+    qkv = torch.randn(Bt, T, 3 * H * 64, generator=g).to(dev()) * 0.3
+    a_sep = (torch.empty(Bt * T, H * 64, dtype=torch.float16, device=dev()), torch.empty(Bt * T, H * 64, dtype=torch.float16, device=dev()))
+    a_il = ops.SplitIL(Bt * T, H * 64, dev())
+    ops.attention(qkv, None, Bt, T, H, 0.125, out_split=a_sep)
+    ops.attention(qkv, None, Bt, T, H, 0.125, out_split=a_il)
+    assert all(torch.equal(a, b_) for a, b_ in zip(a_il.dense(), a_sep))
+    qh, ql = ops.split_act_f16(qkv.reshape(Bt * T, -1)[:, : 2 * H * 64].contiguous())
+    Tp = (T + 31) // 32 * 32
+    vt = (torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev()), torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev()))
+    vt[0][:, :T] = torch.randn(Bt * H * 64, T, generator=g).half().to(dev())
+    ops.attention_f16x3((qh, ql), vt, None, Bt, T, H, 0.125, out_split=a_sep)
+    ops.attention_f16x3((qh, ql), vt, None, Bt, T, H, 0.125, out_split=a_il)
+    assert all(torch.equal(a, b_) for a, b_ in zip(a_il.dense(), a_sep))
+    # only the large-problem kernel can read an interleaved A
+    with pytest.raises(AssertionError):
+        ops.gemm(x[:100], w[:, :D], torch.empty(100, 1024, device=dev()), w_split=ops.split_f16(w[:, :D].contiguous()), a_split=ops.SplitIL(100, D, dev()))
