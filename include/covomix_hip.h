@@ -72,7 +72,17 @@ int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s);
  * range); cvx_gemm_f16x3 multiplies the accumulators by acc_scale = 1/scale (exact) before the epilogue.
  * `io` (may be NULL) lets activations stay in split form between kernels: A_hi/A_lo (and A2_*) give the A operand
  * already split (then a->A / a->A2 are only validated and every tile arrives by LDS-DMA); C_hi/C_lo receive a split
- * copy of the output for the next GEMM, and write_f32 == 0 drops the fp32 store of C altogether. */
+ * copy of the output for the next GEMM, and write_f32 == 0 drops the fp32 store of C altogether.
+ *
+ * Interleaved pairs.  Wherever this header takes an (fp16 hi, fp16 lo) pair of a row-major activation - A_*, A2_*,
+ * C_* here, y_hi/y_lo of cvx_adarmsnorm_f32, out_hi/out_lo of cvx_attention_f32 / cvx_attention_f16x3, hi/lo of
+ * cvx_split_f16 - passing lo == hi + 32 (halves) selects ONE buffer of row length 2*cols in which every block of 32
+ * values is stored as [hi 32 | lo 32]: flat offset o of the two-tensor form lives at ((o >> 5) << 6) | (o & 31) for
+ * hi and 32 halves later for lo; the leading dimension (lda_h, ldc_h) is then the row length of that buffer in
+ * halves (>= 2*cols).  Values are bit-identical to the two-tensor form; the layout makes one K-step of a row one
+ * 128-byte cache line.  cvx_gemm_f16x3 reads interleaved A/A2 only in the large-problem kernel (M >= 2048,
+ * N >= 512) and only together with w_interleaved; A and A2 must then both be interleaved.  lo == NULL always means
+ * "hi only" (single-term fp16). */
 typedef struct {
     const uint16_t* A_hi;  const uint16_t* A_lo;  int64_t lda_h;
     const uint16_t* A2_hi; const uint16_t* A2_lo; int64_t lda2_h;
