@@ -661,6 +661,9 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         CVX_REQUIRE(w_il && io->lda_h >= 2 * (int64_t)(a->A2 ? a->K1 : a->K) &&
                     (!a->A2 || (io->A2_lo == io->A2_hi + 32 && io->lda2_h >= 2 * (int64_t)(a->K - a->K1))),
                     "gemm_f16x3: interleaved A needs interleaved weights, lda_h >= 2K and an interleaved A2");
+    else
+        CVX_REQUIRE(!(io && a->A2 && io->A2_hi && io->A2_lo == io->A2_hi + 32),
+                    "gemm_f16x3: A2 is an interleaved pair but A is not (both operands must use the same layout)");
     if (single)
         CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
                     "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
