@@ -125,6 +125,15 @@ def _rule(name: str, shape) -> Tuple[float, float]:
         return 1.0, 0.0
     if name.endswith(".gamma"):
         return 0.1, 1.0
+    # ---- HuBERT tokeniser (N4)
+    if "layer_norm." in name or name.startswith("feature_extractor.conv_layers.0.2."):
+        return (0.1, 1.0) if name.endswith(".weight") else (0.05, 0.0)
+    if name.startswith("feature_extractor.conv_layers."):
+        return float(np.sqrt(2.0 / max(fan_in, 1))), 0.0
+    if ".self_attn.q_proj.weight" in name or ".self_attn.k_proj.weight" in name:
+        return 3.0 / np.sqrt(max(fan_in, 1)), 0.0          # peaky attention: a random post-LN stack otherwise collapses over frames
+    if ".self_attn.v_proj.weight" in name or ".self_attn.out_proj.weight" in name:
+        return 0.6 / np.sqrt(max(fan_in, 1)), 0.0
     # ---- vocoder (weight-norm parametrisation)
     if name.endswith(".weight_g"):
         g = 0.3 if name.startswith("conv_post") else 1.2
@@ -199,6 +208,57 @@ def t2s_state_dict(shapes: Shapes, seed: int = 0) -> "Dict[str, np.ndarray]":
         if k.endswith("rotary_emb.freqs"):
             sd[k] = np.asarray(rotary_inv_freq(64), dtype=np.float32)
     return sd
+
+
+def hubert_param_shapes(conv_layers=((512, 10, 5),) + ((512, 3, 2),) * 4 + ((512, 2, 2),) * 2, dim: int = 768, ffn: int = 3072,
+                        depth: int = 12, conv_pos: int = 128, conv_pos_groups: int = 16) -> Shapes:
+    """state_dict of the reference HubertModel at HuBERT-Base geometry, in its own order
+    (fairseq-hubert/fairseq/models/hubert/hubert.py:249-329, models/wav2vec/wav2vec2.py:844-947,1012-1063,1261-1306;
+    extractor_mode "default": GroupNorm after the first conv only, no conv bias; post-LN encoder layers)."""
+    sh: Shapes = OrderedDict()
+    sh["mask_emb"] = (dim,)
+    cin = 1
+    for i, (c, k, _s) in enumerate(conv_layers):
+        sh[f"feature_extractor.conv_layers.{i}.0.weight"] = (c, cin, k)
+        if i == 0:
+            sh["feature_extractor.conv_layers.0.2.weight"] = (c,)
+            sh["feature_extractor.conv_layers.0.2.bias"] = (c,)
+        cin = c
+    sh["post_extract_proj.weight"] = (dim, cin)
+    sh["post_extract_proj.bias"] = (dim,)
+    sh["encoder.pos_conv.0.bias"] = (dim,)
+    sh["encoder.pos_conv.0.weight_g"] = (1, 1, conv_pos)
+    sh["encoder.pos_conv.0.weight_v"] = (dim, dim // conv_pos_groups, conv_pos)
+    for i in range(depth):
+        p = f"encoder.layers.{i}."
+        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            sh[p + f"self_attn.{nm}.weight"] = (dim, dim)
+            sh[p + f"self_attn.{nm}.bias"] = (dim,)
+        sh[p + "self_attn_layer_norm.weight"] = (dim,)
+        sh[p + "self_attn_layer_norm.bias"] = (dim,)
+        sh[p + "fc1.weight"] = (ffn, dim)
+        sh[p + "fc1.bias"] = (ffn,)
+        sh[p + "fc2.weight"] = (dim, ffn)
+        sh[p + "fc2.bias"] = (dim,)
+        sh[p + "final_layer_norm.weight"] = (dim,)
+        sh[p + "final_layer_norm.bias"] = (dim,)
+    sh["encoder.layer_norm.weight"] = (dim,)
+    sh["encoder.layer_norm.bias"] = (dim,)
+    sh["layer_norm.weight"] = (cin,)
+    sh["layer_norm.bias"] = (cin,)
+    sh["final_proj.weight"] = (dim, dim)
+    sh["final_proj.bias"] = (dim,)
+    return sh
+
+
+def hubert_state_dict(seed: int = 0, **geometry) -> "Dict[str, np.ndarray]":
+    return synth_state_dict(hubert_param_shapes(**geometry), seed)
+
+
+def hubert_kmeans_centers(seed: int = 0, n_clusters: int = 500, dim: int = 768) -> np.ndarray:
+    """Stand-in for `km_model.cluster_centers_` (dump_km_label.py:27-28): float32 [n_clusters, dim]."""
+    rs = np.random.RandomState((zlib.crc32(b"hubert.kmeans.cluster_centers_") ^ seed) & 0xFFFFFFFF)
+    return rs.standard_normal((n_clusters, dim)).astype(np.float32)
 
 
 def rotary_inv_freq(dim_head: int = 64, theta: float = 10000.0) -> np.ndarray:
