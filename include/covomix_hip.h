@@ -296,6 +296,44 @@ int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream
  * the encoder's feed-forward; ld_out >= F pads the K dimension of the following GEMM). */
 int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F, int64_t ld_out, cvx_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * HuBERT layer-L + k-means prompt tokeniser - SURVEY.md section 8f row N4
+ * (fairseq-hubert/examples/textless_nlp/gslm/speech2unit/pretrained/hubert_feature_reader.py:58-78 ->
+ *  fairseq-hubert/fairseq/models/hubert/hubert.py:433-480 -> fairseq/models/wav2vec/wav2vec2.py:844-946,1078-1163,
+ *  1343-1370; labels: fairseq-hubert/examples/hubert/simple_kmeans/dump_km_label.py:25-43).
+ * Activations are channels-last [frames, channels] fp32 throughout, so that
+ *   - conv layers 1..6 (Conv1d(C, C, k, stride), no bias, GELU) are cvx_gemm_bias_act_f32 calls over OVERLAPPING rows:
+ *     A = previous layer's output, lda = stride*C, K = k*C, W repacked [C_out][k][C_in];
+ *   - post_extract_proj, q|k|v, out_proj, fc1 (+GELU), fc2 (+residual) are the same GEMM, attention is
+ *     cvx_attention_f32 (H = 12 heads of 64, no RoPE);
+ *   - the grouped positional convolution (k = 128, 16 groups) is one GEMM per group over the packed operand below
+ *     (K = k*C/groups, lda = C/groups), bias + GELU + residual in its epilogue, written back at column g*C/groups;
+ *   - x.C^T of the k-means distance is a GEMM against cluster_centers_ [n_clusters, D].
+ * The entry points here are the steps in between. */
+
+/* First conv layer Conv1d(1, C, k, stride) (no bias) + GroupNorm(C, C) (per channel over all frames, biased variance)
+ * + exact GELU:  out[l, c], l < L = (n_samples - k) / stride + 1.   wav2vec2.py:856-910 ("default" extractor mode).
+ * workspace: cvx_hubert_conv0_workspace_floats(L, C) floats. */
+int64_t cvx_hubert_conv0_workspace_floats(int64_t L, int32_t C);
+int cvx_hubert_conv0_gn_gelu_f32(const float* wav, int64_t n_samples, const float* w, int32_t C, int32_t k, int32_t stride,
+                                 const float* gn_gamma, const float* gn_beta, float eps,
+                                 float* out, float* workspace, int64_t workspace_floats, cvx_stream_t s);
+
+/* y[r, :] = (x[r, :] - mean) / sqrt(var + eps) * gamma + beta  (biased variance; fairseq/modules/layer_norm.py).
+ * D % 4 == 0, D <= 1024; y may alias x. */
+int cvx_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                      int64_t rows, int32_t D, float eps, cvx_stream_t s);
+
+/* out[g][j][c] = x[j - halo][g*D/groups + c] for halo <= j < halo + T, else 0;  out = [groups, T + 2*halo, D/groups].
+ * Operand of make_conv_pos's grouped Conv1d (wav2vec2.py:925-946): output frame t of group g reads the contiguous
+ * run out[g][t .. t + k - 1][:] (halo = k / 2; SamePad drops the extra last frame of an even kernel). */
+int cvx_hubert_group_pack_f32(const float* x, float* out, int32_t T, int32_t D, int32_t groups, int32_t halo, cvx_stream_t s);
+
+/* labels[t] = argmin_j ( (|x[t]|^2 - 2 * dots[t, j]) + cnorm[j] ),  dots = x . C^T  [T, K]   (dump_km_label.py:36-43;
+ * ties -> lowest index).  margin (optional) receives second-best minus best distance per frame. */
+int cvx_kmeans_argmin_f32(const float* x, const float* dots, const float* cnorm, int64_t* labels, float* margin,
+                          int64_t T, int32_t D, int32_t K, cvx_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

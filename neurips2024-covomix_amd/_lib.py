@@ -91,6 +91,13 @@ SIGNATURES = {
     "cvx_mel_log_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "cvx_t2s_decode_steps": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p]),
     "cvx_geglu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
+    "cvx_hubert_conv0_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32]),
+    "cvx_hubert_conv0_gn_gelu_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvx_layernorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "cvx_hubert_group_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "cvx_kmeans_argmin_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                        C.c_int32, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),

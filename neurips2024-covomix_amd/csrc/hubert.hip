@@ -1,0 +1,250 @@
+// HuBERT prompt tokeniser: the pieces of the reference's
+// HubertFeatureReader.get_feats / ApplyKmeans path that are not plain GEMMs or attention.
+//   fairseq-hubert/fairseq/models/wav2vec/wav2vec2.py:844-923   conv feature extractor (first layer + GroupNorm here;
+//                                                               layers 1-6 are GEMMs over overlapping channels-last rows)
+//   fairseq-hubert/fairseq/models/wav2vec/wav2vec2.py:925-946   grouped positional convolution (operand packing here)
+//   fairseq-hubert/fairseq/modules/layer_norm.py                LayerNorm
+//   fairseq-hubert/examples/hubert/simple_kmeans/dump_km_label.py:36-43   k-means label = argmin distance
+// All HBM-bound, channel axis innermost (coalesced), no LDS needed except the block reductions.
+#include "cvx_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- first conv layer: Conv1d(1 -> C, k, stride), no bias
+// out[l][c] = sum_j w[c][j] * wav[l*stride + j];  block = 256 channels x 16 frames, the waveform window in LDS.
+constexpr int C0_FR = 16;
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                    float* __restrict__ out, int64_t L, int C, int k, int stride)
+{
+    __shared__ float win[C0_FR * 8 + 32];          // (C0_FR - 1) * stride + k samples, stride <= 8, k <= 32
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t l0 = (int64_t)blockIdx.y * C0_FR;
+    const int nfr = (int)min((int64_t)C0_FR, L - l0);
+    const int nwin = (nfr - 1) * stride + k;
+    for (int i = threadIdx.x; i < nwin; i += 256) win[i] = wav[l0 * stride + i];
+    __syncthreads();
+    if (c >= C) return;
+    float wr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) wr[j] = j < k ? w[(int64_t)c * k + j] : 0.f;
+    for (int f = 0; f < nfr; ++f) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < k) acc = fmaf(wr[j], win[f * stride + j], acc);
+        out[(l0 + f) * C + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- per-channel statistics over time (GroupNorm(C, C))
+// two passes (mean, then centred second moment), each: per-chunk partial sums (thread = channel, coalesced rows) and a
+// fixed-order final reduction in double => deterministic.
+constexpr int ST_ROWS = 128;
+__global__ __launch_bounds__(256) void colstat_partial_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                              float* __restrict__ partial, int64_t L, int C)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * ST_ROWS, r1 = min(r0 + ST_ROWS, L);
+    const float m = mean ? mean[c] : 0.f;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float d = x[r * C + c] - m;
+        s += mean ? d * d : d;
+    }
+    partial[(int64_t)blockIdx.y * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void colstat_final_kernel(const float* __restrict__ partial, int nchunks, int C, int64_t L,
+                                                            float* __restrict__ out, float eps, int rstd)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < nchunks; ++i) s += (double)partial[(int64_t)i * C + c];
+    s /= (double)L;
+    out[c] = rstd ? (float)(1.0 / sqrt(s + (double)eps)) : (float)s;
+}
+
+__global__ __launch_bounds__(256) void groupnorm_gelu_kernel(float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int64_t n4, int C)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    f32x4 v = *reinterpret_cast<f32x4*>(x + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf((v[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e]);
+    *reinterpret_cast<f32x4*>(x + 4 * i) = v;
+}
+
+// ---------------------------------------------------------------- LayerNorm over the last axis: wave per row, row in registers
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int64_t rows, int D, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const int nvec = D >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum_f(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] -= mean; q = fmaf(v[i][e], v[i][e], q); }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_f(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * j);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * j);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[i][e] * rstd * g[e] + b[e];
+            *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- operand of the grouped positional convolution
+// out[g][j][c] = x[j - halo][g*cg + c] for halo <= j < halo + T, else 0   (rows j in [0, T + 2*halo)): the im2col row of
+// output frame t of group g is then the CONTIGUOUS run out[g][t .. t+k-1][:] (k*cg floats, row stride cg).
+__global__ __launch_bounds__(256) void group_pack_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         int T, int D, int G, int halo)
+{
+    const int cg = D / G, rows = T + 2 * halo;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over rows * D, x-order (coalesced reads)
+    if (i >= (int64_t)rows * D) return;
+    const int j = (int)(i / D), col = (int)(i % D);
+    const int g = col / cg, c = col % cg;
+    const int t = j - halo;
+    out[((int64_t)g * rows + j) * cg + c] = (t >= 0 && t < T) ? x[(int64_t)t * D + col] : 0.f;
+}
+
+// ---------------------------------------------------------------- k-means label: argmin_j (|x|^2 - 2 x.C_j) + |C_j|^2
+// one wave per frame; `dots` = x . C^T from the GEMM.  Same operation order as the reference expression
+// (x.pow(2).sum(1) - 2 * matmul + Cnorm); ties -> lowest index (torch.argmin).
+__global__ __launch_bounds__(256) void kmeans_argmin_kernel(const float* __restrict__ x, const float* __restrict__ dots,
+                                                            const float* __restrict__ cnorm, int64_t* __restrict__ labels,
+                                                            float* __restrict__ margin, int64_t T, int D, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    float xx = 0.f;
+    for (int j = lane; j < D; j += 64) { const float v = x[row * D + j]; xx = fmaf(v, v, xx); }
+    xx = wave_sum_f(xx);
+    float best = INFINITY, second = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < K; j += 64) {
+        const float d = (xx - 2.0f * dots[row * K + j]) + cnorm[j];
+        if (d < best) { second = best; best = d; bi = j; }
+        else if (d < second) second = d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { second = fminf(best, os); best = ob; bi = oi; }
+        else second = fminf(second, ob);
+    }
+    if (lane == 0) {
+        labels[row] = bi;
+        if (margin) margin[row] = second - best;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t cvx_hubert_conv0_workspace_floats(int64_t L, int32_t C)
+{
+    return ((L + ST_ROWS - 1) / ST_ROWS + 2) * (int64_t)C;
+}
+
+extern "C" int cvx_hubert_conv0_gn_gelu_f32(const float* wav, int64_t n_samples, const float* w, int32_t C, int32_t k, int32_t stride,
+                                            const float* gn_gamma, const float* gn_beta, float eps,
+                                            float* out, float* workspace, int64_t workspace_floats, cvx_stream_t s)
+{
+    CVX_REQUIRE(wav && w && out && gn_gamma && gn_beta && workspace, "hubert_conv0: null pointer");
+    CVX_REQUIRE(C > 0 && C % 4 == 0 && k > 0 && k <= 32 && stride > 0 && stride <= 8, "hubert_conv0: bad geometry C=%d k=%d stride=%d", C, k, stride);
+    CVX_REQUIRE(n_samples >= k, "hubert_conv0: waveform shorter than one kernel (%ld samples)", (long)n_samples);
+    const int64_t L = (n_samples - k) / stride + 1;
+    CVX_REQUIRE(workspace_floats >= cvx_hubert_conv0_workspace_floats(L, C), "hubert_conv0: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    const int nchunks = (int)((L + ST_ROWS - 1) / ST_ROWS);
+    float* partial = workspace;
+    float* mean = workspace + (int64_t)nchunks * C;
+    float* rstd = mean + C;
+    const unsigned cb = (unsigned)((C + 255) / 256);
+    hipLaunchKernelGGL(conv0_kernel, dim3(cb, (unsigned)((L + C0_FR - 1) / C0_FR)), dim3(256), 0, st, wav, w, out, L, C, k, stride);
+    hipLaunchKernelGGL(colstat_partial_kernel, dim3(cb, nchunks), dim3(256), 0, st, out, (const float*)nullptr, partial, L, C);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3(cb), dim3(256), 0, st, partial, nchunks, C, L, mean, 0.f, 0);
+    hipLaunchKernelGGL(colstat_partial_kernel, dim3(cb, nchunks), dim3(256), 0, st, out, (const float*)mean, partial, L, C);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3(cb), dim3(256), 0, st, partial, nchunks, C, L, rstd, eps, 1);
+    const int64_t n4 = L * C / 4;
+    hipLaunchKernelGGL(groupnorm_gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, out, mean, rstd, gn_gamma, gn_beta, n4, C);
+    CVX_CHECK_LAUNCH("cvx_hubert_conv0_gn_gelu_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                 int64_t rows, int32_t D, float eps, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && gamma && beta && y && rows >= 0, "layernorm: bad arguments");
+    CVX_REQUIRE(D > 0 && D % 4 == 0 && D <= 1024, "layernorm: D must be a multiple of 4, at most 1024 (D=%d)", D);
+    if (rows == 0) return CVX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (D <= 256)      hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, eps);
+    else if (D <= 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, eps);
+    else               hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, eps);
+    CVX_CHECK_LAUNCH("cvx_layernorm_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hubert_group_pack_f32(const float* x, float* out, int32_t T, int32_t D, int32_t groups, int32_t halo, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && out && T > 0 && D > 0 && groups > 0 && D % groups == 0 && halo >= 0, "hubert_group_pack: bad arguments");
+    const int64_t n = (int64_t)(T + 2 * halo) * D;
+    hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, out, T, D, groups, halo);
+    CVX_CHECK_LAUNCH("cvx_hubert_group_pack_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_kmeans_argmin_f32(const float* x, const float* dots, const float* cnorm, int64_t* labels, float* margin,
+                                     int64_t T, int32_t D, int32_t K, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && dots && cnorm && labels && T >= 0 && D > 0 && K > 0, "kmeans_argmin: bad arguments");
+    if (T == 0) return CVX_OK;
+    hipLaunchKernelGGL(kmeans_argmin_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       x, dots, cnorm, labels, margin, T, D, K);
+    CVX_CHECK_LAUNCH("cvx_kmeans_argmin_f32");
+    return CVX_OK;
+}

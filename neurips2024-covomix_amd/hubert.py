@@ -1,0 +1,282 @@
+"""HuBERT layer-L features + k-means labels on MI355X: the prompt tokeniser.
+
+Host-side mirror of the reference's classes, same names / arguments / return types:
+  HubertTokenizer      fairseq-hubert/examples/textless_nlp/dgslm/dgslm_utils.py:19-44   (wav2code, wav2codes)
+  HubertFeatureReader  fairseq-hubert/examples/textless_nlp/gslm/speech2unit/pretrained/hubert_feature_reader.py:15-78
+  ApplyKmeans          fairseq-hubert/examples/hubert/simple_kmeans/dump_km_label.py:25-50
+as driven by fairseq-hubert/get_fisher_semantic_tokens.py:30-40 (`encoder.wav2code(file, 1)` -> "<name>.hubert_code.npy").
+
+The network (fairseq HubertModel.extract_features, hubert.py:433-480,533-549; wav2vec2.py:844-946,1078-1163,1343-1370)
+runs entirely through the C ABI of libcovomix_hip.so, activations channels-last [frames, channels] fp32:
+  conv layer 0 + GroupNorm + GELU      cvx_hubert_conv0_gn_gelu_f32
+  conv layers 1-6 (+GELU)              cvx_gemm_bias_act_f32 over OVERLAPPING rows (lda = stride*C, K = k*C)
+  LayerNorm(512), post_extract_proj    cvx_layernorm_f32, GEMM
+  positional conv (k=128, 16 groups)   cvx_hubert_group_pack_f32 + one GEMM per group (bias + GELU + residual epilogue)
+  12 post-LN layers                    GEMM (q|k|v fused), cvx_attention_f32, GEMM(+residual), LayerNorm, GEMM(+GELU),
+                                       GEMM(+residual), LayerNorm
+  k-means                              GEMM against cluster_centers_, cvx_kmeans_argmin_f32
+torch is used for device memory and one-time weight re-layouts only.  There is no CPU path: `use_cuda=False` raises.
+"""
+from __future__ import annotations
+
+import ast
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops
+
+DEFAULT_CONV_LAYERS = "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"       # hubert.py:136-137
+
+
+def parse_conv_layers(spec: str) -> List[Tuple[int, int, int]]:
+    """The reference eval()s cfg.conv_feature_layers (hubert.py:258); here only list / tuple / int / + / * are accepted."""
+    def ev(n):
+        if isinstance(n, ast.Expression):
+            return ev(n.body)
+        if isinstance(n, ast.Constant) and isinstance(n.value, int):
+            return n.value
+        if isinstance(n, (ast.List, ast.Tuple)):
+            v = [ev(e) for e in n.elts]
+            return v if isinstance(n, ast.List) else tuple(v)
+        if isinstance(n, ast.BinOp) and isinstance(n.op, ast.Add):
+            return ev(n.left) + ev(n.right)
+        if isinstance(n, ast.BinOp) and isinstance(n.op, ast.Mult):
+            return ev(n.left) * ev(n.right)
+        raise ValueError(f"conv_feature_layers: unsupported expression {ast.dump(n)}")
+    layers = ev(ast.parse(spec.strip(), mode="eval"))
+    out = [tuple(int(v) for v in cl) for cl in layers]
+    assert all(len(cl) == 3 for cl in out), "invalid conv definition: " + str(out)       # wav2vec2.py:896
+    return out
+
+
+class HubertEncoder:
+    """Device-resident HuBERT weights in the layouts the kernels read + the forward pass."""
+
+    def __init__(self, state_dict: Dict[str, Union[np.ndarray, torch.Tensor]], model_cfg: Optional[dict] = None,
+                 device: Union[str, torch.device] = "cuda"):
+        cfg = dict(model_cfg or {})
+        if cfg.get("layer_norm_first", False) or cfg.get("extractor_mode", "default") != "default":
+            raise NotImplementedError("only HuBERT-Base style checkpoints (extractor_mode=default, post-LN) are supported")
+        if cfg.get("conv_bias", False) or int(cfg.get("pos_conv_depth", 1)) != 1:
+            raise NotImplementedError("conv_bias / pos_conv_depth > 1 checkpoints are not supported")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("covomix_amd.hubert has no CPU path (device must be a GPU)")
+        f = lambda n: torch.as_tensor(np.asarray(state_dict[n]) if not isinstance(state_dict[n], torch.Tensor) else state_dict[n]) \
+            .to(device=self.device, dtype=torch.float32).contiguous()
+        self.conv_layers = parse_conv_layers(cfg.get("conv_feature_layers", DEFAULT_CONV_LAYERS))
+        self.heads = int(cfg.get("encoder_attention_heads", 12))
+        self.groups = int(cfg.get("conv_pos_groups", 16))
+        # --- conv feature extractor (wav2vec2.py:844-923)
+        w0 = f("feature_extractor.conv_layers.0.0.weight")
+        assert w0.shape == (self.conv_layers[0][0], 1, self.conv_layers[0][1])
+        self.w0 = w0.reshape(w0.shape[0], w0.shape[2]).contiguous()
+        self.gn_w, self.gn_b = f("feature_extractor.conv_layers.0.2.weight"), f("feature_extractor.conv_layers.0.2.bias")
+        self.conv_w = []
+        for i, (c, k, _s) in enumerate(self.conv_layers[1:], start=1):
+            w = f(f"feature_extractor.conv_layers.{i}.0.weight")                          # [C_out, C_in, k]
+            assert w.shape[0] == c and w.shape[2] == k
+            self.conv_w.append(w.permute(0, 2, 1).reshape(c, k * w.shape[1]).contiguous())   # row = (tap, channel): one run of the input
+        self.ln_w, self.ln_b = f("layer_norm.weight"), f("layer_norm.bias")
+        self.proj_w, self.proj_b = f("post_extract_proj.weight"), f("post_extract_proj.bias")
+        self.dim = self.proj_w.shape[0]
+        assert self.dim % (64 * self.heads) == 0 and self.dim // self.heads == 64, "attention kernel: head dim must be 64"
+        # --- positional convolution: fold weight_norm(dim=2) (wav2vec2.py:939), split by group, tap-major rows
+        v, g = f("encoder.pos_conv.0.weight_v"), f("encoder.pos_conv.0.weight_g")
+        w = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        self.pos_k = w.shape[2]
+        cg = self.dim // self.groups
+        assert w.shape == (self.dim, cg, self.pos_k)
+        self.pos_w = [w[gi * cg:(gi + 1) * cg].permute(0, 2, 1).reshape(cg, self.pos_k * cg).contiguous() for gi in range(self.groups)]
+        self.pos_b = f("encoder.pos_conv.0.bias")
+        self.enc_ln = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
+        # --- transformer layers (wav2vec2.py:1261-1370)
+        self.layers = []
+        i = 0
+        while f"encoder.layers.{i}.fc1.weight" in state_dict:
+            p = f"encoder.layers.{i}."
+            self.layers.append(dict(
+                wqkv=torch.cat([f(p + f"self_attn.{n}_proj.weight") for n in "qkv"], 0).contiguous(),
+                bqkv=torch.cat([f(p + f"self_attn.{n}_proj.bias") for n in "qkv"], 0).contiguous(),
+                wo=f(p + "self_attn.out_proj.weight"), bo=f(p + "self_attn.out_proj.bias"),
+                ln1=(f(p + "self_attn_layer_norm.weight"), f(p + "self_attn_layer_norm.bias")),
+                w1=f(p + "fc1.weight"), b1=f(p + "fc1.bias"), w2=f(p + "fc2.weight"), b2=f(p + "fc2.bias"),
+                ln2=(f(p + "final_layer_norm.weight"), f(p + "final_layer_norm.bias"))))
+            i += 1
+
+    # ------------------------------------------------------------------ pieces
+    def n_frames(self, n_samples: int) -> int:
+        n = n_samples
+        for _c, k, s in self.conv_layers:
+            n = (n - k) // s + 1 if n >= k else 0
+        return max(n, 0)
+
+    def conv_features(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [n] fp32 on the device -> [T, 512] (ConvFeatureExtractionModel.forward + transpose)."""
+        x = ops.hubert_conv0_gn_gelu(wav, self.w0, self.gn_w, self.gn_b, self.conv_layers[0][2])
+        for (c, k, s), w in zip(self.conv_layers[1:], self.conv_w):
+            L, cin = x.shape
+            Lout = (L - k) // s + 1
+            a = x.as_strided((Lout, k * cin), (s * cin, 1))           # im2col row = k consecutive channels-last frames
+            y = torch.empty(Lout, c, dtype=torch.float32, device=x.device)
+            ops.gemm(a, w, y, act=ops.ACT_GELU)
+            x = y
+        return x
+
+    def encode(self, feats: torch.Tensor, output_layer: Optional[int] = None) -> torch.Tensor:
+        """[T, 512] conv features -> output of transformer layer `output_layer` (1-based; None = last), [T, D]."""
+        T = feats.shape[0]
+        D, G, k = self.dim, self.groups, self.pos_k
+        cg = D // G
+        dev = feats.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        h = ops.gemm(ops.layernorm(feats, self.ln_w, self.ln_b), self.proj_w, new(T, D), bias=self.proj_b)
+        packed = ops.hubert_group_pack(h, G, k // 2)                  # [G, T + k, cg], zero halos
+        x = new(T, D)
+        for g in range(G):
+            a = packed[g].as_strided((T, k * cg), (cg, 1))
+            ops.gemm(a, self.pos_w[g], x[:, g * cg:(g + 1) * cg], bias=self.pos_b[g * cg:(g + 1) * cg], act=ops.ACT_GELU,
+                     residual=h[:, g * cg:(g + 1) * cg])               # x = h + gelu(conv(h) + b)
+        x = ops.layernorm(x, *self.enc_ln)
+        n_layers = len(self.layers) if output_layer is None else int(output_layer)
+        assert 0 <= n_layers <= len(self.layers), f"output_layer {output_layer} out of range"
+        qkv, att, y, ff = new(T, 3 * D), new(T, D), new(T, D), None
+        for lyr in self.layers[:n_layers]:
+            ops.gemm(x, lyr["wqkv"], qkv, bias=lyr["bqkv"])
+            ops.attention(qkv, att, 1, T, self.heads, 64 ** -0.5)
+            ops.gemm(att, lyr["wo"], y, bias=lyr["bo"], residual=x)
+            x = ops.layernorm(y, *lyr["ln1"], out=x)
+            ff = new(T, lyr["w1"].shape[0]) if ff is None else ff
+            ops.gemm(x, lyr["w1"], ff, bias=lyr["b1"], act=ops.ACT_GELU)
+            ops.gemm(ff, lyr["w2"], y, bias=lyr["b2"], residual=x)
+            x = ops.layernorm(y, *lyr["ln2"], out=x)
+        return x
+
+    def extract_features(self, source: torch.Tensor, output_layer: Optional[int] = None) -> torch.Tensor:
+        """HubertModel.extract_features(source [1, n] or [n], mask=False, output_layer) -> [T, D]."""
+        wav = source.reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
+        if self.n_frames(wav.numel()) == 0:
+            return torch.empty(0, self.dim, dtype=torch.float32, device=self.device)
+        return self.encode(self.conv_features(wav), output_layer)
+
+
+class HubertFeatureReader:
+    """Wrapper class to run inference on a HuBERT checkpoint (hubert_feature_reader.py:15-78)."""
+
+    def __init__(self, checkpoint_path, layer, max_chunk=1600000, use_cuda=True):
+        if not use_cuda:
+            raise RuntimeError("covomix_amd.hubert has no CPU path (use_cuda must be True)")
+        # fairseq checkpoints: {"cfg": plain dict (trainer.py:400-412), "model": state_dict, ...}
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=False) if isinstance(checkpoint_path, str) else checkpoint_path
+        cfg = state.get("cfg") or {}
+        self.task_cfg = dict(cfg.get("task") or {})
+        self.sample_rate = int(self.task_cfg.get("sample_rate", 16000))
+        self.normalize = bool(self.task_cfg.get("normalize", False))
+        self.model = HubertEncoder(state["model"], dict(cfg.get("model") or {}), device="cuda")
+        self.layer = layer
+        self.max_chunk = max_chunk
+        self.use_cuda = use_cuda
+
+    def read_audio(self, path, ref_len=None, channel_id=None):
+        """-> float32 mono waveform at the checkpoint's sample rate (torchaudio.load semantics: int16 / 32768)."""
+        from scipy.io.wavfile import read
+        sr, data = read(path)
+        if data.dtype == np.int16:
+            wav = data.astype(np.float32) / 32768.0
+        elif data.dtype == np.int32:
+            wav = (data.astype(np.float64) / 2147483648.0).astype(np.float32)
+        else:
+            wav = data.astype(np.float32)
+        if wav.ndim == 2:                          # [n, channels]; the reference asserts mono after squeeze(0) (:51-52)
+            if wav.shape[1] == 1:
+                wav = wav[:, 0]
+            elif channel_id is not None:
+                wav = wav[:, int(channel_id) - 1]
+        assert wav.ndim == 1, wav.ndim
+        if sr != self.sample_rate:
+            raise ValueError(f"{path}: {sr} Hz - this build expects {self.sample_rate} Hz input (the reference resamples with "
+                             "torchaudio.transforms.Resample, a third-party filter this build does not restate)")
+        if ref_len is not None and abs(ref_len - len(wav)) > 160:
+            print(f"ref {ref_len} != read {len(wav)} ({path})")
+        return np.ascontiguousarray(wav)
+
+    def get_feats(self, file_path, ref_len=None, channel_id=None):
+        """-> [T, D] fp32 features of layer `self.layer` on the GPU.  `file_path` may also be a waveform array."""
+        x = self.read_audio(file_path, ref_len, channel_id) if isinstance(file_path, str) else np.asarray(file_path, dtype=np.float32)
+        with torch.no_grad():
+            x = torch.from_numpy(np.ascontiguousarray(x)).float().cuda()
+            if self.normalize:                                     # F.layer_norm(x, x.shape) over the whole waveform (:66-67)
+                x = _waveform_layer_norm(x)
+            x = x.view(1, -1)
+            feat = []
+            for start in range(0, x.size(1), self.max_chunk):
+                feat.append(self.model.extract_features(x[:, start: start + self.max_chunk], output_layer=self.layer))
+        return torch.cat(feat, 0)
+
+
+def _waveform_layer_norm(x: torch.Tensor) -> torch.Tensor:
+    """F.layer_norm over the whole 1-D waveform (no affine, eps 1e-5).  A length-n reduction of a vector that is read
+    once per utterance: torch reductions (device plumbing), not a kernel of this library."""
+    m = x.mean()
+    v = (x - m).pow(2).mean()
+    return (x - m) / torch.sqrt(v + 1e-5)
+
+
+class ApplyKmeans(object):
+    """dump_km_label.py:25-50: nearest cluster centre under the squared Euclidean distance."""
+
+    def __init__(self, km_path):
+        if isinstance(km_path, str):
+            import joblib
+            self.km_model = joblib.load(km_path)
+            centers = self.km_model.cluster_centers_
+        else:
+            centers = km_path                                       # an array of centres [n_clusters, D]
+        self.C_np = np.asarray(centers).transpose()
+        self.Cnorm_np = (self.C_np ** 2).sum(0, keepdims=True)
+        self.centers = torch.from_numpy(np.ascontiguousarray(np.asarray(centers), dtype=np.float32)).cuda()   # [K, D] = W of x.C
+        self.Cnorm = torch.from_numpy(np.ascontiguousarray(self.Cnorm_np.reshape(-1), dtype=np.float32)).cuda()
+
+    def labels(self, x: torch.Tensor, with_margin: bool = False):
+        x = x.to(device=self.centers.device, dtype=torch.float32).contiguous()
+        dots = torch.empty(x.shape[0], self.centers.shape[0], dtype=torch.float32, device=x.device)
+        if x.shape[0]:
+            ops.gemm(x, self.centers, dots)
+        return ops.kmeans_argmin(x, dots, self.Cnorm, with_margin=with_margin)
+
+    def __call__(self, x):
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return self.labels(x).cpu().numpy()
+
+
+class HubertTokenizer:
+    """dgslm_utils.py:19-44."""
+
+    def __init__(self, hubert_path, hubert_layer, km_path, use_cuda=True):
+        self.feature_extractor = HubertFeatureReader(hubert_path, hubert_layer, use_cuda=use_cuda)
+        self.quantizer = ApplyKmeans(km_path)
+
+    def wav2code(self, path, channel_id=1):
+        feat = self.feature_extractor.get_feats(path, channel_id=channel_id)
+        code = self.quantizer(feat)
+        return ' '.join(map(str, code))
+
+    def wav2codes(self, path):
+        return [self.wav2code(path, channel_id=1), self.wav2code(path, channel_id=2)]
+
+
+def tokenize_directory(process_dir: str, target_dir: str, hubert_path: str, km_path: str, hubert_layer: int = 12) -> int:
+    """fairseq-hubert/get_fisher_semantic_tokens.py:30-40: every *.wav -> <name>.hubert_code.npy (array of str codes)."""
+    import glob
+    import os
+    encoder = HubertTokenizer(hubert_path=hubert_path, hubert_layer=hubert_layer, km_path=km_path)
+    files = sorted(glob.glob(os.path.join(process_dir, "*.wav")))
+    os.makedirs(target_dir, exist_ok=True)
+    for process_file in files:
+        codes = encoder.wav2code(process_file, 1).split(" ")
+        file_name = process_file.split("/")[-1].split(".")[0]
+        np.save(os.path.join(target_dir, file_name + '.hubert_code'), np.array(codes))
+    return len(files)

@@ -427,3 +427,58 @@ def wav_to_int16(wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
         out = torch.empty(wav.shape, dtype=torch.int16, device=wav.device)
     _lib.check(_lib.load().cvx_wav_to_int16(wav.data_ptr(), out.data_ptr(), wav.numel(), _stream()), "cvx_wav_to_int16")
     return out
+
+
+# ---------------------------------------------------------------- HuBERT tokeniser (N4)
+def hubert_conv0_gn_gelu(wav: torch.Tensor, w: torch.Tensor, gn_gamma: torch.Tensor, gn_beta: torch.Tensor,
+                         stride: int, eps: float = 1e-5) -> torch.Tensor:
+    """First conv layer + GroupNorm(C, C) + GELU of the HuBERT feature extractor: wav [n] -> [L, C] channels-last."""
+    _chk_f32(wav, w, gn_gamma, gn_beta)
+    assert wav.dim() == 1 and wav.is_contiguous() and w.is_contiguous() and w.dim() == 2
+    C, k = w.shape
+    n = wav.numel()
+    L = (n - k) // stride + 1
+    lib = _lib.load()
+    out = torch.empty(max(L, 0), C, dtype=torch.float32, device=wav.device)
+    ws = torch.empty(int(lib.cvx_hubert_conv0_workspace_floats(max(L, 1), C)), dtype=torch.float32, device=wav.device)
+    _lib.check(lib.cvx_hubert_conv0_gn_gelu_f32(wav.data_ptr(), n, w.data_ptr(), C, k, stride, gn_gamma.data_ptr(),
+                                                gn_beta.data_ptr(), eps, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "cvx_hubert_conv0_gn_gelu_f32")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Optional[torch.Tensor] = None,
+              eps: float = 1e-5) -> torch.Tensor:
+    _chk_f32(x, gamma, beta, out)
+    assert x.is_contiguous() and gamma.is_contiguous() and beta.is_contiguous()
+    D = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    assert out.is_contiguous() and out.shape == x.shape
+    _lib.check(_lib.load().cvx_layernorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                             x.numel() // D, D, eps, _stream()), "cvx_layernorm_f32")
+    return out
+
+
+def hubert_group_pack(x: torch.Tensor, groups: int, halo: int) -> torch.Tensor:
+    """x [T, D] -> [groups, T + 2*halo, D/groups] with zero halos (operand of the grouped positional convolution)."""
+    _chk_f32(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    T, D = x.shape
+    out = torch.empty(groups, T + 2 * halo, D // groups, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cvx_hubert_group_pack_f32(x.data_ptr(), out.data_ptr(), T, D, groups, halo, _stream()),
+               "cvx_hubert_group_pack_f32")
+    return out
+
+
+def kmeans_argmin(x: torch.Tensor, dots: torch.Tensor, cnorm: torch.Tensor, with_margin: bool = False):
+    """labels[t] = argmin_j (|x_t|^2 - 2 dots[t, j]) + cnorm[j]  (int64); optionally also the runner-up margin."""
+    _chk_f32(x, dots, cnorm)
+    assert x.dim() == 2 and x.is_contiguous() and dots.is_contiguous() and cnorm.is_contiguous()
+    T, D = x.shape
+    K = cnorm.numel()
+    assert dots.shape == (T, K)
+    labels = torch.empty(T, dtype=torch.int64, device=x.device)
+    margin = torch.empty(T, dtype=torch.float32, device=x.device) if with_margin else None
+    _lib.check(_lib.load().cvx_kmeans_argmin_f32(x.data_ptr(), dots.data_ptr(), cnorm.data_ptr(), labels.data_ptr(),
+                                                 _p(margin), T, D, K, _stream()), "cvx_kmeans_argmin_f32")
+    return (labels, margin) if with_margin else labels

@@ -1,0 +1,181 @@
+"""GPU: the HuBERT + k-means prompt tokeniser through the C ABI, against
+  * tests/golden/hubert_base.npz - outputs of the reference's own HubertModel / ApplyKmeans (make_golden_hubert.py),
+  * the CPU oracle (oracle/hubert_oracle.py) on other inputs, evaluated in fp64.
+Tolerances: two fp32 evaluations of this 12-layer post-LN stack differ by 1e-6 / 4e-6 / 1.1e-5 at layers 1 / 6 / 12
+(measured between the reference and an fp64 evaluation), so features are held to 3e-6 .. 3e-5 relative L2; k-means
+labels must be identical wherever the reference's runner-up margin exceeds the distance error those features imply."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hubert_oracle as ho
+from covomix_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hubert_base.npz")
+FEAT_TOL = {1: 3e-6, 6: 1.2e-5, 12: 3e-5}
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synthetic.hubert_state_dict(seed=0)
+
+
+@pytest.fixture(scope="module")
+def enc(sd):
+    from covomix_amd.hubert import HubertEncoder
+    return HubertEncoder(sd)
+
+
+@pytest.mark.parametrize("rows,D", [(1, 512), (7, 768), (1000, 768), (33, 1024), (5, 256)])
+def test_layernorm_kernel(rows, D):
+    from covomix_amd import ops
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 1.5
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    want = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5)
+    got = ops.layernorm(x.cuda(), w.cuda(), b.cuda())
+    assert rel(got, want) < 5e-7
+    xin = x.cuda()
+    ops.layernorm(xin, w.cuda(), b.cuda(), out=xin)                      # in place
+    assert torch.equal(xin, got)
+
+
+@pytest.mark.parametrize("n", [400, 8000, 5215, 40003])
+def test_conv0_groupnorm_gelu(sd, n):
+    from covomix_amd import ops
+    g = torch.Generator().manual_seed(n)
+    wav = torch.randn(n, generator=g) * 0.1 + 0.03                       # DC offset: the variance must be computed centred
+    w = torch.from_numpy(sd["feature_extractor.conv_layers.0.0.weight"])
+    gw, gb = (torch.from_numpy(sd[f"feature_extractor.conv_layers.0.2.{k}"]) for k in ("weight", "bias"))
+    y = torch.nn.functional.conv1d(wav.double().view(1, 1, -1), w.double(), stride=5)
+    y = torch.nn.functional.gelu(torch.nn.functional.group_norm(y, 512, gw.double(), gb.double(), 1e-5))[0].T
+    got = ops.hubert_conv0_gn_gelu(wav.cuda(), w.reshape(512, 10).contiguous().cuda(), gw.cuda(), gb.cuda(), 5)
+    assert got.shape == y.shape == ((n - 10) // 5 + 1, 512)
+    assert rel(got, y) < 2e-6
+
+
+def test_positional_conv_groups(sd, enc):
+    """group pack + 16 GEMMs == x + gelu(SamePad(grouped Conv1d(x)))  (wav2vec2.py:925-946, 1089-1091)."""
+    from covomix_amd import ops
+    for T in (1, 24, 51, 300):
+        g = torch.Generator().manual_seed(T)
+        h = torch.randn(T, 768, generator=g)
+        w = ho.pos_conv_weight(sd, torch.float64)
+        pc = torch.nn.functional.conv1d(h.double().T[None], w, torch.from_numpy(sd["encoder.pos_conv.0.bias"]).double(), padding=64, groups=16)
+        want = h.double() + torch.nn.functional.gelu(pc[0, :, :-1]).T
+        hd = h.cuda()
+        packed = ops.hubert_group_pack(hd, 16, 64)
+        assert packed.shape == (16, T + 128, 48)
+        assert float(packed[:, :64].abs().max()) == 0 and float(packed[:, 64 + T:].abs().max()) == 0
+        assert torch.equal(packed[3, 64:64 + T], hd[:, 144:192])
+        x = torch.empty(T, 768, device="cuda")
+        for gi in range(16):
+            a = packed[gi].as_strided((T, 128 * 48), (48, 1))
+            ops.gemm(a, enc.pos_w[gi], x[:, gi * 48:(gi + 1) * 48], bias=enc.pos_b[gi * 48:(gi + 1) * 48], act=ops.ACT_GELU,
+                     residual=hd[:, gi * 48:(gi + 1) * 48])
+        assert rel(x, want) < 2e-6, T
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_features_and_codes_match_reference_goldens(gold, enc, tag):
+    from covomix_amd.hubert import ApplyKmeans
+    wav = torch.from_numpy(gold[f"{tag}_wav"]).cuda()
+    conv = enc.conv_features(wav)
+    assert conv.shape == gold[f"{tag}_conv"].shape and rel(conv, gold[f"{tag}_conv"]) < 3e-6
+    for layer in (1, 6, 12):
+        f = enc.extract_features(wav.view(1, -1), output_layer=layer)
+        assert f.shape == gold[f"{tag}_feat{layer}"].shape
+        assert rel(f, gold[f"{tag}_feat{layer}"]) < FEAT_TOL[layer], layer
+    km = ApplyKmeans(synthetic.hubert_kmeans_centers(seed=0))
+    codes = km(f)
+    assert codes.dtype == np.int64 and codes.shape == gold[f"{tag}_codes"].shape
+    # distance error from a 3e-5 feature error: 2 |dx| |c_a - c_b| ~ 2 * 3e-5 * 28 * 39 < 7e-2 (|x| ~ 28, |c_a - c_b| ~ 39)
+    safe = gold[f"{tag}_margin"] > 7e-2
+    assert safe.mean() > 0.9
+    np.testing.assert_array_equal(codes[safe], gold[f"{tag}_codes"][safe])
+    assert (codes != gold[f"{tag}_codes"]).sum() <= 1
+
+
+def test_kmeans_argmin_kernel_vs_oracle_with_ties():
+    from covomix_amd.hubert import ApplyKmeans
+    rs = np.random.RandomState(3)
+    C = rs.standard_normal((500, 768)).astype(np.float32)
+    C[17] = C[5]                                                          # an exact tie: the lowest index wins (torch.argmin)
+    x = (C[rs.randint(0, 500, size=300)] + 0.3 * rs.standard_normal((300, 768))).astype(np.float32)
+    x[0] = C[17]
+    km = ApplyKmeans(C)
+    labels, margin = km.labels(torch.from_numpy(x), with_margin=True)
+    want = ho.apply_kmeans(C, torch.from_numpy(x).double())
+    np.testing.assert_array_equal(labels.cpu().numpy(), want)
+    assert labels[0].item() == 5 and margin[0].item() == 0.0
+    assert float(margin.min()) >= 0
+    assert km(x).tolist() == want.tolist()                                # numpy in -> numpy out, like the reference
+    assert km(np.zeros((0, 768), np.float32)).shape == (0,)
+
+
+def test_other_lengths_vs_fp64_oracle(sd, enc):
+    for n in (400, 719, 720, 3333, 48000):
+        g = torch.Generator().manual_seed(n)
+        t = torch.arange(n) / 16000.0
+        wav = 0.1 * torch.sin(2 * np.pi * 220 * t) + 0.05 * torch.sin(2 * np.pi * 1710 * t + 0.3) + 0.02 * torch.randn(n, generator=g)
+        f = enc.extract_features(wav.cuda(), output_layer=12)
+        assert f.shape == (ho.frames_for(n), 768) == (enc.n_frames(n), 768)
+        with torch.no_grad():
+            want = ho.get_feats(sd, wav.numpy(), layer=12, dtype=torch.float64)
+        assert rel(f, want) < 3e-5, n
+    assert enc.extract_features(torch.zeros(399).cuda()).shape == (0, 768)   # shorter than one frame
+
+
+def test_tokenizer_end_to_end_in_the_reference_file_layouts(gold, sd, tmp_path):
+    """fairseq checkpoint dict + joblib k-means file + wav file -> wav2code string, get_fisher_semantic_tokens.py output."""
+    import joblib
+    import types
+    from scipy.io.wavfile import write
+    from covomix_amd.hubert import HubertTokenizer, HubertFeatureReader, tokenize_directory
+    ckpt = str(tmp_path / "hubert_fisher.pt")
+    torch.save({"cfg": {"model": {"_name": "hubert", "encoder_layers": 12, "encoder_attention_heads": 12, "conv_pos": 128,
+                                  "conv_pos_groups": 16, "extractor_mode": "default", "layer_norm_first": False,
+                                  "conv_feature_layers": "[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2"},
+                        "task": {"_name": "hubert_pretraining", "sample_rate": 16000, "normalize": False}},
+                "model": {k: torch.from_numpy(v) for k, v in sd.items()}}, ckpt)
+    kmp = str(tmp_path / "hubert_fisher_km_500.bin")
+    joblib.dump(types.SimpleNamespace(cluster_centers_=synthetic.hubert_kmeans_centers(seed=0)), kmp)
+    os.makedirs(tmp_path / "wavs")
+    pcm = np.clip(np.round(gold["c_wav"] * 32768.0), -32768, 32767).astype(np.int16)
+    write(str(tmp_path / "wavs" / "utt1.wav"), 16000, pcm)
+    tok = HubertTokenizer(hubert_path=ckpt, hubert_layer=12, km_path=kmp)
+    code = tok.wav2code(str(tmp_path / "wavs" / "utt1.wav"), 1)
+    assert isinstance(code, str)
+    got = np.array(code.split(" "), dtype=np.int64)
+    with torch.no_grad():
+        want = ho.apply_kmeans(synthetic.hubert_kmeans_centers(seed=0), ho.get_feats(sd, pcm.astype(np.float32) / 32768.0, layer=12, dtype=torch.float64))
+    assert got.shape == want.shape and (got != want).sum() <= 1
+    assert tokenize_directory(str(tmp_path / "wavs"), str(tmp_path / "codes"), ckpt, kmp) == 1
+    saved = np.load(str(tmp_path / "codes" / "utt1.hubert_code.npy"))
+    assert saved.dtype.kind == "U" and saved.tolist() == code.split(" ")
+    # normalize=True checkpoints layer-norm the waveform first (hubert_feature_reader.py:66-67); chunking concatenates
+    reader = HubertFeatureReader(ckpt, 12, max_chunk=4000)
+    parts = reader.get_feats(gold["a_wav"])
+    whole = torch.cat([reader.model.extract_features(torch.from_numpy(gold["a_wav"][s:s + 4000]).cuda(), 12) for s in (0, 4000)], 0)
+    assert torch.equal(parts, whole)
+    reader.normalize, reader.max_chunk = True, 1600000
+    assert rel(reader.get_feats(gold["a_wav"]), gold["a_feat12_normalized"]) < 3e-5
+    write(str(tmp_path / "wavs" / "utt8k.wav"), 8000, pcm)
+    with pytest.raises(ValueError):
+        tok.wav2code(str(tmp_path / "wavs" / "utt8k.wav"), 1)
+    with pytest.raises(RuntimeError):
+        HubertTokenizer(hubert_path=ckpt, hubert_layer=12, km_path=kmp, use_cuda=False)
