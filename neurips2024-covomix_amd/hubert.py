@@ -55,7 +55,12 @@ class HubertEncoder:
     """Device-resident HuBERT weights in the layouts the kernels read + the forward pass."""
 
     def __init__(self, state_dict: Dict[str, Union[np.ndarray, torch.Tensor]], model_cfg: Optional[dict] = None,
-                 device: Union[str, torch.device] = "cuda"):
+                 device: Union[str, torch.device] = "cuda", precision: str = "f16x3"):
+        """precision: "f16x3" (default) runs every GEMM with more than 64 rows on the split-precision MFMA kernel
+        (fp32 operands as fp16 hi/lo pairs, three products, fp32 accumulate - 16 k per accumulate step, measured closer
+        to an fp64 evaluation than the fp32 MFMA kernel, which adds 2 k per step); "fp32" uses cvx_gemm_bias_act_f32 only."""
+        assert precision in ("f16x3", "fp32")
+        self.precision = precision
         cfg = dict(model_cfg or {})
         if cfg.get("layer_norm_first", False) or cfg.get("extractor_mode", "default") != "default":
             raise NotImplementedError("only HuBERT-Base style checkpoints (extractor_mode=default, post-LN) are supported")
@@ -106,6 +111,17 @@ class HubertEncoder:
                 ln2=(f(p + "final_layer_norm.weight"), f(p + "final_layer_norm.bias"))))
             i += 1
 
+        self._split: Dict[int, tuple] = {}
+
+    def _gemm(self, a, w, out, **kw):
+        """One nn.Linear / conv-as-GEMM: split weights are made once per weight tensor (load-time packing)."""
+        if self.precision == "f16x3" and w.shape[1] % 32 == 0:
+            ws = self._split.get(id(w))
+            if ws is None:
+                ws = self._split[id(w)] = ops.split_f16(w)
+            return ops.gemm(a, w, out, w_split=ws, **kw)
+        return ops.gemm(a, w, out, **kw)
+
     # ------------------------------------------------------------------ pieces
     def n_frames(self, n_samples: int) -> int:
         n = n_samples
@@ -121,7 +137,7 @@ class HubertEncoder:
             Lout = (L - k) // s + 1
             a = x.as_strided((Lout, k * cin), (s * cin, 1))           # im2col row = k consecutive channels-last frames
             y = torch.empty(Lout, c, dtype=torch.float32, device=x.device)
-            ops.gemm(a, w, y, act=ops.ACT_GELU)
+            self._gemm(a, w, y, act=ops.ACT_GELU)
             x = y
         return x
 
@@ -132,25 +148,25 @@ class HubertEncoder:
         cg = D // G
         dev = feats.device
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        h = ops.gemm(ops.layernorm(feats, self.ln_w, self.ln_b), self.proj_w, new(T, D), bias=self.proj_b)
+        h = self._gemm(ops.layernorm(feats, self.ln_w, self.ln_b), self.proj_w, new(T, D), bias=self.proj_b)
         packed = ops.hubert_group_pack(h, G, k // 2)                  # [G, T + k, cg], zero halos
         x = new(T, D)
         for g in range(G):
             a = packed[g].as_strided((T, k * cg), (cg, 1))
-            ops.gemm(a, self.pos_w[g], x[:, g * cg:(g + 1) * cg], bias=self.pos_b[g * cg:(g + 1) * cg], act=ops.ACT_GELU,
+            self._gemm(a, self.pos_w[g], x[:, g * cg:(g + 1) * cg], bias=self.pos_b[g * cg:(g + 1) * cg], act=ops.ACT_GELU,
                      residual=h[:, g * cg:(g + 1) * cg])               # x = h + gelu(conv(h) + b)
         x = ops.layernorm(x, *self.enc_ln)
         n_layers = len(self.layers) if output_layer is None else int(output_layer)
         assert 0 <= n_layers <= len(self.layers), f"output_layer {output_layer} out of range"
         qkv, att, y, ff = new(T, 3 * D), new(T, D), new(T, D), None
         for lyr in self.layers[:n_layers]:
-            ops.gemm(x, lyr["wqkv"], qkv, bias=lyr["bqkv"])
+            self._gemm(x, lyr["wqkv"], qkv, bias=lyr["bqkv"])
             ops.attention(qkv, att, 1, T, self.heads, 64 ** -0.5)
-            ops.gemm(att, lyr["wo"], y, bias=lyr["bo"], residual=x)
+            self._gemm(att, lyr["wo"], y, bias=lyr["bo"], residual=x)
             x = ops.layernorm(y, *lyr["ln1"], out=x)
             ff = new(T, lyr["w1"].shape[0]) if ff is None else ff
-            ops.gemm(x, lyr["w1"], ff, bias=lyr["b1"], act=ops.ACT_GELU)
-            ops.gemm(ff, lyr["w2"], y, bias=lyr["b2"], residual=x)
+            self._gemm(x, lyr["w1"], ff, bias=lyr["b1"], act=ops.ACT_GELU)
+            self._gemm(ff, lyr["w2"], y, bias=lyr["b2"], residual=x)
             x = ops.layernorm(y, *lyr["ln2"], out=x)
         return x
 

@@ -479,6 +479,8 @@ def kmeans_argmin(x: torch.Tensor, dots: torch.Tensor, cnorm: torch.Tensor, with
     assert dots.shape == (T, K)
     labels = torch.empty(T, dtype=torch.int64, device=x.device)
     margin = torch.empty(T, dtype=torch.float32, device=x.device) if with_margin else None
+    if T == 0:
+        return (labels, margin) if with_margin else labels
     _lib.check(_lib.load().cvx_kmeans_argmin_f32(x.data_ptr(), dots.data_ptr(), cnorm.data_ptr(), labels.data_ptr(),
                                                  _p(margin), T, D, K, _stream()), "cvx_kmeans_argmin_f32")
     return (labels, margin) if with_margin else labels

@@ -1,0 +1,26 @@
+import sys, numpy as np, torch
+sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+import hubert_oracle as ho
+from covomix_amd import synthetic
+from covomix_amd.hubert import HubertEncoder
+sd = synthetic.hubert_state_dict(seed=0); g = np.load("tests/golden/hubert_base.npz")
+import os
+enc = HubertEncoder(sd, precision=os.environ.get('HUBERT_PRECISION', 'f16x3'))
+rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+for tag in "abc":
+    wav = g[f"{tag}_wav"]
+    with torch.no_grad():
+        c64 = ho.conv_features(sd, torch.from_numpy(wav).view(1, -1), torch.float64)[0].numpy()
+    conv = enc.conv_features(torch.from_numpy(wav).cuda()).cpu().numpy()
+    print(tag, "conv: ours-f64", rel(conv, c64), "ref-f64", rel(g[f"{tag}_conv"], c64))
+    for L in (1, 6, 12):
+        with torch.no_grad():
+            f64 = ho.get_feats(sd, wav, layer=L, dtype=torch.float64).numpy()
+        f = enc.extract_features(torch.from_numpy(wav).cuda(), L).cpu().numpy()
+        print(tag, L, "ours-f64", rel(f, f64), "ref-f64", rel(g[f"{tag}_feat{L}"], f64), "ours-ref", rel(f, g[f"{tag}_feat{L}"].astype(np.float64)))
+import time
+wav = torch.randn(160000).cuda() * 0.1
+for _ in range(3): enc.extract_features(wav, 12)
+torch.cuda.synchronize(); t = time.time()
+for _ in range(10): enc.extract_features(wav, 12)
+torch.cuda.synchronize(); print("10 s utterance: %.2f ms" % ((time.time() - t) * 100))
