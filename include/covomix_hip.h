@@ -334,6 +334,13 @@ int cvx_hubert_group_pack_f32(const float* x, float* out, int32_t T, int32_t D, 
 int cvx_kmeans_argmin_f32(const float* x, const float* dots, const float* cnorm, int64_t* labels, float* margin,
                           int64_t T, int32_t D, int32_t K, cvx_stream_t s);
 
+/* Sample-rate conversion in front of the tokeniser (hubert_feature_reader.py:38-41: torchaudio.transforms.Resample,
+ * third-party; its published polyphase windowed-sinc algorithm): out[i*up + j] = sum_k kern[j][k] * x[i*down + k - width]
+ * with x = 0 outside [0, n), kern = [up][2*width + down] computed by the host (covomix_amd.hubert.sinc_resample_kernel),
+ * n_out = ceil(up * n / down). */
+int cvx_resample_fir_f32(const float* x, int64_t n, const float* kern, int32_t up, int32_t down, int32_t width,
+                         float* out, int64_t n_out, cvx_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -248,3 +248,39 @@ extern "C" int cvx_kmeans_argmin_f32(const float* x, const float* dots, const fl
     CVX_CHECK_LAUNCH("cvx_kmeans_argmin_f32");
     return CVX_OK;
 }
+
+// ---------------------------------------------------------------- polyphase FIR resampler (the reader's sample-rate conversion)
+// out[i*up + j] = sum_k kern[j][k] * x[i*down + k - width]   (x = 0 outside [0, n)),  i*up + j < n_out.
+// hubert_feature_reader.py:38-41 resamples with torchaudio.transforms.Resample: a bank of `up` windowed-sinc filters of
+// kw = 2*width + down taps applied at stride `down` (torchaudio.functional.resample, published algorithm; the filter
+// bank itself is computed on the host).
+namespace {
+__global__ __launch_bounds__(256) void resample_fir_kernel(const float* __restrict__ x, const float* __restrict__ kern,
+                                                           float* __restrict__ out, int64_t n, int64_t n_out,
+                                                           int up, int down, int width, int kw)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t i = o / up;
+    const int j = (int)(o % up);
+    const int64_t base = i * down - width;
+    const float* kj = kern + (int64_t)j * kw;
+    float acc = 0.f;
+    for (int k = 0; k < kw; ++k) {
+        const int64_t p = base + k;
+        if (p >= 0 && p < n) acc = fmaf(kj[k], x[p], acc);
+    }
+    out[o] = acc;
+}
+}  // namespace
+
+extern "C" int cvx_resample_fir_f32(const float* x, int64_t n, const float* kern, int32_t up, int32_t down, int32_t width,
+                                    float* out, int64_t n_out, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && kern && out && n >= 0 && n_out >= 0 && up > 0 && down > 0 && width >= 0, "resample_fir: bad arguments");
+    if (n_out == 0) return CVX_OK;
+    hipLaunchKernelGGL(resample_fir_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       x, kern, out, n, n_out, up, down, width, 2 * width + down);
+    CVX_CHECK_LAUNCH("cvx_resample_fir_f32");
+    return CVX_OK;
+}

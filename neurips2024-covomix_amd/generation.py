@@ -12,8 +12,11 @@ Upstream stages:
       this repo does not ship) is decoded on the GPU; otherwise `<text_dir>/<name>.semantic.npy` holds already
       predicted tokens (covosingle / covosinx: int array [n]; covomix: [2, n] or flat [2n], split at half).
   * prompt mel extraction (N3, built: mel.py): `<prompt_dir>/<name>.mel.npy` ([80, T] log-mel) if present, else the
-      log-mel of `<prompt_dir>/<name>.wav` (8 kHz) computed on the GPU; next to `<name>.hubert_code.npy` (the HuBERT
-      tokeniser, N4, is not built); dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
+      log-mel of `<prompt_dir>/<name>.wav` (8 kHz) computed on the GPU
+  * prompt tokens (N4, built: hubert.py): `<prompt_dir>/<name>.hubert_code.npy` if present (what
+      fairseq-hubert/get_fisher_semantic_tokens.py wrote offline), else, with --hubert_ckpt and --km_path, the HuBERT
+      layer-12 + k-means codes of `<prompt_dir>/<name>.wav` computed on the GPU (resampled to the checkpoint's rate);
+      dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
 New relative to the reference: utterances are sharded over ranks (torchrun) and batched by equal length.
 """
 from __future__ import annotations
@@ -46,11 +49,21 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--seed", type=int, default=30, help="random seed")
     p.add_argument("--mode", type=str, choices=["covosingle", "covosinx", "covomix"], default="covosingle")
     p.add_argument("--max_batch", type=int, default=8, help="equal-length utterances per launch")
+    p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
+                   "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
+    p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
     return p
 
 
+_HUBERT = None      # HubertTokenizer, built by main() when --hubert_ckpt / --km_path are given
+
+
 def _load_prompt(prompt_dir: str, name: str):
-    tok = torch.from_numpy(np.load(os.path.join(prompt_dir, name + ".hubert_code.npy")).astype(np.int64))
+    code = os.path.join(prompt_dir, name + ".hubert_code.npy")
+    if os.path.isfile(code) or _HUBERT is None:
+        tok = torch.from_numpy(np.load(code).astype(np.int64))
+    else:                                                  # encoder.wav2code(file, 1) (get_fisher_semantic_tokens.py:35-37, row N4)
+        tok = torch.tensor([int(c) for c in _HUBERT.wav2code(os.path.join(prompt_dir, name + ".wav"), 1).split(" ")], dtype=torch.int64)
     npy = os.path.join(prompt_dir, name + ".mel.npy")
     if os.path.isfile(npy):
         mel = torch.from_numpy(np.load(npy).astype(np.float32))
@@ -166,6 +179,13 @@ def run(dialogue: bool, argv=None) -> int:
         t2s = CoVoMixModel.load_from_checkpoint(args.t2s_ckpt, base_dir="", batch_size=16, num_workers=0)   # :93-96
         t2s.eval()
         t2s = t2s.to(device)
+    global _HUBERT
+    _HUBERT = None
+    if args.hubert_ckpt or args.km_path:
+        assert args.hubert_ckpt and args.km_path and os.path.isfile(args.hubert_ckpt) and os.path.isfile(args.km_path), \
+            "--hubert_ckpt and --km_path must both name existing files"
+        from .hubert import HubertTokenizer
+        _HUBERT = HubertTokenizer(hubert_path=args.hubert_ckpt, hubert_layer=12, km_path=args.km_path)   # get_fisher_semantic_tokens.py:30-32
     stems = set()
     for ext in (".semantic.npy",) + ((".text_ids.npy", ".txt") if t2s is not None else ()):
         stems |= {os.path.basename(p)[: -len(ext)] for p in glob.glob(os.path.join(args.text_dir, "*" + ext))}

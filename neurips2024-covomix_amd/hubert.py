@@ -51,6 +51,42 @@ def parse_conv_layers(spec: str) -> List[Tuple[int, int, int]]:
     return out
 
 
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Filter bank of torchaudio.functional.resample (resampling_method "sinc_interp_hann", the defaults of
+    torchaudio.transforms.Resample that hubert_feature_reader.py:39 constructs) -> (kernels [new, 2*width + orig] fp32,
+    width, orig, new) with the rates divided by their gcd.  torchaudio is third-party and in neither this image nor the
+    reference tree: restated from its published algorithm, PARITY UNPINNED."""
+    import math
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        k = np.where(t == 0, 1.0, np.sin(t) / t)
+    return (k * window * (base / orig)).astype(np.float32), width, orig, new
+
+
+def resample(wav: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """1-D fp32 waveform on the GPU -> resampled waveform, length ceil(new * n / orig)."""
+    if int(orig_freq) == int(new_freq):
+        return wav
+    from . import _lib
+    kern, width, orig, new = sinc_resample_kernel(orig_freq, new_freq)
+    wav = wav.reshape(-1).float().contiguous()
+    n = wav.numel()
+    n_out = -(-new * n // orig)
+    out = torch.empty(n_out, dtype=torch.float32, device=wav.device)
+    k = torch.from_numpy(kern).to(wav.device)
+    _lib.check(_lib.load().cvx_resample_fir_f32(wav.data_ptr(), n, k.data_ptr(), new, orig, width, out.data_ptr(), n_out,
+                                                torch.cuda.current_stream().cuda_stream), "cvx_resample_fir_f32")
+    return out
+
+
 class HubertEncoder:
     """Device-resident HuBERT weights in the layouts the kernels read + the forward pass."""
 
@@ -211,9 +247,8 @@ class HubertFeatureReader:
             elif channel_id is not None:
                 wav = wav[:, int(channel_id) - 1]
         assert wav.ndim == 1, wav.ndim
-        if sr != self.sample_rate:
-            raise ValueError(f"{path}: {sr} Hz - this build expects {self.sample_rate} Hz input (the reference resamples with "
-                             "torchaudio.transforms.Resample, a third-party filter this build does not restate)")
+        if sr != self.sample_rate:                 # resample if needed (:38-41), on the GPU
+            wav = resample(torch.from_numpy(np.ascontiguousarray(wav)).cuda(), sr, self.sample_rate).cpu().numpy()
         if ref_len is not None and abs(ref_len - len(wav)) > 160:
             print(f"ref {ref_len} != read {len(wav)} ({path})")
         return np.ascontiguousarray(wav)

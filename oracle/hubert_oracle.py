@@ -113,3 +113,29 @@ def frames_for(n_samples: int) -> int:
     for _c, k, s in CONV_LAYERS:
         n = (n - k) // s + 1
     return max(n, 0)
+
+
+def sinc_resample(wav: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """torchaudio.functional.resample (sinc_interp_hann defaults; what torchaudio.transforms.Resample applies in
+    hubert_feature_reader.py:38-41), restated from the published algorithm.  PARITY UNPINNED: torchaudio is a
+    third-party package that is in neither this image nor the reference tree; tests check filter properties and
+    agreement with scipy's polyphase resampler instead."""
+    import math
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    if orig == new:
+        return np.asarray(wav, dtype=np.float32)
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base / orig)
+    kernels = kernels.to(torch.float32)
+    x = torch.from_numpy(np.asarray(wav, dtype=np.float32)).view(1, -1)
+    n = x.shape[1]
+    x = F.pad(x, (width, width + orig))
+    y = F.conv1d(x[:, None], kernels, stride=orig).transpose(1, 2).reshape(1, -1)
+    return y[0, : math.ceil(new * n / orig)].numpy()

