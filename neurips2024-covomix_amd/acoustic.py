@@ -164,11 +164,41 @@ class VectorField:
         return dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null)
 
     # ------------------------------------------------------------------ one evaluation (both CFG branches)
-    def evaluate(self, ctx: dict, step: int) -> torch.Tensor:
+    @staticmethod
+    def _ws_rows(ws: dict, b0: int, b1: int, T: int, heads: int) -> dict:
+        """Views of every workspace buffer restricted to sequences [b0, b1) (rows b0*T .. b1*T): an independent
+        half-size problem on the same storage, so two such parts can run concurrently on two streams."""
+        r0, r1 = b0 * T, b1 * T
+
+        def cut(v, lo=r0, hi=r1):
+            if isinstance(v, ops.SplitIL):
+                return v.rows_view(lo, hi)
+            if isinstance(v, tuple):
+                return tuple(None if t is None else t[lo:hi] for t in v)
+            if isinstance(v, list):
+                return [cut(t, lo, hi) for t in v]
+            return v[lo:hi]
+        out = {}
+        for k, v in ws.items():
+            if k == "rope":
+                out[k] = v
+            elif k == "vt16":
+                out[k] = cut(v, b0 * heads * 64, b1 * heads * 64)
+            else:
+                out[k] = cut(v)
+        return out
+
+    def evaluate(self, ctx: dict, step: int, part: Optional[int] = None) -> torch.Tensor:
         """Run the network on ws['xin'] (rows: cond branch then null branch) at evaluation time #step.
-        Returns ws['pred'] [Bt*T, dim_out]."""
+        Returns ws['pred'] [Bt*T, dim_out].  part = i: only the i-th of ctx['parts'] sequence ranges (see _ws_rows)."""
         d, sd, ws = self.d, self.sd, ctx["ws"]
         Bt, T = ctx["Bt"], ctx["T"]
+        if part is not None:
+            b0, b1 = ctx["parts"][part]
+            key = ("part_ws", part)
+            if key not in ctx:
+                ctx[key] = self._ws_rows(ws, b0, b1, T, d["heads"])
+            ws, Bt = ctx[key], b1 - b0
         dim = d["dim"]
         tab = ctx["table"][step]
         free: List[torch.Tensor] = list(ws["h"])
@@ -284,6 +314,7 @@ class FlowMatchingSampler:
 
     def __init__(self, field: VectorField, nfe: int = 32, method: str = "midpoint"):
         self.field, self.nfe, self.method = field, nfe, method
+        self._side = None
 
     # launch-bound regime (short / single utterances): the whole solve - ~2400 kernel launches for 32 NFE - is captured
     # once per input shape into a HIP graph and replayed (env CVX_GRAPH=0 disables, CVX_GRAPH_MAX_ROWS bounds the
@@ -301,15 +332,38 @@ class FlowMatchingSampler:
         x_c.copy_(y.reshape(M1, -1))
         if use_null:
             x_n.copy_(x_c)
+        # Large batches: the sequences are cut into two halves that run as independent kernel chains on two streams.
+        # The chains drift out of phase, so one chain's HBM-bound kernels (norms, GEMM epilogues, attention tails) run
+        # under the other's matrix work instead of every CU hitting the same phase at the same time.
+        Bt = ctx["Bt"]
+        chains = int(os.environ.get("CVX_CHAINS", "1"))
+        if chains == 2 and Bt % 2 == 0 and (Bt // 2) * ctx["T"] >= 2048 and not torch.cuda.is_current_stream_capturing():
+            ctx["parts"] = [(0, Bt // 2), (Bt // 2, Bt)]
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=f.device)
+            side = self._side
+            full_eval = f.evaluate
+
+            def evaluate2(c, step):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    full_eval(c, step, part=1)
+                full_eval(c, step, part=0)
+                main.wait_stream(side)
+                return ws["pred"]
+            evaluate = evaluate2
+        else:
+            evaluate = f.evaluate
         e = 0
         for dt in dts:
             if self.method == "midpoint":
-                pred = f.evaluate(ctx, e); e += 1
+                pred = evaluate(ctx, e); e += 1
                 ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, 0.5 * dt, x_c, x_n)
-                pred = f.evaluate(ctx, e); e += 1
+                pred = evaluate(ctx, e); e += 1
                 ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
             else:
-                pred = f.evaluate(ctx, e); e += 1
+                pred = evaluate(ctx, e); e += 1
                 ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
         return ctx
 

@@ -147,8 +147,11 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                         const int pos = min(row0 + e, p.M - 1) % p.rope_T;
                         const float c = p.rope_cos[pos * 32 + (lane & 31)];
                         const float s = p.rope_sin[pos * 32 + (lane & 31)];
-                        const float nlo = lo[e] * c - hi[e] * s;
-                        const float nhi = hi[e] * c + lo[e] * s;
+                        // fixed contraction (one rounding of the second product, then one fma): with the compiler free to
+                        // pick a different fma pairing per unrolled instance, the same row gave 1-ulp different results
+                        // depending on its position in the tile
+                        const float nlo = __builtin_fmaf(lo[e], c, -__fmul_rn(hi[e], s));
+                        const float nhi = __builtin_fmaf(hi[e], c, __fmul_rn(lo[e], s));
                         lo[e] = nlo; hi[e] = nhi;
                     }
                 }
@@ -206,8 +209,8 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                 const int pos = row % p.rope_T;
                 const float c = p.rope_cos[pos * 32 + (lane & 31)];
                 const float s = p.rope_sin[pos * 32 + (lane & 31)];
-                const float nlo = lo * c - hi * s;
-                const float nhi = hi * c + lo * s;
+                const float nlo = __builtin_fmaf(lo, c, -__fmul_rn(hi, s));      // same fixed contraction as the vector path
+                const float nhi = __builtin_fmaf(hi, c, __fmul_rn(lo, s));
                 lo = nlo; hi = nhi;
             }
             if (p.residual) {

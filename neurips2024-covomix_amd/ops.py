@@ -43,6 +43,12 @@ class SplitIL:
         self.rows, self.cols = rows, cols
         self.buf = torch.empty(rows, 2 * cols, dtype=torch.float16, device=device)
 
+    def rows_view(self, r0: int, r1: int) -> "SplitIL":
+        """The same storage restricted to rows [r0, r1) (a contiguous slice: rows are whole interleaved lines)."""
+        v = SplitIL.__new__(SplitIL)
+        v.rows, v.cols, v.buf = r1 - r0, self.cols, self.buf[r0:r1]
+        return v
+
     def dense(self):
         """(hi, lo) as ordinary [rows, cols] tensors (copies; tests)."""
         b = self.buf.view(self.rows, self.cols // 32, 2, 32)

@@ -170,6 +170,25 @@ def test_full_size_properties():
     assert rel_l2(outp, out[perm.cuda()]) < 1e-5
 
 
+def test_two_chain_schedule_is_bit_identical(monkeypatch):
+    """CVX_CHAINS=2 cuts a large batch into two halves that run as concurrent kernel chains on two streams (opt-in
+    schedule experiment): every row's arithmetic is independent of the partition, so the sampled
+    mel must be BIT-identical to the single-chain run (this is what caught the per-instance fma contraction in the RoPE
+    epilogue)."""
+    from covomix_amd.conditional_model import CoVoMixModel
+    import covomix_amd.synthetic as syn
+    model = CoVoMixModel.from_state_dict(_state("vomix"), nfe=4).eval().to("cuda:0")
+    inp = syn.synthetic_inputs("vomix", 4, 600, 200, seed=11)           # 2 x 4 x 600 rows: halves of 2400 >= 2048
+    args = (inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
+    monkeypatch.setenv("CVX_GRAPH", "0")
+    monkeypatch.setenv("CVX_CHAINS", "1")
+    one = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    monkeypatch.setenv("CVX_CHAINS", "2")
+    two = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(one).all() and torch.equal(one, two)
+
+
 # ---------------------------------------------------------------- opt-in precision="f16" (single-term fp16 operands)
 F16_ROLL_TOL = 1e-3          # BASELINE.json north_star budget: <= 1e-3 rel-L2 on the final mel
 
