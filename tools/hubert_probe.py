@@ -1,10 +1,12 @@
-import sys, numpy as np, torch
-sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+"""HuBERT tokeniser (row N4): distance of this build's and of the reference's features from an fp64 evaluation of the
+oracle at layers 1 / 6 / 12, and time per 10-s utterance.  HUBERT_PRECISION=fp32 selects the fp32 GEMM mode."""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, ROOT)
 import hubert_oracle as ho
 from covomix_amd import synthetic
 from covomix_amd.hubert import HubertEncoder
-sd = synthetic.hubert_state_dict(seed=0); g = np.load("tests/golden/hubert_base.npz")
-import os
+sd = synthetic.hubert_state_dict(seed=0); g = np.load(os.path.join(ROOT, "tests", "golden", "hubert_base.npz"))
 enc = HubertEncoder(sd, precision=os.environ.get('HUBERT_PRECISION', 'f16x3'))
 rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
 for tag in "abc":
