@@ -334,6 +334,40 @@ int cvx_hubert_group_pack_f32(const float* x, float* out, int32_t T, int32_t D, 
 int cvx_kmeans_argmin_f32(const float* x, const float* dots, const float* cnorm, int64_t* labels, float* margin,
                           int64_t T, int32_t D, int32_t K, cvx_stream_t s);
 
+/* The whole feature extractor behind ONE call (HubertModel.extract_features(source, mask=False, output_layer),
+ * hubert.py:433-480, 533-549): all launches are enqueued from C (stepping them from Python costs more host time than the
+ * GPU needs).  HuBERT-Base style models: extractor_mode "default" (GroupNorm after the first conv only, no conv bias),
+ * post-LN encoder layers, head dim 64.  Weights are borrowed; every cvx_linear carries the fp32 weight [N, K] (validated
+ * only) and its cvx_split_f16 halves (w_hi, w_lo = halves of w / inv_scale).  conv[i] (1 <= i < n_conv) is the Conv1d
+ * weight repacked [C_out][k][C_in] (K = k * C_in); pos[g] the weight-norm-folded positional conv of group g repacked
+ * [C/groups][k][C/groups] with bias = the group's slice; qkv = q_proj | k_proj | v_proj stacked.  `layers` and `pos` are
+ * HOST arrays.  out = [cvx_hubert_frames(m, n), dim] fp32, output of encoder layer `output_layer` (1-based, 0 = before
+ * the first layer).  workspace: 256-byte aligned device memory of cvx_hubert_workspace_bytes(m, n) bytes. */
+typedef struct {
+    const float* w; const uint16_t* w_hi; const uint16_t* w_lo; float inv_scale;
+    const float* bias;
+    int32_t N, K;
+} cvx_linear;
+typedef struct {
+    cvx_linear qkv, out, fc1, fc2;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} cvx_hubert_layer;
+typedef struct {
+    int32_t n_conv; int32_t conv_k[8], conv_stride[8], conv_c[8];
+    const float *conv0_w, *gn_g, *gn_b;
+    cvx_linear conv[8];
+    const float *ln_g, *ln_b;
+    cvx_linear proj;
+    int32_t dim, heads, pos_k, pos_groups;
+    const cvx_linear* pos;
+    const float *enc_ln_g, *enc_ln_b;
+    int32_t n_layers; const cvx_hubert_layer* layers;
+} cvx_hubert_model;
+int32_t cvx_hubert_frames(const cvx_hubert_model* m, int64_t n_samples);
+int64_t cvx_hubert_workspace_bytes(const cvx_hubert_model* m, int64_t n_samples);
+int cvx_hubert_extract_features(const cvx_hubert_model* m, const float* wav, int64_t n_samples, int32_t output_layer,
+                                float* out, void* workspace, int64_t workspace_bytes, cvx_stream_t s);
+
 /* Sample-rate conversion in front of the tokeniser (hubert_feature_reader.py:38-41: torchaudio.transforms.Resample,
  * third-party; its published polyphase windowed-sinc algorithm): out[i*up + j] = sum_k kern[j][k] * x[i*down + k - width]
  * with x = 0 outside [0, n), kern = [up][2*width + down] computed by the host (covomix_amd.hubert.sinc_resample_kernel),

@@ -79,6 +79,28 @@ class T2SDecoder(C.Structure):
                                           "x", "q", "att", "h", "logits", "tokens", "state")]
 
 
+class Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("inv_scale", C.c_float),
+                ("bias", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class HubertLayer(C.Structure):
+    _fields_ = [("qkv", Linear), ("out", Linear), ("fc1", Linear), ("fc2", Linear)] + \
+               [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class HubertModel(C.Structure):
+    _fields_ = [("n_conv", C.c_int32), ("conv_k", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8), ("conv_c", C.c_int32 * 8),
+                ("conv0_w", C.c_void_p), ("gn_g", C.c_void_p), ("gn_b", C.c_void_p),
+                ("conv", Linear * 8),
+                ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+                ("proj", Linear),
+                ("dim", C.c_int32), ("heads", C.c_int32), ("pos_k", C.c_int32), ("pos_groups", C.c_int32),
+                ("pos", C.POINTER(Linear)),
+                ("enc_ln_g", C.c_void_p), ("enc_ln_b", C.c_void_p),
+                ("n_layers", C.c_int32), ("layers", C.POINTER(HubertLayer))]
+
+
 # name -> (restype, argtypes); must list every symbol of include/covomix_hip.h
 SIGNATURES = {
     "cvx_version": (C.c_int, []),
@@ -100,6 +122,10 @@ SIGNATURES = {
                                         C.c_int32, C.c_void_p]),
     "cvx_resample_fir_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_int64, C.c_void_p]),
+    "cvx_hubert_frames": (C.c_int32, [C.POINTER(HubertModel), C.c_int64]),
+    "cvx_hubert_workspace_bytes": (C.c_int64, [C.POINTER(HubertModel), C.c_int64]),
+    "cvx_hubert_extract_features": (C.c_int, [C.POINTER(HubertModel), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),

@@ -7,6 +7,7 @@
 //   fairseq-hubert/examples/hubert/simple_kmeans/dump_km_label.py:36-43   k-means label = argmin distance
 // All HBM-bound, channel axis innermost (coalesced), no LDS needed except the block reductions.
 #include "cvx_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -282,5 +283,173 @@ extern "C" int cvx_resample_fir_f32(const float* x, int64_t n, const float* kern
     hipLaunchKernelGGL(resample_fir_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                        x, kern, out, n, n_out, up, down, width, 2 * width + down);
     CVX_CHECK_LAUNCH("cvx_resample_fir_f32");
+    return CVX_OK;
+}
+
+// ---------------------------------------------------------------- whole-network entry point
+// HubertModel.extract_features(source, mask=False, output_layer) (hubert.py:433-480, 533-549) enqueued from ONE call:
+// the ~330 launches of a 10-s utterance cost ~45 us each when stepped from Python (the GPU then idles two thirds of the
+// time); from here they cost the bare launch.  Every GEMM runs on cvx_gemm_f16x3 with pre-split A operands (producers
+// write the (hi, lo) pair, or cvx_split_f16 makes it), so small problems may split K.
+namespace {
+
+struct Bump {
+    char* base; int64_t size, off;
+    template <typename T> T* take(int64_t n)
+    {
+        const int64_t bytes = ((n * (int64_t)sizeof(T)) + 255) & ~(int64_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+struct Pair { uint16_t* hi; uint16_t* lo; };
+
+struct HubertPlan {
+    int64_t L[9];            // frames after conv layer i
+    int T;
+    // workspace carve-up (pointers are NULL in the sizing pass)
+    float* x0; Pair x0s; float* c0ws; int64_t c0ws_floats;
+    Pair cs[8]; float* feats; float* featn; Pair featns; float* h; float* packed; Pair packeds;
+    float *x, *y, *qkv, *ff_dummy; Pair xs, atts, ffs; float* skws; int64_t skws_floats;
+    int64_t bytes;
+};
+
+int plan_hubert(const cvx_hubert_model* m, int64_t n, void* ws, HubertPlan& P)
+{
+    CVX_REQUIRE(m && m->n_conv >= 2 && m->n_conv <= 8, "hubert: bad model (n_conv)");
+    int64_t len = n;
+    for (int i = 0; i < m->n_conv; ++i) {
+        len = len >= m->conv_k[i] ? (len - m->conv_k[i]) / m->conv_stride[i] + 1 : 0;
+        P.L[i] = len;
+    }
+    P.T = (int)len;
+    CVX_REQUIRE(len > 0 && len < (1 << 24), "hubert: the waveform yields %ld frames", (long)len);
+    const int C0 = m->conv_c[0], Cl = m->conv_c[m->n_conv - 1], D = m->dim, T = P.T;
+    int F = 0, Nmax = 3 * D;
+    for (int i = 0; i < m->n_layers; ++i) F = std::max(F, (int)m->layers[i].fc1.N);
+    Nmax = std::max(Nmax, F);
+    Bump b{reinterpret_cast<char*>(ws), 0, 0};
+    P.x0 = b.take<float>(P.L[0] * C0);
+    P.x0s = {b.take<uint16_t>(P.L[0] * C0), b.take<uint16_t>(P.L[0] * C0)};
+    P.c0ws_floats = cvx_hubert_conv0_workspace_floats(P.L[0], C0);
+    P.c0ws = b.take<float>(P.c0ws_floats);
+    for (int i = 1; i < m->n_conv - 1; ++i)
+        P.cs[i] = {b.take<uint16_t>(P.L[i] * m->conv_c[i]), b.take<uint16_t>(P.L[i] * m->conv_c[i])};
+    P.feats = b.take<float>((int64_t)T * Cl);
+    P.featn = b.take<float>((int64_t)T * Cl);
+    P.featns = {b.take<uint16_t>((int64_t)T * Cl), b.take<uint16_t>((int64_t)T * Cl)};
+    P.h = b.take<float>((int64_t)T * D);
+    const int64_t prow = (int64_t)(T + 2 * (m->pos_k / 2)) * D;
+    P.packed = b.take<float>(prow);
+    P.packeds = {b.take<uint16_t>(prow), b.take<uint16_t>(prow)};
+    P.x = b.take<float>((int64_t)T * D);
+    P.y = b.take<float>((int64_t)T * D);
+    P.qkv = b.take<float>((int64_t)T * 3 * D);
+    P.xs = {b.take<uint16_t>((int64_t)T * D), b.take<uint16_t>((int64_t)T * D)};
+    P.atts = {b.take<uint16_t>((int64_t)T * D), b.take<uint16_t>((int64_t)T * D)};
+    P.ffs = {b.take<uint16_t>((int64_t)T * std::max(F, 1)), b.take<uint16_t>((int64_t)T * std::max(F, 1))};
+    // split-K scratch: 4 * M * N floats for the largest GEMM with M <= 2048 rows (encoder GEMMs and the late conv layers)
+    P.skws_floats = T <= 2048 ? (int64_t)4 * T * Nmax : 0;
+    for (int i = 1; i < m->n_conv; ++i)
+        if (P.L[i] <= 2048) P.skws_floats = std::max(P.skws_floats, (int64_t)4 * P.L[i] * m->conv_c[i]);
+    P.skws = P.skws_floats ? b.take<float>(P.skws_floats) : nullptr;
+    P.bytes = b.off;
+    return CVX_OK;
+}
+
+// C[M,N] = epi(A . W^T): A as a pre-split pair with row stride lda_h; optional fp32 / split outputs
+int lin(const cvx_linear& L, Pair a, int64_t lda_h, int M, float* C, int64_t ldc, int act, const float* bias,
+        const float* residual, int64_t ldr, Pair c16, int write_f32, const HubertPlan& P, cvx_stream_t s)
+{
+    cvx_gemm_args g{};
+    g.A = reinterpret_cast<const float*>(a.hi); g.lda = 4;          // validated only (A arrives pre-split)
+    g.W = L.w; g.ldw = L.K;
+    g.C = C; g.ldc = ldc;
+    g.bias = bias; g.residual = residual; g.ldr = ldr;
+    g.M = M; g.N = L.N; g.K = L.K; g.act = act;
+    cvx_gemm_split_io io{};
+    io.A_hi = a.hi; io.A_lo = a.lo; io.lda_h = lda_h;
+    io.C_hi = c16.hi; io.C_lo = c16.lo; io.ldc_h = L.N;
+    io.write_f32 = write_f32;
+    if (M <= 2048) { io.workspace = P.skws; io.workspace_floats = P.skws_floats; }
+    return cvx_gemm_f16x3(&g, L.w_hi, L.w_lo, L.inv_scale, &io, s);
+}
+
+}  // namespace
+
+extern "C" int64_t cvx_hubert_workspace_bytes(const cvx_hubert_model* m, int64_t n_samples)
+{
+    HubertPlan P{};
+    if (plan_hubert(m, n_samples, nullptr, P) != CVX_OK) return -1;
+    return P.bytes;
+}
+
+extern "C" int32_t cvx_hubert_frames(const cvx_hubert_model* m, int64_t n_samples)
+{
+    if (!m) return -1;
+    int64_t len = n_samples;
+    for (int i = 0; i < m->n_conv; ++i) len = len >= m->conv_k[i] ? (len - m->conv_k[i]) / m->conv_stride[i] + 1 : 0;
+    return (int32_t)len;
+}
+
+#define CVX_TRY(expr) do { const int rc_ = (expr); if (rc_ != CVX_OK) return rc_; } while (0)
+
+extern "C" int cvx_hubert_extract_features(const cvx_hubert_model* m, const float* wav, int64_t n_samples, int32_t output_layer,
+                                           float* out, void* workspace, int64_t workspace_bytes, cvx_stream_t s)
+{
+    CVX_REQUIRE(m && wav && out && workspace, "hubert_extract_features: null pointer");
+    CVX_REQUIRE((((uintptr_t)workspace) & 255) == 0, "hubert_extract_features: workspace must be 256-byte aligned");
+    CVX_REQUIRE(output_layer >= 0 && output_layer <= m->n_layers, "hubert_extract_features: output_layer %d out of range", output_layer);
+    CVX_REQUIRE(m->dim == 64 * m->heads && m->dim % m->pos_groups == 0, "hubert_extract_features: head dim must be 64");
+    HubertPlan P{};
+    CVX_TRY(plan_hubert(m, n_samples, workspace, P));
+    CVX_REQUIRE(workspace_bytes >= P.bytes, "hubert_extract_features: workspace too small (%ld < %ld)", (long)workspace_bytes, (long)P.bytes);
+    const int T = P.T, D = m->dim, nc = m->n_conv, Cl = m->conv_c[nc - 1];
+    const Pair none{nullptr, nullptr};
+    // ---- conv feature extractor: layer 0 + GroupNorm + GELU, then GEMMs over overlapping channels-last rows
+    CVX_TRY(cvx_hubert_conv0_gn_gelu_f32(wav, n_samples, m->conv0_w, m->conv_c[0], m->conv_k[0], m->conv_stride[0], m->gn_g, m->gn_b,
+                                         1e-5f, P.x0, P.c0ws, P.c0ws_floats, s));
+    CVX_TRY(cvx_split_f16(P.x0, P.x0s.hi, P.x0s.lo, P.L[0] * m->conv_c[0], 1.0f, s));
+    Pair cur = P.x0s;
+    for (int i = 1; i < nc; ++i) {
+        const bool last = i == nc - 1;
+        const int cin = m->conv_c[i - 1];
+        CVX_REQUIRE(m->conv[i].K == m->conv_k[i] * cin && m->conv[i].N == m->conv_c[i], "hubert: conv layer %d weight shape", i);
+        CVX_TRY(lin(m->conv[i], cur, (int64_t)m->conv_stride[i] * cin, (int)P.L[i], last ? P.feats : P.x0, m->conv_c[i], CVX_ACT_GELU,
+                    nullptr, nullptr, 0, last ? none : P.cs[i], last ? 1 : 0, P, s));
+        cur = P.cs[i];
+    }
+    // ---- LayerNorm, post_extract_proj
+    CVX_TRY(cvx_layernorm_f32(P.feats, m->ln_g, m->ln_b, P.featn, T, Cl, 1e-5f, s));
+    CVX_TRY(cvx_split_f16(P.featn, P.featns.hi, P.featns.lo, (int64_t)T * Cl, 1.0f, s));
+    CVX_TRY(lin(m->proj, P.featns, Cl, T, P.h, D, CVX_ACT_NONE, m->proj.bias, nullptr, 0, none, 1, P, s));
+    // ---- positional convolution: x = h + gelu(conv(h) + b), one GEMM per group over the packed operand
+    const int G = m->pos_groups, cg = D / G, k = m->pos_k, halo = k / 2, prows = T + 2 * halo;
+    CVX_TRY(cvx_hubert_group_pack_f32(P.h, P.packed, T, D, G, halo, s));
+    CVX_TRY(cvx_split_f16(P.packed, P.packeds.hi, P.packeds.lo, (int64_t)prows * D, 1.0f, s));
+    for (int g = 0; g < G; ++g) {
+        const Pair a{P.packeds.hi + (int64_t)g * prows * cg, P.packeds.lo + (int64_t)g * prows * cg};
+        CVX_REQUIRE(m->pos[g].K == k * cg && m->pos[g].N == cg, "hubert: positional conv group %d weight shape", g);
+        // output / bias / residual are column slices of [T, D] tensors
+        CVX_TRY(lin(m->pos[g], a, cg, T, P.x + g * cg, D, CVX_ACT_GELU, m->pos[g].bias, P.h + g * cg, D, none, 1, P, s));
+    }
+    CVX_TRY(cvx_layernorm_f32(P.x, m->enc_ln_g, m->enc_ln_b, P.x, T, D, 1e-5f, s));
+    // ---- post-LN transformer layers
+    for (int i = 0; i < output_layer; ++i) {
+        const cvx_hubert_layer& ly = m->layers[i];
+        CVX_TRY(cvx_split_f16(P.x, P.xs.hi, P.xs.lo, (int64_t)T * D, 1.0f, s));
+        CVX_TRY(lin(ly.qkv, P.xs, D, T, P.qkv, 3 * D, CVX_ACT_NONE, ly.qkv.bias, nullptr, 0, none, 1, P, s));
+        CVX_TRY(cvx_attention_f32(P.qkv, nullptr, P.atts.hi, P.atts.lo, 1, T, m->heads, 0.125f, s));
+        CVX_TRY(lin(ly.out, P.atts, D, T, P.y, D, CVX_ACT_NONE, ly.out.bias, P.x, D, none, 1, P, s));
+        CVX_TRY(cvx_layernorm_f32(P.y, ly.ln1_g, ly.ln1_b, P.x, T, D, 1e-5f, s));
+        CVX_TRY(cvx_split_f16(P.x, P.xs.hi, P.xs.lo, (int64_t)T * D, 1.0f, s));
+        CVX_TRY(lin(ly.fc1, P.xs, D, T, P.y, ly.fc1.N, CVX_ACT_GELU, ly.fc1.bias, nullptr, 0, P.ffs, 0, P, s));
+        CVX_TRY(lin(ly.fc2, P.ffs, ly.fc1.N, T, P.y, D, CVX_ACT_NONE, ly.fc2.bias, P.x, D, none, 1, P, s));
+        CVX_TRY(cvx_layernorm_f32(P.y, ly.ln2_g, ly.ln2_b, P.x, T, D, 1e-5f, s));
+    }
+    CVX_REQUIRE(hipMemcpyAsync(out, P.x, (size_t)T * D * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(s)) == hipSuccess,
+                "hubert_extract_features: output copy failed");
     return CVX_OK;
 }

@@ -91,12 +91,16 @@ class HubertEncoder:
     """Device-resident HuBERT weights in the layouts the kernels read + the forward pass."""
 
     def __init__(self, state_dict: Dict[str, Union[np.ndarray, torch.Tensor]], model_cfg: Optional[dict] = None,
-                 device: Union[str, torch.device] = "cuda", precision: str = "f16x3"):
-        """precision: "f16x3" (default) runs every GEMM with more than 64 rows on the split-precision MFMA kernel
+                 device: Union[str, torch.device] = "cuda", precision: str = "f16x3", stepped: bool = False):
+        """stepped=True drives every kernel from Python (tests, tools); the default enqueues the whole network from one
+        C call (cvx_hubert_extract_features), which is what keeps the GPU busy.  precision: "f16x3" (default) runs every GEMM with more than 64 rows on the split-precision MFMA kernel
         (fp32 operands as fp16 hi/lo pairs, three products, fp32 accumulate - 16 k per accumulate step, measured closer
         to an fp64 evaluation than the fp32 MFMA kernel, which adds 2 k per step); "fp32" uses cvx_gemm_bias_act_f32 only."""
         assert precision in ("f16x3", "fp32")
         self.precision = precision
+        self.stepped = bool(stepped) or precision == "fp32"      # the C entry point is the f16x3 path
+        self._cmodel = None
+        self._ws: Optional[torch.Tensor] = None
         cfg = dict(model_cfg or {})
         if cfg.get("layer_norm_first", False) or cfg.get("extractor_mode", "default") != "default":
             raise NotImplementedError("only HuBERT-Base style checkpoints (extractor_mode=default, post-LN) are supported")
@@ -149,14 +153,29 @@ class HubertEncoder:
 
         self._split: Dict[int, tuple] = {}
 
-    def _gemm(self, a, w, out, **kw):
-        """One nn.Linear / conv-as-GEMM: split weights are made once per weight tensor (load-time packing)."""
+    def _gemm(self, a, w, out, a16=None, **kw):
+        """One nn.Linear / conv-as-GEMM.  f16x3 mode: split weights are made once per weight tensor (load-time packing)
+        and the A operand is handed over as a pre-split (fp16 hi, fp16 lo) pair - `a16`, or split here when the producer
+        only wrote fp32 - so that every tile arrives by LDS-DMA and small problems may split K (see the header)."""
         if self.precision == "f16x3" and w.shape[1] % 32 == 0:
             ws = self._split.get(id(w))
             if ws is None:
                 ws = self._split[id(w)] = ops.split_f16(w)
-            return ops.gemm(a, w, out, w_split=ws, **kw)
+            if a16 is None:
+                a16 = ops.split_act_f16(a)
+            return ops.gemm(a, w, out, w_split=ws, a_split=a16, **kw)
+        kw.pop("out_split", None)
+        kw.pop("write_f32", None)
         return ops.gemm(a, w, out, **kw)
+
+    @property
+    def _f16x3(self) -> bool:
+        return self.precision == "f16x3"
+
+    @staticmethod
+    def _windows(pair, rows: int, width: int, stride: int):
+        """Overlapping-row views (rows x width, row stride `stride`) of both halves of a split pair."""
+        return tuple(t.as_strided((rows, width), (stride, 1), t.storage_offset()) for t in pair)
 
     # ------------------------------------------------------------------ pieces
     def n_frames(self, n_samples: int) -> int:
@@ -168,12 +187,22 @@ class HubertEncoder:
     def conv_features(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [n] fp32 on the device -> [T, 512] (ConvFeatureExtractionModel.forward + transpose)."""
         x = ops.hubert_conv0_gn_gelu(wav, self.w0, self.gn_w, self.gn_b, self.conv_layers[0][2])
-        for (c, k, s), w in zip(self.conv_layers[1:], self.conv_w):
+        x16 = ops.split_act_f16(x) if self._f16x3 else None
+        last = len(self.conv_w) - 1
+        for i, ((c, k, s), w) in enumerate(zip(self.conv_layers[1:], self.conv_w)):
             L, cin = x.shape
             Lout = (L - k) // s + 1
             a = x.as_strided((Lout, k * cin), (s * cin, 1))           # im2col row = k consecutive channels-last frames
             y = torch.empty(Lout, c, dtype=torch.float32, device=x.device)
-            self._gemm(a, w, y, act=ops.ACT_GELU)
+            if self._f16x3 and k * cin % 32 == 0:
+                # the GELU epilogue writes the split pair the next layer reads; fp32 only after the last layer
+                y16 = None if i == last else (torch.empty(Lout, c, dtype=torch.float16, device=x.device),
+                                              torch.empty(Lout, c, dtype=torch.float16, device=x.device))
+                self._gemm(a, w, y, a16=self._windows(x16, Lout, k * cin, s * cin), act=ops.ACT_GELU,
+                           out_split=y16, write_f32=(i == last))
+                x16 = y16
+            else:
+                self._gemm(a, w, y, act=ops.ACT_GELU)
             x = y
         return x
 
@@ -184,34 +213,114 @@ class HubertEncoder:
         cg = D // G
         dev = feats.device
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        new16 = lambda *shape: (torch.empty(*shape, dtype=torch.float16, device=dev), torch.empty(*shape, dtype=torch.float16, device=dev))
         h = self._gemm(ops.layernorm(feats, self.ln_w, self.ln_b), self.proj_w, new(T, D), bias=self.proj_b)
         packed = ops.hubert_group_pack(h, G, k // 2)                  # [G, T + k, cg], zero halos
+        packed16 = ops.split_act_f16(packed.view(-1, cg)) if self._f16x3 else None
         x = new(T, D)
         for g in range(G):
             a = packed[g].as_strided((T, k * cg), (cg, 1))
-            self._gemm(a, self.pos_w[g], x[:, g * cg:(g + 1) * cg], bias=self.pos_b[g * cg:(g + 1) * cg], act=ops.ACT_GELU,
-                     residual=h[:, g * cg:(g + 1) * cg])               # x = h + gelu(conv(h) + b)
+            a16 = None
+            if packed16 is not None:
+                a16 = tuple(t[g * (T + k):(g + 1) * (T + k)].as_strided((T, k * cg), (cg, 1), t.storage_offset() + g * (T + k) * cg)
+                            for t in packed16)
+            self._gemm(a, self.pos_w[g], x[:, g * cg:(g + 1) * cg], a16=a16, bias=self.pos_b[g * cg:(g + 1) * cg], act=ops.ACT_GELU,
+                       residual=h[:, g * cg:(g + 1) * cg])             # x = h + gelu(conv(h) + b)
         x = ops.layernorm(x, *self.enc_ln)
         n_layers = len(self.layers) if output_layer is None else int(output_layer)
         assert 0 <= n_layers <= len(self.layers), f"output_layer {output_layer} out of range"
-        qkv, att, y, ff = new(T, 3 * D), new(T, D), new(T, D), None
+        qkv, att, y = new(T, 3 * D), new(T, D), new(T, D)
+        F = self.layers[0]["w1"].shape[0] if self.layers else 0
+        ff = new(T, F)
+        att16, ff16 = (new16(T, D), new16(T, F)) if self._f16x3 else (None, None)
         for lyr in self.layers[:n_layers]:
             self._gemm(x, lyr["wqkv"], qkv, bias=lyr["bqkv"])
-            ops.attention(qkv, att, 1, T, self.heads, 64 ** -0.5)
-            self._gemm(att, lyr["wo"], y, bias=lyr["bo"], residual=x)
+            if att16 is not None:                                      # the attention writes the split pair out_proj reads
+                ops.attention(qkv, None, 1, T, self.heads, 64 ** -0.5, out_split=att16)
+            else:
+                ops.attention(qkv, att, 1, T, self.heads, 64 ** -0.5)
+            self._gemm(att, lyr["wo"], y, a16=att16, bias=lyr["bo"], residual=x)
             x = ops.layernorm(y, *lyr["ln1"], out=x)
-            ff = new(T, lyr["w1"].shape[0]) if ff is None else ff
-            self._gemm(x, lyr["w1"], ff, bias=lyr["b1"], act=ops.ACT_GELU)
-            self._gemm(ff, lyr["w2"], y, bias=lyr["b2"], residual=x)
+            if ff16 is not None:
+                self._gemm(x, lyr["w1"], ff, bias=lyr["b1"], act=ops.ACT_GELU, out_split=ff16, write_f32=False)
+            else:
+                self._gemm(x, lyr["w1"], ff, bias=lyr["b1"], act=ops.ACT_GELU)
+            self._gemm(ff, lyr["w2"], y, a16=ff16, bias=lyr["b2"], residual=x)
             x = ops.layernorm(y, *lyr["ln2"], out=x)
         return x
 
     def extract_features(self, source: torch.Tensor, output_layer: Optional[int] = None) -> torch.Tensor:
         """HubertModel.extract_features(source [1, n] or [n], mask=False, output_layer) -> [T, D]."""
         wav = source.reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
-        if self.n_frames(wav.numel()) == 0:
+        T = self.n_frames(wav.numel())
+        if T == 0:
             return torch.empty(0, self.dim, dtype=torch.float32, device=self.device)
-        return self.encode(self.conv_features(wav), output_layer)
+        if self.stepped:
+            return self.encode(self.conv_features(wav), output_layer)
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        m = self._c_model()
+        n_layers = len(self.layers) if output_layer is None else int(output_layer)
+        assert 0 <= n_layers <= len(self.layers), f"output_layer {output_layer} out of range"
+        need = int(lib.cvx_hubert_workspace_bytes(C.byref(m), wav.numel()))
+        if need < 0:
+            _lib.check(-22, "cvx_hubert_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None                                        # release before growing
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty(T, self.dim, dtype=torch.float32, device=self.device)
+        _lib.check(lib.cvx_hubert_extract_features(C.byref(m), wav.data_ptr(), wav.numel(), n_layers, out.data_ptr(),
+                                                   self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "cvx_hubert_extract_features")
+        return out
+
+    def _c_model(self):
+        """cvx_hubert_model over this object's device tensors (built once; the tensors stay referenced by self)."""
+        if self._cmodel is not None:
+            return self._cmodel
+        from . import _lib
+        keep = self._keep = []
+
+        def lin(w, bias=None):
+            ws = self._split.get(id(w))
+            if ws is None:
+                ws = self._split[id(w)] = ops.split_f16(w)
+            hi, lo, inv = ws
+            keep.extend((w, hi, lo, bias))
+            L = _lib.Linear()
+            L.w, L.w_hi, L.w_lo, L.inv_scale = w.data_ptr(), hi.data_ptr(), lo.data_ptr(), inv
+            L.bias = bias.data_ptr() if bias is not None else None
+            L.N, L.K = w.shape
+            return L
+        m = _lib.HubertModel()
+        m.n_conv = len(self.conv_layers)
+        assert m.n_conv <= 8
+        for i, (c, k, s) in enumerate(self.conv_layers):
+            m.conv_c[i], m.conv_k[i], m.conv_stride[i] = c, k, s
+        m.conv0_w, m.gn_g, m.gn_b = self.w0.data_ptr(), self.gn_w.data_ptr(), self.gn_b.data_ptr()
+        for i, w in enumerate(self.conv_w, start=1):
+            m.conv[i] = lin(w)
+        m.ln_g, m.ln_b = self.ln_w.data_ptr(), self.ln_b.data_ptr()
+        m.proj = lin(self.proj_w, self.proj_b)
+        m.dim, m.heads, m.pos_k, m.pos_groups = self.dim, self.heads, self.pos_k, self.groups
+        cg = self.dim // self.groups
+        self._pos_bias = [self.pos_b[g * cg:(g + 1) * cg].contiguous() for g in range(self.groups)]
+        self._c_pos = (_lib.Linear * self.groups)(*[lin(self.pos_w[g], self._pos_bias[g]) for g in range(self.groups)])
+        m.pos = self._c_pos
+        m.enc_ln_g, m.enc_ln_b = self.enc_ln[0].data_ptr(), self.enc_ln[1].data_ptr()
+        cl = []
+        for lyr in self.layers:
+            L = _lib.HubertLayer()
+            L.qkv, L.out = lin(lyr["wqkv"], lyr["bqkv"]), lin(lyr["wo"], lyr["bo"])
+            L.fc1, L.fc2 = lin(lyr["w1"], lyr["b1"]), lin(lyr["w2"], lyr["b2"])
+            L.ln1_g, L.ln1_b = lyr["ln1"][0].data_ptr(), lyr["ln1"][1].data_ptr()
+            L.ln2_g, L.ln2_b = lyr["ln2"][0].data_ptr(), lyr["ln2"][1].data_ptr()
+            cl.append(L)
+        self._c_layers = (_lib.HubertLayer * max(len(cl), 1))(*cl)
+        m.n_layers, m.layers = len(cl), self._c_layers
+        self._cmodel = m
+        return m
 
 
 class HubertFeatureReader:

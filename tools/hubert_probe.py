@@ -22,7 +22,10 @@ for tag in "abc":
         print(tag, L, "ours-f64", rel(f, f64), "ref-f64", rel(g[f"{tag}_feat{L}"], f64), "ours-ref", rel(f, g[f"{tag}_feat{L}"].astype(np.float64)))
 import time
 wav = torch.randn(160000).cuda() * 0.1
-for _ in range(3): enc.extract_features(wav, 12)
-torch.cuda.synchronize(); t = time.time()
-for _ in range(10): enc.extract_features(wav, 12)
-torch.cuda.synchronize(); print("10 s utterance: %.2f ms" % ((time.time() - t) * 100))
+for stepped in (False, True):
+    e = HubertEncoder(sd, precision=enc.precision, stepped=stepped)
+    for _ in range(30): e.extract_features(wav, 12)          # also lets the clocks ramp after the CPU-only phase above
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(20): e.extract_features(wav, 12)
+    t1 = time.time(); torch.cuda.synchronize(); t2 = time.time()
+    print(f"10 s utterance, {'Python-stepped' if e.stepped else 'one C call'}: host enqueue {(t1 - t0) * 50:.2f} ms, total {(t2 - t0) * 50:.2f} ms")
