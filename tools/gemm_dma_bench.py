@@ -18,6 +18,8 @@ tot = {3: 0.0, 1: 0.0}
 only = os.environ.get("SHAPES")            # e.g. SHAPES=ff2 TERMS=3 for a PMC run on one kernel
 for (N, K, name, cnt) in [(3072, 1024, "qkv", 8), (1024, 1024, "out", 8), (4096, 1024, "ff1", 8), (1024, 4096, "ff2", 8), (1024, 2048, "skip", 4)]:
     a, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / math.sqrt(K)
+    if os.environ.get("ZERO") == "1":          # power probe: all-zero operands toggle no datapath bits
+        a.zero_(); w.zero_(); w[0, 0] = 1.0
     c = torch.empty(M, N, device=dev)
     ref = None
     if only and name not in only.split(","):
