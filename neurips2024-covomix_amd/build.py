@@ -26,7 +26,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libcovomix_hip.so")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
-           *os.environ.get("CVX_HIPCC_FLAGS", "").split(),          # dev experiments (e.g. -DCVX_ATT_SACC=1)
+           *os.environ.get("CVX_HIPCC_FLAGS", "").split(),          # dev A/B builds (extra -D flags)
            "-o", OUT] + SOURCES
     if verbose:
         print(" ".join(cmd))
