@@ -297,6 +297,37 @@ int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream
 int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F, int64_t ld_out, cvx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Operator-level entry points (the names SURVEY.md section 8(b) lists): compositions of the calls above for a C
+ * caller that works operator by operator.  The Python host uses the finer-grained entry points because it fuses
+ * further (RoPE into the to_qkv GEMM epilogue, the xs accumulation into the last ResBlock convolution).
+ *
+ * cvx_rope_attention_f32: Attention.forward between to_qkv and to_out (acoustic.py:227-235): qkv [Bt, T, 3*H*64]
+ *   WITHOUT rotary embedding; half-split RoPE (:132-137; tables cos/sin [T][32]) on q and k, then the attention of
+ *   cvx_attention_f32.  workspace: Bt*T*3*H*64 floats (the rotated copy).
+ * cvx_hifigan_convt_f32: the ConvTranspose1d upsamplers (models.py:85-88, :103) = cvx_hifigan_conv1d_f32 with
+ *   up = stride (> 1), a transposed-packed weight, pad = ksize - 1 - (ksize - up)/2.
+ * cvx_hifigan_resblock_f32: ResBlock1.forward (models.py:35-42), x [B, C, L] -> out [B, C, L]:
+ *   three times  x = c2(leaky_relu(c1(leaky_relu(x, .1)), .1)) + x  with dilations dil[m] (c1) and 1 (c2);
+ *   the last add can also apply the generator's  xs (+)= ... / num_kernels  (accum, out_scale; models.py:104-110).
+ *   x, tmp, out are three distinct buffers (x is not modified).
+ * cvx_hifigan_pre_post_f32: conv_pre (models.py:81, :100; `pre`, may be NULL) and / or the output stage
+ *   leaky_relu + conv_post + tanh (:112-114; post_x may be NULL) - see cvx_hifigan_post_f32. */
+int cvx_rope_attention_f32(const float* qkv, const float* rope_cos, const float* rope_sin, float* out,
+                           int32_t Bt, int32_t T, int32_t H, float scale, float* workspace, cvx_stream_t s);
+int cvx_hifigan_convt_f32(const cvx_conv_args* a, cvx_stream_t s);
+typedef struct {
+    const float* x; int32_t B, C, L;
+    const float* Wp1[3]; const float* b1[3];     /* convs1[m]: dilation dil[m]   (packed by cvx_hifigan_pack_weight_f32) */
+    const float* Wp2[3]; const float* b2[3];     /* convs2[m]: dilation 1 */
+    int32_t ksize; int32_t dil[3];
+    float* tmp; float* out;
+    const float* accum; float out_scale;         /* out = (resblock(x) (+ accum)) * out_scale; accum may alias out */
+} cvx_resblock_args;
+int cvx_hifigan_resblock_f32(const cvx_resblock_args* a, cvx_stream_t s);
+int cvx_hifigan_pre_post_f32(const cvx_conv_args* pre, const float* post_x, const float* post_w, float post_bias,
+                             float* post_y, int32_t B, int32_t C, int32_t L, float slope, cvx_stream_t s);
+
+/* ------------------------------------------------------------------------
  * HuBERT layer-L + k-means prompt tokeniser - SURVEY.md section 8f row N4
  * (fairseq-hubert/examples/textless_nlp/gslm/speech2unit/pretrained/hubert_feature_reader.py:58-78 ->
  *  fairseq-hubert/fairseq/models/hubert/hubert.py:433-480 -> fairseq/models/wav2vec/wav2vec2.py:844-946,1078-1163,

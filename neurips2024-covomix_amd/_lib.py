@@ -79,6 +79,13 @@ class T2SDecoder(C.Structure):
                                           "x", "q", "att", "h", "logits", "tokens", "state")]
 
 
+class ResblockArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32),
+                ("Wp1", C.c_void_p * 3), ("b1", C.c_void_p * 3), ("Wp2", C.c_void_p * 3), ("b2", C.c_void_p * 3),
+                ("ksize", C.c_int32), ("dil", C.c_int32 * 3),
+                ("tmp", C.c_void_p), ("out", C.c_void_p), ("accum", C.c_void_p), ("out_scale", C.c_float)]
+
+
 class Linear(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("inv_scale", C.c_float),
                 ("bias", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
@@ -126,6 +133,12 @@ SIGNATURES = {
     "cvx_hubert_workspace_bytes": (C.c_int64, [C.POINTER(HubertModel), C.c_int64]),
     "cvx_hubert_extract_features": (C.c_int, [C.POINTER(HubertModel), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p]),
+    "cvx_rope_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_hifigan_convt_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "cvx_hifigan_resblock_f32": (C.c_int, [C.POINTER(ResblockArgs), C.c_void_p]),
+    "cvx_hifigan_pre_post_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),

@@ -1,0 +1,88 @@
+// Operator-level entry points under the names SURVEY.md section 8(b) lists as the minimum symbol set of a replacement
+// library.  Each is a short composition of the kernels behind the finer-grained entry points (which the Python host
+// uses directly, because it fuses further: RoPE into the to_qkv GEMM epilogue, the xs accumulation into the last
+// ResBlock convolution, ...); a C caller that works operator by operator can use these.
+#include "cvx_common.h"
+
+namespace {
+
+// q | k | v rows [M, 3*H*64]: copy with the half-split rotation applied to q and k (acoustic.py:132-137):
+// x'[j] = x[j]*cos - x[j+32]*sin, x'[j+32] = x[j+32]*cos + x[j]*sin, position = row % T, tables [T][32].
+__global__ __launch_bounds__(256) void rope_copy_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+                                                        const float* __restrict__ rsin, float* __restrict__ out,
+                                                        int64_t M, int T, int H)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // over M * 3*H*32 column pairs
+    const int pairs = 3 * H * 32;
+    if (i >= M * pairs) return;
+    const int64_t row = i / pairs;
+    const int pj = (int)(i % pairs), head = pj >> 5, j = pj & 31;     // head over q heads | k heads | v heads
+    const int64_t base = row * (3 * H * 64) + head * 64 + j;
+    const float lo = qkv[base], hi = qkv[base + 32];
+    if (head < 2 * H) {
+        const int pos = (int)(row % T);
+        const float c = rcos[pos * 32 + j], s = rsin[pos * 32 + j];
+        out[base] = __builtin_fmaf(lo, c, -__fmul_rn(hi, s));
+        out[base + 32] = __builtin_fmaf(hi, c, __fmul_rn(lo, s));
+    } else {
+        out[base] = lo; out[base + 32] = hi;
+    }
+}
+
+}  // namespace
+
+extern "C" int cvx_rope_attention_f32(const float* qkv, const float* rope_cos, const float* rope_sin, float* out,
+                                      int32_t Bt, int32_t T, int32_t H, float scale, float* workspace, cvx_stream_t s)
+{
+    CVX_REQUIRE(qkv && rope_cos && rope_sin && out && workspace, "rope_attention: null pointer");
+    CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0, "rope_attention: bad shape");
+    if (Bt == 0) return CVX_OK;
+    const int64_t M = (int64_t)Bt * T, n = M * 3 * H * 32;
+    hipLaunchKernelGGL(rope_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       qkv, rope_cos, rope_sin, workspace, M, T, H);
+    CVX_CHECK_LAUNCH("cvx_rope_attention_f32");
+    return cvx_attention_f32(workspace, out, nullptr, nullptr, Bt, T, H, scale, s);
+}
+
+extern "C" int cvx_hifigan_convt_f32(const cvx_conv_args* a, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->up > 1, "hifigan_convt: a ConvTranspose1d needs up (its stride) > 1");
+    return cvx_hifigan_conv1d_f32(a, s);
+}
+
+extern "C" int cvx_hifigan_resblock_f32(const cvx_resblock_args* a, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->x && a->tmp && a->out && a->tmp != a->x && a->tmp != a->out && a->out != a->x, "hifigan_resblock: bad buffers");
+    CVX_REQUIRE(a->ksize % 2 == 1 && a->B >= 0 && a->C > 0 && a->L > 0, "hifigan_resblock: bad shape");
+    const float* cur = a->x;
+    for (int m = 0; m < 3; ++m) {
+        CVX_REQUIRE(a->Wp1[m] && a->Wp2[m] && a->dil[m] > 0, "hifigan_resblock: missing weights / dilation of pair %d", m);
+        cvx_conv_args c{};
+        c.B = a->B; c.Cin = a->C; c.Lin = a->L; c.Cout = a->C; c.Lout = a->L; c.ksize = a->ksize; c.up = 1; c.in_slope = 0.1f;
+        c.out_scale = 1.0f;
+        // xt = c1(leaky_relu(x)), dilated                      models.py:36-37
+        c.x = cur; c.Wp = a->Wp1[m]; c.bias = a->b1[m]; c.out = a->tmp; c.dil = a->dil[m]; c.pad = (a->ksize - 1) * a->dil[m] / 2;
+        int rc = cvx_hifigan_conv1d_f32(&c, s);
+        if (rc != CVX_OK) return rc;
+        // x = c2(leaky_relu(xt)) + x                           models.py:38-40   (+ the caller's xs accumulate on the last pair)
+        c.x = a->tmp; c.Wp = a->Wp2[m]; c.bias = a->b2[m]; c.out = a->out; c.dil = 1; c.pad = (a->ksize - 1) / 2; c.res = cur;
+        if (m == 2) { c.accum = a->accum; c.out_scale = a->out_scale; }
+        rc = cvx_hifigan_conv1d_f32(&c, s);
+        if (rc != CVX_OK) return rc;
+        cur = a->out;
+    }
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_pre_post_f32(const cvx_conv_args* pre, const float* post_x, const float* post_w, float post_bias,
+                                        float* post_y, int32_t B, int32_t C, int32_t L, float slope, cvx_stream_t s)
+{
+    CVX_REQUIRE(pre || post_x, "hifigan_pre_post: nothing to do");
+    if (pre) {
+        CVX_REQUIRE(pre->up == 1 && pre->in_slope == 1.0f, "hifigan_pre_post: conv_pre is a plain Conv1d (up = 1, no input leaky_relu)");
+        const int rc = cvx_hifigan_conv1d_f32(pre, s);
+        if (rc != CVX_OK) return rc;
+    }
+    if (post_x) return cvx_hifigan_post_f32(post_x, post_w, post_bias, post_y, B, C, L, slope, s);
+    return CVX_OK;
+}

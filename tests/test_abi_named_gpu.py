@@ -1,0 +1,125 @@
+"""GPU: the operator-level entry points named in SURVEY.md section 8(b) (cvx_rope_attention_f32, cvx_hifigan_convt_f32,
+cvx_hifigan_resblock_f32, cvx_hifigan_pre_post_f32) against plain fp64 torch restatements of the reference operators
+(acoustic.py:132-137, 227-235; attend.py:108-126; covomix/vocoder/models.py:35-42, 81, 85-88, 100-114)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("Bt,T,H", [(2, 100, 16), (1, 37, 2), (3, 256, 12)])
+def test_rope_attention(Bt, T, H):
+    from covomix_amd import _lib
+    g = torch.Generator().manual_seed(Bt * 1000 + T)
+    qkv = torch.randn(Bt, T, 3 * H * 64, generator=g)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).double() / 64))
+    ang = torch.arange(T).double()[:, None] * inv[None, :]
+    cos, sin = ang.cos(), ang.sin()
+    q, k, v = (t.view(Bt, T, H, 64).transpose(1, 2).double() for t in qkv.chunk(3, dim=-1))
+
+    def rot(x):                                            # rotate_half / apply_rotary_pos_emb, acoustic.py:132-137
+        c, s = torch.cat((cos, cos), -1), torch.cat((sin, sin), -1)
+        x1, x2 = x[..., :32], x[..., 32:]
+        return x * c + torch.cat((-x2, x1), -1) * s
+    sim = rot(q) @ rot(k).transpose(-1, -2) * 0.125
+    want = (sim.softmax(-1) @ v).transpose(1, 2).reshape(Bt, T, H * 64)
+    qd = qkv.cuda()
+    out = torch.empty(Bt, T, H * 64, device="cuda")
+    ws = torch.empty_like(qd)
+    cs, sn = cos.float().cuda().contiguous(), sin.float().cuda().contiguous()
+    _lib.check(_lib.load().cvx_rope_attention_f32(qd.data_ptr(), cs.data_ptr(), sn.data_ptr(), out.data_ptr(), Bt, T, H, 0.125,
+                                                  ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "cvx_rope_attention_f32")
+    assert rel(out, want) < 5e-6
+    assert torch.equal(qd.cpu(), qkv)                     # the input is not modified
+
+
+def _packed(w, transposed=False):
+    from covomix_amd import ops
+    return ops.hifigan_pack_weight(w, transposed).cuda()
+
+
+@pytest.mark.parametrize("C_,k,dils,L", [(62, 3, (1, 3, 5), 700), (31, 11, (1, 3, 5), 1000), (125, 7, (1, 3, 5), 333)])
+def test_resblock_entry_point(C_, k, dils, L):
+    from covomix_amd import _lib
+    g = torch.Generator().manual_seed(C_ * 100 + k)
+    B = 2
+    x = torch.randn(B, C_, L, generator=g)
+    w1 = [torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5 for _ in range(3)]
+    w2 = [torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5 for _ in range(3)]
+    b1 = [torch.randn(C_, generator=g) * 0.1 for _ in range(3)]
+    b2 = [torch.randn(C_, generator=g) * 0.1 for _ in range(3)]
+    xs = torch.randn(B, C_, L, generator=g)
+    y = x.double()
+    for m in range(3):                                     # ResBlock1.forward, models.py:35-42
+        xt = F.conv1d(F.leaky_relu(y, 0.1), w1[m].double(), b1[m].double(), dilation=dils[m], padding=(k - 1) * dils[m] // 2)
+        xt = F.conv1d(F.leaky_relu(xt, 0.1), w2[m].double(), b2[m].double(), padding=(k - 1) // 2)
+        y = xt + y
+    want = (y + xs.double()) / 3.0
+    a = _lib.ResblockArgs()
+    xd, tmp, out, acc = x.cuda(), torch.empty(B, C_, L, device="cuda"), torch.empty(B, C_, L, device="cuda"), xs.cuda()
+    keep = []
+    for m in range(3):
+        p1, p2, c1, c2 = _packed(w1[m]), _packed(w2[m]), b1[m].cuda(), b2[m].cuda()
+        keep += [p1, p2, c1, c2]
+        a.Wp1[m], a.Wp2[m], a.b1[m], a.b2[m], a.dil[m] = p1.data_ptr(), p2.data_ptr(), c1.data_ptr(), c2.data_ptr(), dils[m]
+    a.x, a.B, a.C, a.L, a.ksize = xd.data_ptr(), B, C_, L, k
+    a.tmp, a.out, a.accum, a.out_scale = tmp.data_ptr(), out.data_ptr(), acc.data_ptr(), 1.0 / 3.0
+    _lib.check(_lib.load().cvx_hifigan_resblock_f32(C.byref(a), torch.cuda.current_stream().cuda_stream), "cvx_hifigan_resblock_f32")
+    assert rel(out, want) < 5e-6
+    assert torch.equal(xd.cpu(), x)
+    a.out = a.x                                            # aliasing x is rejected
+    assert _lib.load().cvx_hifigan_resblock_f32(C.byref(a), torch.cuda.current_stream().cuda_stream) != 0
+
+
+def test_convt_and_pre_post_entry_points():
+    from covomix_amd import _lib
+    from covomix_amd._lib import ConvArgs
+    g = torch.Generator().manual_seed(5)
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    B, Cin, Cout, L, k, u = 2, 62, 31, 300, 4, 2          # ups[3] of config_covomix: ConvTranspose1d(62, 31, 4, 2, padding=1)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cin, Cout, k, generator=g) / (Cin * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    want = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=(k - u) // 2)
+    a = ConvArgs()
+    xd, wp, bd = x.cuda(), _packed(w, True), b.cuda()
+    out = torch.empty(B, Cout, want.shape[2], device="cuda")
+    a.x, a.B, a.Cin, a.Lin, a.Wp, a.bias = xd.data_ptr(), B, Cin, L, wp.data_ptr(), bd.data_ptr()
+    a.out, a.Cout, a.Lout, a.ksize, a.dil, a.pad, a.up = out.data_ptr(), Cout, out.shape[2], k, 1, k - 1 - (k - u) // 2, u
+    a.in_slope, a.res, a.accum, a.out_scale = 0.1, None, None, 1.0
+    _lib.check(lib.cvx_hifigan_convt_f32(C.byref(a), st), "cvx_hifigan_convt_f32")
+    assert rel(out, want) < 5e-6
+    a.up = 1
+    assert lib.cvx_hifigan_convt_f32(C.byref(a), st) != 0           # a plain conv is not a ConvTranspose1d
+    # conv_pre (Conv1d(80, C0, 7, padding=3)) and the output stage, each alone and both in one call
+    C0, T = 64, 50
+    mel = torch.randn(B, 80, T, generator=g)
+    wpre, bpre = torch.randn(C0, 80, 7, generator=g) / 24, torch.randn(C0, generator=g) * 0.1
+    want_pre = F.conv1d(mel.double(), wpre.double(), bpre.double(), padding=3)
+    pre = ConvArgs()
+    md, wpp, bpp = mel.cuda(), _packed(wpre), bpre.cuda()
+    o_pre = torch.empty(B, C0, T, device="cuda")
+    pre.x, pre.B, pre.Cin, pre.Lin, pre.Wp, pre.bias = md.data_ptr(), B, 80, T, wpp.data_ptr(), bpp.data_ptr()
+    pre.out, pre.Cout, pre.Lout, pre.ksize, pre.dil, pre.pad, pre.up = o_pre.data_ptr(), C0, T, 7, 1, 3, 1
+    pre.in_slope, pre.res, pre.accum, pre.out_scale = 1.0, None, None, 1.0
+    hx = torch.randn(B, 31, 400, generator=g)
+    wpost, bpost = torch.randn(1, 31, 7, generator=g) / 15, 0.05
+    want_post = torch.tanh(F.conv1d(F.leaky_relu(hx.double(), 0.01), wpost.double(), torch.tensor([bpost]).double(), padding=3))
+    hd, wd = hx.cuda(), wpost.reshape(31, 7).contiguous().cuda()
+    o_post = torch.empty(B, 1, 400, device="cuda")
+    _lib.check(lib.cvx_hifigan_pre_post_f32(C.byref(pre), hd.data_ptr(), wd.data_ptr(), bpost, o_post.data_ptr(), B, 31, 400, 0.01, st),
+               "cvx_hifigan_pre_post_f32")
+    assert rel(o_pre, want_pre) < 5e-6 and rel(o_post, want_post) < 5e-6
+    o_pre.zero_()
+    _lib.check(lib.cvx_hifigan_pre_post_f32(C.byref(pre), None, None, 0.0, None, 0, 0, 0, 0.0, st), "cvx_hifigan_pre_post_f32")
+    assert rel(o_pre, want_pre) < 5e-6
+    assert lib.cvx_hifigan_pre_post_f32(None, None, None, 0.0, None, 0, 0, 0, 0.0, st) != 0
