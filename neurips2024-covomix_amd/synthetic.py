@@ -279,6 +279,12 @@ HIFIGAN_COVOMIX_CONFIG = {
     "num_mels": 80,
     "sampling_rate": 8000,
     "hop_size": 160,
+    # the fields its command-line callers read (hifi-gan/inference.py:30-31, inference_e2e.py:84)
+    "n_fft": 480,
+    "win_size": 480,
+    "fmin": 0,
+    "fmax": 4000,
+    "seed": 1234,
 }
 
 

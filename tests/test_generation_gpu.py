@@ -187,3 +187,41 @@ def test_cli_from_wav_prompts_only(tmp_path, monkeypatch):
     assert Tp == 24 and seen["ids"].shape == (1, Tp + 40)                  # 0.5 s of audio = 25 mel frames, 24 HuBERT frames
     assert int((seen["ids"][0, :Tp] != tok.clamp(max=501)).sum()) <= 1
     assert float((seen["cond"][0, :Tp] - melp).abs().max()) < 5e-5 and not bool(seen["mask"][0, :Tp].any())
+
+
+def test_hifigan_command_line_callers(tmp_path):
+    """hifi-gan/inference_e2e.py (mel .npy -> wav) and hifi-gan/inference.py (wav -> mel -> wav) on a checkpoint directory in
+    the reference's layout (g_xxxxxxxx + config.json), checked against the CPU oracles."""
+    import covomix_oracle as orc
+    import mel_oracle as mo
+    import covomix_amd.synthetic as syn
+    from scipy.io.wavfile import read, write
+    from covomix_amd import hifigan_inference as hi
+    tmp = str(tmp_path)
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG); h["upsample_initial_channel"] = 32
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    os.makedirs(os.path.join(tmp, "cp"))
+    torch.save({"generator": vsd}, os.path.join(tmp, "cp", "g_00000001"))
+    json.dump(h, open(os.path.join(tmp, "cp", "config.json"), "w"))
+    folded = orc.fold_weight_norm(vsd)
+    g = np.random.RandomState(2)
+    os.makedirs(os.path.join(tmp, "mels")); os.makedirs(os.path.join(tmp, "wavs"))
+    mel = (g.randn(80, 40) * 2 - 6).astype(np.float32)
+    np.save(os.path.join(tmp, "mels", "a.npy"), mel)
+    assert hi.inference_e2e(["--input_mels_dir", os.path.join(tmp, "mels"), "--output_dir", os.path.join(tmp, "o1"),
+                             "--checkpoint_file", os.path.join(tmp, "cp", "g_00000001")]) == 1
+    sr, pcm = read(os.path.join(tmp, "o1", "a_generated_e2e.wav"))
+    ref = orc.wav_to_int16(orc.hifigan_forward(folded, h, torch.from_numpy(mel)))
+    assert sr == 8000 and pcm.shape == ref.shape == (160 * 40 + 32,)
+    assert np.abs(pcm.astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    t = np.arange(8000) / 8000.0
+    wav = (9000 * np.sin(2 * np.pi * 210 * t) + 4000 * np.sin(2 * np.pi * 1500 * t + 0.5) + 300 * g.randn(8000)).astype(np.int16)
+    write(os.path.join(tmp, "wavs", "b.wav"), 8000, wav)
+    assert hi.inference(["--input_wavs_dir", os.path.join(tmp, "wavs"), "--output_dir", os.path.join(tmp, "o2"),
+                         "--checkpoint_file", os.path.join(tmp, "cp", "g_00000001")]) == 1
+    sr, pcm = read(os.path.join(tmp, "o2", "b_generated.wav"))
+    m = mo.mel_spectrogram(torch.from_numpy(wav.astype(np.float32) / 32768.0)[None])[0]
+    ref = orc.wav_to_int16(orc.hifigan_forward(folded, h, m))
+    assert pcm.shape == ref.shape == (160 * 50 + 32,)
+    err = np.abs(pcm.astype(np.int32) - ref.astype(np.int32))
+    assert err.max() <= 16 and (err > 2).mean() < 0.01
