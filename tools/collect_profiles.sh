@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun from the repo root):
 #   bench JSON lines (default precision with the CPU baseline; opt-in f16), rocprofv3 kernel stats of the same command,
-#   and the two PMC passes (FETCH_SIZE / WRITE_SIZE, separately, with --kernel-trace only).
+#   the two HBM PMC passes (FETCH_SIZE / WRITE_SIZE, separately, with --kernel-trace only) and one SQ pass
+#   (cycles, MFMA-busy cycles -> effective clock and matrix-pipe utilisation per kernel: tools/sq_summary.py).
 # Outputs land in gpurun_out/prof/; copy the summaries into profiles/ afterwards (tools/pmc_summary.py, stats_summary.py).
 set -u
 REPO=$(pwd)
@@ -13,6 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_sq -- python $REPO/bench.py --no-cpu-baseline --steps 1 --warmup 1 > $OUT/pmc_sq.log 2>&1
 cd $REPO
 find $OUT -name "*.csv" | head -20
 cat $OUT/bench_n1.json | cut -c1-400
