@@ -432,8 +432,11 @@ def tokenize_directory(process_dir: str, target_dir: str, hubert_path: str, km_p
     """fairseq-hubert/get_fisher_semantic_tokens.py:30-40: every *.wav -> <name>.hubert_code.npy (array of str codes)."""
     import glob
     import os
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:                                           # independent files: one GPU per rank, no collective
+        torch.cuda.set_device(local)
     encoder = HubertTokenizer(hubert_path=hubert_path, hubert_layer=hubert_layer, km_path=km_path)
-    files = sorted(glob.glob(os.path.join(process_dir, "*.wav")))
+    files = sorted(glob.glob(os.path.join(process_dir, "*.wav")))[rank::world]
     os.makedirs(target_dir, exist_ok=True)
     for process_file in files:
         codes = encoder.wav2code(process_file, 1).split(" ")

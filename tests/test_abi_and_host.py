@@ -236,3 +236,29 @@ def test_text2semantic_checkpoint_layout_and_ema_order(tmp_path):
     from covomix_amd._lib import CovomixHipError
     with pytest.raises(CovomixHipError):                        # no CPU fallback
         m.synthesis_sample_text2semantic(torch.tensor([[1, 2]]))
+
+
+def test_tokenizer_cli_shards_files_by_rank(monkeypatch, tmp_path):
+    """fairseq-hubert/get_fisher_semantic_tokens.py drop-in: files are dealt round-robin over RANK / WORLD_SIZE (host logic
+    only - the encoder is stubbed, no GPU)."""
+    import numpy as np
+    import covomix_amd.hubert as hb
+    for n in ("a", "b", "c", "d", "e"):
+        open(tmp_path / f"{n}.wav", "wb").close()
+
+    class Fake:
+        def __init__(self, **kw):
+            pass
+
+        def wav2code(self, path, channel_id=1):
+            return "1 2 3"
+    monkeypatch.setattr(hb, "HubertTokenizer", Fake)
+    monkeypatch.setattr(hb.torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    out = tmp_path / "codes"
+    assert hb.tokenize_directory(str(tmp_path), str(out), "x.pt", "km.bin") == 2
+    import os
+    assert sorted(os.listdir(out)) == ["b.hubert_code.npy", "d.hubert_code.npy"]
+    assert np.load(out / "b.hubert_code.npy").tolist() == ["1", "2", "3"]
