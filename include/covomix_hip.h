@@ -102,7 +102,11 @@ typedef struct {
      * a->ldw >= 2K halves), so that a K-step of a row is a whole 128-byte cache line.  Large-problem kernel only
      * (pre-split A, M >= 2048, N >= 512). */
     int32_t w_interleaved;
+    /* Kernel selection for A/B measurements (0 = default).  Bit 0: keep interleaved large problems on the two-stage
+     * kernel instead of the eight-phase ping-pong kernel (csrc/gemm_f16x3_p8.hip); results agree to fp32 rounding. */
+    int32_t flags;
 } cvx_gemm_split_io;
+#define CVX_GEMM_FLAG_TWO_STAGE 1
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
                    const cvx_gemm_split_io* io, cvx_stream_t s);

@@ -41,6 +41,7 @@ class GemmSplitIO(C.Structure):
         ("Vt_hi", C.c_void_p), ("Vt_lo", C.c_void_p), ("vt_ld", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
         ("w_interleaved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 

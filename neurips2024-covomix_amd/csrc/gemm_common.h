@@ -237,6 +237,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// pre-split A operand of the all-DMA kernels: (hi, lo) fp16 matrices (and the A2 pair of a K-split), row strides in halves
+struct PreSplitA { const _Float16* hi; const _Float16* lo; int64_t ld; const _Float16* hi2; const _Float16* lo2; int64_t ld2; };
+
+// gemm_f16x3_p8.hip: 256 x 256 tile, eight-phase ping-pong main loop on interleaved operands (A and W as [hi 32 | lo 32] lines).
+// Returns false when the problem does not qualify (the caller then uses the two-stage kernel).
+bool launch_gemm_f16x3_p8(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
+                          int map_mode, hipStream_t st);
+
 int validate_gemm_args(const cvx_gemm_args* a);   // shared argument checks (gemm_f32.hip)
 
 }  // namespace cvxg

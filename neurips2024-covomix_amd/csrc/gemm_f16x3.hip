@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 // tiles are requested STAGES-1 steps ahead and retired with a COUNTED vmcnt + a raw s_barrier, so loads stay in
 // flight across barriers (a 24-MFMA step is only ~770 cycles - far shorter than an L2/HBM round trip, which a
 // 2-stage scheme cannot hide).  No staging VGPRs, no split VALU work, no ds_write in the loop.
-struct PreSplitA { const f16* hi; const f16* lo; int64_t ld; const f16* hi2; const f16* lo2; int64_t ld2; };
+// (PreSplitA lives in gemm_common.h: shared with gemm_f16x3_p8.hip)
 
 // Split-K (ksplit > 1, small problems only): blockIdx.y selects a K slice of k_per columns; the block writes its raw
 // partial sums (fp32, no epilogue) to `partial` [ksplit][M][N] and splitk_reduce_kernel finishes the job.
@@ -725,7 +725,10 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         if (single)
             hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
-        else if (w_il && a_il)
+        else if (w_il && a_il && !(io->flags & CVX_GEMM_FLAG_TWO_STAGE) &&
+                 cvxg::launch_gemm_f16x3_p8(*a, A, wh, acc_scale, so, map_mode, st)) {
+            /* eight-phase ping-pong kernel (gemm_f16x3_p8.hip) */
+        } else if (w_il && a_il)
             hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true, true>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
         else if (w_il)

@@ -67,6 +67,9 @@ def _pair(x, rows=None, cols=None):
     return hi.data_ptr(), _p(lo), hi.stride(0) if hi.ndim == 2 else hi.shape[-1]
 
 
+# dev A/B: CVX_GEMM_P8=0 keeps interleaved large problems on the two-stage kernel (read here, never inside the library)
+_GEMM_FLAGS = 0 if __import__("os").environ.get("CVX_GEMM_P8", "1") == "1" else 1
+
 _SPLITK_WS: dict = {}
 
 
@@ -156,6 +159,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                   f"out_split={out_split is not None} vt={vt_split is not None} ws={bool(io.workspace)}", file=sys.stderr, flush=True)
         w_hi_ptr, w_lo_ptr = hi.data_ptr(), _p(lo)
         if use_il:
+            io.flags = _GEMM_FLAGS
             io.w_interleaved, g.ldw = 1, 2 * K
             w_hi_ptr, w_lo_ptr, inv_scale = il.data_ptr(), il.data_ptr() + 64, inv_il
         _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), w_hi_ptr, w_lo_ptr, inv_scale, C.byref(io), _stream()),
