@@ -88,7 +88,7 @@ typedef struct {
     const uint16_t* A2_hi; const uint16_t* A2_lo; int64_t lda2_h;
     uint16_t* C_hi; uint16_t* C_lo; int64_t ldc_h;
     int32_t write_f32;
-    /* QKV mode (optional; needs the RoPE arguments, N = 3*H*64, T % 4 == 0, write_f32 = 0): the v columns are not
+    /* QKV mode (optional; needs the RoPE arguments, N = 3*H*64, write_f32 = 0; T % 4 != 0 is accepted but stores the v columns 2 bytes at a time): the v columns are not
      * written to C_hi/C_lo but TRANSPOSED per (sequence, head) to Vt_*[((b*H + h)*64 + d) * vt_ld + slot(t)] (slot swaps bits 2 and 3
      * of t: four-frame groups in the order 0, 2, 1, 3 inside every 16 frames), the layout
      * cvx_attention_f16x3 reads its V^T tiles from. */
@@ -105,9 +105,18 @@ typedef struct {
     /* Kernel selection for A/B measurements (0 = default).  Bit 0: keep interleaved large problems on the two-stage
      * kernel instead of the eight-phase ping-pong kernel (csrc/gemm_f16x3_p8.hip); results agree to fp32 rounding. */
     int32_t flags;
+    /* Activation scales: DEVICE pointers to one float each (NULL = 1.0), powers of two.  a_scale_dev = the factor the
+     * producer of A_hi/A_lo (and of A2_*: both operands must share it) multiplied the values by before splitting - the
+     * accumulators are divided by it (exact); c_scale_dev / vt_scale_dev = the factor applied to the values written to
+     * C_hi/C_lo and Vt_hi/Vt_lo (the fp32 store of C is never scaled).  They keep split pairs inside fp16's
+     * full-precision window (|x| in [2^-3, 2^16)) whatever the magnitude of the tensor; living in device memory they can
+     * be computed by an earlier kernel without a host round trip (and replayed from a captured graph). */
+    const float* a_scale_dev; const float* c_scale_dev; const float* vt_scale_dev;
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
+/* the same with an additional DEVICE-resident factor (the pair holds w * scale * *scale_dev; scale_dev may be NULL) */
+int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
                    const cvx_gemm_split_io* io, cvx_stream_t s);
 
@@ -119,6 +128,12 @@ int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, fl
                        uint16_t* y_hi, uint16_t* y_lo,   /* optional fp16 (hi, lo) split copy of y; y may then be NULL */
                        int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
                        cvx_stream_t s);
+/* the same; the split copy (y_hi, y_lo) holds y * *split_scale_dev (a power of two in DEVICE memory, NULL = 1: the
+ * activation pre-scale of cvx_gemm_split_io.a_scale_dev).  The fp32 output y is never scaled. */
+int cvx_adarmsnorm_scaled_f32(const float* x, const float* gamma, const float* beta, float* y,
+                              uint16_t* y_hi, uint16_t* y_lo,
+                              int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
+                              const float* split_scale_dev, cvx_stream_t s);
 
 /* out[b,t,h*64+d] = softmax_j( q[b,h,t,:] . k[b,h,j,:] * scale ) @ v[b,h,j,d]
  * Attend.forward non-flash branch (attend.py:108-126) without materialising the T x T
@@ -137,6 +152,13 @@ int cvx_attention_f32(const float* qkv, float* out,
 int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
                         float* out, uint16_t* out_hi, uint16_t* out_lo,
                         int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale, cvx_stream_t s);
+/* the same with activation pre-scales (DEVICE scalars, powers of two, NULL = 1): qk_* hold (q | k) * *qk_scale_dev and
+ * vt_* hold v * *v_scale_dev (cvx_gemm_split_io.c_scale_dev / vt_scale_dev of the to_qkv GEMM); both are divided out
+ * (the fp32 `out` is the true value) and the split output holds out * *out_scale_dev for the to_out GEMM. */
+int cvx_attention_f16x3_scaled(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                               float* out, uint16_t* out_hi, uint16_t* out_lo,
+                               int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale,
+                               const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s);
 
 /* y[b,t,c] = GELU( bias[c] + sum_k w[c,k] * x[b,t+k-K/2,c] ) + x[b,t,c]
  * ConvPositionEmbed + residual (acoustic.py:141-161, :508), channels-last, K == 31. */

@@ -42,6 +42,7 @@ class GemmSplitIO(C.Structure):
         ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
         ("w_interleaved", C.c_int32),
         ("flags", C.c_int32),
+        ("a_scale_dev", C.c_void_p), ("c_scale_dev", C.c_void_p), ("vt_scale_dev", C.c_void_p),
     ]
 
 
@@ -143,6 +144,12 @@ SIGNATURES = {
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "cvx_split_f16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_adarmsnorm_scaled_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_attention_f16x3_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "cvx_gemm_f16x3": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(GemmSplitIO),
                                  C.c_void_p]),
     "cvx_adarmsnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

@@ -91,12 +91,92 @@ class VectorField:
                         ".2.to_qkv" in k or ".2.to_out" in k or ".4.0." in k or ".4.2." in k
                         or (k.startswith("transformer.layers.") and k.endswith(".0.weight")) or k == "to_pred.weight"):
                     self.split[k] = ops.split_f16(v, with_lo=(precision == "f16x3"))
+        self._init_gain_model()
         # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
         self.split_il: Dict[str, tuple] = {}
         if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
             for k, v in self.split.items():
                 if v[0].shape[0] >= 512:
                     self.split_il[k] = ops.split_f16_interleaved(v)
+
+    # ------------------------------------------------------------------ activation pre-scales (scale-free split pairs)
+    # An (fp16 hi, fp16 lo) pair has full (22-bit) precision only while |x| is inside [2^-3, 2^16): below, `lo` falls into
+    # fp16's subnormals (absolute floor 2^-25), above, `hi` saturates.  Every split ACTIVATION tensor is therefore written
+    # times a power of two that puts its expected RMS at 2^4 (full precision for elements from 2^-7 to 2^12 times the RMS),
+    # and the consuming kernel divides it out of its fp32 accumulators - exactly what load-time packing does for the
+    # weights.  The powers come from a GAIN MODEL, not from the data: RMS of an AdaRMSNorm output = sqrt(mean(gamma^2) +
+    # mean(beta^2)) of that evaluation time's table row (exact for RMS-normalised input), RMS after a Linear = input RMS
+    # x ||W||_F / sqrt(N).  They are computed on the device by prepare() (no host round trip: the solve stays
+    # graph-capturable), depend on the weights and the evaluation times only - never on the utterance - and sit in one
+    # small tensor the kernels read through DEVICE pointers (cvx_gemm_split_io.a_scale_dev, ...).
+    N_KINDS = 6          # per (evaluation, layer): normed->qkv, q|k, v, attention out, normed->ff1, ff hidden
+    TARGET_RMS = 16.0
+
+    def _init_gain_model(self) -> None:
+        d, sd = self.d, self.sd
+        inner = d["heads"] * 64
+
+        def fro(w, rows=None):              # ||W||_F / sqrt(N): RMS gain of y = W x for x with unit per-element RMS
+            w = w if rows is None else w[rows[0]:rows[1]]
+            return float(w.double().square().sum().sqrt() / (w.shape[0] ** 0.5))
+        g = dict(qk=[], v=[], o=[], f1=[], b1=[], f2=[], comb=[])
+        for i in range(d["depth"]):
+            p = f"transformer.layers.{i}"
+            wq = sd[p + ".2.to_qkv.weight"]
+            g["qk"].append(fro(wq, (0, 2 * inner))); g["v"].append(fro(wq, (2 * inner, 3 * inner)))
+            g["o"].append(fro(sd[p + ".2.to_out.weight"]))
+            g["f1"].append(fro(sd[p + ".4.0.weight"])); g["b1"].append(float(sd[p + ".4.0.bias"].double().square().mean()))
+            g["f2"].append(fro(sd[p + ".4.2.weight"]))
+            g["comb"].append(fro(sd[p + ".0.weight"]) if (p + ".0.weight") in sd else 0.0)
+        dev = self.device
+        self.gain = {k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in g.items()}
+        # embedding output: x columns (x ~ N(0,1) at t = 0, O(1) later), phoneme-embedding columns (RMS of the table), cond
+        # columns (log-mel prompt frames, |.| of a few units: taken as RMS 4), bias
+        we = sd["to_embed.weight"].double()
+        n_x, n_e = d["dim_out"], d["streams"] * d["dim_emb"]
+        emb_ms = float(sd["to_phoneme_emb.weight"].double().square().mean())
+        ms = lambda w: float(w.square().sum() / w.shape[0])
+        self.embed_ms = (ms(we[:, :n_x]) + emb_ms * ms(we[:, n_x:n_x + n_e]) + 16.0 * ms(we[:, n_x + n_e:])
+                         + float(sd["to_embed.bias"].double().square().mean()))
+        self.has_comb = [c > 0.0 for c in g["comb"]]
+        gf = float(sd["transformer.final_norm.gamma"].double().square().mean().sqrt())
+        self.pred_scale = torch.tensor([self._pow2(self.TARGET_RMS / max(gf, 1e-30))], dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def _pow2(x: float) -> float:
+        import math
+        return 2.0 ** max(-40, min(40, round(math.log2(x)))) if x > 0 and math.isfinite(x) else 1.0
+
+    def _activation_scales(self, table: torch.Tensor) -> tuple:
+        """(S [n_eval, depth, N_KINDS], H [1]) power-of-two pre-scales from the gain model; device tensors, no host sync."""
+        d, gn = self.d, self.gain
+        n, L, dim = table.shape[0], d["depth"], d["dim"]
+        tab = table.view(n, L, 4, dim)
+        ms = tab.square().mean(dim=-1)                                  # [n, L, 4]: mean(gamma_a^2), mean(beta_a^2), gamma_f, beta_f
+        rn_a = (ms[..., 0] + ms[..., 1]).sqrt()
+        rn_f = (ms[..., 2] + ms[..., 3]).sqrt()
+        qk, v = rn_a * gn["qk"], rn_a * gn["v"]
+        att = v * 0.25                                                  # softmax averages values: between v_rms / sqrt(T) and v_rms
+        ff = ((rn_f * gn["f1"]).square() + gn["b1"]).sqrt() * 0.5       # GELU(z) ~ z / 2 .. 0.6 z
+        rms = torch.stack([rn_a, qk, v, att, rn_f, ff], dim=-1)         # [n, L, 6]
+        tiny = torch.finfo(torch.float32).tiny
+        S = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / rms.clamp_min(tiny))).clamp(-40, 40)).contiguous()
+        # residual stream (split twins of h feed the skip combiners; all of them share ONE scale because a combiner reads two
+        # of them as the halves of its K range): embedding output, then every block adds its attention and FF output
+        h2 = torch.full((), self.embed_ms * 2.25, dtype=torch.float32, device=table.device)   # x + GELU(conv(x)): up to 1.5 x
+        hmax = h2
+        att_o = (att * gn["o"]).square().amax(dim=0)                    # [L]: largest over the evaluation times
+        ff_o = (ff * gn["f2"]).square().amax(dim=0)
+        skips = []
+        for i in range(L):
+            if self.has_comb[i]:
+                h2 = (h2 + skips.pop()) * gn["comb"][i].square()
+            else:
+                skips.append(h2)
+            h2 = h2 + att_o[i] + ff_o[i]
+            hmax = torch.maximum(hmax, h2)
+        H = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / hmax.sqrt().clamp_min(tiny))).clamp(-40, 40)).reshape(1).contiguous()
+        return S, H
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, Bt: int, T: int) -> dict:
@@ -161,7 +241,15 @@ class VectorField:
                              d["null_id"], g[M1:], M1)
         w_rest = sd["to_embed.weight"][:, d["dim_out"]:]
         ops.gemm(g, w_rest, ws["base"], bias=sd["to_embed.bias"])
-        return dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null)
+        ctx = dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null)
+        if self.precision in ("f16x3", "f16") and os.environ.get("CVX_ACT_SCALES", "1") == "1":
+            S, H = self._activation_scales(table)
+            ctx["scales"], ctx["h_scale"] = S, H                           # keep the tensors alive as long as the pointers
+            p0 = S.data_ptr()
+            K = self.N_KINDS
+            ctx["sp"] = [[[p0 + 4 * ((e * d["depth"] + i) * K + k) for k in range(K)] for i in range(d["depth"])] for e in range(n)]
+            ctx["hp"] = H.data_ptr()
+        return ctx
 
     # ------------------------------------------------------------------ one evaluation (both CFG branches)
     @staticmethod
@@ -221,9 +309,12 @@ class VectorField:
         # residual-stream tensors that later feed a skip combiner (as x or as the popped skip) also get a split
         # twin, so that GEMM takes both operands pre-split (all-DMA kernel) instead of splitting on the fly
         twin = {id(b): pr for b, pr in zip(ws["h"], ws["h16"])} if split_io else None
+        sp_step = ctx["sp"][step] if (split_io and "sp" in ctx) else None
+        hp = ctx["hp"] if sp_step is not None else None
+        pp = self.pred_scale.data_ptr() if sp_step is not None else None
         if split_io:
             tw = twin[id(h)]
-            ops.split_act_f16(h, tw) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw)
+            ops.split_act_f16(h, tw, scale=hp) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw, scale=hp)
 
         skips: List[torch.Tensor] = []
         for i in range(d["depth"]):
@@ -237,7 +328,7 @@ class VectorField:
                 comb = take()
                 if split_io:
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
-                             a_split=twin[id(h)], a2_split=twin[id(s)])
+                             a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp)
                 else:
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"))
                 free += [h, s]
@@ -247,25 +338,28 @@ class VectorField:
                 keep_input = True
             if split_io:
                 n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
-                ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16)
-                if T % 4 == 0:      # q | k split row-major, v split + transposed, straight into the f16x3 attention
-                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
-                             write_f32=False)
-                    ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
-                else:
-                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16)
-                    ops.attention(ws["qkv"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16)
+                # device pointers of this (evaluation, layer)'s activation pre-scales: normed, q|k, v, attention out, normed, ff
+                s_na, s_qk, s_v, s_at, s_nf, s_ff = sp_step[i] if sp_step is not None else (None,) * 6
+                ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16, split_scale=s_na)
+                # q | k split row-major, v split + transposed, straight into the f16x3 attention (any T: sequences whose
+                # length is not a multiple of 4 store their v columns 2 bytes at a time)
+                ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                         w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
+                         write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
+                ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16,
+                                    qk_scale=s_qk, v_scale=s_v, out_scale=s_at)
                 h_att = take() if keep_input else h
-                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"), a_split=a16)
+                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
+                         a_split=a16, a_scale=s_at)
                 h = h_att
-                ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16)
+                ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
                 ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
-                         w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False)
+                         w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
+                         a_scale=s_nf, c_scale=s_ff)
+                last = i + 1 == d["depth"]
                 ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h,
                          w_split=sp(p + ".4.2.weight"), w_il=il(p + ".4.2.weight"), a_split=f16,
-                         out_split=twin[id(h)] if i + 1 < d["depth"] else None)
+                         out_split=None if last else twin[id(h)], a_scale=s_ff, c_scale=None if last else hp)
                 continue
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])
             ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
@@ -279,8 +373,8 @@ class VectorField:
                      w_split=sp(p + ".4.0.weight"))
             ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h, w_split=sp(p + ".4.2.weight"))
         if split_io:
-            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"])
-            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"])
+            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"], split_scale=pp)
+            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"], a_scale=pp)
         else:
             ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])
             ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"))

@@ -63,8 +63,12 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
                                                                 const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
-                                                                int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e)
+                                                                int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
+                                                                const float* __restrict__ qk_scale, const float* __restrict__ v_scale,
+                                                                const float* __restrict__ out_scale)
 {
+    // activation pre-scales (device scalars, powers of two): scores carry qk_scale^2, O carries v_scale
+    if (qk_scale) { const float q = *qk_scale; scale_log2e /= q * q; }
     __shared__ __attribute__((aligned(16))) f16 smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / l_tot / (v_scale ? *v_scale : 1.f);        // fp32 output: the true value
+    const float osc = out_scale ? *out_scale : 1.f;                        // split output: times the consumer's pre-scale
     if (q_valid) {
         const int64_t o_off = ((int64_t)b * T + qrow) * (H * HD) + head * HD + 4 * g;
 #pragma unroll
@@ -246,6 +251,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
                 *reinterpret_cast<f32x4*>(out + o_off + 32 + 8 * gq) = c;
             }
             if (out_hi) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] *= osc; c[e] *= osc; }
                 store_split4(out_hi, out_lo, o_off + 8 * gq, a);
                 store_split4(out_hi, out_lo, o_off + 32 + 8 * gq, c);
             }
@@ -255,9 +262,10 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
 
 }  // namespace
 
-extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
-                                   float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                   int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale, cvx_stream_t s)
+extern "C" int cvx_attention_f16x3_scaled(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                                          float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                          int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale,
+                                          const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s)
 {
     const bool single = (qk_lo == nullptr);        // hi halves only: plain fp16 operands, one product
     CVX_REQUIRE(qk_hi && vt_hi && ((qk_lo == nullptr) == (vt_lo == nullptr)) && (out || out_hi) &&
@@ -275,13 +283,20 @@ extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo,
                            reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
                            reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
                            out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev);
     else
         hipLaunchKernelGGL(attention_f16x3_kernel<3>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                            reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
                            reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
                            out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev);
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;
+}
+
+extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                                   float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                   int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale, cvx_stream_t s)
+{
+    return cvx_attention_f16x3_scaled(qk_hi, qk_lo, vt_hi, vt_lo, out, out_hi, out_lo, Bt, T, Tp, H, scale, nullptr, nullptr, nullptr, s);
 }

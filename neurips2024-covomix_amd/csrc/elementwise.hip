@@ -56,11 +56,13 @@ template <int NV>
 __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
-                                                        int64_t rows, int D, int64_t rows_per_group, float scale, float eps)
+                                                        int64_t rows, int D, int64_t rows_per_group, float scale, float eps,
+                                                        const float* __restrict__ split_scale)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const float ssc = split_scale ? *split_scale : 1.f;      // power-of-two pre-scale of the split copy (device scalar)
     const float* xr = x + row * D;
     const int64_t g = row / rows_per_group;
     const float* gr = gamma + g * D;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
                 for (int e = 0; e < 4; ++e) o[e] += bb[e];
             }
             if (y) *reinterpret_cast<f32x4*>(yr + 4 * j) = o;
-            if (y_hi) store_split4(y_hi, y_lo, row * D + 4 * j, o);
+            if (y_hi) { const f32x4 os = {o[0] * ssc, o[1] * ssc, o[2] * ssc, o[3] * ssc}; store_split4(y_hi, y_lo, row * D + 4 * j, os); }
         }
     }
 }
@@ -103,11 +105,13 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ y,
                                                                 _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
-                                                                int64_t rows, int D, int64_t rows_per_group, float scale, float eps)
+                                                                int64_t rows, int D, int64_t rows_per_group, float scale, float eps,
+                                                                const float* __restrict__ split_scale)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const float ssc = split_scale ? *split_scale : 1.f;
     const float* xr = x + row * D;
     const int64_t g = row / rows_per_group;
     float ss = 0.f;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
             for (int e = 0; e < 4; ++e) o[e] += bb[e];
         }
         if (y) *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
-        if (y_hi) store_split4(y_hi, y_lo, row * D + 4 * j, o);
+        if (y_hi) { const f32x4 os = {o[0] * ssc, o[1] * ssc, o[2] * ssc, o[3] * ssc}; store_split4(y_hi, y_lo, row * D + 4 * j, os); }
     }
 }
 
@@ -278,10 +282,10 @@ extern "C" int cvx_mel_log_transpose_f32(const float* x, float* y, int64_t T, in
     return CVX_OK;
 }
 
-extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+extern "C" int cvx_adarmsnorm_scaled_f32(const float* x, const float* gamma, const float* beta, float* y,
                                   uint16_t* y_hi_, uint16_t* y_lo_,
                                   int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
-                                  cvx_stream_t s)
+                                  const float* split_scale_dev, cvx_stream_t s)
 {
     CVX_REQUIRE(x && gamma && (y || y_hi_) && (y_hi_ || !y_lo_), "adarmsnorm: null pointer");     // y_lo == NULL: hi halves only
     _Float16* y_hi = reinterpret_cast<_Float16*>(y_hi_);
@@ -290,12 +294,20 @@ extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const floa
     if (rows == 0) return CVX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
-    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
-    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
-    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps);
-    CVX_CHECK_LAUNCH("cvx_adarmsnorm_f32");
+    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
+    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
+    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
+    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
+    CVX_CHECK_LAUNCH("cvx_adarmsnorm_scaled_f32");
     return CVX_OK;
+}
+
+extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                  uint16_t* y_hi, uint16_t* y_lo,
+                                  int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,
+                                  cvx_stream_t s)
+{
+    return cvx_adarmsnorm_scaled_f32(x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, nullptr, s);
 }
 
 extern "C" int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,

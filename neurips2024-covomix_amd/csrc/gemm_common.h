@@ -33,8 +33,19 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 // V^T tiles from.  slot(t) swaps bits 2 and 3 of t: inside every block of 16 frames the four-frame groups are stored
 // in the order 0, 2, 1, 3, so that the eight keys one lane of the attention kernel's O^T += V^T.P^T MFMA needs
 // (keys 16s+4g+{0..3} and 16s+8+4g+{0..3}, the order its P registers already have) are ONE 16-byte LDS read.
+// Activation scales (DEVICE pointers to one float each, NULL = 1): power-of-two factors that keep the split pairs inside
+// fp16's full-precision window whatever the magnitude of the tensor - a_scale is what the PRODUCER of the A (and A2)
+// pair multiplied it by (the accumulators are divided by it, exactly), c_scale / vt_scale multiply the values written to
+// hi/lo and vt_hi/vt_lo (the fp32 store of C is never scaled).
 struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
-                  _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld; };
+                  _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld;
+                  const float* c_scale; const float* vt_scale; const float* a_scale; };
+
+// accumulator factor: 1 / (weight pre-scale) / (activation pre-scale); both powers of two, so the division is exact
+__device__ __forceinline__ float total_acc_scale(float acc_scale, const SplitOut& so)
+{
+    return so.a_scale ? acc_scale / *so.a_scale : acc_scale;
+}
 typedef _Float16 cvx_f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int vt_slot(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
@@ -79,6 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
         const int head = (colw - p.rope_cols) / 64;
         const float b_lo_v = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
         const float b_hi_v = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
+        const float vs = so.vt_scale ? *so.vt_scale : 1.f;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -93,12 +105,12 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                     cvx_f16x4 vh, vl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = fminf(fmaxf(acc[mi][hsel][4 * rg + e] + bias, -65504.f), 65504.f);
+                        const float x = fminf(fmaxf((acc[mi][hsel][4 * rg + e] + bias) * vs, -65504.f), 65504.f);
                         vh[e] = (_Float16)x;
                         vl[e] = (_Float16)(x - (float)vh[e]);
                     }
                     const int64_t base = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld;
-                    if (t0 + 3 < T && row0 + 3 < p.M) {
+                    if ((t0 & 3) == 0 && t0 + 3 < T && row0 + 3 < p.M) {
                         *reinterpret_cast<cvx_f16x4*>(so.vt_hi + base + vt_slot(t0)) = vh;
                         if (so.vt_lo) *reinterpret_cast<cvx_f16x4*>(so.vt_lo + base + vt_slot(t0)) = vl;
                     } else {
@@ -118,6 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
         return;
     }
     const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
+    const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
     const float b_lo = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
     const float b_hi = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
 
@@ -179,8 +192,8 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
                     cvx_f16x4 h0, l0, h1, l1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x0 = fminf(fmaxf(vlo[e], -65504.f), 65504.f);
-                        const float x1 = fminf(fmaxf(vhi[e], -65504.f), 65504.f);
+                        const float x0 = fminf(fmaxf(vlo[e] * cs, -65504.f), 65504.f);
+                        const float x1 = fminf(fmaxf(vhi[e] * cs, -65504.f), 65504.f);
                         h0[e] = (_Float16)x0; l0[e] = (_Float16)(x0 - (float)h0[e]);
                         h1[e] = (_Float16)x1; l1[e] = (_Float16)(x1 - (float)h1[e]);
                     }
@@ -223,8 +236,8 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
             }
             if (so.hi) {
                 const bool il = so.lo == so.hi + 32;
-                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_lo) : c_lo), lo);
-                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_hi) : c_hi), hi);
+                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_lo) : c_lo), lo * cs);
+                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_hi) : c_hi), hi * cs);
             }
         }
     }

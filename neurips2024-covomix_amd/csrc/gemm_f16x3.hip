@@ -25,11 +25,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int TILE_H = 128 * BK;            // halves per operand tile (8 KiB)
 constexpr float F16_MAX = 65504.f;
 
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo)
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo, float pre = 1.0f)
 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float x = fminf(fmaxf(v[e], -F16_MAX), F16_MAX);     // saturate instead of inf - inf
+        const float x = fminf(fmaxf(v[e] * pre, -F16_MAX), F16_MAX);     // saturate instead of inf - inf
         const f16 h = (f16)x;
         hi[e] = h;
         lo[e] = (f16)(x - (float)h);
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 
     f32x4 ra[4];
     const int nk = p.K / BK;
+    const float a_pre = so.a_scale ? *so.a_scale : 1.0f;      // activation pre-scale applied while splitting on the fly
     {   // prologue: tile 0 -> stage 0
         const bool sw = (0 == switch_tile);
 #pragma unroll
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 hi, lo;
-            split4(ra[i], hi, lo);
+            split4(ra[i], hi, lo, a_pre);
             *reinterpret_cast<f16x4*>(S0 + a_st[i]) = hi;
             *reinterpret_cast<f16x4*>(S0 + TILE_H + a_st[i]) = lo;
         }
@@ -180,13 +181,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 hi, lo;
-            split4(ra[i], hi, lo);
+            split4(ra[i], hi, lo, a_pre);
             *reinterpret_cast<f16x4*>(Sn + a_st[i]) = hi;
             *reinterpret_cast<f16x4*>(Sn + TILE_H + a_st[i]) = lo;
         }
         __syncthreads();
     }
-    if (acc_scale != 1.0f) {        // undo the power-of-two weight pre-scale (exact)
+    acc_scale = total_acc_scale(acc_scale, so);
+    if (acc_scale != 1.0f) {        // undo the power-of-two weight (and activation) pre-scale (exact)
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
     float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode, int k_per, float* __restrict__ partial)
 {
     cvx_gemm_args p = p_in;
+    acc_scale = total_acc_scale(acc_scale, so);
     const int k_begin = k_per > 0 ? (int)blockIdx.y * k_per : 0;
     if (k_per > 0) {            // this block: columns [k_begin, k_begin + k_per) of [A | A2] and of W, plain fp32 store
         p.K = k_per;
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc_scale = total_acc_scale(acc_scale, so);
     if (acc_scale != 1.0f) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
@@ -574,10 +578,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
 }
 
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ w, f16* __restrict__ hi,
-                                                       f16* __restrict__ lo, int64_t n, float scale)
+                                                       f16* __restrict__ lo, int64_t n, float scale, const float* __restrict__ scale_dev)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (scale_dev) scale *= *scale_dev;
     const float x = fminf(fmaxf(w[i] * scale, -F16_MAX), F16_MAX);
     const f16 h = (f16)x;
     const int64_t o = (lo == hi + 32) ? (((i >> 5) << 6) | (i & 31)) : i;      // interleaved pair: [hi 32 | lo 32] blocks
@@ -587,15 +592,22 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s)
+extern "C" int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev,
+                                 cvx_stream_t s)
 {
     CVX_REQUIRE(w && hi && n >= 0, "split_f16: bad arguments");      // lo == NULL: plain fp16 cast (saturating)
     if (n == 0) return CVX_OK;
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale);
+                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale, scale_dev);
     CVX_CHECK_LAUNCH("cvx_split_f16");
     return CVX_OK;
 }
+
+extern "C" int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s)
+{
+    return cvx_split_f16_dev(w, hi, lo, n, scale, nullptr, s);
+}
+
 
 // out = epilogue( sum_s partial[s] ) in a fixed order: bias -> act -> residual -> fp32 and / or split store
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, const cvx_gemm_args p, SplitOut so)
@@ -620,8 +632,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     if (so.write_f32) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
     if (so.hi) {
+        const float cs = so.c_scale ? *so.c_scale : 1.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + ((so.lo == so.hi + 32) ? il_col(col + e) : col + e), v[e]);
+        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + ((so.lo == so.hi + 32) ? il_col(col + e) : col + e), v[e] * cs);
     }
 }
 
@@ -675,11 +688,12 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
             so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
         }
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
+        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev;
         if (io->Vt_hi || io->Vt_lo) {
             CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
                         (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= ((a->rope_T + 15) / 16) * 16 && io->vt_ld % 8 == 0 &&
-                        a->M % a->rope_T == 0 && a->rope_T % 4 == 0 && so.write_f32 == 0,
-                        "gemm_f16x3: QKV-transpose output needs the RoPE arguments, N = 3*H*64, T %% 4 == 0, vt_ld >= T rounded up to 16 and write_f32 = 0");
+                        a->M % a->rope_T == 0 && so.write_f32 == 0,
+                        "gemm_f16x3: QKV-transpose output needs the RoPE arguments, N = 3*H*64, vt_ld >= T rounded up to 16 and write_f32 = 0");
             so.vt_hi = reinterpret_cast<f16*>(io->Vt_hi); so.vt_lo = reinterpret_cast<f16*>(io->Vt_lo); so.vt_ld = io->vt_ld;
         }
         if (io->A_hi || io->A_lo) {

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8_kernel(
 
     if (wr == 0) CVX_P8_BARRIER();                      // pairs with group 1's last barrier (both epilogues then run together)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail's dummy pieces before LDS is released
+    acc_scale = total_acc_scale(acc_scale, so);
     if (acc_scale != 1.0f) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)

@@ -83,9 +83,18 @@ def _splitk_workspace(device) -> torch.Tensor:
     return ws
 
 
+def _sp(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of an activation pre-scale: a one-element fp32 CUDA tensor (a view into a scale table), or None = 1."""
+    if t is None or isinstance(t, int):          # (an int is a raw device address from a pre-computed pointer table)
+        return t
+    assert t.is_cuda and t.dtype == torch.float32 and t.numel() == 1
+    return t.data_ptr()
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
-         a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None) -> torch.Tensor:
+         a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None,
+         a_scale=None, c_scale=None, vt_scale=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -93,7 +102,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     a_split / a2_split = (hi, lo) fp16 copies of a / a2 (then every tile arrives by LDS-DMA; `a` is only used for
     its shape); out_split = (hi, lo) receives a split copy of the result; write_f32=False skips the fp32 store.
     Any `lo` may be None: w_split = (hi, None, 1/scale) selects the single-term fp16 kernel (plain fp16 operands,
-    fp32 accumulate; needs a_split and K % 64 == 0), whose inputs / outputs only carry the hi halves."""
+    fp32 accumulate; needs a_split and K % 64 == 0), whose inputs / outputs only carry the hi halves.
+    a_scale / c_scale / vt_scale: one-element fp32 CUDA tensors (powers of two) - the pre-scale the producer of a_split (and
+    a2_split) applied, and the pre-scales to apply to out_split / vt_split (see cvx_gemm_split_io in the header)."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -138,6 +149,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.ldw = hi.stride(0)                       # rows may be padded (row stride > K)
         io = GemmSplitIO()
         io.write_f32 = 1 if write_f32 else 0
+        io.a_scale_dev, io.c_scale_dev, io.vt_scale_dev = _sp(a_scale), _sp(c_scale), _sp(vt_scale)
         if a_split is not None and M <= 2048 and rope is None:          # small problems may split K (see the header)
             ws = _splitk_workspace(a.device)
             io.workspace, io.workspace_floats = ws.data_ptr(), ws.numel()
@@ -166,23 +178,25 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                    "cvx_gemm_f16x3")
         return out
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
+    assert a_scale is None and c_scale is None and vt_scale is None
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
     return out
 
 
-def split_act_f16(x: torch.Tensor, hi=None, lo: Optional[torch.Tensor] = None):
-    """(hi, lo) fp16 halves of an fp32 activation tensor (unscaled) - for GEMMs that take A pre-split.
-    With `hi` given and lo=None only the (saturating) fp16 cast is written; hi may be a SplitIL (interleaved pair)."""
+def split_act_f16(x: torch.Tensor, hi=None, lo: Optional[torch.Tensor] = None, scale=None):
+    """(hi, lo) fp16 halves of an fp32 activation tensor - for GEMMs that take A pre-split.
+    With `hi` given and lo=None only the (saturating) fp16 cast is written; hi may be a SplitIL (interleaved pair).
+    scale: one-element fp32 CUDA tensor, the power-of-two pre-scale (the consumer GEMM's a_scale); None = 1."""
     _chk_f32(x)
     assert x.is_contiguous()
     if isinstance(hi, SplitIL):
         h, l, _ = _pair(hi, x.shape[0], x.shape[1])
-        _lib.check(_lib.load().cvx_split_f16(x.data_ptr(), h, l, x.numel(), 1.0, _stream()), "cvx_split_f16")
+        _lib.check(_lib.load().cvx_split_f16_dev(x.data_ptr(), h, l, x.numel(), 1.0, _sp(scale), _stream()), "cvx_split_f16")
         return hi
     if hi is None:
         hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
         lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    _lib.check(_lib.load().cvx_split_f16(x.data_ptr(), hi.data_ptr(), _p(lo), x.numel(), 1.0, _stream()),
+    _lib.check(_lib.load().cvx_split_f16_dev(x.data_ptr(), hi.data_ptr(), _p(lo), x.numel(), 1.0, _sp(scale), _stream()),
                "cvx_split_f16")
     return hi, lo
 
@@ -214,8 +228,9 @@ def split_f16_interleaved(w_split):
 
 
 def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: Optional[torch.Tensor],
-               rows_per_group: Optional[int] = None, eps: float = 1e-12, out_split=None):
-    """out_split = (hi, lo) fp16 tensors: also (or, with out=None, only) write the result as a split pair."""
+               rows_per_group: Optional[int] = None, eps: float = 1e-12, out_split=None, split_scale=None):
+    """out_split = (hi, lo) fp16 tensors: also (or, with out=None, only) write the result as a split pair (times the
+    one-element device tensor split_scale, if given)."""
     _chk_f32(x, gamma, beta, out)
     assert x.is_contiguous() and (out is None or out.is_contiguous()) and gamma.stride(-1) == 1
     D = x.shape[-1]
@@ -225,8 +240,8 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
         oh, ol, ld = _pair(out_split, rows if isinstance(out_split, SplitIL) else None, D)
         assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == x.numel())
     rpg = rows if rows_per_group is None else rows_per_group
-    _lib.check(_lib.load().cvx_adarmsnorm_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), oh, ol, rows, D, rpg,
-                                              float(D) ** 0.5, eps, _stream()), "cvx_adarmsnorm_f32")
+    _lib.check(_lib.load().cvx_adarmsnorm_scaled_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), oh, ol, rows, D, rpg,
+                                                     float(D) ** 0.5, eps, _sp(split_scale), _stream()), "cvx_adarmsnorm_f32")
     return out if out is not None else out_split
 
 
@@ -250,9 +265,11 @@ def vt_frame_slots(T: int, device=None) -> torch.Tensor:
     return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
 
 
-def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None):
+def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None,
+                    qk_scale=None, v_scale=None, out_scale=None):
     """Split-precision attention on the pairs written by gemm(..., out_split=qk_split, vt_split=vt_split).
-    (hi, None) pairs select the single-term fp16 kernel."""
+    (hi, None) pairs select the single-term fp16 kernel.  qk_scale / v_scale: the pre-scales the producer applied to the
+    pairs (c_scale / vt_scale of the to_qkv GEMM); out_scale: pre-scale of out_split (a_scale of the to_out GEMM)."""
     qh, ql = qk_split
     vh, vl = vt_split
     assert (ql is None) == (vl is None)
@@ -265,8 +282,9 @@ def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T:
     if out_split is not None:
         oh, ol, _ = _pair(out_split, Bt * T if isinstance(out_split, SplitIL) else None, H * 64)
         assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == Bt * T * H * 64)
-    _lib.check(_lib.load().cvx_attention_f16x3(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), oh, ol,
-                                               Bt, T, Tp, H, scale, _stream()), "cvx_attention_f16x3")
+    _lib.check(_lib.load().cvx_attention_f16x3_scaled(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), oh, ol,
+                                                      Bt, T, Tp, H, scale, _sp(qk_scale), _sp(v_scale), _sp(out_scale), _stream()),
+               "cvx_attention_f16x3")
     return out if out is not None else out_split
 
 
