@@ -109,6 +109,7 @@ class VectorField:
     # x ||W||_F / sqrt(N).  They are computed on the device by prepare() (no host round trip: the solve stays
     # graph-capturable), depend on the weights and the evaluation times only - never on the utterance - and sit in one
     # small tensor the kernels read through DEVICE pointers (cvx_gemm_split_io.a_scale_dev, ...).
+    WORKSPACE_SHAPES = 4
     N_KINDS = 6          # per (evaluation, layer): normed->qkv, q|k, v, attention out, normed->ff1, ff hidden
     TARGET_RMS = 16.0
 
@@ -181,8 +182,9 @@ class VectorField:
     # ------------------------------------------------------------------ workspace
     def _workspace(self, Bt: int, T: int) -> dict:
         key = (Bt, T)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is not None:
+            self._ws[key] = ws                                   # most recently used last
             return ws
         d, dev = self.d, self.device
         M = Bt * T
@@ -212,7 +214,9 @@ class VectorField:
         pos = torch.arange(T, device=dev, dtype=torch.float32)
         ang = pos[:, None] * self.inv_freq[None, :]
         ws["rope"] = (ang.cos().contiguous(), ang.sin().contiguous())
-        self._ws = {key: ws}          # keep one shape resident (batches of equal T reuse it)
+        while len(self._ws) >= self.WORKSPACE_SHAPES:          # keep the most recent shapes resident (a directory of
+            self._ws.pop(next(iter(self._ws)))                  # utterances alternates between a few lengths; ~0.4 GB per 1000 rows)
+        self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ per-call setup

@@ -166,6 +166,18 @@ class CoVoMixModel:
         return out.to(cond.device) if cond.device != out.device else out
 
     @torch.no_grad()
+    def _get_t2s(self):
+        """The device-resident text2semantic decoder (built on first use)."""
+        if not self.is_text2semantic:
+            raise TypeError("this checkpoint is an acoustic model: use synthesis_sample")
+        if self._t2s is None:
+            if self.device.type != "cuda":
+                from ._lib import CovomixHipError
+                raise CovomixHipError("CoVoMixModel must be on a GPU (`.to('cuda')`): covomix_amd has no CPU path")
+            from .t2s import TextToSemanticDecoder
+            self._t2s = TextToSemanticDecoder(self.active_state_dict(), self.device)
+        return self._t2s
+
     def synthesis_sample_text2semantic(self, grapheme_token_ids, temprature=1.0, cond_scale=1.0, beam_search_decode=False,
                                        prompt_mel=None, uniforms=None, generator=None, max_length=None):
         """reference conditional_model.py:313-321 -> TextToSemanticWrapper.sample (text2semantic.py:1237-1251): the
@@ -180,12 +192,7 @@ class CoVoMixModel:
                                     "free guidance at inference (text2semantic.py:691; the reference builds the model with 0)")
         if beam_search_decode:
             raise NotImplementedError("beam search decoding is not built (the generation scripts sample)")
-        if self._t2s is None:
-            if self.device.type != "cuda":
-                from ._lib import CovomixHipError
-                raise CovomixHipError("CoVoMixModel must be on a GPU (`.to('cuda')`): covomix_amd has no CPU path")
-            from .t2s import TextToSemanticDecoder
-            self._t2s = TextToSemanticDecoder(self.active_state_dict(), self.device)
+        self._get_t2s()
         ids = grapheme_token_ids
         if isinstance(ids, (list, tuple)):          # extension: several utterances decoded together (bit-identical tokens)
             res = self._t2s.generate_batch(list(ids), uniforms, max_length, float(temprature), generator)

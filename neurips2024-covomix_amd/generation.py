@@ -17,7 +17,13 @@ Upstream stages:
       fairseq-hubert/get_fisher_semantic_tokens.py wrote offline), else, with --hubert_ckpt and --km_path, the HuBERT
       layer-12 + k-means codes of `<prompt_dir>/<name>.wav` computed on the GPU (resampled to the checkpoint's rate);
       dialogue mode uses `<name>_1.*` and `<name>_2.*` (dialogue_generation.py:285-286)
-New relative to the reference: utterances are sharded over ranks (torchrun) and batched by equal length.
+Dialogue covosingle / covosinx decode the text turn by turn (split at "[spkchange]") with alternating prompts / streams
+exactly as dialogue_generation.py:145-193, :205-272 do; pre-tokenised turns are `<name>.turn<k>.semantic.npy` /
+`<name>.turn<k>.text_ids.npy`.
+New relative to the reference: utterances are sharded over ranks (torchrun; the plan is built from file names and sizes
+only, so every rank computes the same one and decodes only its own utterances), batched by equal length through the
+acoustic model and by equal generated length through the vocoder; the sampled tokens and the ODE noise of an utterance
+are seeded from (--seed, name, turn) and therefore do not depend on the number of ranks.
 """
 from __future__ import annotations
 
@@ -32,7 +38,7 @@ import torch
 
 from . import assembly, dp
 from .conditional_model import CoVoMixModel
-from .vocoder import AttrDict, Generator, mel_decode_to_wav
+from .vocoder import AttrDict, Generator
 
 COND_SCALE = 0.7    # every shipped caller (monologue_generation.py:171,238,298)
 
@@ -86,11 +92,52 @@ def remove_punctuation(text: str) -> str:
 _TOKENIZER = None
 
 
-def _text_ids(text_dir: str, name: str) -> torch.Tensor:
-    """[1, n] BERT ids of the utterance text (load_text2semantic_model, monologue_generation.py:92-104)."""
-    npy = os.path.join(text_dir, name + ".text_ids.npy")
-    if os.path.isfile(npy):
-        return torch.from_numpy(np.load(npy).astype(np.int64)).reshape(1, -1)
+def _stable_seed(seed: int, name: str, turn: int, salt: int) -> int:
+    """Per-utterance RNG seed that depends only on (--seed, utterance name, turn): the sampled tokens and the ODE noise of an
+    utterance are the same whatever the number of ranks, the sharding or the batching."""
+    import zlib
+    return (zlib.crc32(f"{name}|{turn}|{salt}".encode()) ^ (int(seed) * 0x9E3779B1)) & 0x7FFFFFFF
+
+
+def _turn_sources(text_dir: str, name: str, multi_turn: bool, have_t2s: bool):
+    """The text turns of one utterance as a list of ("sem", path) / ("ids", path) / ("txt", string) sources.
+    Multi-turn (dialogue covosingle / covosinx: the reference splits the text at "[spkchange]" and decodes every turn on its
+    own, dialogue_generation.py:160-165, :243-247): `<name>.turn<k>.semantic.npy` or `<name>.turn<k>.text_ids.npy`, k = 0, 1,
+    ..., else `<name>.txt` split at "[spkchange]".  Otherwise (or when no turn files exist) the whole utterance is one turn:
+    `<name>.semantic.npy`, `<name>.text_ids.npy` or `<name>.txt`."""
+    j = lambda suffix: os.path.join(text_dir, name + suffix)
+    if multi_turn:
+        turns, k = [], 0
+        while True:
+            if os.path.isfile(j(f".turn{k}.semantic.npy")):
+                turns.append(("sem", j(f".turn{k}.semantic.npy")))
+            elif have_t2s and os.path.isfile(j(f".turn{k}.text_ids.npy")):
+                turns.append(("ids", j(f".turn{k}.text_ids.npy")))
+            else:
+                break
+            k += 1
+        if turns:
+            return turns
+        if have_t2s and os.path.isfile(j(".txt")) and not os.path.isfile(j(".semantic.npy")) and not os.path.isfile(j(".text_ids.npy")):
+            with open(j(".txt"), "r", encoding="utf-8") as f:
+                return [("txt", t) for t in f.read().split("[spkchange]")]
+    if os.path.isfile(j(".semantic.npy")):
+        return [("sem", j(".semantic.npy"))]
+    if have_t2s and os.path.isfile(j(".text_ids.npy")):
+        return [("ids", j(".text_ids.npy"))]
+    if have_t2s and os.path.isfile(j(".txt")):
+        with open(j(".txt"), "r", encoding="utf-8") as f:
+            return [("txt", f.read())]
+    raise FileNotFoundError(f"{name}: no .semantic.npy" + (" / .text_ids.npy / .txt" if have_t2s else " (and no --t2s_ckpt)") + f" in {text_dir}")
+
+
+def _source_cost(src) -> int:
+    """Rank-independent size of a turn (bytes of its file or characters of its text): what the sharding plan is built on."""
+    kind, v = src
+    return len(v) if kind == "txt" else os.path.getsize(v)
+
+
+def _tokenize(txt: str) -> torch.Tensor:
     global _TOKENIZER
     if _TOKENIZER is None:
         from transformers import BertTokenizer
@@ -98,50 +145,93 @@ def _text_ids(text_dir: str, name: str) -> torch.Tensor:
         for t in ("[laughter]", "[spkchange]", "[spka]", "[spkb]", "[partialoverlap]", "[backchannel]"):
             tok.add_tokens([t])
         _TOKENIZER = tok
-    with open(os.path.join(text_dir, name + ".txt"), "r", encoding="utf-8") as f:
-        txt = remove_punctuation(f.read()).lower()
-    return _TOKENIZER([txt], padding=True, truncation=True, return_tensors="pt").input_ids
+    return _TOKENIZER([remove_punctuation(txt).lower()], padding=True, truncation=True, return_tensors="pt").input_ids
 
 
-def _predicted_tokens(text_dir: str, names, t2s, device, batch: int = 8) -> dict:
-    """name -> predicted semantic tokens: read from <name>.semantic.npy when present, otherwise text2semantic on the GPU,
-    `batch` utterances per decode batch (the tokens do not depend on the batching)."""
+def _predict_turns(work, t2s, device, seed: int, batch: int = 8) -> dict:
+    """(name, turn) -> predicted semantic tokens (int64 numpy).  work: list of (name, turn, source).  Sources that are
+    already tokens are read; the others are decoded by text2semantic on the GPU, `batch` turns per decode batch, every turn
+    with its OWN stream of uniforms (seeded from (--seed, name, turn)): the tokens do not depend on batching or ranks."""
     out, todo = {}, []
-    for n in names:
-        sem = os.path.join(text_dir, n + ".semantic.npy")
-        if t2s is None or os.path.isfile(sem):
-            out[n] = np.load(sem).astype(np.int64)
+    for name, k, (kind, v) in work:
+        if kind == "sem":
+            out[(name, k)] = np.load(v).astype(np.int64)
         else:
-            todo.append(n)
+            ids = torch.from_numpy(np.load(v).astype(np.int64)).reshape(1, -1) if kind == "ids" else _tokenize(v)
+            todo.append((name, k, ids))
+    if todo and t2s is None:
+        raise RuntimeError("text sources need --t2s_ckpt")
     for i in range(0, len(todo), batch):
         group = todo[i:i + batch]
-        toks = t2s.synthesis_sample_text2semantic([_text_ids(text_dir, n).to(device) for n in group])
-        for n, t in zip(group, toks):
-            out[n] = t.cpu().numpy().astype(np.int64)
+        dec = t2s._get_t2s()
+        S, V, L = dec.d["streams"], dec.d["vocab"], dec.max_length
+        uniforms = []
+        for name, k, _ in group:
+            g = torch.Generator(device=device).manual_seed(_stable_seed(seed, name, k, 1))
+            uniforms.append(torch.rand(L, S, V, device=device, generator=g))
+        toks = t2s.synthesis_sample_text2semantic([ids.to(device) for _, _, ids in group], uniforms=uniforms)
+        for (name, k, _), t in zip(group, toks):
+            out[(name, k)] = t.cpu().numpy().astype(np.int64)
     return out
 
 
-def _utterance_inputs(mode: str, dialogue: bool, text_dir: str, prompt_dir: str, name: str, pred: np.ndarray):
+def _build_items(mode: str, dialogue: bool, prompt_dir: str, name: str, preds):
+    """One utterance -> list of (phoneme_ids, cond, mask) network inputs (one per OUTPUT SEGMENT; the segments' audio is
+    concatenated).  preds: the predicted tokens of its turns, in order."""
     if mode == "covosingle":
-        sem, mel = _load_prompt(prompt_dir, name)
-        return assembly.build_monologue_inputs(sem, torch.from_numpy(pred.reshape(-1)), mel)
+        if not dialogue:                                                # monologue_generation.py:146-176
+            sem, mel = _load_prompt(prompt_dir, name)
+            return [assembly.build_monologue_inputs(sem, torch.from_numpy(preds[0].reshape(-1)), mel)]
+        prompts = [_load_prompt(prompt_dir, name + "_1"), _load_prompt(prompt_dir, name + "_2")]
+        return [assembly.build_monologue_inputs(prompts[k % 2][0], torch.from_numpy(p.reshape(-1)), prompts[k % 2][1])
+                for k, p in enumerate(preds)]                           # dialogue_generation.py:145-193: turn k speaks with prompt k % 2
     if dialogue:
         sa, ma = _load_prompt(prompt_dir, name + "_1")
         sb, mb = _load_prompt(prompt_dir, name + "_2")
     else:
         sa, ma = _load_prompt(prompt_dir, name)
         sb, mb = sa, ma
-    if mode == "covosinx":                                # second stream silent (:223-224)
-        pa = torch.from_numpy(pred.reshape(-1))
-        pb = torch.ones_like(pa) * assembly.SILENT_TOKEN
-    else:
-        flat = pred.reshape(-1)
+    if mode == "covosinx":                # every turn on one stream, the other filled with 157; streams alternate per turn
+        pa, pb = [], []                   # (dialogue_generation.py:243-259; one turn, stream A: monologue_generation.py:222-226)
+        for k, p in enumerate(preds):
+            t = torch.from_numpy(p.reshape(-1))
+            sil = torch.ones_like(t) * assembly.SILENT_TOKEN
+            pa.append(t if k % 2 == 0 else sil)
+            pb.append(sil if k % 2 == 0 else t)
+        pa, pb = torch.cat(pa), torch.cat(pb)
+    else:                                 # covomix: one decode yields both streams, split at half (comix_pred, :316-320)
+        flat = preds[0].reshape(-1)
         half = flat.shape[0] // 2
         pa, pb = torch.from_numpy(flat[:half].copy()), torch.from_numpy(flat[half:].copy())
-    return assembly.build_dialogue_inputs(sa, sb, pa, pb, ma, mb)
+    return [assembly.build_dialogue_inputs(sa, sb, pa, pb, ma, mb)]
+
+
+def utterance_plan(text_dir: str, dialogue: bool, mode: str, have_t2s: bool, world: int):
+    """(names, sources, plan): the sorted utterance names, their text turns, and plan[r] = the names rank r generates.
+    RANK-INVARIANT by construction: built from file names and sizes only, before anything is sampled, so every rank
+    computes the same plan, every utterance is generated exactly once, and a rank decodes only its own text."""
+    stems = set()
+    multi_turn = dialogue and mode in ("covosingle", "covosinx")
+    for ext in (".semantic.npy",) + ((".text_ids.npy", ".txt") if have_t2s else ()):
+        for p in glob.glob(os.path.join(text_dir, "*" + ext)):
+            stem = os.path.basename(p)[: -len(ext)]
+            if multi_turn and ".turn" in stem and stem.rsplit(".turn", 1)[1].isdigit():
+                stem = stem.rsplit(".turn", 1)[0]
+            stems.add(stem)
+    names = sorted(stems)
+    if not names:
+        raise FileNotFoundError(f"no utterances in --text_dir {text_dir} (looked for *.semantic.npy"
+                                + (", *.text_ids.npy, *.txt" if have_t2s else "; text sources need --t2s_ckpt") + ")")
+    sources = {n: _turn_sources(text_dir, n, multi_turn, have_t2s) for n in names}
+    cost = [sum(_source_cost(s) for s in sources[n]) for n in names]
+    plan = [[names[i] for i in sorted(idx)] for idx in dp.shard_utterances(cost, world)]
+    return names, sources, plan
 
 
 def run(dialogue: bool, argv=None) -> int:
+    import time
+    from scipy.io.wavfile import write
+    from . import ops
     args = build_parser().parse_args(argv)
     print(args)
     os.makedirs(args.saved_dir, exist_ok=True)
@@ -153,7 +243,7 @@ def run(dialogue: bool, argv=None) -> int:
         from ._lib import CovomixHipError
         raise CovomixHipError("generation needs an MI355X: covomix_amd has no CPU path")
     torch.cuda.set_device(local)
-    torch.cuda.manual_seed(args.seed + rank)
+    torch.cuda.manual_seed(args.seed)
     device = torch.device("cuda", local)
 
     config_file = os.path.join(os.path.split(args.hifigan_ckpt)[0], "vocoder_config.json")   # :368
@@ -175,7 +265,8 @@ def run(dialogue: bool, argv=None) -> int:
             f.write("acoustic model: " + args.acous_ckpt + "\n")
 
     t2s = None
-    if args.t2s_ckpt and os.path.isfile(args.t2s_ckpt):
+    if args.t2s_ckpt:
+        assert os.path.isfile(args.t2s_ckpt), f"--t2s_ckpt {args.t2s_ckpt}: no such file (monologue_generation.py:46)"
         t2s = CoVoMixModel.load_from_checkpoint(args.t2s_ckpt, base_dir="", batch_size=16, num_workers=0)   # :93-96
         t2s.eval()
         t2s = t2s.to(device)
@@ -186,29 +277,56 @@ def run(dialogue: bool, argv=None) -> int:
             "--hubert_ckpt and --km_path must both name existing files"
         from .hubert import HubertTokenizer
         _HUBERT = HubertTokenizer(hubert_path=args.hubert_ckpt, hubert_layer=12, km_path=args.km_path)   # get_fisher_semantic_tokens.py:30-32
-    stems = set()
-    for ext in (".semantic.npy",) + ((".text_ids.npy", ".txt") if t2s is not None else ()):
-        stems |= {os.path.basename(p)[: -len(ext)] for p in glob.glob(os.path.join(args.text_dir, "*" + ext))}
-    names = sorted(stems)
-    pred = _predicted_tokens(args.text_dir, names, t2s, device)
-    items = [_utterance_inputs(args.mode, dialogue, args.text_dir, args.prompt_dir, n, pred[n]) for n in names]
+
+    names, sources, plan = utterance_plan(args.text_dir, dialogue, args.mode, t2s is not None, world)
+    mine = plan[rank]
+
+    # ---- text2semantic for this rank's utterances only
+    work = [(n, k, s) for n in mine for k, s in enumerate(sources[n])]
+    pred = _predict_turns(work, t2s, device, args.seed)
+    items, owner = [], []                                         # network inputs; (name, segment index) of each
+    for n in mine:
+        for seg, it in enumerate(_build_items(args.mode, dialogue, args.prompt_dir, n, [pred[(n, k)] for k in range(len(sources[n]))])):
+            items.append(it)
+            owner.append((n, seg))
     lengths = [int(it[0].shape[0]) for it in items]
-    mine = dp.shard_utterances(lengths, world)[rank]
-    done = 0
-    for batch in dp.batch_equal_length(mine, lengths, args.max_batch):
+    segments = {n: {} for n in mine}
+    done, frames = 0, 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for batch in dp.batch_equal_length(list(range(len(items))), lengths, args.max_batch):
         ids = torch.stack([items[i][0] for i in batch]).to(device)
         cond = torch.stack([items[i][1] for i in batch]).to(device)
         mask = torch.stack([items[i][2] for i in batch]).to(device)
-        sampled = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=COND_SCALE)
+        T = ids.shape[1]
+        y0 = torch.stack([torch.randn(T, 80, device=device, generator=torch.Generator(device=device).manual_seed(
+            _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch])      # acoustic.py:647-650, per utterance
+        sampled = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=COND_SCALE, y0=y0)
+        # vocoder: utterances of the batch with the same number of generated frames go through HiFi-GAN together; one
+        # device-to-host copy per group
+        n_prompt = [int((~items[i][2]).sum()) for i in batch]
+        groups = {}
         for j, i in enumerate(batch):
-            valid = assembly.select_generated_frames(sampled[j:j + 1], mask[j])
-            if valid.shape[1] == 0:
-                continue
-            audio = mel_decode_to_wav(generator, valid.contiguous())
-            from scipy.io.wavfile import write
-            out = os.path.join(args.saved_dir, names[i] + ".wav")
-            write(out, 8000, audio)
-            print("Saved wavfile", out)
-            done += 1
-    print(f"rank {rank}: {done} utterances")
+            if T - n_prompt[j] > 0:
+                groups.setdefault(n_prompt[j], []).append(j)
+        for npmt, js in groups.items():
+            mel = sampled[js, npmt:, :].permute(0, 2, 1).contiguous()                   # [g, 80, Tgen] (:299-300: mask is a suffix)
+            pcm = ops.wav_to_int16(generator(mel).squeeze(1).contiguous()).cpu().numpy()   # mel_decode_to_wav (:52-59), batched
+            frames += mel.shape[0] * mel.shape[2]
+            for r, j in enumerate(js):
+                n, seg = owner[batch[j]]
+                segments[n][seg] = pcm[r]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    for n in mine:
+        if not segments[n]:
+            continue
+        audio = np.concatenate([segments[n][k] for k in sorted(segments[n])])           # dialogue covosingle: turns in order (:190)
+        out = os.path.join(args.saved_dir, n + ".wav")
+        write(out, 8000, audio)
+        print("Saved wavfile", out)
+        done += 1
+    print(f"rank {rank}: {done} utterances, {frames} generated frames in {elapsed:.3f} s ({frames / max(elapsed, 1e-9):.1f} frames/s, "
+          f"sampling + vocoder, excluding model load and text2semantic)")
+    run.last_stats = dict(utterances=done, frames=frames, seconds=elapsed)
     return done

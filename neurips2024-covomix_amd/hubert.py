@@ -342,14 +342,8 @@ class HubertFeatureReader:
 
     def read_audio(self, path, ref_len=None, channel_id=None):
         """-> float32 mono waveform at the checkpoint's sample rate (torchaudio.load semantics: int16 / 32768)."""
-        from scipy.io.wavfile import read
-        sr, data = read(path)
-        if data.dtype == np.int16:
-            wav = data.astype(np.float32) / 32768.0
-        elif data.dtype == np.int32:
-            wav = (data.astype(np.float64) / 2147483648.0).astype(np.float32)
-        else:
-            wav = data.astype(np.float32)
+        from .audio import read_wav
+        sr, wav = read_wav(path)                   # float by the STORED sample type (int16 / 2^15, int32 / 2^31, uint8, float)
         if wav.ndim == 2:                          # [n, channels]; the reference asserts mono after squeeze(0) (:51-52)
             if wav.shape[1] == 1:
                 wav = wav[:, 0]

@@ -8,12 +8,16 @@ Follows data_preparation/generate_mel.py:49-72 (`mel_spectrogram`) as called by 
     reflect-pad (n_fft - hop)/2 = 160 samples on both sides -> torch.stft(center=False, hann window) ->
     sqrt(re^2 + im^2 + 1e-9) -> mel basis [80, 241] @ magnitude -> log(clamp(., 1e-5)).
 
-PARITY UNPINNED against the reference: the mel basis is `librosa.filters.mel` (third-party, absent from this image
-and from /root/reference) and generate_mel.py cannot be imported (librosa, torchaudio, wespeakerruntime, soundfile).
-`slaney_mel_basis` restates librosa's published algorithm (Slaney mel scale: linear below 1 kHz, log above with
-step log(6.4)/27; triangular filters on the FFT bin frequencies; slaney area normalisation 2 / (f[i+2] - f[i])) and is
-cross-checked in tests/test_mel_oracle.py against an independent implementation of the same algorithm that IS installed
-here (transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")).  The STFT is torch's own.
+PINNED against outputs of the reference itself: hifi-gan/hifigan_test/input_wav/*.wav -> input_mel/*.npy were written by
+the reference's own `mel_spectrogram` (hifi-gan/meldataset.py:49-72 - the same function as
+data_preparation/generate_mel.py:49-72, with librosa's filter bank) at 16 kHz, n_fft = win = 1024, hop 256, fmax 8000;
+tests/golden/make_golden_mel.py packs the two pairs into tests/golden/mel_ref_16k.npz and tests/test_mel_oracle.py holds
+this restatement to them (measured: max |log-mel difference| 9.5e-7).  The mel basis is `librosa.filters.mel`
+(third-party, absent from this image): `slaney_mel_basis` restates its published algorithm (Slaney mel scale: linear
+below 1 kHz, log above with step log(6.4)/27; triangular filters on the FFT bin frequencies; slaney area normalisation
+2 / (f[i+2] - f[i])), additionally cross-checked against the independent implementation in
+transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney").  The STFT is torch's own.  Every function
+takes the analysis parameters (sr, n_fft, hop, win, n_mels, fmin, fmax); the defaults are the generation scripts' 8 kHz set.
 """
 import math
 
@@ -55,13 +59,14 @@ def slaney_mel_basis(sr=SR, n_fft=N_FFT, n_mels=N_MELS, fmin=FMIN, fmax=FMAX) ->
     return (weights * enorm[:, None]).astype(np.float32)
 
 
-def mel_spectrogram(y: torch.Tensor, basis: torch.Tensor = None) -> torch.Tensor:
-    """y [B, n] float32 in [-1, 1] -> [B, 80, T] log-mel, T = n // 160 (generate_mel.py:49-72)."""
+def mel_spectrogram(y: torch.Tensor, basis: torch.Tensor = None, sr=SR, n_fft=N_FFT, hop=HOP, win=WIN, n_mels=N_MELS,
+                    fmin=FMIN, fmax=FMAX) -> torch.Tensor:
+    """y [B, n] float32 in [-1, 1] -> [B, n_mels, T] log-mel, T = n // hop (generate_mel.py:49-72 = hifi-gan/meldataset.py:49-72)."""
     if basis is None:
-        basis = torch.from_numpy(slaney_mel_basis())
-    pad = (N_FFT - HOP) // 2
+        basis = torch.from_numpy(slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax))
+    pad = int((n_fft - hop) / 2)
     y = torch.nn.functional.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
-    spec = torch.stft(y, N_FFT, hop_length=HOP, win_length=WIN, window=torch.hann_window(WIN), center=False,
+    spec = torch.stft(y, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False,
                       pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
     spec = torch.view_as_real(spec)
     spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)

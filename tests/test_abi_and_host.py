@@ -262,3 +262,34 @@ def test_tokenizer_cli_shards_files_by_rank(monkeypatch, tmp_path):
     import os
     assert sorted(os.listdir(out)) == ["b.hubert_code.npy", "d.hubert_code.npy"]
     assert np.load(out / "b.hubert_code.npy").tolist() == ["1", "2", "3"]
+
+
+def test_generation_plan_is_rank_invariant_and_turn_aware(tmp_path):
+    """The sharding plan of the generation driver is built from file names and sizes only (per-rank sampled
+    lengths made ranks disagree): every rank computes the same partition, every utterance appears exactly once, turns of
+    a dialogue stay on one rank, and the per-utterance RNG seeds do not depend on the rank."""
+    import numpy as np
+    from covomix_amd import generation as g
+    tdir = str(tmp_path)
+    rs = np.random.RandomState(0)
+    for i in range(7):
+        np.save(os.path.join(tdir, f"utt{i}.semantic.npy"), rs.randint(0, 500, size=20 + 13 * i))
+    for k in range(3):
+        np.save(os.path.join(tdir, f"dlg.turn{k}.semantic.npy"), rs.randint(0, 500, size=30 + k))
+    with open(os.path.join(tdir, "spoken.txt"), "w") as f:
+        f.write("hello there [spkchange] general kenobi [spkchange] bye")
+    names, sources, plan = g.utterance_plan(tdir, True, "covosingle", True, 3)
+    assert names == sorted(["dlg", "spoken"] + [f"utt{i}" for i in range(7)])
+    assert len(sources["dlg"]) == 3 and [s[0] for s in sources["dlg"]] == ["sem"] * 3
+    assert [s[0] for s in sources["spoken"]] == ["txt"] * 3 and sources["spoken"][1][1].strip() == "general kenobi"
+    assert sorted(n for r in plan for n in r) == names and all(len(r) >= 2 for r in plan)
+    assert g.utterance_plan(tdir, True, "covosingle", True, 3)[2] == plan                  # deterministic
+    # monologue / covomix: the whole text is one turn; without text2semantic text files are not utterances
+    mono = g.utterance_plan(tdir, False, "covosingle", True, 1)
+    assert len(mono[1]["spoken"]) == 1 and "dlg.turn1" in mono[0] and "dlg" not in mono[0]
+    assert "spoken" not in g.utterance_plan(tdir, True, "covosingle", False, 1)[0]
+    assert g._stable_seed(30, "utt1", 0, 1) == g._stable_seed(30, "utt1", 0, 1) != g._stable_seed(30, "utt1", 1, 1)
+    assert g._stable_seed(30, "utt1", 0, 1) != g._stable_seed(31, "utt1", 0, 1)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        g.utterance_plan(os.path.join(tdir, "nothing_here"), False, "covosingle", False, 1)

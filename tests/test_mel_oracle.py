@@ -1,6 +1,8 @@
-"""CPU: the prompt-mel oracle (oracle/mel_oracle.py).  The reference's mel basis is
-librosa's (absent here: parity unpinned); the restated Slaney filter bank is cross-checked against the independent
-implementation in `transformers`, and the STFT chain against a direct DFT."""
+"""CPU: the prompt-mel oracle (oracle/mel_oracle.py) against (i) the reference-held
+fixtures tests/golden/mel_ref_16k.npz (outputs of the reference's own mel_spectrogram, hifi-gan/hifigan_test), (ii) the
+independent Slaney filter bank in `transformers`, (iii) a direct DFT."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -31,3 +33,20 @@ def test_mel_spectrogram_shape_and_direct_dft():
     mag = torch.sqrt((torch.cos(k) @ fr) ** 2 + (torch.sin(k) @ fr) ** 2 + 1e-9)
     want = torch.log(torch.clamp(torch.from_numpy(mo.slaney_mel_basis()).double() @ mag, min=1e-5))
     assert float((mel[0, :, 3].double() - want).abs().max()) < 1e-4
+
+
+def test_oracle_reproduces_reference_mel_fixtures():
+    """The reference's own wav -> log-mel pairs (hifi-gan/meldataset.py:49-72 with librosa's filter bank; 16 kHz, n_fft =
+    win = 1024, hop 256, fmax 8000): the restatement must reproduce them (measured 9.5e-7 max abs on the log-mel)."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "mel_ref_16k.npz"))
+    kw = dict(sr=int(g["sr"]), n_fft=int(g["n_fft"]), hop=int(g["hop"]), win=int(g["win"]), n_mels=int(g["n_mels"]),
+              fmin=float(g["fmin"]), fmax=float(g["fmax"]))
+    for i in range(2):
+        wav = torch.from_numpy(g[f"wav{i}"].astype(np.float32) / 32768.0)[None]
+        mel = mo.mel_spectrogram(wav, **kw)[0]
+        ref = torch.from_numpy(g[f"mel{i}"])
+        assert mel.shape == ref.shape
+        err = float((mel - ref).abs().max())
+        print("mel fixture", i, tuple(ref.shape), "max abs err", err)
+        assert err < 5e-6
