@@ -121,9 +121,10 @@ def host_cores() -> int:
 
 
 def cpu_baseline(cpu_sd):
-    """The oracle (== the reference's PyTorch path, pinned <=1e-5 in tests/golden) on this box's host
-    cores: bounded sample = 3 CFG evaluations (6 network forwards) + 1 HiFi-GAN call at B=1, T=1000,
-    extrapolated to the 32-NFE + vocoder pipeline.  Reported, never the target."""
+    """The oracle (== the reference's PyTorch path, pinned <= 1e-5 in tests/golden) on this box's host cores AT THE METRIC
+    CONFIGURATION (B=8 utterances x T=1000 frames): bounded sample = 2 timed CFG evaluations (4 network forwards on
+    8 x 1000 frames, after a B=1 warm-up), each standing for one of the 32 NFE, + one HiFi-GAN call on the 8 x 1000
+    frames.  Reported, never the target."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import covomix_oracle as orc
     import covomix_amd.synthetic as syn
@@ -132,12 +133,12 @@ def cpu_baseline(cpu_sd):
     sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
     cores = host_cores()
     torch.set_num_threads(cores)
-    inp = syn.synthetic_inputs("vomix", 1, T, PROMPT, seed=1234)
+    inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1234)
     tm = torch.tensor(0.25)
     with torch.inference_mode():
-        orc.forward_with_cond_scale(sd, inp["y0"], tm, inp["phoneme_ids"], inp["cond"], COND_SCALE)   # warm-up
+        orc.forward_with_cond_scale(sd, inp["y0"][:1], tm, inp["phoneme_ids"][:1], inp["cond"][:1], COND_SCALE)   # warm-up (B=1)
         t0 = time.perf_counter()
-        n_eval = 3
+        n_eval = 2
         for _ in range(n_eval):
             orc.forward_with_cond_scale(sd, inp["y0"], tm, inp["phoneme_ids"], inp["cond"], COND_SCALE)
         t_eval = (time.perf_counter() - t0) / n_eval
@@ -146,10 +147,38 @@ def cpu_baseline(cpu_sd):
         t0 = time.perf_counter()
         orc.hifigan_forward(folded, syn.HIFIGAN_COVOMIX_CONFIG, mel)
         t_voc = time.perf_counter() - t0
-    fps = T / (NFE * t_eval + t_voc)
+    fps = B * T / (NFE * t_eval + t_voc)
     return {"value": round(fps, 2), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU restatement of the reference PyTorch path), B=1 T={T}: {n_eval} timed CFG evals "
-                      f"({t_eval:.3f} s each, x{NFE}) + 1 HiFi-GAN call ({t_voc:.3f} s), torch {torch.get_num_threads()} threads"}
+            "sample": f"oracle (CPU restatement of the reference PyTorch path) at the metric config B={B} x T={T}: {n_eval} timed "
+                      f"CFG evals ({t_eval:.3f} s each, x{NFE} = the 32-NFE solve) + 1 HiFi-GAN call on {B} x {T} frames "
+                      f"({t_voc:.3f} s), torch {torch.get_num_threads()} threads"}
+
+
+def fp32_exact(dev, rank, world, steps: int = 2):
+    """The same step with precision='fp32' (v_mfma_f32_32x32x2_f32 everywhere): the exact-fp32 number that backs the
+    precision statement of `dtype` (extra key of the JSON line, N=1 only, a few steps)."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd import ops
+    from covomix_amd.vocoder import AttrDict, Generator
+    model, _, _ = make_models(dev, rank, world, "fp32")
+    gen = Generator(AttrDict(syn.HIFIGAN_COVOMIX_CONFIG), precision="fp32").to(dev)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(syn.HIFIGAN_COVOMIX_CONFIG), seed=0).items()}
+    gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
+    inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1234 + rank)
+    ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
+
+    def step():
+        mel = model.synthesis_sample(ids, cond, mask, COND_SCALE, y0=torch.randn(B, T, 80, device=dev))
+        return ops.wav_to_int16(gen(mel.permute(0, 2, 1).contiguous()).squeeze(1).contiguous())
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * T * steps / dt, 2), "unit": "mel-frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32 GEMM / attention / vocoder)"}
 
 
 def main():
@@ -158,6 +187,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-exact", action="store_true")
     ap.add_argument("--precision", choices=["f16x3", "f16", "fp32"], default=None,
                     help="default f16x3 (fp32-class); f16 = opt-in single-term fp16 operands (<= 1e-3 rel-L2 budget)")
     args = ap.parse_args()
@@ -169,8 +199,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import contextlib
+    t_load = time.perf_counter()
     with contextlib.redirect_stdout(sys.stderr):          # keep stdout to the single JSON line
         model, gen, cpu_sd = make_models(dev, rank, world, args.precision)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t_load                 # weight generation (rank 0) + ONE bucketed RCCL broadcast + packing
 
     inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1234 + rank)
     ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
@@ -198,8 +231,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer.remove()
+    my_elapsed = elapsed
     assert pcm.shape == (B, 160 * T + 32) and pcm.dtype == torch.int16
     frames, elapsed = dp.reduce_metric(float(B * T * args.steps), elapsed, dev)
+    per_rank = [my_elapsed]
+    loads = [t_load]
+    if world > 1:                                        # diagnosis of the first hardware scaling runs: who was slow, and where
+        buf = torch.tensor([my_elapsed, t_load], dtype=torch.float64, device=dev)
+        allb = [torch.zeros_like(buf) for _ in range(world)]
+        torch.distributed.all_gather(allb, buf)
+        per_rank = [float(b[0]) for b in allb]
+        loads = [float(b[1]) for b in allb]
 
     if rank == 0:
         value = frames / elapsed
@@ -207,7 +249,8 @@ def main():
         achieved = flops / gemm_s / 1e12
         split = model.precision in ("f16x3", "f16")
         terms = {"f16x3": 3, "f16": 1, "fp32": 1}[model.precision]
-        kname = "gemm_f16x3_dma256_kernel" if split else "gemm_f32_glds_kernel"
+        p8 = model.precision == "f16x3" and ops._GEMM_FLAGS == 0
+        kname = ("gemm_f16x3_p8_kernel" if p8 else "gemm_f16x3_dma256_kernel") if split else "gemm_f32_glds_kernel"
         peak = PEAK_F16_MFMA if split else PEAK_F32_MFMA
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -242,6 +285,14 @@ def main():
                          "avg_launch_ms": round(gemm_s / launches * 1e3, 4),
                          "time_share_of_step": round(gemm_s / launches * all_launches / elapsed, 4)},
         }
+        if world > 1:
+            out["ranks"] = {"elapsed_s": [round(x, 4) for x in per_rank], "skew_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 4),
+                            "load_and_broadcast_s": [round(x, 3) for x in loads]}
+        if world == 1 and not args.no_fp32_exact and model.precision == "f16x3":
+            del model, gen
+            torch.cuda.empty_cache()
+            with contextlib.redirect_stdout(sys.stderr):
+                out["fp32_exact"] = fp32_exact(dev, rank, world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_sd)
         print(json.dumps(out), flush=True)

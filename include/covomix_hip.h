@@ -119,6 +119,9 @@ int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float s
 int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
                    const cvx_gemm_split_io* io, cvx_stream_t s);
+/* Size (in floats) of cvx_gemm_split_io.workspace that lets a problem of this shape split K (0: this shape never does).
+ * K1 = the A | A2 boundary of a K-split operand, 0 without A2. */
+int64_t cvx_gemm_f16x3_workspace_floats(int32_t M, int32_t N, int32_t K, int32_t K1);
 
 /* y[r,:] = x[r,:] / max(||x[r,:]||_2, eps) * scale * gamma[g,:] + beta[g,:],  g = r / rows_per_group
  * AdaptiveRMSNorm.forward (acoustic.py:198-204) with gamma/beta = the already projected
@@ -340,6 +343,7 @@ int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F, int64_t l
  *   leaky_relu + conv_post + tanh (:112-114; post_x may be NULL) - see cvx_hifigan_post_f32. */
 int cvx_rope_attention_f32(const float* qkv, const float* rope_cos, const float* rope_sin, float* out,
                            int32_t Bt, int32_t T, int32_t H, float scale, float* workspace, cvx_stream_t s);
+int64_t cvx_rope_attention_workspace_floats(int32_t Bt, int32_t T, int32_t H);
 int cvx_hifigan_convt_f32(const cvx_conv_args* a, cvx_stream_t s);
 typedef struct {
     const float* x; int32_t B, C, L;

@@ -144,6 +144,8 @@ SIGNATURES = {
     "cvx_last_error_string": (C.c_char_p, []),
     "cvx_gemm_bias_act_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "cvx_gemm_f16x3_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "cvx_rope_attention_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "cvx_split_f16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_adarmsnorm_scaled_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256) void rope_copy_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" int64_t cvx_rope_attention_workspace_floats(int32_t Bt, int32_t T, int32_t H)
+{
+    return (Bt > 0 && T > 0 && H > 0) ? (int64_t)Bt * T * 3 * H * 64 : 0;
+}
+
 extern "C" int cvx_rope_attention_f32(const float* qkv, const float* rope_cos, const float* rope_sin, float* out,
                                       int32_t Bt, int32_t T, int32_t H, float scale, float* workspace, cvx_stream_t s)
 {

@@ -21,6 +21,20 @@ void cvx_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* cvx_last_error_string(void) { return g_err; }
+
+#include <mutex>
+#include <set>
+#include <utility>
+void cvx_allow_dynamic_lds(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.insert(std::make_pair(dev, kernel)).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 extern "C" int cvx_version(void) { return 100; }
 
 namespace {

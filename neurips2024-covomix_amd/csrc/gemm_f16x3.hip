@@ -13,7 +13,6 @@
 // LDS tiles are [128][32] fp16 (64-byte rows) with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3,
 // which makes the ds_read_b128 fragment reads conflict-free (a 256-byte bank row holds 4 rows x 4 chunks).
 #include "gemm_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -644,14 +643,30 @@ static void launch_dma(const cvx_gemm_args& a, const PreSplitA& A, const f16* wh
                        int k_per = 0, float* partial = nullptr)
 {
     const size_t lds = (size_t)STAGES * 4 * TILE_H * sizeof(f16);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<STAGES, NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<STAGES, NT>), (int)lds);
     hipLaunchKernelGGL((gemm_f16x3_dma_kernel<STAGES, NT>), grid, dim3(256), lds, st, a, A, wh, wl, acc_scale, so,
                        tiles_m, tiles_n, map_mode, k_per, partial);
+}
+
+constexpr int SPLITK_MAX_GRID = 128;      // small problems only: at most this many 128 x 128 output tiles
+
+// K slices a small pre-split problem is cut into (1 = never): few output tiles and a long K
+static int splitk_factor(int M, int N, int K, int K1, bool has_a2)
+{
+    const int tiles = ((N + BN - 1) / BN) * ((((M + 127) / 128) + 7) / 8 * 8);
+    if (tiles > SPLITK_MAX_GRID || N % 4 != 0) return 1;
+    for (int cand = 4; cand >= 2; cand >>= 1) {
+        const int kp = K / cand;
+        if (K % cand == 0 && kp % 64 == 0 && kp >= 512 && (!has_a2 || K1 % kp == 0)) return cand;
+    }
+    return 1;
+}
+
+extern "C" int64_t cvx_gemm_f16x3_workspace_floats(int32_t M, int32_t N, int32_t K, int32_t K1)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int f = splitk_factor(M, N, K, K1, K1 > 0);
+    return f > 1 ? (int64_t)f * M * N : 0;
 }
 
 extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
@@ -709,32 +724,23 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     }
     if (a->M == 0) return CVX_OK;
     const int tiles_n = (a->N + BN - 1) / BN, tiles_m = (a->M + 127) / 128;
-    static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    const int map_mode = 1;             // XCD-aware block -> tile map (gemm_common.h)
     const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
     dim3 grid((unsigned)(grid_m * tiles_n));
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const f16* wh = reinterpret_cast<const f16*>(W_hi);
     const f16* wl = reinterpret_cast<const f16*>(W_lo);
-    static const int big = [] { const char* e = getenv("CVX_GEMM_TILE256"); return e ? atoi(e) : 1; }();
     // Measured on MI355X (tools/bench_kernels.py, M=16000): the 256x256 tile wins on every transformer shape
     // (284-349 vs 263-312 TFLOP/s).  Deeper rings (3-4 stages, K-step 16, 256x128x3) were tried and are slower:
     // the kernel is bound by the per-CU LDS-DMA delivery rate (~35 GB/s/CU), not by DMA latency.
-    if (A.hi && big && a->M >= 2048 && a->N >= 512) {
+    if (A.hi && a->M >= 2048 && a->N >= 512) {
         const int tn = (a->N + 255) / 256, tm = (a->M + 255) / 256;
         const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
         const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB
-        static bool attr256 = false;
-        if (!attr256) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<1, false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-            attr256 = true;
-        }
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, false, false>), (int)lds256);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, false>), (int)lds256);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, true>), (int)lds256);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<1, false, false>), (int)lds256);
         const dim3 g256((unsigned)(gm * tn));
         if (single)
             hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
@@ -758,21 +764,15 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         //     (partials in fp32, summed in a fixed order by splitk_reduce_kernel, which also applies the epilogue);
         //   * a 4-stage DMA ring when the whole grid fits the chip at one block per CU.
         // Large grids keep the 2-stage kernel at two blocks per CU.
-        static const int splitk_on = [] { const char* e = getenv("CVX_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
-        static const int small_stages = [] { const char* e = getenv("CVX_GEMM_SMALL_STAGES"); return e ? atoi(e) : 4; }();
-        static const int splitk_max_grid = [] { const char* e = getenv("CVX_GEMM_SPLITK_GRID"); return e ? atoi(e) : 128; }();
         int ksplit = 1;
-        if (splitk_on && io && io->workspace && !a->rope_cos && !so.vt_hi && (int)grid.x <= splitk_max_grid && a->N % 4 == 0 && a->ldc % 4 == 0) {
-            for (int cand = 4; cand >= 2; cand >>= 1) {
-                const int kp = a->K / cand;
-                if (a->K % cand == 0 && kp % 64 == 0 && kp >= 512 && (!a->A2 || a->K1 % kp == 0) &&
-                    io->workspace_floats >= (int64_t)cand * a->M * a->N) { ksplit = cand; break; }
-            }
+        if (io && io->workspace && !a->rope_cos && !so.vt_hi && a->ldc % 4 == 0) {
+            const int f = splitk_factor(a->M, a->N, a->K, a->K1, a->A2 != nullptr);
+            if (f > 1 && io->workspace_floats >= (int64_t)f * a->M * a->N) ksplit = f;
         }
         const int k_per = ksplit > 1 ? a->K / ksplit : 0;
         float* part = ksplit > 1 ? io->workspace : nullptr;
         dim3 g2(grid.x, (unsigned)ksplit);
-        const bool deep = (int)(grid.x * ksplit) <= 256 && small_stages == 4;
+        const bool deep = (int)(grid.x * ksplit) <= 256;
         if (deep) {
             if (single) launch_dma<4, 1>(*a, A, wh, wl, acc_scale, so, g2, tiles_m, tiles_n, map_mode, st, k_per, part);
             else launch_dma<4, 3>(*a, A, wh, wl, acc_scale, so, g2, tiles_m, tiles_n, map_mode, st, k_per, part);
@@ -784,11 +784,7 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         }
     } else {
         const size_t lds = (size_t)2 * 4 * TILE_H * sizeof(f16);      // 64 KiB
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f16x3_kernel), (int)lds);
         hipLaunchKernelGGL(gemm_f16x3_kernel, grid, dim3(256), lds, st, *a, wh, wl, acc_scale, so, tiles_m, tiles_n, map_mode);
     }
     CVX_CHECK_LAUNCH("cvx_gemm_f16x3");

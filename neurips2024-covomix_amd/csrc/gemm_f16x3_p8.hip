@@ -238,16 +238,8 @@ bool launch_gemm_f16x3_p8(const cvx_gemm_args& a, const PreSplitA& A, const f16*
     (void)k1;
     const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
     const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_done[64] = {};                      // per device, not per process
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        attr_done[dev] = true;
-    }
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<false>), LDS_B);
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<true>), LDS_B);
     const dim3 grid((unsigned)(gm * tn));
     if (A.hi2)
         hipLaunchKernelGGL((gemm_f16x3_p8_kernel<true>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, map_mode);

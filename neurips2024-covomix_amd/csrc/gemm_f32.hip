@@ -353,28 +353,16 @@ int launch_gemm(const cvx_gemm_args& a, hipStream_t st)
     constexpr int BM = TM * 64;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     const bool fast = (a.K % BK == 0);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fast]) {
-        const void* fn = fast ? reinterpret_cast<const void*>(gemm_f32_kernel<TM>)
-                              : reinterpret_cast<const void*>(gemm_f32_generic_kernel<TM>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { cvx_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return CVX_EHIP; }
-        attr_set[fast] = true;
-    }
+    cvx_allow_dynamic_lds(fast ? reinterpret_cast<const void*>(gemm_f32_kernel<TM>)
+                               : reinterpret_cast<const void*>(gemm_f32_generic_kernel<TM>), (int)lds);
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    static const int map_mode = [] { const char* e = getenv("CVX_GEMM_MAP"); return e ? atoi(e) : 1; }();
-    static const int use_glds = [] { const char* e = getenv("CVX_GEMM_GLDS"); return e ? atoi(e) : 1; }();
+    const int map_mode = 1;             // XCD-aware block -> tile map (gemm_common.h)
     const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
     dim3 grid((unsigned)(grid_m * tiles_n));
     if constexpr (TM == 2) {
-        if (fast && use_glds) {
+        if (fast) {
             const size_t lds_dma = (size_t)4 * 128 * BK * sizeof(float);
-            static bool dma_attr = false;
-            if (!dma_attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
-                dma_attr = true;
-            }
+            cvx_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_glds_kernel), (int)lds_dma);
             hipLaunchKernelGGL(gemm_f32_glds_kernel, grid, dim3(256), lds_dma, st, a, tiles_m, tiles_n, map_mode);
             CVX_CHECK_LAUNCH("cvx_gemm_bias_act_f32");
             return CVX_OK;

@@ -275,13 +275,8 @@ __global__ __launch_bounds__(256) void cl_to_cm_kernel(const float* __restrict__
 template <int TMI, int TNI, int WN>
 void launch_conv16(const Conv16Args& a, int B, hipStream_t st)
 {
-    static bool attr = false;
     const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN>), (int)lds);
     dim3 grid((unsigned)((a.L + TMB - 1) / TMB), (unsigned)B);
     hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN>), grid, dim3(512), lds, st, a);
 }
