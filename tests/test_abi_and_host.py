@@ -300,7 +300,7 @@ def test_workspace_queries():
     from covomix_amd import _lib
     lib = _lib.load()
     assert lib.cvx_gemm_f16x3_workspace_floats(1000, 1024, 4096, 0) == 4 * 1000 * 1024          # one utterance, long K: 4 slices
-    assert lib.cvx_gemm_f16x3_workspace_floats(1000, 1024, 2048, 1024) == 2 * 1000 * 1024       # skip combiner: split at A | A2
+    assert lib.cvx_gemm_f16x3_workspace_floats(1000, 1024, 2048, 1024) == 4 * 1000 * 1024       # skip combiner: slices end at A | A2
     assert lib.cvx_gemm_f16x3_workspace_floats(16000, 1024, 4096, 0) == 0                       # large grids never split K
     assert lib.cvx_gemm_f16x3_workspace_floats(1000, 80, 1024, 0) == 2 * 1000 * 80
     assert lib.cvx_rope_attention_workspace_floats(2, 130, 4) == 2 * 130 * 3 * 4 * 64
