@@ -102,8 +102,8 @@ typedef struct {
      * a->ldw >= 2K halves), so that a K-step of a row is a whole 128-byte cache line.  Large-problem kernel only
      * (pre-split A, M >= 2048, N >= 512). */
     int32_t w_interleaved;
-    /* Kernel selection for A/B measurements (0 = default).  Bit 0: keep interleaved large problems on the two-stage
-     * kernel instead of the eight-phase ping-pong kernel (csrc/gemm_f16x3_p8.hip); results agree to fp32 rounding. */
+    /* Kernel selection for A/B measurements (0 = default): CVX_GEMM_FLAG_* below; bits 8.. are timing experiments
+     * (dev).  Results of the kernels agree to fp32 rounding. */
     int32_t flags;
     /* Activation scales: DEVICE pointers to one float each (NULL = 1.0), powers of two.  a_scale_dev = the factor the
      * producer of A_hi/A_lo (and of A2_*: both operands must share it) multiplied the values by before splitting - the
@@ -114,6 +114,7 @@ typedef struct {
     const float* a_scale_dev; const float* c_scale_dev; const float* vt_scale_dev;
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
+#define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 /* the same with an additional DEVICE-resident factor (the pair holds w * scale * *scale_dev; scale_dev may be NULL) */
 int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev, cvx_stream_t s);

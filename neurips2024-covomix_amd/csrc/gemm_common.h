@@ -39,7 +39,8 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 // hi/lo and vt_hi/vt_lo (the fp32 store of C is never scaled).
 struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
                   _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld;
-                  const float* c_scale; const float* vt_scale; const float* a_scale; };
+                  const float* c_scale; const float* vt_scale; const float* a_scale;
+                  int dbg; unsigned long long* trace; };   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
 
 // accumulator factor: 1 / (weight pre-scale) / (activation pre-scale); both powers of two, so the division is exact
 __device__ __forceinline__ float total_acc_scale(float acc_scale, const SplitOut& so)
@@ -74,11 +75,36 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
     v0 = b1 ? rx : a0; v1 = b1 ? ry : a1; v2 = b1 ? a2 : rx; v3 = b1 ? a3 : ry;
 }
 
-template <int TM>
-__device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&acc)[TM][2], int m0, int n0,
+// EPI: compile-time specialisation of the epilogue for the five call patterns of the transformer block.  The generic
+// epilogue carries every combination (activation kinds, RoPE, residual, fp32 / split / transposed stores, vector and
+// scalar paths) as straight-line code - a few hundred KiB that every wave walks through once per tile, far more than the
+// instruction cache holds; a specialised instance pins the switches to constants (and relies on the launcher having
+// checked that the 16-byte vector path applies), so the compiler drops the rest.
+enum : int { EPI_GENERIC = 0, EPI_QKV = 1,      // RoPE on q|k, split q|k + transposed split v, no fp32 store, no bias
+             EPI_RES = 2,                       // (+ bias) + residual, fp32 store (+ optional split twin): to_out, ff2
+             EPI_GELU_SPLIT = 3,                // bias + GELU, split store only: ff1
+             EPI_BIAS = 4 };                    // bias, fp32 store: skip combiners
+
+template <int TM, int EPI = EPI_GENERIC>
+__device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 (&acc)[TM][2], int m0, int n0,
                                               int wm, int wn, int lane,
-                                              const SplitOut so = SplitOut{nullptr, nullptr, 0, 1, nullptr, nullptr, 0})
+                                              const SplitOut so_in = SplitOut{nullptr, nullptr, 0, 1, nullptr, nullptr, 0})
 {
+    cvx_gemm_args p = p_in;
+    SplitOut so = so_in;
+    if constexpr (EPI == EPI_QKV) {
+        p.act = CVX_ACT_NONE; p.bias = nullptr; p.residual = nullptr; so.write_f32 = 0;
+        __builtin_assume(p.rope_cos != nullptr); __builtin_assume(so.vt_hi != nullptr); __builtin_assume(so.hi != nullptr);
+    } else if constexpr (EPI == EPI_RES) {
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; so.write_f32 = 1; so.vt_hi = nullptr; so.vt_lo = nullptr;
+        __builtin_assume(p.residual != nullptr);
+    } else if constexpr (EPI == EPI_GELU_SPLIT) {
+        p.act = CVX_ACT_GELU; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 0; so.vt_hi = nullptr; so.vt_lo = nullptr;
+        __builtin_assume(p.bias != nullptr); __builtin_assume(so.hi != nullptr);
+    } else if constexpr (EPI == EPI_BIAS) {
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1; so.vt_hi = nullptr; so.vt_lo = nullptr;
+        so.hi = nullptr; so.lo = nullptr;
+    }
     const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
     const int c_lo = colw + (lane & 31);
     const int c_hi = c_lo + 32;
@@ -137,10 +163,10 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p, f32x16 (&a
     // ---- vector path (wave-uniform choice): the MFMA layout gives a lane ONE column of 4 consecutive rows per
     // register group; a 4x4 quad transpose turns that into 4 consecutive COLUMNS of one row, so every store /
     // residual load is 16 bytes (8 bytes per fp16 half) instead of 4 (2): 4x fewer memory instructions.
-    const bool vec_ok = (colw + 64 <= p.N) &&
+    const bool vec_ok = (EPI != EPI_GENERIC) || ((colw + 64 <= p.N) &&
                         (!so.write_f32 || (((uintptr_t)p.C & 15) == 0 && (p.ldc & 3) == 0)) &&
                         (!p.residual || (((uintptr_t)p.residual & 15) == 0 && (p.ldr & 3) == 0)) &&
-                        (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0));
+                        (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0)));
     if (vec_ok) {
         const int q = lane & 3;
         const int c4_lo = colw + 4 * ((lane & 31) >> 2);          // this lane's 4 columns after the transpose
@@ -257,6 +283,14 @@ struct PreSplitA { const _Float16* hi; const _Float16* lo; int64_t ld; const _Fl
 // Returns false when the problem does not qualify (the caller then uses the two-stage kernel).
 bool launch_gemm_f16x3_p8(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
                           int map_mode, hipStream_t st);
+
+// gemm_f16x3_p8s.hip: the same main loop on the 16x16x32 MFMA with swapped operands and a transpose-free epilogue; only
+// problems whose epilogue can run 16-byte vectors (N % 64 == 0, aligned pointers); false -> the caller falls back
+bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
+                           int map_mode, hipStream_t st);
+
+// which specialised epilogue (EPI_*) covers this call; EPI_GENERIC when none does or the vector-path conditions fail
+int classify_epilogue(const cvx_gemm_args& a, const SplitOut& so);
 
 int validate_gemm_args(const cvx_gemm_args* a);   // shared argument checks (gemm_f32.hip)
 

@@ -703,7 +703,7 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
             so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
         }
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
-        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev;
+        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev; so.dbg = io->flags >> 8; so.trace = (so.dbg & 4) ? reinterpret_cast<unsigned long long*>(io->workspace) : nullptr;
         if (io->Vt_hi || io->Vt_lo) {
             CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
                         (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= ((a->rope_T + 15) / 16) * 16 && io->vt_ld % 8 == 0 &&
@@ -745,9 +745,12 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         if (single)
             hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);
-        else if (w_il && a_il && !(io->flags & CVX_GEMM_FLAG_TWO_STAGE) &&
+        else if (w_il && a_il && !(io->flags & (CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32)) &&
+                 cvxg::launch_gemm_f16x3_p8s(*a, A, wh, acc_scale, so, map_mode, st)) {
+            /* eight-phase ping-pong kernel on the 16x16x32 MFMA (gemm_f16x3_p8s.hip) */
+        } else if (w_il && a_il && !(io->flags & CVX_GEMM_FLAG_TWO_STAGE) &&
                  cvxg::launch_gemm_f16x3_p8(*a, A, wh, acc_scale, so, map_mode, st)) {
-            /* eight-phase ping-pong kernel (gemm_f16x3_p8.hip) */
+            /* eight-phase ping-pong kernel on the 32x32x16 MFMA (gemm_f16x3_p8.hip): ragged N, unaligned epilogues */
         } else if (w_il && a_il)
             hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true, true>), g256, dim3(512), lds256, st, *a, A, wh, wl,
                                acc_scale, so, tm, tn, map_mode);

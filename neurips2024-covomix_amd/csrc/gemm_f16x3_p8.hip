@@ -55,12 +55,14 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
 #define CVX_P8_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define CVX_P8_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <bool HAS_A2>
+template <bool HAS_A2, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ W, float acc_scale, SplitOut so,
     int tiles_m, int tiles_n, int map_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_p8[];
+    const unsigned long long ts0 = so.trace ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long rt0 = so.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;                      // wave group (M half), N quarter
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8_kernel(
     CVX_P8_WAIT_DMA();                                  // 4 quarters may stay in flight: A0(0), B0(0) have landed
     CVX_P8_BARRIER();
     if (wr == 1) CVX_P8_BARRIER();          // group 1 runs one interval behind group 0
+    const unsigned long long ts1 = so.trace ? __builtin_readcyclecounter() : 0ull;
 
     f16x8 fah[2][2], fal[2][2];                         // A fragments of the current M half: [tile][k slice]
     f16x8 fbh[2][2], fbl[2][2];                         // B fragments: [n half][k slice]
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8_kernel(
 #undef CVX_P8_READ_A
 #undef CVX_P8_READ_B
 
+    const unsigned long long ts2 = so.trace ? __builtin_readcyclecounter() : 0ull;
     if (wr == 0) CVX_P8_BARRIER();                      // pairs with group 1's last barrier (both epilogues then run together)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail's dummy pieces before LDS is released
     acc_scale = total_acc_scale(acc_scale, so);
@@ -220,7 +224,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
     }
-    gemm_epilogue<4>(p, acc, m0, n0, wr, wc, lane, so);
+    if (so.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.C[0] = 1.f; return; }      // timing experiment: main loop only
+    gemm_epilogue<4, EPI>(p, acc, m0, n0, wr, wc, lane, so);
+    if (so.trace) {       // dev: cycle stamps of wave `wid` of this block: start, main loop start, main loop end, stores issued, stores done
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts4 = __builtin_readcyclecounter();
+        if (lane == 0) {
+            unsigned long long* t = so.trace + ((size_t)blockIdx.x * 8 + wid) * 8;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            hw = (hw & 0xffffff) | ((xcc & 0xf) << 24);
+            t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = ts4; t[5] = __builtin_amdgcn_s_memrealtime(); t[6] = rt0; t[7] = hw;
+        }
+    }
 }
 
 }  // namespace
@@ -238,14 +256,43 @@ bool launch_gemm_f16x3_p8(const cvx_gemm_args& a, const PreSplitA& A, const f16*
     (void)k1;
     const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
     const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
-    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<false>), LDS_B);
-    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<true>), LDS_B);
     const dim3 grid((unsigned)(gm * tn));
-    if (A.hi2)
-        hipLaunchKernelGGL((gemm_f16x3_p8_kernel<true>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, map_mode);
-    else
-        hipLaunchKernelGGL((gemm_f16x3_p8_kernel<false>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, map_mode);
+    const int epi = (so.dbg & 2) ? EPI_GENERIC : classify_epilogue(a, so);
+#define CVX_P8_LAUNCH(A2, E)                                                                                            \
+    do {                                                                                                                \
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8_kernel<A2, E>), LDS_B);                      \
+        hipLaunchKernelGGL((gemm_f16x3_p8_kernel<A2, E>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, map_mode); \
+    } while (0)
+    if (A.hi2) {
+        if (epi == EPI_BIAS) CVX_P8_LAUNCH(true, EPI_BIAS); else CVX_P8_LAUNCH(true, EPI_GENERIC);
+    } else {
+        switch (epi) {
+            case EPI_QKV: CVX_P8_LAUNCH(false, EPI_QKV); break;
+            case EPI_RES: CVX_P8_LAUNCH(false, EPI_RES); break;
+            case EPI_GELU_SPLIT: CVX_P8_LAUNCH(false, EPI_GELU_SPLIT); break;
+            case EPI_BIAS: CVX_P8_LAUNCH(false, EPI_BIAS); break;
+            default: CVX_P8_LAUNCH(false, EPI_GENERIC); break;
+        }
+    }
+#undef CVX_P8_LAUNCH
     return true;
+}
+
+int classify_epilogue(const cvx_gemm_args& a, const SplitOut& so)
+{
+    // the specialised epilogues only have the 16-byte vector path: whole 64-column wave tiles, aligned pointers and strides
+    const bool vec = (a.N % 64 == 0) &&
+                     (!so.write_f32 || (((uintptr_t)a.C & 15) == 0 && (a.ldc & 3) == 0)) &&
+                     (!a.residual || (((uintptr_t)a.residual & 15) == 0 && (a.ldr & 3) == 0)) &&
+                     (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0));
+    if (!vec) return EPI_GENERIC;
+    const bool rope = a.rope_cos != nullptr;
+    if (rope && so.vt_hi && so.hi && !so.write_f32 && !a.bias && !a.residual && a.act == CVX_ACT_NONE) return EPI_QKV;
+    if (rope || so.vt_hi) return EPI_GENERIC;
+    if (a.residual && so.write_f32 && a.act == CVX_ACT_NONE) return EPI_RES;
+    if (a.bias && a.act == CVX_ACT_GELU && !a.residual && so.hi && !so.write_f32) return EPI_GELU_SPLIT;
+    if (a.act == CVX_ACT_NONE && !a.residual && so.write_f32 && !so.hi) return EPI_BIAS;
+    return EPI_GENERIC;
 }
 
 }  // namespace cvxg

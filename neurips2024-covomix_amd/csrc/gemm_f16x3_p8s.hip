@@ -1,0 +1,418 @@
+// Split-precision GEMM, large-problem kernel, second form: the eight-phase ping-pong main loop of gemm_f16x3_p8.hip on
+// v_mfma_f32_16x16x32_f16 with SWAPPED operands, and an epilogue that needs no register transposes.
+//
+//   * 16x16x32 instead of 32x32x16: an accumulator register is read and written once per 32 k instead of once per 16 k.
+//     The main loop of the 32x32 kernel already issues an MFMA every 32 cycles (99 % of its cycles) - what limits it is
+//     the clock the chip sustains under that load (power), and the 16x16x32 shape moves fewer register bytes per MAC.
+//   * swapped operands, D = W_frag . A_frag^T: a lane then holds 4 CONSECUTIVE COLUMNS of one output row (row = lane & 15,
+//     columns 4 * (lane >> 4) + 0..3 of a 16 x 16 tile), so every epilogue access (fp32 store, residual load, split
+//     store, bias / RoPE table loads) is a 16-byte (8-byte fp16) vector without the DPP quad transposes of the 32x32
+//     epilogue (5 VALU instructions per value there).  Blocks that own V columns of a to_qkv projection run the
+//     UN-swapped product instead: a lane then holds 4 consecutive FRAMES of one head-dim column, which is what the
+//     transposed V^T store wants.
+// Everything else (256 x 256 tile, wave groups one barrier interval apart, quarter-tile DMA ring six pieces ahead with
+// counted vmcnt, inline-asm LDS-DMA, chunk ^ ((row >> 1) & 7) swizzle) is as documented in gemm_f16x3_p8.hip.
+// Same contract as cvx_gemm_f16x3 (reference acoustic.py:225-246, :306-310); only full 64-column wave tiles with aligned
+// pointers are accepted (the launcher returns false otherwise and the 32x32 kernel takes the problem).
+#include "gemm_common.h"
+
+namespace {
+
+using namespace cvxg;
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TILE_B = 256 * 128;                  // bytes per operand tile
+constexpr int BUF_B = 2 * TILE_B;                  // A | W
+constexpr int DUMP_B = 2 * BUF_B;                  // dump area offset (8 KiB)
+constexpr int LDS_B = DUMP_B + 8 * 1024;
+
+__device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0a, uint32_t m0b, const void* sbase)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %4\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff0), "v"(voff1), "s"(m0a), "s"(m0b), "s"(sbase)
+                 : "memory");
+}
+
+#define CVX_P8_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define CVX_P8_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define CVX_P8_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions, exact residual by v_fma_mix
+__device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo)
+{
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    const f16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2), h23 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
+    const f16x2 l01 = __builtin_convertvector(f32x2{x[0] - (float)h01[0], x[1] - (float)h01[1]}, f16x2);
+    const f16x2 l23 = __builtin_convertvector(f32x2{x[2] - (float)h23[0], x[3] - (float)h23[1]}, f16x2);
+    hi = f16x4{h01[0], h01[1], h23[0], h23[1]};
+    lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
+}
+
+// erf to ~1 ulp without branches (both polynomial pieces, one select): |x| <= 0.927734375: x + x * P(x^2); beyond:
+// 1 - exp(Q(|x|)).  The library erff is several times longer and branchy; GELU runs on 4096 columns of every row.
+__device__ __forceinline__ float erf_fast(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f);
+    r = copysignf(r, a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
+__device__ __forceinline__ float gelu_fast(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
+
+// ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (&acc)[8][4], int row0, int col0, int lane,
+                                              const SplitOut& so_in, float acc_scale)
+{
+    cvx_gemm_args p = p_in;
+    SplitOut so = so_in;
+    if constexpr (EPI == EPI_QKV) {
+        p.act = CVX_ACT_NONE; p.bias = nullptr; p.residual = nullptr; so.write_f32 = 0;
+    } else if constexpr (EPI == EPI_RES) {
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; so.write_f32 = 1;
+    } else if constexpr (EPI == EPI_GELU_SPLIT) {
+        p.act = CVX_ACT_GELU; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 0;
+    } else if constexpr (EPI == EPI_BIAS) {
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1; so.hi = nullptr; so.lo = nullptr;
+    }
+    const int lr = lane & 15, lc = 4 * (lane >> 4);
+    const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);          // wave-uniform (64-column wave tile = one head)
+    const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
+    const bool il = so.hi && so.lo == so.hi + 32;
+    f32x4 bias[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        if (p.bias) bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+        else bias[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int row = row0 + 16 * mi + lr;
+        const bool live = row < p.M;
+        const int rr = live ? row : p.M - 1;
+        f32x4 v[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = fmaf(acc[mi][ni][e], acc_scale, bias[ni][e]);
+                if (p.act == CVX_ACT_GELU) x = gelu_fast(x);
+                else if (p.act == CVX_ACT_SILU) x = silu(x);
+                v[ni][e] = x;
+            }
+        }
+        if (do_rope) {      // half-split rotation: column j of the head pairs with j + 32 = tile ni + 2, same lane, same register
+            const int pos = rr % p.rope_T;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
+                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = v[ni][e], hi = v[ni + 2][e];
+                    v[ni][e] = __builtin_fmaf(lo, c[e], -__fmul_rn(hi, s[e]));          // fixed contraction, as in the 32x32 epilogue
+                    v[ni + 2][e] = __builtin_fmaf(hi, c[e], __fmul_rn(lo, s[e]));
+                }
+            }
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[ni][e] += r[e];
+            }
+        }
+        if (!live) continue;
+        if (so.write_f32) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + 16 * ni + lc) = v[ni];
+        }
+        if (so.hi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int c = col0 + 16 * ni + lc;
+                const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
+                f16x4 h, l;
+                split4_pk(f32x4{v[ni][0] * cs, v[ni][1] * cs, v[ni][2] * cs, v[ni][3] * cs}, h, l);
+                *reinterpret_cast<f16x4*>(so.hi + o) = h;
+                if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = l;
+            }
+        }
+    }
+}
+
+// ---- epilogue of a V block of a to_qkv projection, UN-swapped layout:
+// acc[mi][ni][r] = C[row0 + 16 mi + 4 (lane >> 4) + r][col0 + 16 ni + (lane & 15)]: 4 consecutive frames per lane ->
+// vt[((b*H + head)*64 + d) * vt_ld + slot(t)], 8 bytes per store when the four frames are one aligned slot group
+__device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)[8][4], int row0, int col0, int lane,
+                                            const SplitOut& so, float acc_scale)
+{
+    const int H = p.rope_cols / 128, T = p.rope_T;
+    const int head = (col0 - p.rope_cols) / 64;
+    const float vs = (so.vt_scale ? *so.vt_scale : 1.f) * acc_scale;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int r0 = row0 + 16 * mi + 4 * (lane >> 4);
+        if (r0 >= p.M) continue;
+        const int b = r0 / T, t0 = r0 - b * T;
+        const bool vec = (t0 & 3) == 0 && t0 + 3 < T && r0 + 3 < p.M;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int d = 16 * ni + (lane & 15);
+            const float bv = p.bias ? p.bias[col0 + d] * (so.vt_scale ? *so.vt_scale : 1.f) : 0.f;
+            f16x4 h, l;
+            split4_pk(f32x4{fmaf(acc[mi][ni][0], vs, bv), fmaf(acc[mi][ni][1], vs, bv), fmaf(acc[mi][ni][2], vs, bv), fmaf(acc[mi][ni][3], vs, bv)}, h, l);
+            if (vec) {
+                const int64_t o = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld + vt_slot(t0);
+                *reinterpret_cast<f16x4*>(so.vt_hi + o) = h;
+                if (so.vt_lo) *reinterpret_cast<f16x4*>(so.vt_lo + o) = l;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = r0 + e;
+                    if (row >= p.M) break;
+                    const int bb = row / T, tt = row - bb * T;
+                    const int64_t o = ((int64_t)(bb * H + head) * 64 + d) * so.vt_ld + vt_slot(tt);
+                    so.vt_hi[o] = h[e];
+                    if (so.vt_lo) so.vt_lo[o] = l[e];
+                }
+            }
+        }
+    }
+}
+
+// the main loop for one output tile; SWAP selects the operand order of every MFMA (see the header)
+template <bool HAS_A2, bool SWAP>
+__device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
+                                              int m0, int n0, int lane, int wid, int wr, int wc, f32x4 (&acc)[8][4])
+{
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t offA[2][2], offA2[2][2], offW[2][2];                // per-lane source byte offsets
+    uint32_t dstA[2][2], dstW[2][2];                             // LDS byte offsets inside a buffer (wave-uniform)
+    const int64_t ldaB = A.ld * 2, lda2B = A.ld2 * 2, ldwB = p.ldw * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pr0 = 8 * (2 * wid + j);
+            const int ra0 = (pr0 >> 6) * 128 + h * 64 + (pr0 & 63);
+            const int rb0 = (pr0 >> 5) * 64 + h * 32 + (pr0 & 31);
+            const int ra = ra0 + (lane >> 3), rb = rb0 + (lane >> 3);
+            const uint32_t ca = (uint32_t)(((lane & 7) ^ ((ra >> 1) & 7)) * 16);
+            const uint32_t cb = (uint32_t)(((lane & 7) ^ ((rb >> 1) & 7)) * 16);
+            const int64_t ga = min(m0 + ra, p.M - 1), gb = min(n0 + rb, p.N - 1);
+            offA[h][j] = (uint32_t)(ga * ldaB) + ca;
+            offA2[h][j] = HAS_A2 ? (uint32_t)(ga * lda2B) + ca : 0u;
+            offW[h][j] = (uint32_t)(gb * ldwB) + cb;
+            dstA[h][j] = (uint32_t)(ra0 * 128);
+            dstW[h][j] = (uint32_t)(TILE_B + rb0 * 128);
+        }
+    const int nk = p.K / 32;
+    const int t_sw = HAS_A2 ? p.K1 / 32 : 0x7fffffff;
+    const char* const a1base = reinterpret_cast<const char*>(A.hi);
+    const char* const a2base = reinterpret_cast<const char*>(A.hi2);
+    const char* const wbase = reinterpret_cast<const char*>(W);
+    const uint32_t dump = lds0 + DUMP_B + (uint32_t)wid * 1024u;
+
+    auto issue_A = [&](int h, int tt) {
+        const bool live = tt < nk;
+        const uint32_t b = lds0 + (uint32_t)(tt & 1) * BUF_B;
+        const char* base = a1base + (int64_t)tt * 128;
+        uint32_t v0 = offA[h][0], v1 = offA[h][1];
+        if constexpr (HAS_A2) {
+            if (tt >= t_sw) { base = a2base + (int64_t)(tt - t_sw) * 128; v0 = offA2[h][0]; v1 = offA2[h][1]; }
+        }
+        if (!live) { base = wbase; v0 = 0u; v1 = 0u; }
+        dma2(v0, v1, live ? b + dstA[h][0] : dump, live ? b + dstA[h][1] : dump, base);
+    };
+    auto issue_W = [&](int h, int tt) {
+        const bool live = tt < nk;
+        const uint32_t b = lds0 + (uint32_t)(tt & 1) * BUF_B;
+        const char* base = live ? wbase + (int64_t)tt * 128 : wbase;
+        dma2(live ? offW[h][0] : 0u, live ? offW[h][1] : 0u, live ? b + dstW[h][0] : dump, live ? b + dstW[h][1] : dump, base);
+    };
+
+    // fragment addresses: row (lane & 15) of a 16-row MFMA tile, k chunk (lane >> 4) for hi / 4 + (lane >> 4) for lo
+    const int lr = lane & 15, kg = lane >> 4, sw8 = lr >> 1;
+    const int aoh = (wr * 128 + lr) * 128 + 16 * (kg ^ sw8);
+    const int aol = (wr * 128 + lr) * 128 + 16 * ((4 + kg) ^ sw8);
+    const int boh = TILE_B + (wc * 64 + lr) * 128 + 16 * (kg ^ sw8);
+    const int bol = TILE_B + (wc * 64 + lr) * 128 + 16 * ((4 + kg) ^ sw8);
+
+    issue_A(0, 0); issue_W(0, 0); issue_W(1, 0); issue_A(1, 0); issue_A(0, 1); issue_W(0, 1);
+    CVX_P8_WAIT_DMA();
+    CVX_P8_BARRIER();
+    if (wr == 1) CVX_P8_BARRIER();
+
+    f16x8 fah[4], fal[4];                               // A fragments of the current M half (4 tiles of 16 rows)
+    f16x8 fbh[2][2], fbl[2][2];                         // W fragments: [n half][tile]
+
+#define CVX_P8S_READ_A(buf, mh)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+        fah[i] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((mh) * 4 + i) * 16 * 128 + aoh);        \
+        fal[i] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((mh) * 4 + i) * 16 * 128 + aol);        \
+    }
+#define CVX_P8S_READ_B(buf, nh)                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+        fbh[nh][j] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((nh) * 2 + j) * 16 * 128 + boh);    \
+        fbl[nh][j] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((nh) * 2 + j) * 16 * 128 + bol);    \
+    }
+#define CVX_P8S_MM(x, y, c) (SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(y, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0))
+    // quadrant (mh, nh): 4 x 2 tiles x three terms = 24 MFMAs, term-major (consecutive MFMAs hit different accumulators)
+#define CVX_P8S_MFMA(mh, nh)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
+        acc[(mh) * 4 + i][(nh) * 2 + j] = CVX_P8S_MM(fal[i], fbh[nh][j], acc[(mh) * 4 + i][(nh) * 2 + j]);       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
+        acc[(mh) * 4 + i][(nh) * 2 + j] = CVX_P8S_MM(fah[i], fbl[nh][j], acc[(mh) * 4 + i][(nh) * 2 + j]);       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
+        acc[(mh) * 4 + i][(nh) * 2 + j] = CVX_P8S_MM(fah[i], fbh[nh][j], acc[(mh) * 4 + i][(nh) * 2 + j]);       \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    CVX_P8_BARRIER();
+#define CVX_P8S_SYNC()                                                                                           \
+    CVX_P8_WAIT_DMA();                                                                                           \
+    CVX_P8_BARRIER();                                                                                            \
+    CVX_P8_WAIT_LDS();
+#define CVX_P8S_KTILE(buf, t)                                                                                    \
+    {                                                                                                            \
+        CVX_P8S_READ_B(buf, 0) CVX_P8S_READ_A(buf, 0)                                                            \
+        issue_W(1, (t) + 1);                                                                                     \
+        CVX_P8S_SYNC() CVX_P8S_MFMA(0, 0)                                                                        \
+        CVX_P8S_READ_B(buf, 1)                                                                                   \
+        issue_A(1, (t) + 1);                                                                                     \
+        CVX_P8S_SYNC() CVX_P8S_MFMA(0, 1)                                                                        \
+        CVX_P8S_READ_A(buf, 1)                                                                                   \
+        issue_A(0, (t) + 2);                                                                                     \
+        CVX_P8S_SYNC() CVX_P8S_MFMA(1, 1)                                                                        \
+        issue_W(0, (t) + 2);                                                                                     \
+        CVX_P8S_SYNC() CVX_P8S_MFMA(1, 0)                                                                        \
+    }
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        CVX_P8S_KTILE(0, t)
+        CVX_P8S_KTILE(1, t + 1)
+    }
+    if (t < nk) CVX_P8S_KTILE(0, t)
+#undef CVX_P8S_KTILE
+#undef CVX_P8S_SYNC
+#undef CVX_P8S_MFMA
+#undef CVX_P8S_MM
+#undef CVX_P8S_READ_A
+#undef CVX_P8S_READ_B
+    if (wr == 0) CVX_P8_BARRIER();                      // pairs with group 1's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail's dummy pieces before LDS is released
+}
+
+template <bool HAS_A2, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
+    const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ W, float acc_scale, SplitOut so,
+    int tiles_m, int tiles_n, int map_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_p8s[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    int tile_m, tile_n;
+    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
+    if (tile_m >= tiles_m) return;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    acc_scale = total_acc_scale(acc_scale, so);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+    if constexpr (EPI == EPI_QKV) {
+        if (n0 >= p.rope_cols) {                        // block-uniform: this block owns V columns
+            tile_mainloop<HAS_A2, false>(p, A, W, smem_p8s, m0, n0, lane, wid, wr, wc, acc);
+            if (so.dbg & 1) { if (acc[0][0][0] == 12345.678f) so.vt_hi[0] = (f16)1.f; return; }
+            epilogue_vt(p, acc, row0, col0, lane, so, acc_scale);
+            return;
+        }
+    }
+    tile_mainloop<HAS_A2, true>(p, A, W, smem_p8s, m0, n0, lane, wid, wr, wc, acc);
+    if (so.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.C[0] = 1.f; return; }      // timing experiment: main loop only
+    epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);
+}
+
+}  // namespace
+
+namespace cvxg {
+
+bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16* w_il, float acc_scale, const SplitOut& so,
+                           int map_mode, hipStream_t st)
+{
+    if (a.K % 32 != 0 || (A.hi2 && a.K1 % 32 != 0) || a.N % 64 != 0) return false;
+    if ((int64_t)a.M * A.ld * 2 >= (int64_t)1 << 32 || (A.hi2 && (int64_t)a.M * A.ld2 * 2 >= (int64_t)1 << 32) ||
+        (int64_t)a.N * a.ldw * 2 >= (int64_t)1 << 32) return false;
+    // 16-byte vector epilogue only: aligned pointers and strides, bias / RoPE tables included
+    const bool vec = (!so.write_f32 || (((uintptr_t)a.C & 15) == 0 && (a.ldc & 3) == 0)) &&
+                     (!a.residual || (((uintptr_t)a.residual & 15) == 0 && (a.ldr & 3) == 0)) &&
+                     (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0)) &&
+                     (!a.bias || ((uintptr_t)a.bias & 15) == 0) &&
+                     (!a.rope_cos || ((((uintptr_t)a.rope_cos | (uintptr_t)a.rope_sin) & 15) == 0 && a.rope_cols % 256 == 0));
+    if (!vec) return false;
+    if (so.vt_hi && !(a.rope_cos && so.hi && !so.write_f32 && !a.residual && a.act == CVX_ACT_NONE)) return false;   // V^T only in QKV form
+    const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
+    const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
+    const dim3 grid((unsigned)(gm * tn));
+    int epi = classify_epilogue(a, so);
+    if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;
+    if (epi == EPI_GENERIC && so.vt_hi) return false;
+#define CVX_P8S_LAUNCH(A2, E)                                                                                           \
+    do {                                                                                                                \
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8s_kernel<A2, E>), LDS_B);                     \
+        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, map_mode); \
+    } while (0)
+    if (A.hi2) {
+        if (epi == EPI_BIAS) CVX_P8S_LAUNCH(true, EPI_BIAS); else CVX_P8S_LAUNCH(true, EPI_GENERIC);
+    } else {
+        switch (epi) {
+            case EPI_QKV: CVX_P8S_LAUNCH(false, EPI_QKV); break;
+            case EPI_RES: CVX_P8S_LAUNCH(false, EPI_RES); break;
+            case EPI_GELU_SPLIT: CVX_P8S_LAUNCH(false, EPI_GELU_SPLIT); break;
+            case EPI_BIAS: CVX_P8S_LAUNCH(false, EPI_BIAS); break;
+            default: CVX_P8S_LAUNCH(false, EPI_GENERIC); break;
+        }
+    }
+#undef CVX_P8S_LAUNCH
+    return true;
+}
+
+}  // namespace cvxg
