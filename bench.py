@@ -250,7 +250,8 @@ def main():
         split = model.precision in ("f16x3", "f16")
         terms = {"f16x3": 3, "f16": 1, "fp32": 1}[model.precision]
         p8 = model.precision == "f16x3" and ops._GEMM_FLAGS == 0
-        kname = ("gemm_f16x3_p8_kernel" if p8 else "gemm_f16x3_dma256_kernel") if split else "gemm_f32_glds_kernel"
+        kname = ("gemm_f16x3_p8s_kernel" if p8 else "gemm_f16x3_dma256_kernel") if split else "gemm_f32_glds_kernel"
+        mfma = "v_mfma_f32_16x16x32_f16" if p8 else "v_mfma_f32_32x32x16_f16"
         peak = PEAK_F16_MFMA if split else PEAK_F32_MFMA
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -276,7 +277,7 @@ def main():
             # dominant kernel.  achieved = ALGORITHMIC flops (2*M*N*K per launch) / HIP-event time of the launches;
             # the split kernel executes 3 MFMA products per algorithmic product, so its matrix-pipe work is 3x that.
             "roofline": {"bound": "mfma",
-                         "kernel": kname + ((" (v_mfma_f32_32x32x16_f16 x%d)" % terms) if split else " (v_mfma_f32_32x32x2_f32)"),
+                         "kernel": kname + ((" (%s x%d)" % (mfma, terms)) if split else " (v_mfma_f32_32x32x2_f32)"),
                          "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic,
                          "executed_mfma_frac": round(achieved * terms / (peak / 1e12), 4),
