@@ -248,6 +248,11 @@ typedef struct {
     float out_scale;
     uint16_t *out_zhi, *out_zlo;
     float z_slope;
+    /* Activation pre-scale of this ResBlock stage (DEVICE scalar, power of two, NULL = 1): z_hi/z_lo hold
+     * leaky_relu(x) * *z_scale_dev (the accumulators are divided by it, exactly) and out_zhi/out_zlo are written times
+     * it; res / accum / out_x are true fp32 values.  Keeps the split pairs inside fp16's full-precision window whatever
+     * the magnitude of the stage's activations (cvx_amax_pow2_scale_f32 measures it from the stage input). */
+    const float* z_scale_dev;
 } cvx_conv16_args;
 int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s);
 
@@ -256,8 +261,16 @@ int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s);
  * leaky_relu(x, slope) (z_hi/z_lo, optional); from_channels_last the reverse of the fp32 copy. */
 int cvx_hifigan_to_channels_last(const float* x, float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int32_t B, int32_t C,
                                  int32_t L, int32_t Lp, int32_t Cp, int32_t halo_l, float slope, cvx_stream_t s);
+int cvx_hifigan_to_channels_last_scaled(const float* x, float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int32_t B, int32_t C,
+                                        int32_t L, int32_t Lp, int32_t Cp, int32_t halo_l, float slope,
+                                        const float* z_scale_dev /* the pair holds leaky_relu(x) * *z_scale_dev; NULL = 1 */,
+                                        cvx_stream_t s);
 int cvx_hifigan_from_channels_last(const float* x_cl, float* x, int32_t B, int32_t C, int32_t L, int32_t Lp,
                                    int32_t Cp, int32_t halo_l, cvx_stream_t s);
+/* *scale_dev = 2^round(log2(target / max|x|)) (1 when x is all zero; exponent clamped to +-40): the power-of-two factor that
+ * brings the largest magnitude of x to about `target`.  Everything stays on the device (scratch_dev: one uint32 of
+ * caller-owned scratch), so a consumer kernel can use the scale without a host round trip. */
+int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, float* scale_dev, uint32_t* scratch_dev, cvx_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Prompt mel extraction - SURVEY.md section 8f row N3 (data_preparation/generate_mel.py:49-72 as called by

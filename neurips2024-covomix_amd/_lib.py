@@ -65,6 +65,7 @@ class Conv16Args(C.Structure):
         ("Np", C.c_int32), ("ksize", C.c_int32), ("dil", C.c_int32),
         ("res", C.c_void_p), ("accum", C.c_void_p), ("out_x", C.c_void_p), ("out_scale", C.c_float),
         ("out_zhi", C.c_void_p), ("out_zlo", C.c_void_p), ("z_slope", C.c_float),
+        ("z_scale_dev", C.c_void_p),
     ]
 
 
@@ -146,6 +147,9 @@ SIGNATURES = {
     "cvx_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "cvx_gemm_f16x3_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cvx_rope_attention_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "cvx_hifigan_to_channels_last_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                      C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_amax_pow2_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvx_split_f16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_adarmsnorm_scaled_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -324,6 +324,46 @@ extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const floa
     return cvx_adarmsnorm_scaled_f32(x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, nullptr, s);
 }
 
+// ---------------------------------------------------------------- measured power-of-two pre-scale of a tensor
+namespace {
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ amax_bits)
+{
+    float m = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        } else {
+            for (int64_t j = i; j < n; ++j) m = fmaxf(m, fabsf(x[j]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < __builtin_inff()) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+__global__ void pow2_scale_kernel(const unsigned* __restrict__ amax_bits, float target, float* __restrict__ scale)
+{
+    const float a = __uint_as_float(*amax_bits);
+    float e = 0.f;
+    if (a > 0.f) e = fminf(fmaxf(rintf(log2f(target / a)), -40.f), 40.f);
+    *scale = exp2f(e);
+}
+}  // namespace
+
+extern "C" int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, float* scale_dev, uint32_t* scratch_dev, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && scale_dev && scratch_dev && n >= 0 && target > 0.f && ((uintptr_t)x & 15) == 0, "amax_pow2_scale: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    if (hipMemsetAsync(scratch_dev, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("amax_pow2_scale: memset failed"); return CVX_EHIP; }
+    if (n > 0) {
+        const unsigned blocks = (unsigned)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
+        hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, n, scratch_dev);
+    }
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, scratch_dev, target, scale_dev);
+    CVX_CHECK_LAUNCH("cvx_amax_pow2_scale_f32");
+    return CVX_OK;
+}
+
 extern "C" int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
                                          int32_t Bt, int32_t T, int32_t C, cvx_stream_t s)
 {

@@ -44,6 +44,7 @@ struct Conv16Args {
     f16* out_zhi; f16* out_zlo;        // [B][Lp][Np] or NULL
     int L, Lp, Cp_in, Np, ksize, dil, pad, halo_l;
     float acc_scale, out_scale, z_slope;
+    const float* z_scale;              // device scalar (power of two) carried by z and applied to out_z, or NULL = 1
 };
 
 template <int TMI, int TNI, int WN>
@@ -59,6 +60,8 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
+    const float zs = p.z_scale ? *p.z_scale : 1.f;          // activation pre-scale of this stage's split pairs
+    const float a_sc = p.acc_scale / zs;                    // (exact: both are powers of two)
     const int l0 = blockIdx.x * TMB;
     const int b = blockIdx.y;
     const int n_chunks = p.Cp_in / CK;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
                 const int l = l0 + wm * TMI * 32 + mi * 32 + 8 * rg + 4 * g + q;
                 if (l >= p.L) continue;
                 const int64_t o = ((int64_t)b * p.Lp + p.halo_l + l) * NP + co;
-                f32x4 v = {v0 * p.acc_scale + bv[0], v1 * p.acc_scale + bv[1], v2 * p.acc_scale + bv[2], v3 * p.acc_scale + bv[3]};
+                f32x4 v = {v0 * a_sc + bv[0], v1 * a_sc + bv[1], v2 * a_sc + bv[2], v3 * a_sc + bv[3]};
                 if (p.res) {
                     const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + o);
 #pragma unroll
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
                     cvx_f16x4 zh, zl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float z = v[e] > 0.f ? v[e] : v[e] * p.z_slope;
+                        float z = (v[e] > 0.f ? v[e] : v[e] * p.z_slope) * zs;
                         z = fminf(fmaxf(z, -65504.f), 65504.f);
                         zh[e] = (_Float16)z;
                         zl[e] = (_Float16)(z - (float)zh[e]);
@@ -216,9 +219,11 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 // channel-major fp32 [B][C][L]  ->  channels-last [B][Lp][Cp]: fp32 copy (optional) + split fp16 of leaky_relu(x)
 __global__ __launch_bounds__(256) void cm_to_cl_kernel(const float* __restrict__ x, float* __restrict__ x_cl,
                                                       f16* __restrict__ z_hi, f16* __restrict__ z_lo,
-                                                      int C, int L, int Lp, int Cp, int halo_l, float slope)
+                                                      int C, int L, int Lp, int Cp, int halo_l, float slope,
+                                                      const float* __restrict__ z_scale)
 {
     __shared__ float tile[32][65];
+    const float zs = z_scale ? *z_scale : 1.f;
     const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 32, b = blockIdx.z;
     const int tid = threadIdx.x;
     {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void cm_to_cl_kernel(const float* __restrict__
         const int64_t o = ((int64_t)b * Lp + halo_l + l) * Cp + c0 + c;
         if (x_cl) x_cl[o] = v;
         if (z_hi) {
-            float z = v > 0.f ? v : v * slope;
+            float z = (v > 0.f ? v : v * slope) * zs;
             z = fminf(fmaxf(z, -65504.f), 65504.f);
             const f16 h = (f16)z;
             z_hi[o] = h;
@@ -300,7 +305,7 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
     Conv16Args k{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
                  reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
-                 a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope};
+                 a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     if (a->Np == 256) launch_conv16<4, 2, 4>(k, a->B, st);
     else if (a->Np == 128) launch_conv16<2, 2, 2>(k, a->B, st);
@@ -313,12 +318,19 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
 extern "C" int cvx_hifigan_to_channels_last(const float* x, float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int32_t B, int32_t C,
                                             int32_t L, int32_t Lp, int32_t Cp, int32_t halo_l, float slope, cvx_stream_t s)
 {
+    return cvx_hifigan_to_channels_last_scaled(x, x_cl, z_hi, z_lo, B, C, L, Lp, Cp, halo_l, slope, nullptr, s);
+}
+
+extern "C" int cvx_hifigan_to_channels_last_scaled(const float* x, float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int32_t B, int32_t C,
+                                                   int32_t L, int32_t Lp, int32_t Cp, int32_t halo_l, float slope,
+                                                   const float* z_scale_dev, cvx_stream_t s)
+{
     CVX_REQUIRE(x && (x_cl || z_hi) && ((z_hi == nullptr) == (z_lo == nullptr)) && B >= 0 && C > 0 && L > 0 && Cp >= C && Cp % 32 == 0 &&
                 halo_l >= 0 && Lp >= halo_l + L, "to_channels_last: bad arguments");
     if (B == 0) return CVX_OK;
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
     hipLaunchKernelGGL(cm_to_cl_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, x_cl,
-                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope);
+                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope, z_scale_dev);
     CVX_CHECK_LAUNCH("cvx_hifigan_to_channels_last");
     return CVX_OK;
 }

@@ -393,8 +393,17 @@ def hifigan_pack_weight_f16x3(w: torch.Tensor):
     return hi, lo, inv, np_, cp
 
 
+def amax_pow2_scale(x: torch.Tensor, target: float, scale: torch.Tensor, scratch: torch.Tensor) -> torch.Tensor:
+    """scale[0] = 2^round(log2(target / max|x|)) computed on the device (scratch: one int32 element)."""
+    _chk_f32(x, scale)
+    assert x.is_contiguous() and scale.numel() == 1 and scratch.is_cuda and scratch.dtype == torch.int32 and scratch.numel() >= 1
+    _lib.check(_lib.load().cvx_amax_pow2_scale_f32(x.data_ptr(), x.numel(), float(target), scale.data_ptr(), scratch.data_ptr(), _stream()),
+               "cvx_amax_pow2_scale_f32")
+    return scale
+
+
 def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, res=None, accum=None, out_x=None,
-                         out_scale: float = 1.0, out_z=None, z_slope: float = 0.1) -> None:
+                         out_scale: float = 1.0, out_z=None, z_slope: float = 0.1, z_scale=None) -> None:
     """z = (hi, lo) channels-last [B, Lp, Cp_in]; wpk from hifigan_pack_weight_f16x3; bias [Np] (zero padded)."""
     zh, zl = z
     w_hi, w_lo, inv, np_, cp = wpk
@@ -415,10 +424,11 @@ def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, 
     else:
         a.out_zhi, a.out_zlo = None, None
     a.z_slope = z_slope
+    a.z_scale_dev = _sp(z_scale)
     _lib.check(_lib.load().cvx_hifigan_conv1d_f16x3(C.byref(a), _stream()), "cvx_hifigan_conv1d_f16x3")
 
 
-def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, slope: float) -> None:
+def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, slope: float, z_scale=None) -> None:
     """x [B, C, L] fp32 channel-major -> x_cl [B, Lp, Cp] fp32 and / or z = split(leaky_relu(x)) [B, Lp, Cp]."""
     _chk_f32(x, x_cl)
     B, Cc, L = x.shape
@@ -426,8 +436,8 @@ def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, s
     Lp, Cp = ref.shape[1], ref.shape[2]
     assert x.is_contiguous() and ref.is_contiguous() and ref.shape[0] == B
     zh, zl = z if z is not None else (None, None)
-    _lib.check(_lib.load().cvx_hifigan_to_channels_last(x.data_ptr(), _p(x_cl), _p(zh), _p(zl), B, Cc, L, Lp, Cp, HIFI_HALO_L,
-                                                        slope, _stream()), "cvx_hifigan_to_channels_last")
+    _lib.check(_lib.load().cvx_hifigan_to_channels_last_scaled(x.data_ptr(), _p(x_cl), _p(zh), _p(zl), B, Cc, L, Lp, Cp, HIFI_HALO_L,
+                                                               slope, _sp(z_scale), _stream()), "cvx_hifigan_to_channels_last")
 
 
 def hifigan_from_channels_last(x_cl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:

@@ -71,6 +71,7 @@ class Generator:
         if self.precision not in ("f16x3", "fp32"):
             raise ValueError(f"vocoder precision must be 'f16x3' or 'fp32', got {self.precision!r}")
         self._cl: Dict[tuple, dict] = {}
+        self.act_scales = os.environ.get("CVX_ACT_SCALES", "1") == "1"
         self.h = h
         self.num_kernels = len(h["resblock_kernel_sizes"])
         self.num_upsamples = len(h["upsample_rates"])
@@ -225,21 +226,27 @@ class Generator:
         """xs = sum_j ResBlock1_j(x) / num_kernels  (models.py:104-110, :35-42) for one upsampling stage."""
         B, C, L = x.shape
         buf = self._cl_buffers(B, C, L)
-        ops.hifigan_to_channels_last(x, buf["x0"], buf["z0"], LRELU_SLOPE)
+        # activation pre-scale of this stage's split pairs: the power of two that brings max|x| of the stage input to 2^10
+        # (measured on the device; the intermediates of a ResBlock stay within a few binades of its input)
+        if "zs" not in buf:
+            buf["zs"] = torch.ones(1, dtype=torch.float32, device=self.device)
+            buf["zs_scratch"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        zs = ops.amax_pow2_scale(x, 1024.0, buf["zs"], buf["zs_scratch"]) if self.act_scales else None
+        ops.hifigan_to_channels_last(x, buf["x0"], buf["z0"], LRELU_SLOPE, z_scale=zs)
         nblk = len(blocks)
         for j, block in enumerate(blocks):
             cur_x, cur_z = buf["x0"], buf["z0"]
             for m, (c1, c2) in enumerate(block):
-                ops.hifigan_conv1d_f16x3(cur_z, c1.w16, c1.bias16, B, L, ksize=c1.k, dil=c1.dil, out_z=buf["t"], z_slope=LRELU_SLOPE)
+                ops.hifigan_conv1d_f16x3(cur_z, c1.w16, c1.bias16, B, L, ksize=c1.k, dil=c1.dil, out_z=buf["t"], z_slope=LRELU_SLOPE, z_scale=zs)
                 if m + 1 < len(block):
                     ox, oz = (buf["r0"], buf["rz0"]) if m % 2 == 0 else (buf["r1"], buf["rz1"])
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x, out_x=ox,
-                                             out_z=oz, z_slope=LRELU_SLOPE)
+                                             out_z=oz, z_slope=LRELU_SLOPE, z_scale=zs)
                     cur_x, cur_z = ox, oz
                 else:                                                    # last pair: fold into xs
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x,
                                              accum=buf["xs"] if j > 0 else None, out_x=buf["xs"],
-                                             out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0)
+                                             out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
         out = torch.empty_like(x)
         return ops.hifigan_from_channels_last(buf["xs"], out)
 

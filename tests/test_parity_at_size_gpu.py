@@ -191,3 +191,28 @@ def test_gemm_split_pairs_with_activation_scale_kernel_level():
     out = torch.empty(300, N, device=dev)
     ops.gemm(a, w, out, w_split=ws)
     assert rel_l2(out, a.double() @ w.double().T) > 3e-6          # the hole the scales close
+
+
+@pytest.mark.parametrize("exp", [-7, 0, 7])
+def test_vocoder_split_precision_is_scale_free(exp):
+    """HiFi-GAN with conv_pre (weight and bias) multiplied by 2^exp: every activation of the ResBlock stack scales with it
+    (leaky_relu is positively homogeneous).  The split-precision ResBlock convolutions measure each stage's magnitude on the
+    device and pre-scale their fp16 pairs, so the waveform stays fp32-class against an fp64 evaluation of the oracle."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd.vocoder import AttrDict, Generator
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    folded = orc.fold_weight_norm(vsd)
+    for k in ("conv_pre.weight", "conv_pre.bias"):
+        folded[k] = folded[k] * (2.0 ** exp)
+    gen = Generator(AttrDict(h)).to("cuda:0")
+    gen.load_state_dict(folded)
+    gen.eval()
+    mel = (torch.randn(2, 80, 120, generator=torch.Generator().manual_seed(9)) * 2 - 6).clamp(-11.52, 2.0)
+    y = gen(mel.cuda())
+    ref64 = orc.hifigan_forward({k: v.double() for k, v in folded.items()}, h, mel.double())
+    ref32 = orc.hifigan_forward(folded, h, mel)
+    e, e32 = rel_l2(y, ref64), rel_l2(ref32, ref64)
+    print(f"vocoder conv_pre x 2^{exp}: this build {e:.3e}, fp32 oracle {e32:.3e} (vs fp64)")
+    assert torch.isfinite(y).all() and e < 1e-5 and e < 6 * e32 + 1e-6
