@@ -67,8 +67,9 @@ def _pair(x, rows=None, cols=None):
     return hi.data_ptr(), _p(lo), hi.stride(0) if hi.ndim == 2 else hi.shape[-1]
 
 
-# dev A/B: CVX_GEMM_P8=0 keeps interleaved large problems on the two-stage kernel (read here, never inside the library)
-_GEMM_FLAGS = 0 if __import__("os").environ.get("CVX_GEMM_P8", "1") == "1" else 1
+# dev A/B (read here, never inside the library): CVX_GEMM_P8 = 1 (default) eight-phase kernel on the 16x16x32 MFMA,
+# 32 = eight-phase kernel on the 32x32x16 MFMA, 0 = two-stage kernel.  cvx_gemm_split_io.flags.
+_GEMM_FLAGS = {"1": 0, "32": 2, "0": 1}.get(__import__("os").environ.get("CVX_GEMM_P8", "1"), 0)
 
 _SPLITK_WS: dict = {}
 
