@@ -256,6 +256,30 @@ typedef struct {
 } cvx_conv16_args;
 int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s);
 
+/* ResBlock1.forward (covomix/vocoder/models.py:35-42) on the split-precision convolution above - the operator-level
+ * form of section 8(b)'s cvx_hifigan_resblock_* for the path the host actually runs: three times
+ *     x = c2(leaky_relu(c1(leaky_relu(x, .1)), .1)) + x        (c1: dilation dil[m], c2: dilation 1)
+ * on channels-last buffers [B][Lp][Np] (layout rules of cvx_conv16_args; Np = the stage's padded channel count for
+ * inputs and outputs).  x (fp32) and z = split(leaky_relu(x) * *z_scale_dev) are the block's input and are not
+ * modified; t, xa/za, xb/zb are caller-owned scratch of the same shapes (xa/za, xb/zb alternate as the intermediate
+ * x / z of the pairs).  The last pair writes out = (x_final (+ accum)) * out_scale (accum may alias out): the
+ * generator's xs (+)= resblock(x), / num_kernels on the last block (models.py:104-110).  Six launches. */
+typedef struct {
+    const uint16_t *w_hi, *w_lo; float acc_scale; const float* bias;     /* one convolution: cvx_conv16_args fields */
+} cvx_conv16_weights;
+typedef struct {
+    const float* x; const uint16_t *z_hi, *z_lo;
+    int32_t B, L, Lp, Np, halo_l;
+    cvx_conv16_weights c1[3], c2[3];
+    int32_t ksize; int32_t dil[3];
+    uint16_t *t_hi, *t_lo;
+    float* xa; uint16_t *za_hi, *za_lo;
+    float* xb; uint16_t *zb_hi, *zb_lo;
+    const float* accum; float* out; float out_scale;
+    const float* z_scale_dev;
+} cvx_resblock16_args;
+int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stream_t s);
+
 /* Layout converters between the channel-major fp32 tensors of cvx_hifigan_conv1d_f32 ([B][C][L]) and the
  * channels-last buffers above: to_channels_last writes the fp32 copy (x_cl, optional) and / or the split pair of
  * leaky_relu(x, slope) (z_hi/z_lo, optional); from_channels_last the reverse of the fp32 copy. */

@@ -69,6 +69,22 @@ class Conv16Args(C.Structure):
     ]
 
 
+class Conv16Weights(C.Structure):
+    _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("bias", C.c_void_p)]
+
+
+class Resblock16Args(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("z_hi", C.c_void_p), ("z_lo", C.c_void_p),
+                ("B", C.c_int32), ("L", C.c_int32), ("Lp", C.c_int32), ("Np", C.c_int32), ("halo_l", C.c_int32),
+                ("c1", Conv16Weights * 3), ("c2", Conv16Weights * 3),
+                ("ksize", C.c_int32), ("dil", C.c_int32 * 3),
+                ("t_hi", C.c_void_p), ("t_lo", C.c_void_p),
+                ("xa", C.c_void_p), ("za_hi", C.c_void_p), ("za_lo", C.c_void_p),
+                ("xb", C.c_void_p), ("zb_hi", C.c_void_p), ("zb_lo", C.c_void_p),
+                ("accum", C.c_void_p), ("out", C.c_void_p), ("out_scale", C.c_float),
+                ("z_scale_dev", C.c_void_p)]
+
+
 class T2SLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c",
                                           "gamma_f", "w1", "b1", "w2", "b2", "k_cache", "v_cache")]
@@ -140,6 +156,7 @@ SIGNATURES = {
                                          C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_hifigan_convt_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "cvx_hifigan_resblock_f32": (C.c_int, [C.POINTER(ResblockArgs), C.c_void_p]),
+    "cvx_hifigan_resblock_f16x3": (C.c_int, [C.POINTER(Resblock16Args), C.c_void_p]),
     "cvx_hifigan_pre_post_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),

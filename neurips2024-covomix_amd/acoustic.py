@@ -443,9 +443,13 @@ class FlowMatchingSampler:
             side = self._side
             full_eval = f.evaluate
 
+            skew = int(float(os.environ.get("CVX_CHAIN_SKEW_US", "0")) * 1000)      # dev: start the second chain late (ns of spin)
+
             def evaluate2(c, step):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
+                    if skew:
+                        torch.cuda._sleep(skew * 2)             # ~cycles at 2 GHz
                     full_eval(c, step, part=1)
                 full_eval(c, step, part=0)
                 main.wait_stream(side)

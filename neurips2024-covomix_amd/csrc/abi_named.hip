@@ -79,6 +79,42 @@ extern "C" int cvx_hifigan_resblock_f32(const cvx_resblock_args* a, cvx_stream_t
     return CVX_OK;
 }
 
+extern "C" int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->x && a->z_hi && a->z_lo && a->t_hi && a->t_lo && a->out, "hifigan_resblock_f16x3: null pointer");
+    CVX_REQUIRE(a->xa && a->za_hi && a->za_lo && a->xb && a->zb_hi && a->zb_lo, "hifigan_resblock_f16x3: missing scratch buffers");
+    const float* cur_x = a->x;
+    const uint16_t *cur_zh = a->z_hi, *cur_zl = a->z_lo;
+    for (int m = 0; m < 3; ++m) {
+        CVX_REQUIRE(a->c1[m].w_hi && a->c2[m].w_hi && a->dil[m] > 0, "hifigan_resblock_f16x3: missing weights / dilation of pair %d", m);
+        cvx_conv16_args c{};
+        c.B = a->B; c.L = a->L; c.Lp = a->Lp; c.Cp_in = a->Np; c.halo_l = a->halo_l; c.Np = a->Np; c.ksize = a->ksize;
+        c.z_slope = 0.1f; c.out_scale = 1.0f; c.z_scale_dev = a->z_scale_dev;
+        // t = split(leaky_relu(c1(z)))                                     models.py:36-38
+        c.z_hi = cur_zh; c.z_lo = cur_zl; c.dil = a->dil[m];
+        c.w_hi = a->c1[m].w_hi; c.w_lo = a->c1[m].w_lo; c.acc_scale = a->c1[m].acc_scale; c.bias = a->c1[m].bias;
+        c.out_zhi = a->t_hi; c.out_zlo = a->t_lo;
+        int rc = cvx_hifigan_conv1d_f16x3(&c, s);
+        if (rc != CVX_OK) return rc;
+        // x' = c2(t) + x ; z' = split(leaky_relu(x'))                       models.py:38-40
+        c.z_hi = a->t_hi; c.z_lo = a->t_lo; c.dil = 1;
+        c.w_hi = a->c2[m].w_hi; c.w_lo = a->c2[m].w_lo; c.acc_scale = a->c2[m].acc_scale; c.bias = a->c2[m].bias;
+        c.res = cur_x;
+        if (m < 2) {
+            float* ox = (m == 0) ? a->xa : a->xb;
+            c.out_x = ox; c.out_zhi = (m == 0) ? a->za_hi : a->zb_hi; c.out_zlo = (m == 0) ? a->za_lo : a->zb_lo;
+            rc = cvx_hifigan_conv1d_f16x3(&c, s);
+            if (rc != CVX_OK) return rc;
+            cur_x = ox; cur_zh = c.out_zhi; cur_zl = c.out_zlo;
+        } else {                                                            // last pair: fold into the generator's xs
+            c.out_x = a->out; c.accum = a->accum; c.out_scale = a->out_scale; c.out_zhi = nullptr; c.out_zlo = nullptr;
+            rc = cvx_hifigan_conv1d_f16x3(&c, s);
+            if (rc != CVX_OK) return rc;
+        }
+    }
+    return CVX_OK;
+}
+
 extern "C" int cvx_hifigan_pre_post_f32(const cvx_conv_args* pre, const float* post_x, const float* post_w, float post_bias,
                                         float* post_y, int32_t B, int32_t C, int32_t L, float slope, cvx_stream_t s)
 {

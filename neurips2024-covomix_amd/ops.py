@@ -429,6 +429,30 @@ def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, 
     _lib.check(_lib.load().cvx_hifigan_conv1d_f16x3(C.byref(a), _stream()), "cvx_hifigan_conv1d_f16x3")
 
 
+def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, accum=None, out=None, out_scale: float = 1.0, z_scale=None) -> None:
+    """One ResBlock1 (three conv pairs) through the operator-level C entry point cvx_hifigan_resblock_f16x3.
+    block: list of 3 (c1, c2) pairs of objects with .w16 = hifigan_pack_weight_f16x3(...), .bias16, .k, .dil;
+    scratch: dict with t, rz0, rz1 (split pairs) and r0, r1 (fp32), all [B, Lp, Np] like x_cl / z."""
+    a = _lib.Resblock16Args()
+    zh, zl = z
+    a.x, a.z_hi, a.z_lo = x_cl.data_ptr(), zh.data_ptr(), zl.data_ptr()
+    a.B, a.L, a.Lp, a.Np, a.halo_l = B, L, x_cl.shape[1], x_cl.shape[2], HIFI_HALO_L
+    for m, (c1, c2) in enumerate(block):
+        for dst, c in ((a.c1[m], c1), (a.c2[m], c2)):
+            w_hi, w_lo, inv, np_, cp = c.w16
+            assert np_ == cp == x_cl.shape[2] and c.bias16.numel() == np_
+            dst.w_hi, dst.w_lo, dst.acc_scale, dst.bias = w_hi.data_ptr(), w_lo.data_ptr(), inv, c.bias16.data_ptr()
+        a.dil[m] = c1.dil
+        assert c2.dil == 1 and c1.k == c2.k
+    a.ksize = block[0][0].k
+    a.t_hi, a.t_lo = scratch["t"][0].data_ptr(), scratch["t"][1].data_ptr()
+    a.xa, a.za_hi, a.za_lo = scratch["r0"].data_ptr(), scratch["rz0"][0].data_ptr(), scratch["rz0"][1].data_ptr()
+    a.xb, a.zb_hi, a.zb_lo = scratch["r1"].data_ptr(), scratch["rz1"][0].data_ptr(), scratch["rz1"][1].data_ptr()
+    a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
+    a.z_scale_dev = _sp(z_scale)
+    _lib.check(_lib.load().cvx_hifigan_resblock_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_f16x3")
+
+
 def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, slope: float, z_scale=None) -> None:
     """x [B, C, L] fp32 channel-major -> x_cl [B, Lp, Cp] fp32 and / or z = split(leaky_relu(x)) [B, Lp, Cp]."""
     _chk_f32(x, x_cl)

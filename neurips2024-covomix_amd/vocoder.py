@@ -235,7 +235,11 @@ class Generator:
         ops.hifigan_to_channels_last(x, buf["x0"], buf["z0"], LRELU_SLOPE, z_scale=zs)
         nblk = len(blocks)
         for j, block in enumerate(blocks):
-            cur_x, cur_z = buf["x0"], buf["z0"]
+            if len(block) == 3:                   # one C call per ResBlock (six convolutions): cvx_hifigan_resblock_f16x3
+                ops.hifigan_resblock_f16x3(buf["x0"], buf["z0"], block, B, L, buf, accum=buf["xs"] if j > 0 else None, out=buf["xs"],
+                                           out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
+                continue
+            cur_x, cur_z = buf["x0"], buf["z0"]   # other dilation counts: convolution by convolution
             for m, (c1, c2) in enumerate(block):
                 ops.hifigan_conv1d_f16x3(cur_z, c1.w16, c1.bias16, B, L, ksize=c1.k, dil=c1.dil, out_z=buf["t"], z_slope=LRELU_SLOPE, z_scale=zs)
                 if m + 1 < len(block):
@@ -243,7 +247,7 @@ class Generator:
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x, out_x=ox,
                                              out_z=oz, z_slope=LRELU_SLOPE, z_scale=zs)
                     cur_x, cur_z = ox, oz
-                else:                                                    # last pair: fold into xs
+                else:
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x,
                                              accum=buf["xs"] if j > 0 else None, out_x=buf["xs"],
                                              out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)

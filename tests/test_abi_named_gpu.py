@@ -123,3 +123,56 @@ def test_convt_and_pre_post_entry_points():
     _lib.check(lib.cvx_hifigan_pre_post_f32(C.byref(pre), None, None, 0.0, None, 0, 0, 0, 0.0, st), "cvx_hifigan_pre_post_f32")
     assert rel(o_pre, want_pre) < 5e-6
     assert lib.cvx_hifigan_pre_post_f32(None, None, None, 0.0, None, 0, 0, 0, 0.0, st) != 0
+
+
+@pytest.mark.parametrize("C_,k,dils,L", [(62, 3, (1, 3, 5), 700), (31, 11, (1, 3, 5), 1000), (125, 7, (1, 3, 5), 333), (250, 3, (1, 3, 5), 300)])
+def test_resblock_f16x3_entry_point(C_, k, dils, L):
+    """cvx_hifigan_resblock_f16x3: the operator-level ResBlock1 on the split-precision convolutions - the form the host
+    runs (channels-last buffers, device-resident activation pre-scale) - against the fp64 torch restatement."""
+    from types import SimpleNamespace
+    from covomix_amd import ops
+    g = torch.Generator().manual_seed(C_ * 100 + k + 1)
+    B = 2
+    x = torch.randn(B, C_, L, generator=g) * 3.0
+    w1 = [torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5 for _ in range(3)]
+    w2 = [torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5 for _ in range(3)]
+    b1 = [torch.randn(C_, generator=g) * 0.1 for _ in range(3)]
+    b2 = [torch.randn(C_, generator=g) * 0.1 for _ in range(3)]
+    xs = torch.randn(B, C_, L, generator=g)
+    y = x.double()
+    for m in range(3):                                     # ResBlock1.forward, models.py:35-42
+        xt = F.conv1d(F.leaky_relu(y, 0.1), w1[m].double(), b1[m].double(), dilation=dils[m], padding=(k - 1) * dils[m] // 2)
+        xt = F.conv1d(F.leaky_relu(xt, 0.1), w2[m].double(), b2[m].double(), padding=(k - 1) // 2)
+        y = xt + y
+    want = (y + xs.double()) / 3.0
+    dev = torch.device("cuda:0")
+    np_ = 32 if C_ <= 32 else 64 if C_ <= 64 else 128 if C_ <= 128 else 256
+    Lp = ops.hifigan_cl_rows(L)
+    f32 = lambda: torch.zeros(B, Lp, np_, dtype=torch.float32, device=dev)
+    f16 = lambda: (torch.zeros(B, Lp, np_, dtype=torch.float16, device=dev), torch.zeros(B, Lp, np_, dtype=torch.float16, device=dev))
+    buf = dict(x0=f32(), z0=f16(), t=f16(), r0=f32(), r1=f32(), rz0=f16(), rz1=f16(), xs=f32(), acc=f32())
+    xd = x.to(dev)
+    scale = torch.ones(1, device=dev)
+    ops.amax_pow2_scale(xd, 1024.0, scale, torch.zeros(1, dtype=torch.int32, device=dev))
+    assert float(scale) == 2.0 ** round(float(torch.log2(1024.0 / x.abs().max())))
+    ops.hifigan_to_channels_last(xd, buf["x0"], buf["z0"], 0.1, z_scale=scale)
+    ops.hifigan_to_channels_last(xs.to(dev), buf["acc"], None, 0.1)
+
+    def conv(w, b):
+        c = SimpleNamespace(k=k, dil=1)
+        c.w16 = ops.hifigan_pack_weight_f16x3(w.to(dev))
+        c.bias16 = torch.zeros(np_, device=dev)
+        c.bias16[:C_] = b.to(dev)
+        return c
+    block = []
+    for m in range(3):
+        c1, c2 = conv(w1[m], b1[m]), conv(w2[m], b2[m])
+        c1.dil = dils[m]
+        block.append((c1, c2))
+    x0_before = buf["x0"].clone()
+    ops.hifigan_resblock_f16x3(buf["x0"], buf["z0"], block, B, L, buf, accum=buf["acc"], out=buf["xs"], out_scale=1.0 / 3.0, z_scale=scale)
+    out = torch.empty(B, C_, L, device=dev)
+    ops.hifigan_from_channels_last(buf["xs"], out)
+    assert rel(out, want) < 5e-6
+    assert torch.equal(buf["x0"], x0_before)               # the block input is not modified
+    assert float(buf["xs"][:, :, C_:].abs().max() if np_ > C_ else 0.0) == 0.0      # padded channels stay zero
