@@ -213,16 +213,19 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
 }
 
 // the main loop for one output tile; SWAP selects the operand order of every MFMA (see the header)
+// first: this is the block's first tile (issue the six-quarter prologue); (m0n, n0n): the block's NEXT tile, whose first
+// six quarters take the place of the tail's dummy pieces (m0n < 0: no next tile), so that it starts without a prologue.
 template <bool HAS_A2, bool SWAP>
 __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
-                                              int m0, int n0, int lane, int wid, int wr, int wc, f32x4 (&acc)[8][4])
+                                              int m0, int n0, int m0n, int n0n, bool first, int lane, int wid, int wr, int wc,
+                                              f32x4 (&acc)[8][4])
 {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    uint32_t offA[2][2], offA2[2][2], offW[2][2];                // per-lane source byte offsets
+    uint32_t offA[2][2], offA2[2][2], offW[2][2];                // per-lane source byte offsets of the tile being FETCHED
     uint32_t dstA[2][2], dstW[2][2];                             // LDS byte offsets inside a buffer (wave-uniform)
     const int64_t ldaB = A.ld * 2, lda2B = A.ld2 * 2, ldwB = p.ldw * 2;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
+    const bool has_next = m0n >= 0;
+    auto set_offsets = [&](int h, int mm, int nn) {               // quarters A_h / W_h of the tile at (mm, nn)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pr0 = 8 * (2 * wid + j);
@@ -231,13 +234,16 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
             const int ra = ra0 + (lane >> 3), rb = rb0 + (lane >> 3);
             const uint32_t ca = (uint32_t)(((lane & 7) ^ ((ra >> 1) & 7)) * 16);
             const uint32_t cb = (uint32_t)(((lane & 7) ^ ((rb >> 1) & 7)) * 16);
-            const int64_t ga = min(m0 + ra, p.M - 1), gb = min(n0 + rb, p.N - 1);
-            offA[h][j] = (uint32_t)(ga * ldaB) + ca;
-            offA2[h][j] = HAS_A2 ? (uint32_t)(ga * lda2B) + ca : 0u;
-            offW[h][j] = (uint32_t)(gb * ldwB) + cb;
+            const uint32_t ga = (uint32_t)min(mm + ra, p.M - 1), gb = (uint32_t)min(nn + rb, p.N - 1);
+            offA[h][j] = ga * (uint32_t)ldaB + ca;                 // (every operand spans < 4 GiB: checked by the launcher)
+            offA2[h][j] = HAS_A2 ? ga * (uint32_t)lda2B + ca : 0u;
+            offW[h][j] = gb * (uint32_t)ldwB + cb;
             dstA[h][j] = (uint32_t)(ra0 * 128);
             dstW[h][j] = (uint32_t)(TILE_B + rb0 * 128);
         }
+    };
+    set_offsets(0, m0, n0);
+    set_offsets(1, m0, n0);
     const int nk = p.K / 32;
     const int t_sw = HAS_A2 ? p.K1 / 32 : 0x7fffffff;
     const char* const a1base = reinterpret_cast<const char*>(A.hi);
@@ -245,21 +251,29 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     const char* const wbase = reinterpret_cast<const char*>(W);
     const uint32_t dump = lds0 + DUMP_B + (uint32_t)wid * 1024u;
 
+    // quarter A_h / W_h of K-tile tt -> buffer tt & 1.  tt >= nk: K-tile tt - nk of the NEXT tile (nk is even whenever a
+    // block has a next tile, so the buffer parity continues; the offsets were switched to that tile before the first such
+    // quarter, see the K loop), or, without a next tile, a dummy 16-byte re-read into the dump area that keeps the vmcnt
+    // arithmetic uniform
     auto issue_A = [&](int h, int tt) {
-        const bool live = tt < nk;
+        const bool cur = tt < nk;
+        const bool live = cur || has_next;
+        const int u = cur ? tt : tt - nk;
         const uint32_t b = lds0 + (uint32_t)(tt & 1) * BUF_B;
-        const char* base = a1base + (int64_t)tt * 128;
+        const char* base = a1base + (int64_t)u * 128;
         uint32_t v0 = offA[h][0], v1 = offA[h][1];
         if constexpr (HAS_A2) {
-            if (tt >= t_sw) { base = a2base + (int64_t)(tt - t_sw) * 128; v0 = offA2[h][0]; v1 = offA2[h][1]; }
+            if (u >= t_sw) { base = a2base + (int64_t)(u - t_sw) * 128; v0 = offA2[h][0]; v1 = offA2[h][1]; }
         }
         if (!live) { base = wbase; v0 = 0u; v1 = 0u; }
         dma2(v0, v1, live ? b + dstA[h][0] : dump, live ? b + dstA[h][1] : dump, base);
     };
     auto issue_W = [&](int h, int tt) {
-        const bool live = tt < nk;
+        const bool cur = tt < nk;
+        const bool live = cur || has_next;
+        const int u = cur ? tt : tt - nk;
         const uint32_t b = lds0 + (uint32_t)(tt & 1) * BUF_B;
-        const char* base = live ? wbase + (int64_t)tt * 128 : wbase;
+        const char* base = live ? wbase + (int64_t)u * 128 : wbase;
         dma2(live ? offW[h][0] : 0u, live ? offW[h][1] : 0u, live ? b + dstW[h][0] : dump, live ? b + dstW[h][1] : dump, base);
     };
 
@@ -270,10 +284,12 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     const int boh = TILE_B + (wc * 64 + lr) * 128 + 16 * (kg ^ sw8);
     const int bol = TILE_B + (wc * 64 + lr) * 128 + 16 * ((4 + kg) ^ sw8);
 
-    issue_A(0, 0); issue_W(0, 0); issue_W(1, 0); issue_A(1, 0); issue_A(0, 1); issue_W(0, 1);
-    CVX_P8_WAIT_DMA();
-    CVX_P8_BARRIER();
-    if (wr == 1) CVX_P8_BARRIER();
+    if (first) {          // (the quarters of a later tile were issued by the previous tile's tail and waited for by its last phases)
+        issue_A(0, 0); issue_W(0, 0); issue_W(1, 0); issue_A(1, 0); issue_A(0, 1); issue_W(0, 1);
+        CVX_P8_WAIT_DMA();
+        CVX_P8_BARRIER();
+    }
+    if (wr == 1) CVX_P8_BARRIER();                      // group 1 runs one interval behind group 0
 
     f16x8 fah[4], fal[4];                               // A fragments of the current M half (4 tiles of 16 rows)
     f16x8 fbh[2][2], fbl[2][2];                         // W fragments: [n half][tile]
@@ -306,8 +322,12 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     CVX_P8_WAIT_DMA();                                                                                           \
     CVX_P8_BARRIER();                                                                                            \
     CVX_P8_WAIT_LDS();
+    // Offsets switch to the NEXT tile at the top of a K-tile, where no fragment register is live: the A0 / W0 quarters
+    // issued from K-tile nk-2 on and the W1 / A1 quarters issued from K-tile nk-1 on belong to it (nk is even then, so
+    // nk-2 is a buffer-0 instance and nk-1 a buffer-1 instance).
 #define CVX_P8S_KTILE(buf, t)                                                                                    \
     {                                                                                                            \
+        if (has_next && (t) == nk - 2 + (buf)) set_offsets((buf), m0n, n0n);                                     \
         CVX_P8S_READ_B(buf, 0) CVX_P8S_READ_A(buf, 0)                                                            \
         issue_W(1, (t) + 1);                                                                                     \
         CVX_P8S_SYNC() CVX_P8S_MFMA(0, 0)                                                                        \
@@ -332,58 +352,70 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
 #undef CVX_P8S_MM
 #undef CVX_P8S_READ_A
 #undef CVX_P8S_READ_B
-    if (wr == 0) CVX_P8_BARRIER();                      // pairs with group 1's last barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail's dummy pieces before LDS is released
+    if (wr == 0) CVX_P8_BARRIER();                      // pairs with group 1's last barrier: both epilogues then run together
+    if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail's dummy pieces before LDS is released
 }
 
 template <bool HAS_A2, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ W, float acc_scale, SplitOut so,
-    int tiles_m, int tiles_n, int map_mode)
+    int tiles_m, int tiles_n, int n_slots)
 {
+    // PERSISTENT over output tiles: block b walks tile slots b, b + gridDim.x, ... (gridDim.x is a multiple of 8, so all of
+    // them sit on the XCD that owns their row panels: slot s -> XCD s & 7, row panel (s & 7) + 8 * ((s >> 3) / tiles_n)).
+    // The LDS-DMA stream never stops at a tile boundary: the tail of a tile fetches the first six quarters of the next one,
+    // which therefore starts without a prologue, behind the epilogue of its predecessor.
     extern __shared__ __attribute__((aligned(16))) char smem_p8s[];
-    const unsigned long long ts0 = so.trace ? __builtin_readcyclecounter() : 0ull;
-    const unsigned long long rt0 = so.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
-    int tile_m, tile_n;
-    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
-    if (tile_m >= tiles_m) return;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
     acc_scale = total_acc_scale(acc_scale, so);
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
-    if constexpr (EPI == EPI_QKV) {
-        if (n0 >= p.rope_cols) {                        // block-uniform: this block owns V columns
-            tile_mainloop<HAS_A2, false>(p, A, W, smem_p8s, m0, n0, lane, wid, wr, wc, acc);
-            if (so.dbg & 1) { if (acc[0][0][0] == 12345.678f) so.vt_hi[0] = (f16)1.f; return; }
-            epilogue_vt(p, acc, row0, col0, lane, so, acc_scale);
-            return;
-        }
+    auto tile_of_slot = [&](int s, int& m0, int& n0) {          // -> false for the padding slots of the XCD map
+        const int xcd = s & 7, q = s >> 3;
+        const int tm = xcd + 8 * (q / tiles_n), tn = q % tiles_n;
+        m0 = tm * 256; n0 = tn * 256;
+        return tm < tiles_m;
+    };
+    auto next_slot = [&](int s) {                                // next slot of this block that holds a real tile, or -1
+        int m, n;
+        for (s += (int)gridDim.x; s < n_slots; s += (int)gridDim.x)
+            if (tile_of_slot(s, m, n)) return s;
+        return -1;
+    };
+    int slot = (int)blockIdx.x, m0, n0;
+    if (!tile_of_slot(slot, m0, n0)) {
+        slot = next_slot(slot);
+        if (slot < 0) return;
+        tile_of_slot(slot, m0, n0);
     }
-    tile_mainloop<HAS_A2, true>(p, A, W, smem_p8s, m0, n0, lane, wid, wr, wc, acc);
-    if (so.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.C[0] = 1.f; return; }      // timing experiment: main loop only
-    const unsigned long long ts2 = so.trace ? __builtin_readcyclecounter() : 0ull;
-    epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);
-    if (so.trace) {       // dev: cycle stamps of wave `wid` of this block: start, -, main loop end, stores issued, stores done
-        const unsigned long long ts3 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long ts4 = __builtin_readcyclecounter();
-        if (lane == 0) {
-            unsigned long long* t = so.trace + ((size_t)blockIdx.x * 8 + wid) * 8;
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            hw = (hw & 0xffffff) | ((xcc & 0xf) << 24);
-            t[0] = ts0; t[1] = ts0; t[2] = ts2; t[3] = ts3; t[4] = ts4; t[5] = __builtin_amdgcn_s_memrealtime(); t[6] = rt0; t[7] = hw;
+    bool first = true;
+    while (true) {
+        const int nslot = next_slot(slot);
+        int m0n = -1, n0n = -1;
+        if (nslot >= 0) tile_of_slot(nslot, m0n, n0n);
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+        bool v_block = false;
+        if constexpr (EPI == EPI_QKV) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
+        if (v_block) {
+            tile_mainloop<HAS_A2, false>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
+            if (!(so.dbg & 1)) epilogue_vt(p, acc, row0, col0, lane, so, acc_scale);
+        } else {
+            tile_mainloop<HAS_A2, true>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
+            if (!(so.dbg & 1)) epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);      // (dbg bit 0: main loop only, timing)
         }
+        if (nslot < 0) break;
+        // the epilogue's own loads / stores share the vmcnt counter with the DMA: start the next tile from a clean count
+        // (its first quarters landed long ago: the last phases of this tile already waited for them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        slot = nslot; m0 = m0n; n0 = n0n;
+        first = false;
     }
 }
 
@@ -406,15 +438,29 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     if (!vec) return false;
     if (so.vt_hi && !(a.rope_cos && so.hi && !so.write_f32 && !a.residual && a.act == CVX_ACT_NONE)) return false;   // V^T only in QKV form
     const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
-    const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
-    const dim3 grid((unsigned)(gm * tn));
+    const int n_slots = ((tm + 7) / 8) * 8 * tn;                 // XCD map: an XCD owns whole row panels (padding slots are skipped)
+    (void)map_mode;
+    // persistent grid: one block per CU (136 KiB of LDS each), a multiple of 8; a next tile needs an even number of K-tiles
+    // (the two LDS buffers alternate across the tile boundary), otherwise every tile gets its own block
+    static int n_cu[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = v;
+    }
+    int g = n_slots;
+    if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < (n_cu[dev] / 8) * 8 ? n_slots : (n_cu[dev] / 8) * 8;
+    const dim3 grid((unsigned)g);
     int epi = classify_epilogue(a, so);
     if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;
     if (epi == EPI_GENERIC && so.vt_hi) return false;
 #define CVX_P8S_LAUNCH(A2, E)                                                                                           \
     do {                                                                                                                \
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8s_kernel<A2, E>), LDS_B);                     \
-        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, map_mode); \
+        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, n_slots); \
     } while (0)
     if (A.hi2) {
         if (epi == EPI_BIAS) CVX_P8S_LAUNCH(true, EPI_BIAS); else CVX_P8S_LAUNCH(true, EPI_GENERIC);

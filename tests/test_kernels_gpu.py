@@ -688,3 +688,59 @@ def test_gemm_large_problem_kernels_every_epilogue(ops, M):
                 assert float(vt[0][:, T:].abs().max() if Tp > T else 0) == 0
     finally:
         ops._GEMM_FLAGS = saved
+
+
+def test_gemm_persistent_blocks_walk_several_tiles(ops):
+    """More output tiles than CUs: a block of the eight-phase kernel then walks several tiles and fetches the first quarters
+    of the next tile during the tail of the current one.  M = 5000 rows (20 row panels -> 24 slots per tile column on the XCD
+    map, padding slots included) x N = 4096 = 384 slots: QKV-style (V blocks included), GELU-split and residual epilogues
+    against fp64, and bit-identity with one tile per block (dbg flag 8 << 8)."""
+    dev_ = dev()
+    g = torch.Generator().manual_seed(4)
+    M, K = 5000, 1024
+    x = torch.randn(M, K, generator=g).to(dev_)
+    il = ops.SplitIL(M, K, dev_); ops.split_act_f16(x, il)
+    xs = il.dense()[0].double() + il.dense()[1].double()
+    w = (torch.randn(4096, K, generator=g) / math.sqrt(K)).to(dev_)
+    ws = ops.split_f16(w); wil = ops.split_f16_interleaved(ws)
+    b = torch.randn(4096, generator=g).to(dev_)
+    saved = ops._GEMM_FLAGS
+    try:
+        outs = []
+        for flags in (0, 8 << 8):
+            ops._GEMM_FLAGS = flags
+            o = ops.SplitIL(M, 4096, dev_)
+            ops.gemm(x, w, torch.empty(M, 4096, device=dev_), w_split=ws, w_il=wil, a_split=il, bias=b, act=1, out_split=o, write_f32=False)
+            outs.append(o.buf.clone())
+        want = F.gelu(xs @ w.double().T + b.double())
+        got = outs[0].view(M, 128, 2, 32)
+        assert rel_l2(got[:, :, 0].reshape(M, 4096).double() + got[:, :, 1].reshape(M, 4096).double(), want) < 1e-6
+        assert torch.equal(outs[0], outs[1])
+        # residual + fp32 on a narrower N (4 tile columns x 24 slots = 96 slots: one tile per block) and a wide one
+        r = torch.randn(M, 4096, generator=g).to(dev_)
+        c = torch.full((M, 4096), float("nan"), device=dev_)
+        ops._GEMM_FLAGS = 0
+        ops.gemm(x, w, c, w_split=ws, w_il=wil, a_split=il, residual=r)
+        assert rel_l2(c, xs @ w.double().T + r.double()) < 1e-6
+        # QKV form with 16 heads: 12 tile columns x 24 slots = 288 slots, V blocks interleaved with q | k blocks in a block's walk
+        H, T = 16, 1000
+        wq = (torch.randn(3 * H * 64, K, generator=g) / math.sqrt(K)).to(dev_)
+        wqs = ops.split_f16(wq); wqil = ops.split_f16_interleaved(wqs)
+        inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+        ang = torch.arange(T).float()[:, None] * inv[None, :]
+        cos, sin = ang.cos().to(dev_).contiguous(), ang.sin().to(dev_).contiguous()
+        Bt = M // T
+        qk = (torch.empty(M, 2 * H * 64, dtype=torch.float16, device=dev_), torch.empty(M, 2 * H * 64, dtype=torch.float16, device=dev_))
+        Tp = (T + 31) // 32 * 32
+        vt = (torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev_), torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev_))
+        ops.gemm(x, wq, torch.empty(M, 3 * H * 64, device=dev_), w_split=wqs, w_il=wqil, a_split=il, rope=(cos, sin), rope_cols=2 * H * 64,
+                 out_split=qk, vt_split=vt, write_f32=False)
+        z = xs @ wq.double().T
+        zq = z[:, : 2 * H * 64].reshape(Bt, T, 2 * H, 64)
+        c_, s_ = torch.cat((ang.cos(), ang.cos()), -1).double().to(dev_), torch.cat((ang.sin(), ang.sin()), -1).double().to(dev_)
+        rot = torch.cat((-zq[..., 32:], zq[..., :32]), -1)
+        assert rel_l2(qk[0].double() + qk[1].double(), (zq * c_[None, :, None, :] + rot * s_[None, :, None, :]).reshape(M, -1)) < 1e-6
+        v = z[:, 2 * H * 64:].reshape(Bt, T, H, 64).permute(0, 2, 3, 1).reshape(Bt * H * 64, T)
+        assert rel_l2((vt[0].double() + vt[1].double())[:, ops.vt_frame_slots(T, dev_)], v) < 1e-6
+    finally:
+        ops._GEMM_FLAGS = saved
