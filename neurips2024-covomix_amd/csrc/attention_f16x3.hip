@@ -59,8 +59,11 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 }
 
 // NT = 3: split operands, three products.  NT = 1: hi halves only (plain fp16 operands, fp32 accumulate and softmax).
+#ifndef CVX_ATT_WAVES
+#define CVX_ATT_WAVES 2
+#endif
 template <int NT>
-__global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
+__global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
                                                                 const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
                                                                 int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
@@ -133,10 +136,18 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
     // (a 3-stage ring - tiles requested two ahead - measured the same: the loop is not DMA-latency bound)
     const int ntiles = (T + KT - 1) / KT;
     issue(0, 0);
+#ifdef CVX_ATT_TRACE
+    unsigned long long tr[5] = {0, 0, 0, 0, 0};
+#define TSTAMP(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); tr[i] += now_ - tlast_; tlast_ = now_; }
+    unsigned long long tlast_ = __builtin_readcyclecounter();
+#else
+#define TSTAMP(i)
+#endif
     for (int it = 0; it < ntiles; ++it) {
         const int cur = it & 1, key0 = it * KT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // tile `it` landed everywhere; stage cur^1 is free
+        TSTAMP(0)
         if (it + 1 < ntiles) issue(key0 + KT, cur ^ 1);
         const f16* S = smem + cur * STAGE;
 
@@ -162,6 +173,11 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
             }
         }
 
+#ifdef CVX_ATT_TRACE
+        asm volatile("" : "+v"(sacc));
+        { float t_ = sacc[0]; asm volatile("s_nop 0" : "+v"(t_)); }
+#endif
+        TSTAMP(1)
         // ---- online softmax (this lane: 16 keys of query l31; partner lane^32 holds the other 16).
         // The running max m_run is kept in the scaled log2 domain; scores stay raw and the scale is folded into one
         // fma per element: p = exp2(s*c - m).  Only the last tile can contain keys >= T (wave-uniform branch), and
@@ -213,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
             for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
         }
 
+        TSTAMP(2)
         // ---- O^T += V^T . P^T
         const f16* Vh = S + 2 * TILE;
         const f16* Vl = S + 3 * TILE;
@@ -234,7 +251,19 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const f16* __re
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], ph[s], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], ph[s], o1, 0, 0, 0);
         }
+#ifdef CVX_ATT_TRACE
+        asm volatile("" : "+v"(o0), "+v"(o1));
+        { float t_ = o0[0] + o1[0]; asm volatile("s_nop 0" : "+v"(t_)); }
+#endif
+        TSTAMP(3)
     }
+#ifdef CVX_ATT_TRACE
+    if (out && lane == 0) {
+        unsigned long long* tb = reinterpret_cast<unsigned long long*>(out) + ((size_t)blockIdx.x * 4 + wid) * 8;
+        tb[0] = tr[0]; tb[1] = tr[1]; tb[2] = tr[2]; tb[3] = tr[3]; tb[4] = ntiles;
+    }
+    out = nullptr;
+#endif
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot / (v_scale ? *v_scale : 1.f);        // fp32 output: the true value
