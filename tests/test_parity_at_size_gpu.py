@@ -216,3 +216,19 @@ def test_vocoder_split_precision_is_scale_free(exp):
     e, e32 = rel_l2(y, ref64), rel_l2(ref32, ref64)
     print(f"vocoder conv_pre x 2^{exp}: this build {e:.3e}, fp32 oracle {e32:.3e} (vs fp64)")
     assert torch.isfinite(y).all() and e < 1e-5 and e < 6 * e32 + 1e-6
+
+
+@pytest.mark.parametrize("kind,B,T,prompt", [("vomix", 3, 777, 250), ("vosingle", 5, 1234, 400)])
+def test_ragged_full_width_shapes_vs_oracle(kind, B, T, prompt):
+    """Full width on the large-problem kernels with nothing aligned: row counts that are not multiples of the 256-row tile
+    (2 x 3 x 777 = 4,662; 2 x 5 x 1,234 = 12,340: persistent blocks with ragged last panels), T % 4 = 1 and 2 (per-element
+    V^T stores, masked last key tile), odd batch sizes - one midpoint step against the oracle."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    sd = _state(kind)
+    inp = syn.synthetic_inputs(kind, B, T, prompt, seed=123)
+    out = _run(sd, inp, 2)
+    ref = orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2)
+    e = rel_l2(out, ref)
+    print(f"{kind} B={B} T={T}: rel-L2 vs oracle {e:.3e}")
+    assert out.shape == (B, T, 80) and e < AT_SIZE_TOL
