@@ -216,6 +216,21 @@ int64_t cvx_hifigan_packed_weight_floats(int32_t Cout, int32_t Cin, int32_t ksiz
 int     cvx_hifigan_pack_weight_f32(const float* w, int32_t Cout, int32_t Cin, int32_t ksize,
                                     int32_t transposed, float* Wp);
 
+/* ConvTranspose1d (models.py:85-88, :102-103: leaky_relu then ups[i]) in POLYPHASE form: output l = stride*m + r only sees the
+ * taps kk = kk0 + stride*j of the flipped kernel, so every phase r is a stride-1 convolution with ceil((k - kk0)/stride) taps
+ * over the input as it is - 1/stride of the matrix work of the zero-stuffed form (cvx_hifigan_conv1d_f32 with up > 1, which
+ * stays as the cross-check).  `a` is read exactly like cvx_hifigan_conv1d_f32 reads it for that form (up = stride, dil = 1,
+ * pad = ksize - 1 - padding, Lout = (Lin-1)*up + 1 + 2*pad - (ksize-1); no res / accum) except that a->Wp is the phase-major
+ * packed weight written by cvx_hifigan_pack_conv_transpose1d_f32 (w = the module's [Cin, Cout, k] weight, pad_t = its padding;
+ * cvx_hifigan_conv_transpose1d_packed_floats floats).  amax_bits_dev (optional, DEVICE uint32, zero before the call): the
+ * launch leaves the bit pattern of max|out| there - cvx_pow2_scale_from_amax_f32 turns it into the next stage's
+ * activation pre-scale (as cvx_amax_pow2_scale_f32 would from a separate pass over out) and zeroes it again. */
+int     cvx_hifigan_conv_transpose1d_f32(const cvx_conv_args* a, uint32_t* amax_bits_dev, cvx_stream_t s);
+int64_t cvx_hifigan_conv_transpose1d_packed_floats(int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t);
+int     cvx_hifigan_pack_conv_transpose1d_f32(const float* w, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                                              int32_t pad_t, float* Wp);
+int     cvx_pow2_scale_from_amax_f32(uint32_t* amax_bits_dev, float target, float* scale_dev, cvx_stream_t s);
+
 /* y[b,0,l] = tanh( bias + sum_{ci,k} w[ci,k] * leaky_relu(x[b,ci,l+k-3], slope) )
  * final leaky_relu (default slope 0.01, models.py:112) + conv_post + tanh (:113-114). ksize == 7. */
 int cvx_hifigan_post_f32(const float* x, const float* w, float bias, float* y,
@@ -279,6 +294,23 @@ typedef struct {
     const float* z_scale_dev;
 } cvx_resblock16_args;
 int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stream_t s);
+
+/* One ResBlock1 pair  out = (c2(leaky_relu(c1(leaky_relu(x, .1)), .1)) + x (+ accum)) * out_scale  (models.py:36-40; c1:
+ * dilation dil, c2: dilation 1, both kernel size ksize) as ONE kernel for the narrow stages (Np = 32 or 64): the
+ * intermediate activation stays in LDS and no split pair exists in HBM - the launch reads x (with a halo) and writes
+ * out.  x / accum / out: fp32 channels-last [B][Lp][Np] with the layout rules of cvx_conv16_args, and at least
+ * (ksize-1)*(dil+1)/2 zero rows on either side of the signal; out must not alias x (accum may alias out).
+ * *z_scale_dev (power of two, NULL = 1) is the pre-scale the in-kernel split pairs of leaky_relu(x) and of the
+ * intermediate carry.  cvx_hifigan_resblock_f16x3 uses it for Np <= 64 (its z / t / za / zb buffers may then be NULL). */
+typedef struct {
+    const float* x;
+    int32_t B, L, Lp, Np, halo_l;
+    cvx_conv16_weights c1, c2;
+    int32_t ksize, dil;
+    const float* accum; float* out; float out_scale;
+    const float* z_scale_dev;
+} cvx_respair16_args;
+int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_stream_t s);
 
 /* Layout converters between the channel-major fp32 tensors of cvx_hifigan_conv1d_f32 ([B][C][L]) and the
  * channels-last buffers above: to_channels_last writes the fp32 copy (x_cl, optional) and / or the split pair of

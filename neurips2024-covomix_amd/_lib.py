@@ -85,6 +85,15 @@ class Resblock16Args(C.Structure):
                 ("z_scale_dev", C.c_void_p)]
 
 
+class Respair16Args(C.Structure):
+    _fields_ = [("x", C.c_void_p),
+                ("B", C.c_int32), ("L", C.c_int32), ("Lp", C.c_int32), ("Np", C.c_int32), ("halo_l", C.c_int32),
+                ("c1", Conv16Weights), ("c2", Conv16Weights),
+                ("ksize", C.c_int32), ("dil", C.c_int32),
+                ("accum", C.c_void_p), ("out", C.c_void_p), ("out_scale", C.c_float),
+                ("z_scale_dev", C.c_void_p)]
+
+
 class T2SLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c",
                                           "gamma_f", "w1", "b1", "w2", "b2", "k_cache", "v_cache")]
@@ -157,6 +166,11 @@ SIGNATURES = {
     "cvx_hifigan_convt_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "cvx_hifigan_resblock_f32": (C.c_int, [C.POINTER(ResblockArgs), C.c_void_p]),
     "cvx_hifigan_resblock_f16x3": (C.c_int, [C.POINTER(Resblock16Args), C.c_void_p]),
+    "cvx_hifigan_resblock_pair_f16x3": (C.c_int, [C.POINTER(Respair16Args), C.c_void_p]),
+    "cvx_hifigan_conv_transpose1d_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p]),
+    "cvx_hifigan_conv_transpose1d_packed_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "cvx_hifigan_pack_conv_transpose1d_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "cvx_pow2_scale_from_amax_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_hifigan_pre_post_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_last_error_string": (C.c_char_p, []),

@@ -81,8 +81,24 @@ extern "C" int cvx_hifigan_resblock_f32(const cvx_resblock_args* a, cvx_stream_t
 
 extern "C" int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stream_t s)
 {
-    CVX_REQUIRE(a && a->x && a->z_hi && a->z_lo && a->t_hi && a->t_lo && a->out, "hifigan_resblock_f16x3: null pointer");
-    CVX_REQUIRE(a->xa && a->za_hi && a->za_lo && a->xb && a->zb_hi && a->zb_lo, "hifigan_resblock_f16x3: missing scratch buffers");
+    CVX_REQUIRE(a && a->x && a->out && a->xa && a->xb, "hifigan_resblock_f16x3: null pointer");
+    if (a->Np <= 64) {                                                      // narrow stages: one kernel per pair, no split pairs in HBM
+        const float* cur = a->x;
+        for (int m = 0; m < 3; ++m) {
+            cvx_respair16_args r{};
+            r.x = cur; r.B = a->B; r.L = a->L; r.Lp = a->Lp; r.Np = a->Np; r.halo_l = a->halo_l;
+            r.c1 = a->c1[m]; r.c2 = a->c2[m]; r.ksize = a->ksize; r.dil = a->dil[m]; r.z_scale_dev = a->z_scale_dev;
+            r.out_scale = 1.0f;
+            if (m < 2) r.out = (m == 0) ? a->xa : a->xb;
+            else { r.out = a->out; r.accum = a->accum; r.out_scale = a->out_scale; }
+            const int rc = cvx_hifigan_resblock_pair_f16x3(&r, s);
+            if (rc != CVX_OK) return rc;
+            cur = r.out;
+        }
+        return CVX_OK;
+    }
+    CVX_REQUIRE(a->z_hi && a->z_lo && a->t_hi && a->t_lo, "hifigan_resblock_f16x3: null pointer");
+    CVX_REQUIRE(a->za_hi && a->za_lo && a->zb_hi && a->zb_lo, "hifigan_resblock_f16x3: missing scratch buffers");
     const float* cur_x = a->x;
     const uint16_t *cur_zh = a->z_hi, *cur_zl = a->z_lo;
     for (int m = 0; m < 3; ++m) {

@@ -364,6 +364,16 @@ extern "C" int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, 
     return CVX_OK;
 }
 
+extern "C" int cvx_pow2_scale_from_amax_f32(uint32_t* amax_bits_dev, float target, float* scale_dev, cvx_stream_t s)
+{
+    CVX_REQUIRE(amax_bits_dev && scale_dev && target > 0.f, "pow2_scale_from_amax: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits_dev, target, scale_dev);
+    if (hipMemsetAsync(amax_bits_dev, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("pow2_scale_from_amax: memset failed"); return CVX_EHIP; }
+    CVX_CHECK_LAUNCH("cvx_pow2_scale_from_amax_f32");
+    return CVX_OK;
+}
+
 extern "C" int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
                                          int32_t Bt, int32_t T, int32_t C, cvx_stream_t s)
 {

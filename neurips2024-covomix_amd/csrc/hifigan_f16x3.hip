@@ -19,6 +19,7 @@
 // Epilogue (rows = positions, so a lane quad transposes 4x4 blocks and stores 4 consecutive channels): bias, ResBlock
 // residual, the running xs accumulate / scale, an fp32 store of the new residual stream and / or the split fp16 store
 // of leaky_relu(value) = the next convolution's input - no separate activation pass exists.
+#include <algorithm>
 #include "gemm_common.h"
 
 namespace {
@@ -215,6 +216,262 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     }
 }
 
+// ---------------------------------------------------------------- fused ResBlock pair (narrow stages: Np = 32 / 64)
+// x' = c2(leaky_relu(c1(leaky_relu(x)))) + x   (models.py:36-40) in ONE kernel: the intermediate t never leaves the CU
+// and neither split pair (z = split(lrelu(x)), t) exists in HBM - a pair moves read x + write x' (+ the xs accumulate)
+// instead of z, t (write), t (read), x, x', z'.  The narrow stages are HBM / fixed-cost bound with one launch per
+// convolution; the wide ones (Np = 128 / 256) are matrix bound and their tiles do not fit, they keep it.
+//
+// Persistent blocks walk tiles of TM_out = 256 - (k - 1) output positions.  Per tile:
+//   (0) the fp32 x rows [l0 - h2 - pad1, + 320) (h2 = (k-1)/2, pad1 = (k-1)*dil/2; all channels, one contiguous range of
+//       the channels-last buffer) were loaded into registers during the previous tile's second pass; leaky_relu, the
+//       stage's power-of-two pre-scale and the fp16 split happen on the way into LDS (swizzled chunk tiles, as above);
+//   (1) pass 1: t rows [l0 - h2, + 256) = conv1 over the z tile (tap = row offset tap*dil), weights staged as above;
+//       epilogue 1 writes split(lrelu(acc*s + b1)) - zero outside [0, L), which is what conv2's padding sees - into
+//       LDS OVER the z tile (dead by then);
+//   (2) pass 2: conv2 over the t tile (tap = row offset tap): output row r = position l0 + r needs t rows r .. r + k - 1, so
+//       rows r < TM_out are complete (the others are computed and dropped: <= 4 % of the MFMAs, no ragged wave);
+//       epilogue 2 adds bias and the fp32 residual (re-read from global: an L2 hit, the tile was read a pass earlier)
+//       and stores x' (or folds it into xs).
+// The weight stages of both passes and of consecutive tiles form one double-buffered stream.
+struct PairArgs {
+    const float* x;                    // [B][Lp][NP] fp32
+    const f16 *w1h, *w1l, *w2h, *w2l;  // [chunk][tap][NP][32]
+    const float *b1, *b2;              // [NP]
+    const float* accum;                // [B][Lp][NP] or NULL
+    float* out;                        // [B][Lp][NP]
+    int B, L, Lp, ksize, dil, halo_l, tiles_per_seq, n_tiles;
+    float acc1, acc2, out_scale, slope;
+    const float* z_scale;
+};
+
+// (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions
+__device__ __forceinline__ void pair_split4(const f32x4 v, cvx_f16x4& hi, cvx_f16x4& lo)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    const f16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2), h23 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
+    const f16x2 l01 = __builtin_convertvector(f32x2{x[0] - (float)h01[0], x[1] - (float)h01[1]}, f16x2);
+    const f16x2 l23 = __builtin_convertvector(f32x2{x[2] - (float)h23[0], x[3] - (float)h23[1]}, f16x2);
+    hi = cvx_f16x4{h01[0], h01[1], h23[0], h23[1]};
+    lo = cvx_f16x4{l01[0], l01[1], l23[0], l23[1]};
+}
+
+constexpr int PAIR_TS = 4;                                // taps per weight stage of the pair kernel
+template <int TNI> struct PairCfg {
+    static constexpr int NP = 32 * TNI;
+    static constexpr int W_ST = PAIR_TS * NP * CK;        // halves of one (hi or lo) weight stage: 8 / 16 KiB
+    static constexpr int LDS_HALVES = TNI * 2 * A_TILE + 2 * 2 * W_ST;        // 72 KiB (two blocks per CU) / 144 KiB
+};
+
+template <int TNI>
+__global__ __launch_bounds__(512, TNI == 1 ? 4 : 2) void resblock_pair_f16x3_kernel(const PairArgs p)
+{
+    using Cfg = PairCfg<TNI>;
+    constexpr int NP = Cfg::NP, NCH = TNI, TS = PAIR_TS, W_ST = Cfg::W_ST;
+    constexpr int ZR = A_ROWS;                            // rows of the z / t tile
+    constexpr int NF = ZR * NP / 4 / 512;                 // float4 loads per thread for one x tile (5 / 10)
+    extern __shared__ __attribute__((aligned(16))) f16 smem_c[];
+    f16* const Zs = smem_c;                               // [NCH chunks][hi | lo][ZR][32]   (z tile, then t tile)
+    f16* const Ws = smem_c + NCH * 2 * A_TILE;            // [2 stages][hi | lo][TS taps * NP][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid;                                   // 8 x 1 waves: 32 rows x all NP channels each
+    const float zs = p.z_scale ? *p.z_scale : 1.f;
+    const float a1 = p.acc1 / zs, a2 = p.acc2 / zs;       // (exact: powers of two)
+    const int k = p.ksize, h2 = (k - 1) / 2, pad1 = (k - 1) * p.dil / 2;
+    const int tm_out = TMB - 2 * h2;
+    const int n_groups = (k + TS - 1) / TS;
+    const int S = NCH * n_groups;
+    const uint32_t last_row = (uint32_t)p.B * (uint32_t)p.Lp - 1u;     // (the launcher checks that a tensor spans < 4 GiB: 32-bit offsets)
+    const bool has_accum = p.accum != nullptr;
+
+    const int prow = lane >> 2;
+    auto issue_w = [&](const f16* wh, const f16* wl, int st, int par) {
+        const int chunk = st / n_groups, grp = st - chunk * n_groups;
+        const int t0 = grp * TS, nt = min(TS, k - t0);
+        f16* dst = Ws + par * 2 * W_ST;
+        const int64_t base = ((int64_t)chunk * k + t0) * NP * CK;
+        for (int pc = wid; pc < nt * NP / 16; pc += 8) {
+            const int r = 16 * pc + prow;
+            const int c4 = (lane & 3) ^ ((r >> 2) & 3);
+            const int64_t src = base + (int64_t)r * CK + 8 * c4;
+            glds16(wh + src, dst + 16 * pc * CK);
+            glds16(wl + src, dst + W_ST + 16 * pc * CK);
+        }
+    };
+    // x tile of tile id `tile`: NF float4 per thread, one contiguous global range (rows clamped to the allocation)
+    f32x4 xr[NF];
+    auto load_x = [&](int tile) {
+        const int b = tile / p.tiles_per_seq, l0 = (tile - b * p.tiles_per_seq) * tm_out;
+        const uint32_t g0 = (uint32_t)(b * p.Lp + p.halo_l + l0 - h2 - pad1);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = tid + 512 * i;
+            const int row = f / (NP / 4), c4 = f % (NP / 4);
+            const uint32_t gr = min(g0 + (uint32_t)row, last_row);
+            xr[i] = *reinterpret_cast<const f32x4*>(p.x + (gr * (uint32_t)NP + 4u * (uint32_t)c4));
+        }
+    };
+    const float zs_neg = zs * p.slope;
+    auto store_z = [&]() {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = tid + 512 * i;
+            const int row = f / (NP / 4), c4 = f % (NP / 4);
+            f32x4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = xr[i][e] * (xr[i][e] > 0.f ? zs : zs_neg);
+            cvx_f16x4 zh, zl;
+            pair_split4(z, zh, zl);
+            const int off = ((c4 >> 3) * 2 * ZR + row) * CK + 8 * (((c4 & 7) >> 1) ^ ((row >> 2) & 3)) + 4 * (c4 & 1);
+            *reinterpret_cast<cvx_f16x4*>(Zs + off) = zh;
+            *reinterpret_cast<cvx_f16x4*>(Zs + off + A_TILE) = zl;
+        }
+    };
+
+    const int i31 = lane & 31, g = lane >> 5, q = lane & 3, c4e = 4 * (i31 >> 2);
+    const int wswz = (i31 >> 2) & 3;
+    int woff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) woff[s] = i31 * CK + 8 * ((2 * s + g) ^ wswz);
+    const int arow_base = wm * 32 + i31;
+
+    f32x16 acc[TNI];
+    int seq = 0;                                          // weight stages issued so far by the block (buffer = seq & 1)
+    // One pass: acc = sum over (chunk, tap) of A[row + tap*dil] . W[tap].  (nwh, nwl): weights of the pass that follows
+    // (nullptr: none); prefetch_x: request the next tile's x rows behind the first weight stage.
+    auto run_pass = [&](const f16* wh, const f16* wl, const f16* nwh, const f16* nwl, int dil, bool prefetch_x, int next_tile) {
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+        for (int st = 0; st < S; ++st, ++seq) {
+            const int chunk = st / n_groups, grp = st - chunk * n_groups;
+            const int t0 = grp * TS, nt = min(TS, k - t0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // this stage's weights landed, the tile written before the pass is visible
+            if (st + 1 < S) issue_w(wh, wl, st + 1, (seq + 1) & 1);
+            else if (nwh) issue_w(nwh, nwl, 0, (seq + 1) & 1);
+            if (st == 0 && prefetch_x) load_x(next_tile);
+            const f16* Ah = Zs + chunk * 2 * A_TILE;
+            const f16* Al = Ah + A_TILE;
+            const f16* Wh = Ws + (seq & 1) * 2 * W_ST;
+            const f16* Wl = Wh + W_ST;
+            for (int tl = 0; tl < nt; ++tl) {
+                const int arow = arow_base + (t0 + tl) * dil;
+                const int aswz = (arow >> 2) & 3;
+                const f16* wth = Wh + tl * NP * CK;
+                const f16* wtl = Wl + tl * NP * CK;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int aoff = arow * CK + 8 * ((2 * s + g) ^ aswz);
+                    const f16x8 fah = *reinterpret_cast<const f16x8*>(Ah + aoff);
+                    const f16x8 fal = *reinterpret_cast<const f16x8*>(Al + aoff);
+                    f16x8 fwh[TNI], fwl[TNI];
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni) {
+                        fwh[ni] = *reinterpret_cast<const f16x8*>(wth + ni * 32 * CK + woff[s]);
+                        fwl[ni] = *reinterpret_cast<const f16x8*>(wtl + ni * 32 * CK + woff[s]);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fwh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fwl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+                    for (int ni = 0; ni < TNI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fwh[ni], acc[ni], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // every wave is done reading the tile: it may be overwritten
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= p.n_tiles) return;
+#ifdef CVX_PAIR_TRACE
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast_ = __builtin_readcyclecounter();
+#define PSTAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tr[i] += now_ - tlast_; tlast_ = now_; }
+#else
+#define PSTAMP(i)
+#endif
+    load_x(tile);
+    issue_w(p.w1h, p.w1l, 0, 0);
+    store_z();
+    PSTAMP(0)
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        const int b = tile / p.tiles_per_seq, l0 = (tile - b * p.tiles_per_seq) * tm_out;
+        const int next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < p.n_tiles;
+
+        run_pass(p.w1h, p.w1l, p.w2h, p.w2l, p.dil, false, 0);            // pass 1: conv1 over the z tile
+        PSTAMP(1)
+        // ---- epilogue 1: t = split(lrelu(acc*a1 + b1) * zs), zero outside the signal, over the z tile
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b1 + ni * 32 + c4e);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v0 = acc[ni][4 * rg + 0], v1 = acc[ni][4 * rg + 1], v2 = acc[ni][4 * rg + 2], v3 = acc[ni][4 * rg + 3];
+                quad_transpose(v0, v1, v2, v3, lane);
+                const int row = wm * 32 + 8 * rg + 4 * g + q;
+                const int pos = l0 - h2 + row;
+                const bool inside = pos >= 0 && pos < p.L;
+                const float sp = inside ? zs : 0.f, sn = inside ? zs_neg : 0.f;
+                f32x4 v = {fmaf(v0, a1, bv[0]), fmaf(v1, a1, bv[1]), fmaf(v2, a1, bv[2]), fmaf(v3, a1, bv[3])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= v[e] > 0.f ? sp : sn;
+                cvx_f16x4 zh, zl;
+                pair_split4(v, zh, zl);
+                const int off = (ni * 2 * ZR + row) * CK + 8 * ((c4e >> 3) ^ ((row >> 2) & 3)) + (c4e & 7);
+                *reinterpret_cast<cvx_f16x4*>(Zs + off) = zh;
+                *reinterpret_cast<cvx_f16x4*>(Zs + off + A_TILE) = zl;
+            }
+        }
+        PSTAMP(2)
+        run_pass(p.w2h, p.w2l, has_next ? p.w1h : nullptr, p.w1l, 1, has_next, next_tile);      // pass 2: conv2 over the t tile
+        PSTAMP(3)
+        if (has_next) store_z();                   // the next tile's z (its x rows arrived during pass 2)
+        PSTAMP(4)
+        // ---- epilogue 2: x' = acc*a2 + b2 + x   (rows r < tm_out, positions < L)
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) {
+            const int co = ni * 32 + c4e;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + co);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v0 = acc[ni][4 * rg + 0], v1 = acc[ni][4 * rg + 1], v2 = acc[ni][4 * rg + 2], v3 = acc[ni][4 * rg + 3];
+                quad_transpose(v0, v1, v2, v3, lane);
+                const int row = wm * 32 + 8 * rg + 4 * g + q;
+                const int l = l0 + row;
+                if (row >= tm_out || l >= p.L) continue;
+                const uint32_t o = (uint32_t)(b * p.Lp + p.halo_l + l) * (uint32_t)NP + (uint32_t)co;
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.x + o);
+                f32x4 v = {fmaf(v0, a2, bv[0]) + r4[0], fmaf(v1, a2, bv[1]) + r4[1], fmaf(v2, a2, bv[2]) + r4[2], fmaf(v3, a2, bv[3]) + r4[3]};
+                if (has_accum) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.accum + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += a4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+                *reinterpret_cast<f32x4*>(p.out + o) = v;
+            }
+        }
+        PSTAMP(5)
+    }
+#ifdef CVX_PAIR_TRACE
+    if (lane == 0 && p.accum == nullptr && p.out_scale == 0.f) {      // (trace build: out_scale 0 makes the output all zero; stamps go on top)
+        unsigned long long* tb = reinterpret_cast<unsigned long long*>(p.out) + ((size_t)blockIdx.x * 8 + wid) * 8;
+        for (int i = 0; i < 6; ++i) tb[i] = tr[i];
+    }
+#endif
+}
+
 // ---------------------------------------------------------------- layout converters (HBM-bound transposes)
 // channel-major fp32 [B][C][L]  ->  channels-last [B][Lp][Cp]: fp32 copy (optional) + split fp16 of leaky_relu(x)
 __global__ __launch_bounds__(256) void cm_to_cl_kernel(const float* __restrict__ x, float* __restrict__ x_cl,
@@ -312,6 +569,47 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
     else if (a->Np == 64) launch_conv16<1, 2, 1>(k, a->B, st);
     else launch_conv16<1, 1, 1>(k, a->B, st);
     CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_f16x3");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->x && a->out && a->c1.w_hi && a->c1.w_lo && a->c2.w_hi && a->c2.w_lo && a->c1.bias && a->c2.bias,
+                "resblock_pair_f16x3: null pointer");
+    CVX_REQUIRE(a->out != a->x, "resblock_pair_f16x3: out must not alias x (tiles read a halo of x)");
+    CVX_REQUIRE(a->B >= 0 && a->L > 0 && (a->Np == 32 || a->Np == 64), "resblock_pair_f16x3: Np must be 32 or 64 (got %d)", a->Np);
+    CVX_REQUIRE(a->ksize > 0 && a->ksize % 2 == 1 && a->dil > 0 && (a->ksize - 1) * a->dil + (a->ksize - 1) <= A_ROWS - TMB - 4,
+                "resblock_pair_f16x3: (ksize-1)*(dil+1) = %d must be <= 60 and ksize odd", (a->ksize - 1) * (a->dil + 1));
+    const int h2 = (a->ksize - 1) / 2, pad1 = (a->ksize - 1) * a->dil / 2;
+    CVX_REQUIRE(a->halo_l >= h2 + pad1 && a->Lp >= a->halo_l + a->L + pad1 + h2,
+                "resblock_pair_f16x3: buffers need %d zero rows in front of and behind the signal (halo_l=%d Lp=%d L=%d)",
+                h2 + pad1, a->halo_l, a->Lp, a->L);
+    if (a->B == 0) return CVX_OK;
+    const int tm_out = TMB - 2 * h2;
+    const int tps = (a->L + tm_out - 1) / tm_out;
+    const int64_t n_tiles = (int64_t)tps * a->B;
+    CVX_REQUIRE(n_tiles < (1ll << 30) && (int64_t)a->B * a->Lp * a->Np * 4 < (1ll << 32), "resblock_pair_f16x3: a tensor must span < 4 GiB");
+    PairArgs k{a->x, reinterpret_cast<const f16*>(a->c1.w_hi), reinterpret_cast<const f16*>(a->c1.w_lo),
+               reinterpret_cast<const f16*>(a->c2.w_hi), reinterpret_cast<const f16*>(a->c2.w_lo), a->c1.bias, a->c2.bias,
+               a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
+               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev};
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (a->Np == 32 ? 2 : 1));      // (Np = 32: two blocks per CU)
+    if (a->Np == 32) {
+        const size_t lds = (size_t)PairCfg<1>::LDS_HALVES * sizeof(f16);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_f16x3_kernel<1>), (int)lds);
+        hipLaunchKernelGGL((resblock_pair_f16x3_kernel<1>), dim3(grid), dim3(512), lds, st, k);
+    } else {
+        const size_t lds = (size_t)PairCfg<2>::LDS_HALVES * sizeof(f16);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_f16x3_kernel<2>), (int)lds);
+        hipLaunchKernelGGL((resblock_pair_f16x3_kernel<2>), dim3(grid), dim3(512), lds, st, k);
+    }
+    CVX_CHECK_LAUNCH("cvx_hifigan_resblock_pair_f16x3");
     return CVX_OK;
 }
 

@@ -31,25 +31,48 @@ constexpr int LT = 256;           // output positions per block
 constexpr int MAX_HALO = 64;      // (ksize-1)*dil <= 50 for every conv of config_covomix.json
 constexpr int X_LD = LT + MAX_HALO;
 
-template <int MT>   // MFMA tiles per wave along co; CO_T = 32*MT
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const cvx_conv_args p, int n_chunks)
+// POLY: one phase of a ConvTranspose1d (stride s = pin.up) per block - blockIdx.y = phase * co_blocks + co block.
+// Output l = s*m + r only sees the taps kk = kk0 + s*j of the flipped kernel (kk0 = (pad' - r) mod s, pad' = the pad of
+// the zero-stuffed form) at input positions m + d + j, d = (r - pad' + kk0) / s: a stride-1 convolution with
+// nt = ceil((k - kk0) / s) taps over the UN-stuffed input, written with stride s.  1/s of the zero-stuffed form's MFMAs.
+// pin.Wp holds the s per-phase kernels Wf[:, :, kk0::s] packed like Conv1d weights, concatenated in phase order.
+template <int MT, bool POLY>   // MFMA tiles per wave along co; CO_T = 32*MT
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const cvx_conv_args pin, int n_chunks, unsigned* __restrict__ amax_bits)
 {
     constexpr int CO_T = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [CK][X_LD]
     float* Ws = smem + CK * X_LD;           // [ksize][CO_T][W_LD]
 
+    cvx_conv_args p = pin;
+    int co_blk = blockIdx.y, ostride = 1, ooff = 0, Lm = pin.Lout;
+    int64_t w_phase_off = 0;
+    if constexpr (POLY) {
+        const int s = pin.up, co_blocks = (pin.Cout + CO_T - 1) / CO_T;
+        const int r = blockIdx.y / co_blocks;
+        co_blk = blockIdx.y - r * co_blocks;
+        int kk0 = 0, nt = 0;
+        for (int rr = 0; rr <= r; ++rr) {                       // weight offset of this phase: the phases before it
+            kk0 = ((pin.pad - rr) % s + s) % s;
+            nt = kk0 < pin.ksize ? (pin.ksize - kk0 + s - 1) / s : 0;
+            if (rr < r) w_phase_off += (int64_t)co_blocks * n_chunks * nt * CO_T * CK;
+        }
+        p.up = 1; p.dil = 1; p.ksize = nt;
+        p.pad = -((r - pin.pad + kk0) / s);                    // (exact division: r - pad' + kk0 = 0 mod s)
+        ostride = s; ooff = r;
+        Lm = (pin.Lout - r + s - 1) / s;                        // outputs of this phase
+    }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int l0 = blockIdx.x * LT;
-    const int co_blk = blockIdx.y;
     const int b = blockIdx.z;
+    if (l0 >= Lm) return;
     const int halo = (p.ksize - 1) * p.dil;
     const int xw = LT + halo;                                   // staged positions per channel
     const int64_t Lv = (int64_t)(p.Lin - 1) * p.up + 1;         // virtual (zero-stuffed) length
     const float* xb = p.x + (int64_t)b * p.Cin * p.Lin;
     const int w_chunk_floats = p.ksize * CO_T * CK;
-    const float* wblk = p.Wp + (int64_t)co_blk * n_chunks * w_chunk_floats;
+    const float* wblk = p.Wp + w_phase_off + (int64_t)co_blk * n_chunks * w_chunk_floats;
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -113,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const cvx_conv_args
     }
 
     // ---- epilogue: row = co, col = position
+    float vmax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
@@ -123,14 +147,21 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const cvx_conv_args
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int l = l0 + wid * 64 + ni * 32 + l31;
-                if (l >= p.Lout) continue;
-                const int64_t o = ((int64_t)b * p.Cout + co) * p.Lout + l;
+                if (l >= Lm) continue;
+                const int64_t o = ((int64_t)b * p.Cout + co) * p.Lout + (int64_t)l * ostride + ooff;
                 float v = acc[mi][ni][r] + bv;
                 if (p.res) v += p.res[o];
                 if (p.accum) v += p.accum[o];
-                p.out[o] = v * p.out_scale;
+                v *= p.out_scale;
+                p.out[o] = v;
+                vmax = fmaxf(vmax, fabsf(v));
             }
         }
+    }
+    if (amax_bits) {                        // max |out| of the launch (non-negative floats order like their bits)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if (lane == 0 && vmax > 0.f && vmax < __builtin_inff()) atomicMax(amax_bits, __float_as_uint(vmax));
     }
 }
 
@@ -206,21 +237,77 @@ extern "C" int cvx_hifigan_conv1d_f32(const cvx_conv_args* a, cvx_stream_t s)
     const size_t lds = sizeof(float) * ((size_t)CK * X_LD + (size_t)a->ksize * cot * W_LD);
     dim3 grid((a->Lout + LT - 1) / LT, (a->Cout + cot - 1) / cot, a->B);
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    static size_t lds_set[2] = {0, 0};
     if (cot == 32) {
-        if (lds > lds_set[0]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_set[0] = lds;
-        }
-        hipLaunchKernelGGL(conv1d_mfma_kernel<1>, grid, dim3(256), lds, st, *a, n_chunks);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv1d_mfma_kernel<1, false>), (int)lds);
+        hipLaunchKernelGGL((conv1d_mfma_kernel<1, false>), grid, dim3(256), lds, st, *a, n_chunks, (unsigned*)nullptr);
     } else {
-        if (lds > lds_set[1]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_set[1] = lds;
-        }
-        hipLaunchKernelGGL(conv1d_mfma_kernel<2>, grid, dim3(256), lds, st, *a, n_chunks);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv1d_mfma_kernel<2, false>), (int)lds);
+        hipLaunchKernelGGL((conv1d_mfma_kernel<2, false>), grid, dim3(256), lds, st, *a, n_chunks, (unsigned*)nullptr);
     }
     CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_f32");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_conv_transpose1d_f32(const cvx_conv_args* a, uint32_t* amax_bits_dev, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->x && a->Wp && a->out, "conv_transpose1d: null pointer");
+    CVX_REQUIRE(a->B >= 0 && a->Cin > 0 && a->Lin > 0 && a->Cout > 0 && a->Lout > 0, "conv_transpose1d: bad shape");
+    CVX_REQUIRE(a->ksize > 0 && a->dil == 1 && a->up > 1 && a->pad >= 0 && a->pad < a->ksize, "conv_transpose1d: bad conv parameters (dil must be 1, up = stride > 1)");
+    CVX_REQUIRE(a->Lout == (int64_t)(a->Lin - 1) * a->up + 1 + 2 * a->pad - (a->ksize - 1), "conv_transpose1d: Lout %d inconsistent with geometry", a->Lout);
+    CVX_REQUIRE(!a->res && !a->accum, "conv_transpose1d: no residual / accumulate inputs");
+    CVX_REQUIRE(a->x != a->out, "conv_transpose1d: in-place on the input is not supported");
+    if (a->B == 0) return CVX_OK;
+    const int cot = co_tile(a->Cout);
+    const int n_chunks = (a->Cin + CK - 1) / CK;
+    const int nt_max = (a->ksize + a->up - 1) / a->up;
+    const size_t lds = sizeof(float) * ((size_t)CK * X_LD + (size_t)nt_max * cot * W_LD);
+    const int lm = (a->Lout + a->up - 1) / a->up;
+    dim3 grid((lm + LT - 1) / LT, ((a->Cout + cot - 1) / cot) * a->up, a->B);
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    if (cot == 32) {
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv1d_mfma_kernel<1, true>), (int)lds);
+        hipLaunchKernelGGL((conv1d_mfma_kernel<1, true>), grid, dim3(256), lds, st, *a, n_chunks, amax_bits_dev);
+    } else {
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv1d_mfma_kernel<2, true>), (int)lds);
+        hipLaunchKernelGGL((conv1d_mfma_kernel<2, true>), grid, dim3(256), lds, st, *a, n_chunks, amax_bits_dev);
+    }
+    CVX_CHECK_LAUNCH("cvx_hifigan_conv_transpose1d_f32");
+    return CVX_OK;
+}
+
+extern "C" int64_t cvx_hifigan_conv_transpose1d_packed_floats(int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t)
+{
+    if (Cout <= 0 || Cin <= 0 || ksize <= 0 || stride <= 0 || pad_t < 0 || pad_t >= ksize) return 0;
+    int64_t n = 0;
+    for (int r = 0; r < stride; ++r) {
+        const int kk0 = (((ksize - 1 - pad_t) - r) % stride + stride) % stride;
+        const int nt = kk0 < ksize ? (ksize - kk0 + stride - 1) / stride : 0;
+        n += cvx_hifigan_packed_weight_floats(Cout, Cin, nt);
+    }
+    return n;
+}
+
+extern "C" int cvx_hifigan_pack_conv_transpose1d_f32(const float* w, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride,
+                                                     int32_t pad_t, float* Wp)
+{
+    CVX_REQUIRE(w && Wp && Cout > 0 && Cin > 0 && ksize > 0 && stride > 0 && pad_t >= 0 && pad_t < ksize, "pack_conv_transpose1d: bad arguments");
+    const int cot = co_tile(Cout);
+    const int chunks = (Cin + CK - 1) / CK;
+    memset(Wp, 0, sizeof(float) * (size_t)cvx_hifigan_conv_transpose1d_packed_floats(Cout, Cin, ksize, stride, pad_t));
+    float* dst = Wp;
+    for (int r = 0; r < stride; ++r) {
+        const int kk0 = (((ksize - 1 - pad_t) - r) % stride + stride) % stride;
+        const int nt = kk0 < ksize ? (ksize - kk0 + stride - 1) / stride : 0;
+        for (int co = 0; co < Cout; ++co)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int j = 0; j < nt; ++j) {
+                    const int kk = kk0 + stride * j;                           // tap of the flipped kernel
+                    const float v = w[((int64_t)ci * Cout + co) * ksize + (ksize - 1 - kk)];
+                    const int cb = co / cot, cw = co % cot, chn = ci / CK, cc = ci % CK;
+                    dst[((((int64_t)cb * chunks + chn) * nt + j) * cot + cw) * CK + cc] = v;
+                }
+        dst += cvx_hifigan_packed_weight_floats(Cout, Cin, nt);
+    }
     return CVX_OK;
 }
 

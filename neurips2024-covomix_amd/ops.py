@@ -372,6 +372,42 @@ def hifigan_pack_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
     return wp
 
 
+def hifigan_pack_conv_transpose1d(w: torch.Tensor, stride: int, padding: int) -> torch.Tensor:
+    """ConvTranspose1d weight [Cin, Cout, k] -> the phase-major packed weight of cvx_hifigan_conv_transpose1d_f32 (host side)."""
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    cin, cout, k = w.shape
+    lib = _lib.load()
+    wp = torch.empty(lib.cvx_hifigan_conv_transpose1d_packed_floats(cout, cin, k, stride, padding), dtype=torch.float32)
+    _lib.check(lib.cvx_hifigan_pack_conv_transpose1d_f32(w.data_ptr(), cin, cout, k, stride, padding, wp.data_ptr()),
+               "cvx_hifigan_pack_conv_transpose1d_f32")
+    return wp
+
+
+def hifigan_conv_transpose1d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, cout: int, ksize: int,
+                             stride: int, padding: int, in_slope: float = 1.0, amax_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = ConvTranspose1d(leaky_relu(x, in_slope)) in polyphase form; amax_bits (int32[1] on the device, zero): receives the
+    bit pattern of max|out| (pow2_scale_from_amax turns it into an activation pre-scale and zeroes it)."""
+    _chk_f32(x, wp, bias, out)
+    B, Cin, Lin = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape[0] == B and out.shape[1] == cout
+    a = ConvArgs()
+    a.x, a.B, a.Cin, a.Lin = x.data_ptr(), B, Cin, Lin
+    a.Wp, a.bias = wp.data_ptr(), _p(bias)
+    a.out, a.Cout, a.Lout = out.data_ptr(), cout, out.shape[2]
+    a.ksize, a.dil, a.pad, a.up = ksize, 1, ksize - 1 - padding, stride
+    a.in_slope, a.out_scale = in_slope, 1.0
+    _lib.check(_lib.load().cvx_hifigan_conv_transpose1d_f32(C.byref(a), _p(amax_bits), _stream()), "cvx_hifigan_conv_transpose1d_f32")
+    return out
+
+
+def pow2_scale_from_amax(amax_bits: torch.Tensor, target: float, scale: torch.Tensor) -> torch.Tensor:
+    """scale[0] = 2^round(log2(target / amax)) from the bit pattern a producer kernel left in amax_bits; amax_bits is zeroed."""
+    assert amax_bits.is_cuda and amax_bits.dtype == torch.int32 and scale.is_cuda and scale.dtype == torch.float32
+    _lib.check(_lib.load().cvx_pow2_scale_from_amax_f32(amax_bits.data_ptr(), float(target), scale.data_ptr(), _stream()),
+               "cvx_pow2_scale_from_amax_f32")
+    return scale
+
+
 HIFI_HALO_L = 32        # zero rows in front of position 0 of every channels-last vocoder buffer (>= largest pad, 25)
 
 
@@ -434,8 +470,10 @@ def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, acc
     block: list of 3 (c1, c2) pairs of objects with .w16 = hifigan_pack_weight_f16x3(...), .bias16, .k, .dil;
     scratch: dict with t, rz0, rz1 (split pairs) and r0, r1 (fp32), all [B, Lp, Np] like x_cl / z."""
     a = _lib.Resblock16Args()
-    zh, zl = z
-    a.x, a.z_hi, a.z_lo = x_cl.data_ptr(), zh.data_ptr(), zl.data_ptr()
+    narrow = x_cl.shape[2] <= 64              # fused pair kernel: no split pairs in HBM (z / t / rz0 / rz1 unused)
+    zh, zl = z if z is not None else (None, None)
+    assert narrow or z is not None
+    a.x, a.z_hi, a.z_lo = x_cl.data_ptr(), _p(zh), _p(zl)
     a.B, a.L, a.Lp, a.Np, a.halo_l = B, L, x_cl.shape[1], x_cl.shape[2], HIFI_HALO_L
     for m, (c1, c2) in enumerate(block):
         for dst, c in ((a.c1[m], c1), (a.c2[m], c2)):
@@ -445,12 +483,31 @@ def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, acc
         a.dil[m] = c1.dil
         assert c2.dil == 1 and c1.k == c2.k
     a.ksize = block[0][0].k
-    a.t_hi, a.t_lo = scratch["t"][0].data_ptr(), scratch["t"][1].data_ptr()
-    a.xa, a.za_hi, a.za_lo = scratch["r0"].data_ptr(), scratch["rz0"][0].data_ptr(), scratch["rz0"][1].data_ptr()
-    a.xb, a.zb_hi, a.zb_lo = scratch["r1"].data_ptr(), scratch["rz1"][0].data_ptr(), scratch["rz1"][1].data_ptr()
+    a.xa, a.xb = scratch["r0"].data_ptr(), scratch["r1"].data_ptr()
+    if not narrow:
+        a.t_hi, a.t_lo = scratch["t"][0].data_ptr(), scratch["t"][1].data_ptr()
+        a.za_hi, a.za_lo = scratch["rz0"][0].data_ptr(), scratch["rz0"][1].data_ptr()
+        a.zb_hi, a.zb_lo = scratch["rz1"][0].data_ptr(), scratch["rz1"][1].data_ptr()
     a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
     a.z_scale_dev = _sp(z_scale)
     _lib.check(_lib.load().cvx_hifigan_resblock_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_f16x3")
+
+
+def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None, out_scale: float = 1.0, z_scale=None) -> None:
+    """out = (c2(lrelu(c1(lrelu(x)))) + x (+ accum)) * out_scale as one kernel (cvx_hifigan_resblock_pair_f16x3; Np = 32 / 64).
+    x_cl / out / accum: fp32 channels-last [B, Lp, Np]; c1, c2: objects with .w16, .bias16, .k, .dil (c2.dil == 1)."""
+    a = _lib.Respair16Args()
+    a.x = x_cl.data_ptr()
+    a.B, a.L, a.Lp, a.Np, a.halo_l = B, L, x_cl.shape[1], x_cl.shape[2], HIFI_HALO_L
+    for dst, c in ((a.c1, c1), (a.c2, c2)):
+        w_hi, w_lo, inv, np_, cp = c.w16
+        assert np_ == cp == x_cl.shape[2] and c.bias16.numel() == np_
+        dst.w_hi, dst.w_lo, dst.acc_scale, dst.bias = w_hi.data_ptr(), w_lo.data_ptr(), inv, c.bias16.data_ptr()
+    assert c2.dil == 1 and c1.k == c2.k
+    a.ksize, a.dil = c1.k, c1.dil
+    a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
+    a.z_scale_dev = _sp(z_scale)
+    _lib.check(_lib.load().cvx_hifigan_resblock_pair_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_pair_f16x3")
 
 
 def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, slope: float, z_scale=None) -> None:

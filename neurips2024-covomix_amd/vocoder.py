@@ -60,7 +60,7 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 class _Conv:
-    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn", "w16", "bias16")
+    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn", "w16", "bias16", "wp_poly", "padding")
 
 
 class Generator:
@@ -121,6 +121,9 @@ class Generator:
             c.pad = pad
         c.dil, c.up = dil, up
         c.wp = ops.hifigan_pack_weight(w, transposed).to(self.device)
+        c.wp_poly, c.padding = None, pad
+        if transposed and up > 1:                 # polyphase form: 1/stride of the zero-stuffed form's matrix work
+            c.wp_poly = ops.hifigan_pack_conv_transpose1d(w, up, pad).to(self.device)
         c.bias = sd[name + ".bias"].float().to(self.device).contiguous()
         c.w16 = c.bias16 = None
         if (self.precision == "f16x3" and not transposed and up == 1 and name.startswith("resblocks.") and c.cout <= 256
@@ -176,10 +179,23 @@ class Generator:
         x = x.contiguous()
         x = self._run(pk["pre"], x)
         for i in range(self.num_upsamples):
-            x = self._run(pk["ups"][i], x, in_slope=LRELU_SLOPE)            # leaky_relu + ConvTranspose1d
-            if all(c.w16 is not None for block in pk["res"][i] for pair in block for c in pair):
-                x = self._resblocks_f16x3(pk["res"][i], x)
-                continue
+            up = pk["ups"][i]
+            split = all(c.w16 is not None for block in pk["res"][i] for pair in block for c in pair)
+            if up.wp_poly is not None:                                      # leaky_relu + ConvTranspose1d (polyphase)
+                B, _, lin = x.shape
+                lout = (lin - 1) * up.up + 1 + 2 * up.pad - (up.k - 1)
+                buf = self._cl_buffers(B, up.cout, lout) if split and self.act_scales else None
+                y = torch.empty(B, up.cout, lout, dtype=torch.float32, device=x.device)
+                x = ops.hifigan_conv_transpose1d(x, up.wp_poly, up.bias, y, cout=up.cout, ksize=up.k, stride=up.up, padding=up.padding,
+                                                 in_slope=LRELU_SLOPE, amax_bits=buf["zs_scratch"] if buf is not None else None)
+                if split:
+                    x = self._resblocks_f16x3(pk["res"][i], x, measured=buf is not None)
+                    continue
+            else:
+                x = self._run(up, x, in_slope=LRELU_SLOPE)
+                if split:
+                    x = self._resblocks_f16x3(pk["res"][i], x)
+                    continue
             t = torch.empty_like(x)
             r = torch.empty_like(x)
             xs = torch.empty_like(x)
@@ -216,28 +232,47 @@ class Generator:
             f32 = lambda: torch.zeros(B, Lp, Cp, dtype=torch.float32, device=self.device)
             f16 = lambda: (torch.zeros(B, Lp, Cp, dtype=torch.float16, device=self.device),
                            torch.zeros(B, Lp, Cp, dtype=torch.float16, device=self.device))
-            buf = dict(x0=f32(), r0=f32(), r1=f32(), xs=f32(), z0=f16(), t=f16(), rz0=f16(), rz1=f16())
+            buf = dict(x0=f32(), r0=f32(), r1=f32(), xs=f32())
+            buf["zs"] = torch.ones(1, dtype=torch.float32, device=self.device)
+            buf["zs_scratch"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if Cp > 64:                           # (the narrow stages run one kernel per conv pair: no split pairs in HBM)
+                buf.update(z0=f16(), t=f16(), rz0=f16(), rz1=f16())
             if len(self._cl) >= 8:
                 self._cl.clear()
             self._cl[key] = buf
         return buf
 
-    def _resblocks_f16x3(self, blocks, x: torch.Tensor) -> torch.Tensor:
+    def _resblocks_f16x3(self, blocks, x: torch.Tensor, measured: bool = False) -> torch.Tensor:
         """xs = sum_j ResBlock1_j(x) / num_kernels  (models.py:104-110, :35-42) for one upsampling stage."""
         B, C, L = x.shape
         buf = self._cl_buffers(B, C, L)
         # activation pre-scale of this stage's split pairs: the power of two that brings max|x| of the stage input to 2^10
         # (measured on the device; the intermediates of a ResBlock stay within a few binades of its input)
-        if "zs" not in buf:
-            buf["zs"] = torch.ones(1, dtype=torch.float32, device=self.device)
-            buf["zs_scratch"] = torch.zeros(1, dtype=torch.int32, device=self.device)
-        zs = ops.amax_pow2_scale(x, 1024.0, buf["zs"], buf["zs_scratch"]) if self.act_scales else None
-        ops.hifigan_to_channels_last(x, buf["x0"], buf["z0"], LRELU_SLOPE, z_scale=zs)
+        # (measured: the ConvTranspose1d that produced x left max|x| in zs_scratch)
+        if not self.act_scales:
+            zs = None
+        elif measured:
+            zs = ops.pow2_scale_from_amax(buf["zs_scratch"], 1024.0, buf["zs"])
+        else:
+            zs = ops.amax_pow2_scale(x, 1024.0, buf["zs"], buf["zs_scratch"])
+        narrow = "z0" not in buf
+        ops.hifigan_to_channels_last(x, buf["x0"], buf.get("z0"), LRELU_SLOPE, z_scale=zs)
         nblk = len(blocks)
         for j, block in enumerate(blocks):
-            if len(block) == 3:                   # one C call per ResBlock (six convolutions): cvx_hifigan_resblock_f16x3
-                ops.hifigan_resblock_f16x3(buf["x0"], buf["z0"], block, B, L, buf, accum=buf["xs"] if j > 0 else None, out=buf["xs"],
+            if len(block) == 3:                   # one C call per ResBlock: cvx_hifigan_resblock_f16x3 (6 launches, or 3 fused pairs)
+                ops.hifigan_resblock_f16x3(buf["x0"], buf.get("z0"), block, B, L, buf, accum=buf["xs"] if j > 0 else None, out=buf["xs"],
                                            out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
+                continue
+            if narrow:                            # other dilation counts: pair by pair
+                cur = buf["x0"]
+                for m, (c1, c2) in enumerate(block):
+                    if m + 1 < len(block):
+                        nxt = buf["r0"] if m % 2 == 0 else buf["r1"]
+                        ops.hifigan_resblock_pair_f16x3(cur, c1, c2, B, L, nxt, z_scale=zs)
+                        cur = nxt
+                    else:
+                        ops.hifigan_resblock_pair_f16x3(cur, c1, c2, B, L, buf["xs"], accum=buf["xs"] if j > 0 else None,
+                                                        out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
                 continue
             cur_x, cur_z = buf["x0"], buf["z0"]   # other dilation counts: convolution by convolution
             for m, (c1, c2) in enumerate(block):

@@ -176,3 +176,81 @@ def test_resblock_f16x3_entry_point(C_, k, dils, L):
     assert rel(out, want) < 5e-6
     assert torch.equal(buf["x0"], x0_before)               # the block input is not modified
     assert float(buf["xs"][:, :, C_:].abs().max() if np_ > C_ else 0.0) == 0.0      # padded channels stay zero
+
+
+@pytest.mark.parametrize("C_,k,dil,L,B", [(31, 11, 5, 40000, 2), (62, 7, 3, 36000, 2), (31, 3, 1, 70000, 1), (62, 11, 5, 517, 3), (20, 7, 5, 100, 1)])
+def test_resblock_pair_fused_kernel(C_, k, dil, L, B):
+    """cvx_hifigan_resblock_pair_f16x3 (one kernel per conv pair, intermediate in LDS, persistent blocks walking several
+    tiles when B * ceil(L / (256 - (k-1))) exceeds the CU count) against the fp64 torch restatement of models.py:36-40,
+    with the xs accumulate / scale of Generator.forward; the zero halos and padded channels stay zero."""
+    from types import SimpleNamespace
+    from covomix_amd import ops
+    g = torch.Generator().manual_seed(C_ * 1000 + k * 10 + dil)
+    x = torch.randn(B, C_, L, generator=g) * 0.05                 # (small: the measured pre-scale does the work)
+    w1 = torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5
+    w2 = torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5
+    b1, b2 = torch.randn(C_, generator=g) * 0.01, torch.randn(C_, generator=g) * 0.01
+    xs = torch.randn(B, C_, L, generator=g) * 0.05
+    xt = F.conv1d(F.leaky_relu(x.double(), 0.1), w1.double(), b1.double(), dilation=dil, padding=(k - 1) * dil // 2)
+    xt = F.conv1d(F.leaky_relu(xt, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)
+    want_x = xt + x.double()
+    want_xs = (want_x + xs.double()) * 0.5
+    dev = torch.device("cuda:0")
+    np_ = 32 if C_ <= 32 else 64
+    Lp = ops.hifigan_cl_rows(L)
+    f32 = lambda: torch.zeros(B, Lp, np_, dtype=torch.float32, device=dev)
+    x0, o1, o2, acc = f32(), f32(), f32(), f32()
+    xd = x.to(dev)
+    scale = torch.ones(1, device=dev)
+    ops.amax_pow2_scale(xd, 1024.0, scale, torch.zeros(1, dtype=torch.int32, device=dev))
+    ops.hifigan_to_channels_last(xd, x0, None, 0.1)
+    ops.hifigan_to_channels_last(xs.to(dev), acc, None, 0.1)
+
+    def conv(w, b, d):
+        c = SimpleNamespace(k=k, dil=d)
+        c.w16 = ops.hifigan_pack_weight_f16x3(w.to(dev))
+        c.bias16 = torch.zeros(np_, device=dev)
+        c.bias16[:C_] = b.to(dev)
+        return c
+    c1, c2 = conv(w1, b1, dil), conv(w2, b2, 1)
+    ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, o1, z_scale=scale)
+    ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, o2, accum=acc, out_scale=0.5, z_scale=scale)
+    for buf, want in ((o1, want_x), (o2, want_xs)):
+        out = torch.empty(B, C_, L, device=dev)
+        ops.hifigan_from_channels_last(buf, out)
+        assert rel(out, want) < 5e-6
+        assert float(buf[:, : ops.HIFI_HALO_L].abs().max()) == 0.0 and float(buf[:, ops.HIFI_HALO_L + L:].abs().max()) == 0.0
+        if np_ > C_:
+            assert float(buf[:, :, C_:].abs().max()) == 0.0
+    # accum may alias out (the generator's running xs)
+    ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, acc, accum=acc, out_scale=0.5, z_scale=scale)
+    assert torch.equal(acc, o2)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,u,pad,L,B", [(500, 250, 8, 5, 1, 130, 2), (250, 125, 8, 4, 2, 300, 2), (125, 62, 4, 4, 0, 777, 1),
+                                                  (62, 31, 4, 2, 1, 1000, 3), (20, 10, 3, 5, 0, 50, 1), (16, 40, 7, 3, 2, 64, 2)])
+def test_conv_transpose1d_polyphase(Cin, Cout, k, u, pad, L, B):
+    """cvx_hifigan_conv_transpose1d_f32 (one stride-1 convolution per output phase) against torch's fp64 conv_transpose1d of
+    leaky_relu(x) - the four upsamplers of config_covomix.json (models.py:85-88), a kernel shorter than the stride (phases
+    that see no tap at all: bias only) and an odd one - and the fused max|out| against the tensor's own maximum."""
+    from covomix_amd import ops
+    g = torch.Generator().manual_seed(Cin * 7 + k * 3 + u)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cin, Cout, k, generator=g) / (Cin * k / u) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    want = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=pad)
+    dev = torch.device("cuda:0")
+    wp = ops.hifigan_pack_conv_transpose1d(w, u, pad).to(dev)
+    out = torch.full((B, Cout, want.shape[2]), float("nan"), device=dev)
+    bits = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.hifigan_conv_transpose1d(x.to(dev), wp, b.to(dev), out, cout=Cout, ksize=k, stride=u, padding=pad, in_slope=0.1, amax_bits=bits)
+    assert rel(out, want) < 5e-6
+    assert float(bits.view(torch.float32)) == float(out.abs().max())
+    scale = torch.zeros(1, device=dev)
+    ops.pow2_scale_from_amax(bits, 1024.0, scale)
+    assert float(scale) == 2.0 ** round(float(torch.log2(1024.0 / out.abs().max()))) and int(bits) == 0
+    # the zero-stuffed form of the same operator (cvx_hifigan_conv1d_f32 with up > 1) agrees to rounding
+    if k - 1 - pad >= 0 and (k - 1) <= 50:
+        ref = torch.empty_like(out)
+        ops.hifigan_conv1d(x.to(dev), ops.hifigan_pack_weight(w, True).to(dev), b.to(dev), ref, cout=Cout, ksize=k, pad=k - 1 - pad, up=u, in_slope=0.1)
+        assert rel(out, ref.double()) < 2e-6
