@@ -16,6 +16,8 @@ def timeit(fn, iters=30, warm=5):
     return s.elapsed_time(e) / iters * 1e3
 q = torch.randn(Bt * T, 2 * H * 64, device=dev)
 v = torch.randn(Bt * H * 64, Tp, device=dev)
+if os.environ.get('ZERO') == '1':
+    q.zero_(); v.zero_()          # power probe: same instruction stream, no operand toggling
 qh, ql = ops.split_act_f16(q)
 vh, vl = ops.split_act_f16(v)
 oh = torch.empty(Bt * T, H * 64, dtype=torch.float16, device=dev); ol = torch.empty_like(oh)
