@@ -54,7 +54,10 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     constexpr int WM = 8 / WN;
     constexpr int NP = WN * TNI * 32;
     constexpr int TS = 256 / NP;                         // taps per weight stage
-    static_assert(WM * TMI * 32 == TMB, "block tile must be 256 positions");
+    constexpr int TMB = WM * TMI * 32;                   // positions per block: 256, or 192 where that fills the chip better
+    constexpr int A_ROWS = TMB + 64;                     // + halo (<= 50) rounded up to the 16-row DMA piece
+    constexpr int A_TILE = A_ROWS * CK;
+    static_assert(TMB <= ::TMB && TMB % 32 == 0, "block tile: at most 256 positions");
     extern __shared__ __attribute__((aligned(16))) f16 smem_c[];
     f16* const As = smem_c;                              // [2 buffers][hi | lo][A_ROWS][32]
     f16* const Ws = smem_c + 4 * A_TILE;                 // [2 stages][hi | lo][256][32]
@@ -72,12 +75,13 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     // ---- DMA addressing: a piece = 16 rows x 64 bytes; lane -> (row = lane >> 2, 16-byte chunk = lane & 3, swizzled)
     const int prow = lane >> 2;
     const int64_t a_row0 = (int64_t)b * p.Lp + p.halo_l + l0 - p.pad;            // global row of tile row 0 (>= 0)
+    const int64_t last_row = (int64_t)gridDim.y * p.Lp - 1;
     auto issue_a = [&](int chunk) {
         f16* dst = As + (chunk & 1) * 2 * A_TILE;
         for (int pc = wid; pc < A_ROWS / 16; pc += 8) {
             const int r = 16 * pc + prow;
             const int c4 = (lane & 3) ^ ((r >> 2) & 3);
-            const int64_t src = (a_row0 + r) * p.Cp_in + chunk * CK + 8 * c4;
+            const int64_t src = min(a_row0 + r, last_row) * p.Cp_in + chunk * CK + 8 * c4;      // (192-row tiles may reach past roundup(L, 256) + 64)
             glds16(p.z_hi + src, dst + 16 * pc * CK);
             glds16(p.z_lo + src, dst + A_TILE + 16 * pc * CK);
         }
@@ -537,9 +541,10 @@ __global__ __launch_bounds__(256) void cl_to_cm_kernel(const float* __restrict__
 template <int TMI, int TNI, int WN>
 void launch_conv16(const Conv16Args& a, int B, hipStream_t st)
 {
+    constexpr int tmb = (8 / WN) * TMI * 32;
     const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
     cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN>), (int)lds);
-    dim3 grid((unsigned)((a.L + TMB - 1) / TMB), (unsigned)B);
+    dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B);
     hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN>), grid, dim3(512), lds, st, a);
 }
 
@@ -564,7 +569,17 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
                  a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    if (a->Np == 256) launch_conv16<4, 2, 4>(k, a->B, st);
+    if (a->Np == 256) {
+        // one block per CU: when the 256-position tiles leave more than a quarter of the chip idle in their last (or only)
+        // round and 192-position tiles fit in fewer block-rows of work, take those (stage 0 of the bench shape: 160 -> 216
+        // blocks of 3/4 the work each on 256 CUs)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+        const int64_t n256 = (int64_t)((a->L + 255) / 256) * a->B, n192 = (int64_t)((a->L + 191) / 192) * a->B;
+        const int64_t t256 = (n256 + cus - 1) / cus * 4, t192 = (n192 + cus - 1) / cus * 3;      // rounds x tile size
+        if (t192 < t256) launch_conv16<3, 2, 4>(k, a->B, st);
+        else launch_conv16<4, 2, 4>(k, a->B, st);
+    }
     else if (a->Np == 128) launch_conv16<2, 2, 2>(k, a->B, st);
     else if (a->Np == 64) launch_conv16<1, 2, 1>(k, a->B, st);
     else launch_conv16<1, 1, 1>(k, a->B, st);
