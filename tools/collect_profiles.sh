@@ -7,7 +7,7 @@
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python bench.py --no-cpu-baseline --no-fp32-exact --precision f16 > $OUT/bench_n1_f16.json 2> $OUT/bench_n1_f16.err
 cd /tmp && export TMPDIR=/tmp
