@@ -309,6 +309,7 @@ typedef struct {
     int32_t ksize, dil;
     const float* accum; float* out; float out_scale;
     const float* z_scale_dev;
+    int32_t flags;      /* 0; bit 0 (dev A/B): Np = 64 on 128-row tiles, two blocks per CU, instead of 256-row tiles, one per CU */
 } cvx_respair16_args;
 int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_stream_t s);
 

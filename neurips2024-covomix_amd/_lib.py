@@ -91,7 +91,7 @@ class Respair16Args(C.Structure):
                 ("c1", Conv16Weights), ("c2", Conv16Weights),
                 ("ksize", C.c_int32), ("dil", C.c_int32),
                 ("accum", C.c_void_p), ("out", C.c_void_p), ("out_scale", C.c_float),
-                ("z_scale_dev", C.c_void_p)]
+                ("z_scale_dev", C.c_void_p), ("flags", C.c_int32)]
 
 
 class T2SLayer(C.Structure):

@@ -264,20 +264,29 @@ __device__ __forceinline__ void pair_split4(const f32x4 v, cvx_f16x4& hi, cvx_f1
     lo = cvx_f16x4{l01[0], l01[1], l23[0], l23[1]};
 }
 
-constexpr int PAIR_TS = 4;                                // taps per weight stage of the pair kernel
-template <int TNI> struct PairCfg {
+// TNI: 32-channel tiles (Np = 32 TNI); NW: waves per block = 32-row slices of the block's tile (ROWS = 32 NW).
+// <1, 8>: 256 rows, 72 KiB, two blocks per CU (one block's epilogues and tile conversion run under the other's MFMA
+// passes); <2, 8>: 256 rows, 144 KiB, one block per CU.  <2, 4> (128 rows, 2-tap weight stages, 80 KiB, two blocks per
+// CU) buys the same overlap at Np = 64 with more halo and shorter stages: measured 0 ... 10 % SLOWER than <2, 8>, kept for
+// A/B through cvx_respair16_args.flags.
+template <int TNI, int NW> struct PairCfg {
     static constexpr int NP = 32 * TNI;
-    static constexpr int W_ST = PAIR_TS * NP * CK;        // halves of one (hi or lo) weight stage: 8 / 16 KiB
-    static constexpr int LDS_HALVES = TNI * 2 * A_TILE + 2 * 2 * W_ST;        // 72 KiB (two blocks per CU) / 144 KiB
+    static constexpr int ROWS = 32 * NW;                  // t rows per tile (outputs: ROWS - (k - 1))
+    static constexpr int ZR = ROWS + 64;                  // rows of the z / t tile (+ halo <= 60, 16-row pieces)
+    static constexpr int Z_TILE = ZR * CK;                // halves of one (chunk, hi or lo) tile
+    static constexpr int TS = (TNI == 2 && NW == 4) ? 2 : 4;                  // taps per weight stage
+    static constexpr int W_ST = TS * NP * CK;             // halves of one (hi or lo) weight stage
+    static constexpr int LDS_HALVES = TNI * 2 * Z_TILE + 2 * 2 * W_ST;
 };
 
-template <int TNI>
-__global__ __launch_bounds__(512, TNI == 1 ? 4 : 2) void resblock_pair_f16x3_kernel(const PairArgs p)
+template <int TNI, int NW>
+__global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void resblock_pair_f16x3_kernel(const PairArgs p)
 {
-    using Cfg = PairCfg<TNI>;
-    constexpr int NP = Cfg::NP, NCH = TNI, TS = PAIR_TS, W_ST = Cfg::W_ST;
-    constexpr int ZR = A_ROWS;                            // rows of the z / t tile
-    constexpr int NF = ZR * NP / 4 / 512;                 // float4 loads per thread for one x tile (5 / 10)
+    using Cfg = PairCfg<TNI, NW>;
+    constexpr int NP = Cfg::NP, NCH = TNI, TS = Cfg::TS, W_ST = Cfg::W_ST, ZR = Cfg::ZR, ROWS = Cfg::ROWS;
+    constexpr int NT = 64 * NW;                           // threads per block
+    constexpr int A_TILE = Cfg::Z_TILE;                   // (shadows the convolution kernel's constant: this kernel's tile)
+    constexpr int NF = (ZR * NP / 4 + NT - 1) / NT;       // float4 loads per thread for one x tile
     extern __shared__ __attribute__((aligned(16))) f16 smem_c[];
     f16* const Zs = smem_c;                               // [NCH chunks][hi | lo][ZR][32]   (z tile, then t tile)
     f16* const Ws = smem_c + NCH * 2 * A_TILE;            // [2 stages][hi | lo][TS taps * NP][32]
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(512, TNI == 1 ? 4 : 2) void resblock_pair_f16x3_ker
     const float zs = p.z_scale ? *p.z_scale : 1.f;
     const float a1 = p.acc1 / zs, a2 = p.acc2 / zs;       // (exact: powers of two)
     const int k = p.ksize, h2 = (k - 1) / 2, pad1 = (k - 1) * p.dil / 2;
-    const int tm_out = TMB - 2 * h2;
+    const int tm_out = ROWS - 2 * h2;
     const int n_groups = (k + TS - 1) / TS;
     const int S = NCH * n_groups;
     const uint32_t last_row = (uint32_t)p.B * (uint32_t)p.Lp - 1u;     // (the launcher checks that a tensor spans < 4 GiB: 32-bit offsets)
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(512, TNI == 1 ? 4 : 2) void resblock_pair_f16x3_ker
         const int t0 = grp * TS, nt = min(TS, k - t0);
         f16* dst = Ws + par * 2 * W_ST;
         const int64_t base = ((int64_t)chunk * k + t0) * NP * CK;
-        for (int pc = wid; pc < nt * NP / 16; pc += 8) {
+        for (int pc = wid; pc < nt * NP / 16; pc += NW) {
             const int r = 16 * pc + prow;
             const int c4 = (lane & 3) ^ ((r >> 2) & 3);
             const int64_t src = base + (int64_t)r * CK + 8 * c4;
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(512, TNI == 1 ? 4 : 2) void resblock_pair_f16x3_ker
         const uint32_t g0 = (uint32_t)(b * p.Lp + p.halo_l + l0 - h2 - pad1);
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            const int f = tid + 512 * i;
+            const int f = min(tid + NT * i, ZR * NP / 4 - 1);   // (the last round of a tile may be partial: re-read, not stored)
             const int row = f / (NP / 4), c4 = f % (NP / 4);
             const uint32_t gr = min(g0 + (uint32_t)row, last_row);
             xr[i] = *reinterpret_cast<const f32x4*>(p.x + (gr * (uint32_t)NP + 4u * (uint32_t)c4));
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(512, TNI == 1 ? 4 : 2) void resblock_pair_f16x3_ker
     auto store_z = [&]() {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            const int f = tid + 512 * i;
+            const int f = tid + NT * i;
+            if (f >= ZR * NP / 4) continue;
             const int row = f / (NP / 4), c4 = f % (NP / 4);
             f32x4 z;
 #pragma unroll
@@ -593,14 +603,16 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
                 "resblock_pair_f16x3: null pointer");
     CVX_REQUIRE(a->out != a->x, "resblock_pair_f16x3: out must not alias x (tiles read a halo of x)");
     CVX_REQUIRE(a->B >= 0 && a->L > 0 && (a->Np == 32 || a->Np == 64), "resblock_pair_f16x3: Np must be 32 or 64 (got %d)", a->Np);
-    CVX_REQUIRE(a->ksize > 0 && a->ksize % 2 == 1 && a->dil > 0 && (a->ksize - 1) * a->dil + (a->ksize - 1) <= A_ROWS - TMB - 4,
+    CVX_REQUIRE(a->ksize > 0 && a->ksize % 2 == 1 && a->dil > 0 && (a->ksize - 1) * a->dil + (a->ksize - 1) <= 60,
                 "resblock_pair_f16x3: (ksize-1)*(dil+1) = %d must be <= 60 and ksize odd", (a->ksize - 1) * (a->dil + 1));
     const int h2 = (a->ksize - 1) / 2, pad1 = (a->ksize - 1) * a->dil / 2;
     CVX_REQUIRE(a->halo_l >= h2 + pad1 && a->Lp >= a->halo_l + a->L + pad1 + h2,
                 "resblock_pair_f16x3: buffers need %d zero rows in front of and behind the signal (halo_l=%d Lp=%d L=%d)",
                 h2 + pad1, a->halo_l, a->Lp, a->L);
     if (a->B == 0) return CVX_OK;
-    const int tm_out = TMB - 2 * h2;
+    const bool big64 = a->Np == 64 && !(a->flags & 1);                    // default: 256-row tiles, one block per CU
+    const int rows = (a->Np == 64 && !big64) ? 128 : 256;
+    const int tm_out = rows - 2 * h2;
     const int tps = (a->L + tm_out - 1) / tm_out;
     const int64_t n_tiles = (int64_t)tps * a->B;
     CVX_REQUIRE(n_tiles < (1ll << 30) && (int64_t)a->B * a->Lp * a->Np * 4 < (1ll << 32), "resblock_pair_f16x3: a tensor must span < 4 GiB");
@@ -614,16 +626,17 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (a->Np == 32 ? 2 : 1));      // (Np = 32: two blocks per CU)
-    if (a->Np == 32) {
-        const size_t lds = (size_t)PairCfg<1>::LDS_HALVES * sizeof(f16);
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_f16x3_kernel<1>), (int)lds);
-        hipLaunchKernelGGL((resblock_pair_f16x3_kernel<1>), dim3(grid), dim3(512), lds, st, k);
-    } else {
-        const size_t lds = (size_t)PairCfg<2>::LDS_HALVES * sizeof(f16);
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_f16x3_kernel<2>), (int)lds);
-        hipLaunchKernelGGL((resblock_pair_f16x3_kernel<2>), dim3(grid), dim3(512), lds, st, k);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU
+#define CVX_LAUNCH_PAIR(TNI_, NW_)                                                                                       \
+    {                                                                                                                    \
+        const size_t lds = (size_t)PairCfg<TNI_, NW_>::LDS_HALVES * sizeof(f16);                                         \
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_f16x3_kernel<TNI_, NW_>), (int)lds);          \
+        hipLaunchKernelGGL((resblock_pair_f16x3_kernel<TNI_, NW_>), dim3(grid), dim3(64 * NW_), lds, st, k);             \
     }
+    if (a->Np == 32) CVX_LAUNCH_PAIR(1, 8)
+    else if (big64) CVX_LAUNCH_PAIR(2, 8)
+    else CVX_LAUNCH_PAIR(2, 4)
+#undef CVX_LAUNCH_PAIR
     CVX_CHECK_LAUNCH("cvx_hifigan_resblock_pair_f16x3");
     return CVX_OK;
 }

@@ -493,7 +493,7 @@ def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, acc
     _lib.check(_lib.load().cvx_hifigan_resblock_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_f16x3")
 
 
-def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None, out_scale: float = 1.0, z_scale=None) -> None:
+def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None, out_scale: float = 1.0, z_scale=None, flags: int = 0) -> None:
     """out = (c2(lrelu(c1(lrelu(x)))) + x (+ accum)) * out_scale as one kernel (cvx_hifigan_resblock_pair_f16x3; Np = 32 / 64).
     x_cl / out / accum: fp32 channels-last [B, Lp, Np]; c1, c2: objects with .w16, .bias16, .k, .dil (c2.dil == 1)."""
     a = _lib.Respair16Args()
@@ -507,6 +507,7 @@ def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None
     a.ksize, a.dil = c1.k, c1.dil
     a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
     a.z_scale_dev = _sp(z_scale)
+    a.flags = flags
     _lib.check(_lib.load().cvx_hifigan_resblock_pair_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_pair_f16x3")
 
 

@@ -222,6 +222,12 @@ def test_resblock_pair_fused_kernel(C_, k, dil, L, B):
         assert float(buf[:, : ops.HIFI_HALO_L].abs().max()) == 0.0 and float(buf[:, ops.HIFI_HALO_L + L:].abs().max()) == 0.0
         if np_ > C_:
             assert float(buf[:, :, C_:].abs().max()) == 0.0
+    if np_ == 64:                                           # the 128-row / two-blocks-per-CU variant of the same kernel (A/B flag)
+        o3 = f32()
+        ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, o3, z_scale=scale, flags=1)
+        out = torch.empty(B, C_, L, device=dev)
+        ops.hifigan_from_channels_last(o3, out)
+        assert rel(out, want_x) < 5e-6
     # accum may alias out (the generator's running xs)
     ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, acc, accum=acc, out_scale=0.5, z_scale=scale)
     assert torch.equal(acc, o2)

@@ -31,7 +31,7 @@ for C_, L in ((31, 160032), (62, 80016)):
                 c.bias16 = torch.zeros(np_, device=dev)
                 return c
             c1, c2 = conv(dil), conv(1)
-            us = timeit(lambda: ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, o, z_scale=scale))
+            us = timeit(lambda: ops.hifigan_resblock_pair_f16x3(x0, c1, c2, B, L, o, z_scale=scale, flags=int(os.environ.get('FLAGS', '0'))))
             hbm = 2 * B * L * np_ * 4 / 5.0e12 * 1e6
             mm = 2 * 3 * 2 * np_ * np_ * k * B * L / 1.2e15 * 1e6
             tot += us
