@@ -9,9 +9,12 @@ typedef float f32x4  __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void cvx_set_error(const char* fmt, ...);
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): function attributes are per device, so a
-// once-per-process flag is wrong for the second GPU a process uses.  Thread-safe; a hash lookup after the first call.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (device, kernel), raised whenever a launch asks for more than was
+// granted so far: function attributes are per device, so a once-per-process flag is wrong for the second GPU a process
+// uses.  Thread-safe; a map lookup after the first call.
 void cvx_allow_dynamic_lds(const void* kernel, int bytes);
+// compute units of the current device (cached per device)
+int cvx_device_cus();
 
 #define CVX_REQUIRE(cond, ...)                       \
     do {                                             \

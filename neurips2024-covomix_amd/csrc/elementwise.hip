@@ -23,17 +23,35 @@ void cvx_set_error(const char* fmt, ...)
 extern "C" const char* cvx_last_error_string(void) { return g_err; }
 
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 void cvx_allow_dynamic_lds(const void* kernel, int bytes)
 {
     static std::mutex mu;
-    static std::set<std::pair<int, const void*>> done;
+    static std::map<std::pair<int, const void*>, int> granted;       // largest size asked for so far, per (device, kernel)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lock(mu);
-    if (done.insert(std::make_pair(dev, kernel)).second)
+    int& g = granted[std::make_pair(dev, kernel)];
+    if (bytes > g) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        g = bytes;
+    }
+}
+int cvx_device_cus()
+{
+    static std::mutex mu;
+    static int n_cu[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = v;
+    }
+    return n_cu[dev];
 }
 extern "C" int cvx_version(void) { return 100; }
 

@@ -583,8 +583,7 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
         // one block per CU: when the 256-position tiles leave more than a quarter of the chip idle in their last (or only)
         // round and 192-position tiles fit in fewer block-rows of work, take those (stage 0 of the bench shape: 160 -> 216
         // blocks of 3/4 the work each on 256 CUs)
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+        const int cus = cvx_device_cus();
         const int64_t n256 = (int64_t)((a->L + 255) / 256) * a->B, n192 = (int64_t)((a->L + 191) / 192) * a->B;
         const int64_t t256 = (n256 + cus - 1) / cus * 4, t192 = (n192 + cus - 1) / cus * 3;      // rounds x tile size
         if (t192 < t256) launch_conv16<3, 2, 4>(k, a->B, st);
@@ -621,11 +620,7 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
                a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
                a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
+    const int cus = cvx_device_cus();
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU
 #define CVX_LAUNCH_PAIR(TNI_, NW_)                                                                                       \
     {                                                                                                                    \
