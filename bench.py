@@ -6,7 +6,9 @@ One "step" = one pass of the hot path over one synthetic batch per GPU:
     forwards) on B=8 utterances of T=1000 frames (dual-channel 160-dim prompt of 400 frames)
     followed by the HiFi-GAN generator on all 8 x 1000 generated frames and the int16 cast.
 Weights: reference-shaped random checkpoints from covomix_amd.synthetic (no pretrained weights
-exist); inputs resident in HBM before the timed region.  N > 1: one process per GPU (torchrun),
+exist); inputs resident in HBM before the timed region.  N > 1: one process per GPU - under torch.distributed.run
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, started from a plain shell, self-launched
+(`python bench.py --gpus 8` re-executes itself under torch.distributed.run with a free rendezvous port);
 utterances sharded (8 per rank, weak scaling), weights broadcast once over RCCL, no data-path collective.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -194,8 +196,12 @@ def main():
 
     from covomix_amd import dp, ops
     import covomix_amd.synthetic as syn
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started from a plain shell: become the launcher of N ranks (one process per GPU, free rendezvous port) - the
+        # reference's own multi-GPU entry point spawns its ranks itself too (hifi-gan/train.py:268-278)
+        sys.exit(dp.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank, world, local = dp.init_from_env("nccl")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import contextlib
@@ -216,6 +222,7 @@ def main():
         return ops.wav_to_int16(wav.squeeze(1).contiguous())
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -237,11 +244,9 @@ def main():
     per_rank = [my_elapsed]
     loads = [t_load]
     if world > 1:                                        # diagnosis of the first hardware scaling runs: who was slow, and where
-        buf = torch.tensor([my_elapsed, t_load], dtype=torch.float64, device=dev)
-        allb = [torch.zeros_like(buf) for _ in range(world)]
-        torch.distributed.all_gather(allb, buf)
-        per_rank = [float(b[0]) for b in allb]
-        loads = [float(b[1]) for b in allb]
+        allb = dp.gather_floats([my_elapsed, t_load], dev)
+        per_rank = [b[0] for b in allb]
+        loads = [b[1] for b in allb]
 
     if rank == 0:
         value = frames / elapsed
@@ -254,10 +259,13 @@ def main():
         mfma = "v_mfma_f32_16x16x32_f16" if p8 else "v_mfma_f32_32x32x16_f16"
         peak = PEAK_F16_MFMA if split else PEAK_F32_MFMA
         traffic = None
+        traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.isfile(pmc) and model.precision == "f16x3":      # the committed PMC passes profile the default precision
             try:
                 traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+                # NOT measured by this run: PMC counters need their own rocprofv3 --pmc passes (tools/collect_profiles.sh)
+                traffic_source = "profiles/pmc_summary.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
             except Exception:
                 traffic = None
         out = {
@@ -279,7 +287,7 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": kname + ((" (%s x%d)" % (mfma, terms)) if split else " (v_mfma_f32_32x32x2_f32)"),
                          "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic,
+                         "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic, "traffic_source": traffic_source,
                          "executed_mfma_frac": round(achieved * terms / (peak / 1e12), 4),
                          "vs_f32_mfma_peak": round(achieved / (PEAK_F32_MFMA / 1e12), 4),
                          "launches": all_launches, "timed_launches": launches,

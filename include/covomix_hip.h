@@ -102,8 +102,9 @@ typedef struct {
      * a->ldw >= 2K halves), so that a K-step of a row is a whole 128-byte cache line.  Large-problem kernel only
      * (pre-split A, M >= 2048, N >= 512). */
     int32_t w_interleaved;
-    /* Kernel selection for A/B measurements (0 = default): CVX_GEMM_FLAG_* below; bits 8.. are timing experiments
-     * (dev).  Results of the kernels agree to fp32 rounding. */
+    /* Kernel selection for A/B measurements (0 = default): CVX_GEMM_FLAG_* below.  Results of the kernels agree to fp32
+     * rounding.  (Bits 8.. are timing experiments that exist only in -DCVX_DEV_FLAGS builds of the library; the shipped
+     * library ignores them.) */
     int32_t flags;
     /* Activation scales: DEVICE pointers to one float each (NULL = 1.0), powers of two.  a_scale_dev = the factor the
      * producer of A_hi/A_lo (and of A2_*: both operands must share it) multiplied the values by before splitting - the
@@ -115,6 +116,7 @@ typedef struct {
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
 #define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */
+#define CVX_GEMM_FLAG_ONE_TILE 4    /* eight-phase 16x16x32 kernel: one output tile per block instead of persistent blocks (bit-identical results) */
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 /* the same with an additional DEVICE-resident factor (the pair holds w * scale * *scale_dev; scale_dev may be NULL) */
 int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev, cvx_stream_t s);
@@ -404,8 +406,9 @@ int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F, int64_t l
  * cvx_rope_attention_f32: Attention.forward between to_qkv and to_out (acoustic.py:227-235): qkv [Bt, T, 3*H*64]
  *   WITHOUT rotary embedding; half-split RoPE (:132-137; tables cos/sin [T][32]) on q and k, then the attention of
  *   cvx_attention_f32.  workspace: Bt*T*3*H*64 floats (the rotated copy).
- * cvx_hifigan_convt_f32: the ConvTranspose1d upsamplers (models.py:85-88, :103) = cvx_hifigan_conv1d_f32 with
- *   up = stride (> 1), a transposed-packed weight, pad = ksize - 1 - (ksize - up)/2.
+ * cvx_hifigan_convt_f32: the ConvTranspose1d upsamplers (models.py:85-88, :103) = cvx_hifigan_conv_transpose1d_f32
+ *   (the polyphase kernel the host path runs) without the max|out| side output: up = stride (> 1),
+ *   pad = ksize - 1 - (ksize - up)/2, a->Wp packed by cvx_hifigan_pack_conv_transpose1d_f32.
  * cvx_hifigan_resblock_f32: ResBlock1.forward (models.py:35-42), x [B, C, L] -> out [B, C, L]:
  *   three times  x = c2(leaky_relu(c1(leaky_relu(x, .1)), .1)) + x  with dilations dil[m] (c1) and 1 (c2);
  *   the last add can also apply the generator's  xs (+)= ... / num_kernels  (accum, out_scale; models.py:104-110).

@@ -485,6 +485,8 @@ class FlowMatchingSampler:
         B, T, _ = cond.shape
         if y0 is None:                       # acoustic.py:647-650 (VoMix draws 80 channels)
             y0 = torch.randn(B, T, d["dim_out"], device=dev, dtype=torch.float32)
+        if tuple(y0.shape) != (B, T, d["dim_out"]):
+            raise AssertionError(f"y0 must be [B,T,{d['dim_out']}] = {(B, T, d['dim_out'])}, got {tuple(y0.shape)}")
         y = y0.to(device=dev, dtype=torch.float32).contiguous().clone()
         use_null = float(cond_scale) != 1.0          # acoustic.py:423
         s = float(cond_scale)

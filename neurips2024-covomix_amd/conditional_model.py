@@ -165,7 +165,6 @@ class CoVoMixModel:
         out = sampler.sample(phoneme_ids=phoneme_ids, cond=cond, mask=mask, cond_scale=cond_scale, y0=y0)
         return out.to(cond.device) if cond.device != out.device else out
 
-    @torch.no_grad()
     def _get_t2s(self):
         """The device-resident text2semantic decoder (built on first use)."""
         if not self.is_text2semantic:
@@ -178,6 +177,7 @@ class CoVoMixModel:
             self._t2s = TextToSemanticDecoder(self.active_state_dict(), self.device)
         return self._t2s
 
+    @torch.no_grad()
     def synthesis_sample_text2semantic(self, grapheme_token_ids, temprature=1.0, cond_scale=1.0, beam_search_decode=False,
                                        prompt_mel=None, uniforms=None, generator=None, max_length=None):
         """reference conditional_model.py:313-321 -> TextToSemanticWrapper.sample (text2semantic.py:1237-1251): the

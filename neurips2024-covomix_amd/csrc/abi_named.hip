@@ -52,7 +52,7 @@ extern "C" int cvx_rope_attention_f32(const float* qkv, const float* rope_cos, c
 extern "C" int cvx_hifigan_convt_f32(const cvx_conv_args* a, cvx_stream_t s)
 {
     CVX_REQUIRE(a && a->up > 1, "hifigan_convt: a ConvTranspose1d needs up (its stride) > 1");
-    return cvx_hifigan_conv1d_f32(a, s);
+    return cvx_hifigan_conv_transpose1d_f32(a, nullptr, s);          // the polyphase kernel the host path runs
 }
 
 extern "C" int cvx_hifigan_resblock_f32(const cvx_resblock_args* a, cvx_stream_t s)

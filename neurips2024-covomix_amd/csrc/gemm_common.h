@@ -106,6 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
         so.hi = nullptr; so.lo = nullptr;
     }
     const int colw = n0 + wn * 64;                 // first column of this wave (multiple of 64)
+    if (colw >= p.N) return;                       // wave entirely past the last column (256-wide tiles, N % 256 != 0; wave-uniform)
     const int c_lo = colw + (lane & 31);
     const int c_hi = c_lo + 32;
     if (so.vt_hi != nullptr && colw >= p.rope_cols) {

@@ -703,7 +703,13 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
             so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
         }
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
-        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev; so.dbg = io->flags >> 8; so.trace = (so.dbg & 4) ? reinterpret_cast<unsigned long long*>(io->workspace) : nullptr;
+        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev; 
+#ifdef CVX_DEV_FLAGS          // timing experiments (tools/): epilogue skipping, per-block stamps, one tile per block - never in the shipped library
+        so.dbg = io->flags >> 8; so.trace = (so.dbg & 4) ? reinterpret_cast<unsigned long long*>(io->workspace) : nullptr;
+#else
+        so.dbg = 0; so.trace = nullptr;
+#endif
+        if (io->flags & CVX_GEMM_FLAG_ONE_TILE) so.dbg |= 8;      // scheduling only: same arithmetic, bit-identical results
         if (io->Vt_hi || io->Vt_lo) {
             CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
                         (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= ((a->rope_T + 15) / 16) * 16 && io->vt_ld % 8 == 0 &&

@@ -93,6 +93,7 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (&acc)[8][4], int row0, int col0, int lane,
                                               const SplitOut& so_in, float acc_scale)
 {
+    if (col0 >= p_in.N) return;                 // wave tile entirely past the last column (N % 256 != 0; wave-uniform)
     cvx_gemm_args p = p_in;
     SplitOut so = so_in;
     if constexpr (EPI == EPI_QKV) {
@@ -178,6 +179,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)[8][4], int row0, int col0, int lane,
                                             const SplitOut& so, float acc_scale)
 {
+    if (col0 >= p.N) return;                    // wave tile entirely past the last column (H % 4 != 0; wave-uniform)
     const int H = p.rope_cols / 128, T = p.rope_T;
     const int head = (col0 - p.rope_cols) / 64;
     const float vs = (so.vt_scale ? *so.vt_scale : 1.f) * acc_scale;
@@ -442,17 +444,9 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     (void)map_mode;
     // persistent grid: one block per CU (136 KiB of LDS each), a multiple of 8; a next tile needs an even number of K-tiles
     // (the two LDS buffers alternate across the tile boundary), otherwise every tile gets its own block
-    static int n_cu[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (n_cu[dev] == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n_cu[dev] = v;
-    }
+    const int n_cu = cvx_device_cus();                           // (mutex-protected per-device cache, cvx_common.h)
     int g = n_slots;
-    if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < (n_cu[dev] / 8) * 8 ? n_slots : (n_cu[dev] / 8) * 8;
+    if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < (n_cu / 8) * 8 ? n_slots : (n_cu / 8) * 8;
     const dim3 grid((unsigned)g);
     int epi = classify_epilogue(a, so);
     if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;

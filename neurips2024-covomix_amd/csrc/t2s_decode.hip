@@ -361,11 +361,8 @@ void launch_gemv_b(const GemvArgs& g, int pairs, hipStream_t st)
 {
     const int Kin = (MODE == MODE_LOGITS) ? g.K * g.streams : g.K;
     const size_t lds = sizeof(float) * (size_t)BQ * Kin;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    if (lds > 48 * 1024)          // per-(device, kernel) bookkeeping, mutex-protected (cvx_common.h)
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ>), (int)lds);
     hipLaunchKernelGGL((gemv_kernel<MODE, BQ>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), lds, st, g);
 }
 

@@ -13,20 +13,58 @@ import torch
 import torch.distributed as dist
 
 
+def free_port() -> int:
+    """A TCP port that is free on 127.0.0.1 right now (chosen by the kernel)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def single_device_test_mode() -> bool:
+    """TEST-ONLY switch (env CVX_DP_SINGLE_DEVICE=1): every rank uses cuda:0 and the process group runs on gloo, so the
+    N > 1 code path (sharding, weight broadcast, metric reduction, one output per utterance) can be exercised on a box with a
+    single GPU.  RCCL cannot put two ranks on one device; production launches never set this."""
+    return os.environ.get("CVX_DP_SINGLE_DEVICE", "0") == "1"
+
+
+def launch_ranks(script: str, argv: Sequence[str], n: int) -> int:
+    """Run `script argv...` as n ranks of ONE node under torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1 at a free port) and return its exit code.  What `bench.py --gpus N` / the generation scripts do when they are
+    started from a plain shell - the reference's multi-GPU entry point spawns its own ranks too (hifi-gan/train.py:268-278)."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script, *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """(rank, world, local_rank) from torchrun env; initialises the process group when world > 1."""
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group when world > 1.
+    MASTER_ADDR defaults to 127.0.0.1; MASTER_PORT must come from the launcher (torch.distributed.run sets it; launch_ranks
+    picks a free one) - ranks cannot agree on a port by themselves."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if single_device_test_mode():
+        backend, local = "gloo", 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            raise RuntimeError("WORLD_SIZE > 1 but no MASTER_PORT: start the ranks with `python -m torch.distributed.run "
+                               "--master-addr 127.0.0.1 --master-port <free port> ...` or covomix_amd.dp.launch_ranks")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _on_gloo() -> bool:
+    return dist.is_initialized() and dist.get_backend() == "gloo"
 
 
 def shard_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
@@ -72,8 +110,10 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], device: torch.device, src:
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([sd[k].to(device=device, dtype=torch.float32).reshape(-1) for k in bucket])
+        cdev = torch.device("cpu") if _on_gloo() else device       # gloo (tests): collectives on host tensors
+        flat = torch.cat([sd[k].to(device=cdev, dtype=torch.float32).reshape(-1) for k in bucket])
         dist.broadcast(flat, src=src)
+        flat = flat.to(device)
         off = 0
         for k in bucket:
             n = sd[k].numel()
@@ -95,8 +135,22 @@ def reduce_metric(frames: float, seconds: float, device: torch.device) -> tuple[
     """(sum of frames over ranks, max of elapsed over ranks)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return frames, seconds
+    if _on_gloo():
+        device = torch.device("cpu")
     t = torch.tensor([frames], dtype=torch.float64, device=device)
     m = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return float(t.item()), float(m.item())
+
+
+def gather_floats(values: Sequence[float], device: torch.device) -> List[List[float]]:
+    """Every rank's list of floats, on every rank (diagnostics of a scaling run)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [list(values)]
+    if _on_gloo():
+        device = torch.device("cpu")
+    buf = torch.tensor(list(values), dtype=torch.float64, device=device)
+    allb = [torch.zeros_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(allb, buf)
+    return [[float(x) for x in b] for b in allb]

@@ -58,6 +58,8 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
                    "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
     p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
+    p.add_argument("--gpus", type=int, default=1, help="extension: from a plain shell, start this many ranks (one per GPU, "
+                   "utterances sharded; under torch.distributed.run the launcher's WORLD_SIZE is used instead)")
     return p
 
 
@@ -232,7 +234,13 @@ def run(dialogue: bool, argv=None) -> int:
     import time
     from scipy.io.wavfile import write
     from . import ops
+    import sys
     args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # spawn our own ranks (hifi-gan/train.py:268-278 does the same)
+        rc = dp.launch_ranks(os.path.abspath(sys.argv[0]), list(sys.argv[1:] if argv is None else argv), args.gpus)
+        if rc:
+            raise SystemExit(rc)
+        return 0
     print(args)
     os.makedirs(args.saved_dir, exist_ok=True)
     torch.manual_seed(args.seed)
@@ -291,6 +299,7 @@ def run(dialogue: bool, argv=None) -> int:
             owner.append((n, seg))
     lengths = [int(it[0].shape[0]) for it in items]
     segments = {n: {} for n in mine}
+    n_out = model._get_field().d["dim_out"]       # acoustic.py:647-650: 80 channels (twocondition_oneoutput) or as wide as cond
     done, frames = 0, 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -299,7 +308,7 @@ def run(dialogue: bool, argv=None) -> int:
         cond = torch.stack([items[i][1] for i in batch]).to(device)
         mask = torch.stack([items[i][2] for i in batch]).to(device)
         T = ids.shape[1]
-        y0 = torch.stack([torch.randn(T, 80, device=device, generator=torch.Generator(device=device).manual_seed(
+        y0 = torch.stack([torch.randn(T, n_out, device=device, generator=torch.Generator(device=device).manual_seed(
             _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch])      # acoustic.py:647-650, per utterance
         sampled = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=COND_SCALE, y0=y0)
         # vocoder: utterances of the batch with the same number of generated frames go through HiFi-GAN together; one

@@ -68,8 +68,8 @@ def _pair(x, rows=None, cols=None):
 
 
 # dev A/B (read here, never inside the library): CVX_GEMM_P8 = 1 (default) eight-phase kernel on the 16x16x32 MFMA,
-# 32 = eight-phase kernel on the 32x32x16 MFMA, 0 = two-stage kernel.  cvx_gemm_split_io.flags.
-_GEMM_FLAGS = {"1": 0, "32": 2, "0": 1, "1t": 8 << 8}.get(__import__("os").environ.get("CVX_GEMM_P8", "1"), 0)
+# 32 = eight-phase kernel on the 32x32x16 MFMA, 0 = two-stage kernel, 1t = one tile per block.  cvx_gemm_split_io.flags.
+_GEMM_FLAGS = {"1": 0, "32": 2, "0": 1, "1t": 4}.get(__import__("os").environ.get("CVX_GEMM_P8", "1"), 0)
 
 _SPLITK_WS: dict = {}
 

@@ -193,7 +193,8 @@ torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 print('RANK_OK', rank, flush=True)
 """)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    from covomix_amd import dp
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(dp.free_port()))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
@@ -305,3 +306,27 @@ def test_workspace_queries():
     assert lib.cvx_gemm_f16x3_workspace_floats(1000, 80, 1024, 0) == 2 * 1000 * 80
     assert lib.cvx_rope_attention_workspace_floats(2, 130, 4) == 2 * 130 * 3 * 4 * 64
     assert lib.cvx_rope_attention_workspace_floats(0, 130, 4) == 0
+
+
+def test_launch_ranks_self_spawns_two_gloo_ranks(tmp_path):
+    """dp.launch_ranks (what `bench.py --gpus N` and the generation scripts use from a plain shell): N ranks under
+    torch.distributed.run on a free port; init_from_env refuses WORLD_SIZE > 1 without a launcher-provided MASTER_PORT."""
+    from covomix_amd import dp
+    script = tmp_path / "ranks.py"
+    script.write_text(f"""
+import sys, os, torch
+sys.path.insert(0, {ROOT!r})
+from covomix_amd import dp
+rank, world, local = dp.init_from_env("gloo")
+assert world == 2 and os.environ["MASTER_ADDR"] == "127.0.0.1"
+allv = dp.gather_floats([float(rank), 10.0 + rank], torch.device("cpu"))
+assert allv == [[0.0, 10.0], [1.0, 11.0]], allv
+open(os.path.join({str(tmp_path)!r}, f"rank{{rank}}.ok"), "w").write(sys.argv[1])
+torch.distributed.destroy_process_group()
+""")
+    assert dp.launch_ranks(str(script), ["hello"], 2) == 0
+    assert (tmp_path / "rank0.ok").read_text() == "hello" and (tmp_path / "rank1.ok").read_text() == "hello"
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); from covomix_amd import dp; dp.init_from_env('gloo')"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True)
+    assert r.returncode != 0 and "MASTER_PORT" in r.stderr

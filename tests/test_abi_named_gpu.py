@@ -91,7 +91,8 @@ def test_convt_and_pre_post_entry_points():
     b = torch.randn(Cout, generator=g) * 0.1
     want = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=(k - u) // 2)
     a = ConvArgs()
-    xd, wp, bd = x.cuda(), _packed(w, True), b.cuda()
+    from covomix_amd import ops
+    xd, wp, bd = x.cuda(), ops.hifigan_pack_conv_transpose1d(w, u, (k - u) // 2).cuda(), b.cuda()      # polyphase packing
     out = torch.empty(B, Cout, want.shape[2], device="cuda")
     a.x, a.B, a.Cin, a.Lin, a.Wp, a.bias = xd.data_ptr(), B, Cin, L, wp.data_ptr(), bd.data_ptr()
     a.out, a.Cout, a.Lout, a.ksize, a.dil, a.pad, a.up = out.data_ptr(), Cout, out.shape[2], k, 1, k - 1 - (k - u) // 2, u

@@ -691,11 +691,77 @@ def test_gemm_large_problem_kernels_every_epilogue(ops, M):
         ops._GEMM_FLAGS = saved
 
 
+def test_gemm_large_problem_kernels_n_not_multiple_of_256(ops):
+    """N % 64 == 0 but N % 256 != 0 on the 256-column-tile kernels (N = 576, 640; QKV with H = 5 heads): the trailing wave
+    tiles lie past column N and must neither read bias / residual / RoPE tables nor write C, the split pair or V^T there.
+    Outputs live inside wider NaN-filled buffers (ldc > N), so a stray store shows up as a finite value in the guard."""
+    dev_ = dev()
+    g = torch.Generator().manual_seed(99)
+    M, K = 2100, 1024
+    x = torch.randn(M, K, generator=g).to(dev_)
+    il = ops.SplitIL(M, K, dev_); ops.split_act_f16(x, il)
+    xs = il.dense()[0].double() + il.dense()[1].double()
+    saved = ops._GEMM_FLAGS
+    try:
+        for flags in (0, 2, 1):
+            ops._GEMM_FLAGS = flags
+            for N in (576, 640):
+                w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev_)
+                ws = ops.split_f16(w); wil = ops.split_f16_interleaved(ws)
+                b = torch.randn(N, generator=g).to(dev_)
+                rwide = torch.randn(M, N + 256, generator=g).to(dev_)
+                ref = xs @ w.double().T
+                cw = torch.full((M + 1, N + 256), float("nan"), device=dev_)         # guard columns and one guard row
+                ops.gemm(x, w, cw[:M, :N], w_split=ws, w_il=wil, a_split=il, bias=b, residual=rwide[:, :N])
+                assert rel_l2(cw[:M, :N], ref + b.double() + rwide[:, :N].double()) < 1e-6, (flags, N)
+                assert bool(torch.isnan(cw[:, N:]).all()) and bool(torch.isnan(cw[M]).all()), (flags, N)
+                # bias + GELU + split only (no fp32 store): pair inside a wider NaN-filled pair
+                oh = torch.full((M + 1, N + 256), float("nan"), dtype=torch.float16, device=dev_)
+                ol = torch.full((M + 1, N + 256), float("nan"), dtype=torch.float16, device=dev_)
+                guard = torch.full((M, N), 7.0, device=dev_)
+                ops.gemm(x, w, guard, w_split=ws, w_il=wil, a_split=il, bias=b, act=1, out_split=(oh[:M, :N], ol[:M, :N]), write_f32=False)
+                assert rel_l2(oh[:M, :N].double() + ol[:M, :N].double(), F.gelu(ref + b.double())) < 1e-6, (flags, N)
+                assert bool(torch.isnan(oh[:, N:]).all()) and bool(torch.isnan(ol[:, N:]).all()) and bool(torch.isnan(oh[M]).all()), (flags, N)
+                assert bool((guard == 7.0).all())
+            # QKV with 5 heads: N = 960, rope_cols = 640 (the 16x16 kernel declines; the 32x32 / two-stage kernels take it)
+            H, T = 5, 700
+            Bt = M // T
+            Mq = Bt * T
+            wq = (torch.randn(3 * H * 64, K, generator=g) / math.sqrt(K)).to(dev_)
+            wqs = ops.split_f16(wq); wqil = ops.split_f16_interleaved(wqs)
+            inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+            ang = torch.arange(T).float()[:, None] * inv[None, :]
+            cos, sin = ang.cos().to(dev_).contiguous(), ang.sin().to(dev_).contiguous()
+            xq = x[:Mq].contiguous()
+            ilq = ops.SplitIL(Mq, K, dev_); ops.split_act_f16(xq, ilq)
+            qh = torch.full((Mq + 1, 2 * H * 64 + 128), float("nan"), dtype=torch.float16, device=dev_)
+            ql = torch.full((Mq + 1, 2 * H * 64 + 128), float("nan"), dtype=torch.float16, device=dev_)
+            Tp = (T + 31) // 32 * 32
+            rows = Bt * H * 64
+            vh = torch.zeros(rows + 64, Tp, dtype=torch.float16, device=dev_); vl = torch.zeros(rows + 64, Tp, dtype=torch.float16, device=dev_)
+            vh[rows:] = float("nan"); vl[rows:] = float("nan")                       # guard: the rows a sixth head of the last sequence would own
+            ops.gemm(xq, wq, torch.empty(Mq, 3 * H * 64, device=dev_), w_split=wqs, w_il=wqil, a_split=ilq, rope=(cos, sin),
+                     rope_cols=2 * H * 64, out_split=(qh[:Mq, : 2 * H * 64], ql[:Mq, : 2 * H * 64]), vt_split=(vh[:rows], vl[:rows]), write_f32=False)
+            z = (ilq.dense()[0].double() + ilq.dense()[1].double()) @ wq.double().T
+            zq = z[:, : 2 * H * 64].reshape(Bt, T, 2 * H, 64)
+            c_, s_ = torch.cat((ang.cos(), ang.cos()), -1).double().to(dev_), torch.cat((ang.sin(), ang.sin()), -1).double().to(dev_)
+            rot = torch.cat((-zq[..., 32:], zq[..., :32]), -1)
+            want_qk = (zq * c_[None, :, None, :] + rot * s_[None, :, None, :]).reshape(Mq, -1)
+            assert rel_l2(qh[:Mq, : 2 * H * 64].double() + ql[:Mq, : 2 * H * 64].double(), want_qk) < 1e-6, flags
+            assert bool(torch.isnan(qh[:, 2 * H * 64:]).all()) and bool(torch.isnan(qh[Mq]).all()), flags
+            v = z[:, 2 * H * 64:].reshape(Bt, T, H, 64).permute(0, 2, 3, 1).reshape(rows, T)
+            slots = ops.vt_frame_slots(T, dev_)
+            assert rel_l2((vh[:rows].double() + vl[:rows].double())[:, slots], v) < 1e-6, flags
+            assert bool(torch.isnan(vh[rows:]).all()) and bool(torch.isnan(vl[rows:]).all()), flags
+    finally:
+        ops._GEMM_FLAGS = saved
+
+
 def test_gemm_persistent_blocks_walk_several_tiles(ops):
     """More output tiles than CUs: a block of the eight-phase kernel then walks several tiles and fetches the first quarters
     of the next tile during the tail of the current one.  M = 5000 rows (20 row panels -> 24 slots per tile column on the XCD
     map, padding slots included) x N = 4096 = 384 slots: QKV-style (V blocks included), GELU-split and residual epilogues
-    against fp64, and bit-identity with one tile per block (dbg flag 8 << 8)."""
+    against fp64, and bit-identity with one tile per block (CVX_GEMM_FLAG_ONE_TILE)."""
     dev_ = dev()
     g = torch.Generator().manual_seed(4)
     M, K = 5000, 1024
@@ -708,7 +774,7 @@ def test_gemm_persistent_blocks_walk_several_tiles(ops):
     saved = ops._GEMM_FLAGS
     try:
         outs = []
-        for flags in (0, 8 << 8):
+        for flags in (0, 4):
             ops._GEMM_FLAGS = flags
             o = ops.SplitIL(M, 4096, dev_)
             ops.gemm(x, w, torch.empty(M, 4096, device=dev_), w_split=ws, w_il=wil, a_split=il, bias=b, act=1, out_split=o, write_f32=False)

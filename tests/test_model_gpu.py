@@ -1,7 +1,9 @@
 """Model-level parity on the GPU: the HIP path against (i) the committed golden vectors that the
 REFERENCE modules produced (tests/golden/*.npz, see make_golden.py) and (ii) the CPU oracle on
-the same seeded inputs.  Tolerance: 1e-4 rel-L2 per evaluation / 2e-4 after a 32-NFE rollout
-(north_star budget is 1e-3; fp32 floor measured by the survey is 2-7e-7)."""
+the same seeded inputs.  Tolerance for the fp32-class paths (f16x3 default and fp32): 1e-5 rel-L2 per evaluation /
+2e-5 after a 32-NFE rollout - 10x above what is measured (5e-7 ... 1.9e-6; the fp32 floor the survey measured is
+2-7e-7), 50x below the north_star budget of 1e-3, so a regression to 5e-5 fails here.  Only the opt-in f16 mode is
+held to the 1e-3 budget."""
 import os
 
 import numpy as np
@@ -12,8 +14,8 @@ from conftest import GOLDEN, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-EVAL_TOL = 1e-4
-ROLL_TOL = 2e-4
+EVAL_TOL = 1e-5
+ROLL_TOL = 2e-5
 
 
 def _state(kind, **kw):
@@ -147,7 +149,7 @@ def test_hifigan_vs_reference_golden(tag, c0):
     assert yu.shape == g["wav_unbatched"].shape
     e_u = rel_l2(yu, torch.from_numpy(g["wav_unbatched"]))
     print(tag, "batched", e_b, "unbatched", e_u)
-    assert e_b < 1e-4 and e_u < 1e-4
+    assert e_b < 1e-5 and e_u < 1e-5
     pcm = mel_decode_to_wav(gen, mel[0].cuda())
     assert pcm.dtype == np.int16 and pcm.shape == g["int16_unbatched"].shape
     assert np.abs(pcm.astype(np.int32) - g["int16_unbatched"].astype(np.int32)).max() <= 1

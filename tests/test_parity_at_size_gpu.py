@@ -67,6 +67,46 @@ def test_c3_vomix_b8_t1000_two_nfe_vs_oracle():
     assert e < AT_SIZE_TOL and worst < 2 * AT_SIZE_TOL
 
 
+@pytest.mark.slow
+def test_c3_vomix_b8_t1000_eight_nfe_vs_oracle():
+    """BASELINE config 3 at its own size over FOUR midpoint steps (8 NFE = 16 network forwards on 8 x 1000 frames; about a
+    minute of CPU for the oracle): error growth along the rollout at the metric configuration, not only one step."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    sd = _state("vomix")
+    inp = syn.synthetic_inputs("vomix", 8, 1000, 400, seed=4321)
+    out = _run(sd, inp, 8)
+    ref = orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=8)
+    e = rel_l2(out, ref)
+    worst = max(rel_l2(out[b], ref[b]) for b in range(8))
+    print("C3 VoMix B=8 T=1000 8-NFE rel-L2 vs oracle:", e, "worst utterance", worst)
+    assert e < AT_SIZE_TOL and worst < 2 * AT_SIZE_TOL
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_c1_c4_vocoder_t1000_vs_oracle(B):
+    """HiFi-GAN config_covomix at BASELINE size against the CPU oracle (not only against this build's own fp32 path):
+    B = 1 x 1000 frames (config 1) and B = 8 x 1000 frames (config 4's per-rank batch), waveform and int16 PCM."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd import ops
+    from covomix_amd.vocoder import AttrDict, Generator
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    gen = Generator(AttrDict(h)).to("cuda:0")
+    gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
+    mel = (torch.randn(B, 80, 1000, generator=torch.Generator().manual_seed(50 + B)) * 2 - 6).clamp(-11.52, 2.0)
+    wav = gen(mel.cuda())
+    ref = orc.hifigan_forward(orc.fold_weight_norm(vsd), h, mel)
+    e = rel_l2(wav, ref)
+    worst = max(rel_l2(wav[b], ref[b]) for b in range(B))
+    print(f"vocoder B={B} T=1000 rel-L2 vs oracle: {e:.3e} (worst item {worst:.3e})")
+    assert wav.shape == (B, 1, 160032) and e < AT_SIZE_TOL and worst < 2 * AT_SIZE_TOL
+    pcm = ops.wav_to_int16(wav.squeeze(1).contiguous()).cpu().numpy().astype("int32")
+    want = orc.wav_to_int16(ref.squeeze(1)).astype("int32").reshape(pcm.shape)
+    assert abs(pcm - want).max() <= 1
+
+
 @pytest.mark.parametrize("T", [200, 203])
 def test_c5_64nfe_vs_oracle(T):
     """BASELINE config 5's acoustic setting: 64 NFE = 32 midpoint steps of 1/32 (full width, B=1; T=203 also covers a
