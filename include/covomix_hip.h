@@ -150,6 +150,22 @@ int cvx_attention_f32(const float* qkv, float* out,
                       uint16_t* out_hi, uint16_t* out_lo,  /* optional fp16 (hi, lo) split copy; out may then be NULL */
                       int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * RAGGED BATCHES (utterances of different length in one launch; the reference runs them one at a time,
+ * monologue_generation.py:259-304, and its network has no key-padding mask, acoustic.py:313, so an utterance must
+ * never see another one).  The n sequences are PACKED: sequence i owns rows [cu_seqlens[i], cu_seqlens[i+1]) of every
+ * [M, width] tensor (M = cu_seqlens[n]; cu_seqlens: n+1 int32 in DEVICE memory; max_T = the longest sequence, which
+ * sizes the grid).  Everything row-wise (GEMMs, norms, CFG combine, embedding gather) needs nothing; the three
+ * operators that look along the time axis take the table:
+ *   - attention: keys restricted to the own sequence (the *_varlen entry points below);
+ *   - RoPE: run the to_qkv GEMM with rope_T = M and per-ROW tables cos/sin [M][32] (row r: its position inside its
+ *     sequence), which also makes its V^T output ONE row set per head over all M columns: vt [H*64, vt_ld],
+ *     column = slot(row) - the layout cvx_attention_f16x3_varlen reads (vt_ld >= M rounded up to 32);
+ *   - ConvPositionEmbed: zero padding at the ends of every sequence (cvx_dwconv31_gelu_res_varlen_f32).
+ * Results per utterance equal its B = 1 run up to fp32 summation order (key tiles stay aligned to 32 packed rows). */
+int cvx_attention_varlen_f32(const float* qkv, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                             const int32_t* cu_seqlens_dev, int32_t n_seq, int32_t max_T, int32_t H, float scale, cvx_stream_t s);
+
 /* Split-precision variant of cvx_attention_f32 (same reference computation, attend.py:108-126) on
  * v_mfma_f32_32x32x16_f16: inputs are the (fp16 hi, fp16 lo) pairs written by cvx_gemm_f16x3 in QKV mode -
  * qk_* [Bt*T, 2*H*64] (q | k after RoPE) and vt_* [Bt*H*64, Tp] (v transposed per (sequence, head), Tp >= T
@@ -165,11 +181,19 @@ int cvx_attention_f16x3_scaled(const uint16_t* qk_hi, const uint16_t* qk_lo, con
                                float* out, uint16_t* out_hi, uint16_t* out_lo,
                                int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale,
                                const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s);
+/* ragged batch (see RAGGED BATCHES above): qk_* [M, 2*H*64], vt_* [H*64, vt_ld] over all M packed rows */
+int cvx_attention_f16x3_varlen(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                               float* out, uint16_t* out_hi, uint16_t* out_lo, const int32_t* cu_seqlens_dev,
+                               int32_t n_seq, int32_t max_T, int64_t M, int32_t vt_ld, int32_t H, float scale,
+                               const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s);
 
 /* y[b,t,c] = GELU( bias[c] + sum_k w[c,k] * x[b,t+k-K/2,c] ) + x[b,t,c]
  * ConvPositionEmbed + residual (acoustic.py:141-161, :508), channels-last, K == 31. */
 int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
                               int32_t Bt, int32_t T, int32_t C, cvx_stream_t s);
+/* ragged batch (see RAGGED BATCHES above): x, y [M, C] packed */
+int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, const float* bias, float* y,
+                                     const int32_t* cu_seqlens_dev, int32_t n_seq, int32_t max_T, int32_t C, cvx_stream_t s);
 
 /* v = f_c*(1+s) - s*f_n   (f_n == NULL: v = f_c)        CFG combine, acoustic.py:428
  * out = y + coef*v ; out2, out3 = optional extra copies  ODE stage update (torchdiffeq midpoint:

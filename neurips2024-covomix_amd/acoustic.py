@@ -180,14 +180,25 @@ class VectorField:
         return S, H
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, Bt: int, T: int) -> dict:
-        key = (Bt, T)
+    RAGGED_ROW_QUANTUM = 1024       # ragged batches: workspaces are sized in steps of this many rows and shared by every
+                                    # batch composition that fits (a directory never repeats a composition)
+
+    def _workspace(self, Bt: int, T: int, ragged_rows: int = 0) -> dict:
+        """Buffers of one batch shape.  Equal-length batch: Bt sequences of T frames.  Ragged batch (ragged_rows = M > 0):
+        capacity rounded up to RAGGED_ROW_QUANTUM rows, ONE V^T row set per head over all packed rows, no RoPE table (it
+        depends on the composition: prepare() builds it per call); callers use a row-cut view (_ws_cut)."""
+        d, dev = self.d, self.device
+        if ragged_rows:
+            q = self.RAGGED_ROW_QUANTUM
+            M = (ragged_rows + q - 1) // q * q
+            key = ("ragged", M, ragged_rows >= 2048)             # (the interleaved-pair choice below depends on the real row count)
+        else:
+            M = Bt * T
+            key = (Bt, T)
         ws = self._ws.pop(key, None)
         if ws is not None:
             self._ws[key] = ws                                   # most recently used last
             return ws
-        d, dev = self.d, self.device
-        M = Bt * T
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         ws = dict(
             h=[f(M, d["dim"]) for _ in range(d["depth"] // 2 + 3)],
@@ -202,31 +213,50 @@ class VectorField:
             # GEMM A operands: for the large-problem kernel (M >= 2048, interleaved weights available) as INTERLEAVED pairs
             # ([hi 32 | lo 32] per K-step: whole cache lines for the DMA), otherwise as two separate fp16 tensors
             a16 = h16
-            if lo_too and M >= 2048 and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
+            if lo_too and (ragged_rows or M) >= 2048 and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
                 a16 = lambda rows, cols: ops.SplitIL(rows, cols, dev)
             ws["normed16"], ws["att16"], ws["ff16"] = a16(M, d["dim"]), a16(M, d["heads"] * 64), a16(M, 4 * d["dim"])
             ws["pred16"] = h16(M, d["dim"])                      # final norm -> to_pred (N = 80: small-N kernel, plain pair)
             ws["qk16"] = h16(M, 2 * d["heads"] * 64)
             ws["h16"] = [a16(M, d["dim"]) for _ in ws["h"]]      # split twins of the residual-stream buffers (skip GEMMs)
-            Tp = ((T + 31) // 32) * 32           # V^T rows, zero beyond T (read by the last key tile, weight 0)
-            ws["vt16"] = (torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev),
-                          torch.zeros(Bt * d["heads"] * 64, Tp, dtype=torch.float16, device=dev) if lo_too else None)
-        pos = torch.arange(T, device=dev, dtype=torch.float32)
-        ang = pos[:, None] * self.inv_freq[None, :]
-        ws["rope"] = (ang.cos().contiguous(), ang.sin().contiguous())
+            # V^T rows, zero (always finite) beyond the last frame: read by the last key tile with weight 0
+            vt_rows, Tp = (d["heads"] * 64, M) if ragged_rows else (Bt * d["heads"] * 64, ((T + 31) // 32) * 32)
+            ws["vt16"] = (torch.zeros(vt_rows, Tp, dtype=torch.float16, device=dev),
+                          torch.zeros(vt_rows, Tp, dtype=torch.float16, device=dev) if lo_too else None)
+        if not ragged_rows:
+            ws["rope"] = self._rope_tables(torch.arange(T, device=dev, dtype=torch.float32))
         while len(self._ws) >= self.WORKSPACE_SHAPES:          # keep the most recent shapes resident (a directory of
             self._ws.pop(next(iter(self._ws)))                  # utterances alternates between a few lengths; ~0.4 GB per 1000 rows)
         self._ws[key] = ws
         return ws
 
+    def _rope_tables(self, pos: torch.Tensor) -> tuple:
+        """(cos, sin) [len(pos), 32] of the half-split rotary embedding at the given positions (acoustic.py:120-137)."""
+        ang = pos[:, None] * self.inv_freq[None, :]
+        return ang.cos().contiguous(), ang.sin().contiguous()
+
     # ------------------------------------------------------------------ per-call setup
-    def prepare(self, phoneme_ids: torch.Tensor, cond: torch.Tensor, times: torch.Tensor, use_null: bool) -> dict:
+    def prepare(self, phoneme_ids: torch.Tensor, cond: torch.Tensor, times: torch.Tensor, use_null: bool,
+                lengths: Optional[List[int]] = None) -> dict:
         """Everything that does not depend on the ODE state x:
-        time MLP + adaptive-norm tables for every evaluation time, and the step-invariant part of to_embed."""
+        time MLP + adaptive-norm tables for every evaluation time, and the step-invariant part of to_embed.
+        lengths: ragged batch - phoneme_ids [M1(, S)] and cond [M1, C] hold the utterances back to back (M1 = sum(lengths));
+        the null-branch rows repeat the same sequence structure behind them."""
         d, sd = self.d, self.sd
-        B, T, _ = cond.shape
-        Bt = 2 * B if use_null else B
-        ws = self._workspace(Bt, T)
+        rg = None
+        if lengths is not None:
+            B, T, M1 = len(lengths), None, int(sum(lengths))
+            assert cond.ndim == 2 and cond.shape[0] == M1 and phoneme_ids.shape[0] == M1
+            Bt = 2 * B if use_null else B
+            rg = ops.Ragged(lengths, self.device, repeat=2 if use_null else 1)
+            full = self._workspace(0, 0, ragged_rows=rg.M)
+            ws = self._ws_cut(full, 0, rg.M, vt=None)            # row views of the capacity-sized buffers; V^T stays whole
+            ws["rope"] = self._rope_tables(rg.positions())       # per-ROW tables: the to_qkv epilogue then runs with rope_T = M
+        else:
+            B, T, _ = cond.shape
+            Bt = 2 * B if use_null else B
+            M1 = B * T
+            ws = self._workspace(Bt, T)
         n = times.numel()
         four = torch.empty(n, d["dim"], dtype=torch.float32, device=self.device)
         ops.time_fourier(times, sd["sinu_pos_emb.0.weights"], four)
@@ -234,8 +264,7 @@ class VectorField:
         ops.gemm(four, sd["sinu_pos_emb.1.weight"], temb, bias=sd["sinu_pos_emb.1.bias"], act=ops.ACT_SILU)
         table = torch.empty(n, self.ada_w.shape[0], dtype=torch.float32, device=self.device)
         ops.gemm(temb, self.ada_w, table, bias=self.ada_b)
-        # step-invariant to_embed columns: rows [0, B*T) conditional, rows [B*T, 2*B*T) null branch
-        M1 = B * T
+        # step-invariant to_embed columns: rows [0, M1) conditional, rows [M1, 2*M1) null branch
         g = ws["gathered"]
         ids = phoneme_ids.to(torch.int64).contiguous()
         ops.embed_gather(ids, d["streams"], sd["to_phoneme_emb.weight"], cond.contiguous(), None, d["dim_cond"],
@@ -245,7 +274,7 @@ class VectorField:
                              d["null_id"], g[M1:], M1)
         w_rest = sd["to_embed.weight"][:, d["dim_out"]:]
         ops.gemm(g, w_rest, ws["base"], bias=sd["to_embed.bias"])
-        ctx = dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null)
+        ctx = dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null, M=(2 * M1 if use_null else M1), ragged=rg)
         if self.precision in ("f16x3", "f16") and os.environ.get("CVX_ACT_SCALES", "1") == "1":
             S, H = self._activation_scales(table)
             ctx["scales"], ctx["h_scale"] = S, H                           # keep the tensors alive as long as the pointers
@@ -257,10 +286,9 @@ class VectorField:
 
     # ------------------------------------------------------------------ one evaluation (both CFG branches)
     @staticmethod
-    def _ws_rows(ws: dict, b0: int, b1: int, T: int, heads: int) -> dict:
-        """Views of every workspace buffer restricted to sequences [b0, b1) (rows b0*T .. b1*T): an independent
-        half-size problem on the same storage, so two such parts can run concurrently on two streams."""
-        r0, r1 = b0 * T, b1 * T
+    def _ws_cut(ws: dict, r0: int, r1: int, vt) -> dict:
+        """Views of every workspace buffer restricted to rows [r0, r1); vt = (lo, hi): the V^T rows that go with them
+        (None: V^T is shared whole - ragged batches)."""
 
         def cut(v, lo=r0, hi=r1):
             if isinstance(v, ops.SplitIL):
@@ -275,22 +303,29 @@ class VectorField:
             if k == "rope":
                 out[k] = v
             elif k == "vt16":
-                out[k] = cut(v, b0 * heads * 64, b1 * heads * 64)
+                out[k] = v if vt is None else cut(v, vt[0], vt[1])
             else:
                 out[k] = cut(v)
         return out
+
+    @staticmethod
+    def _ws_rows(ws: dict, b0: int, b1: int, T: int, heads: int) -> dict:
+        """Views restricted to sequences [b0, b1) of an equal-length batch (rows b0*T .. b1*T): an independent half-size
+        problem on the same storage, so two such parts can run concurrently on two streams."""
+        return VectorField._ws_cut(ws, b0 * T, b1 * T, vt=(b0 * heads * 64, b1 * heads * 64))
 
     def evaluate(self, ctx: dict, step: int, part: Optional[int] = None) -> torch.Tensor:
         """Run the network on ws['xin'] (rows: cond branch then null branch) at evaluation time #step.
         Returns ws['pred'] [Bt*T, dim_out].  part = i: only the i-th of ctx['parts'] sequence ranges (see _ws_rows)."""
         d, sd, ws = self.d, self.sd, ctx["ws"]
-        Bt, T = ctx["Bt"], ctx["T"]
+        Bt, T, M, rg = ctx["Bt"], ctx["T"], ctx["M"], ctx.get("ragged")
         if part is not None:
             b0, b1 = ctx["parts"][part]
             key = ("part_ws", part)
             if key not in ctx:
                 ctx[key] = self._ws_rows(ws, b0, b1, T, d["heads"])
             ws, Bt = ctx[key], b1 - b0
+            M = Bt * T
         dim = d["dim"]
         tab = ctx["table"][step]
         free: List[torch.Tensor] = list(ws["h"])
@@ -299,16 +334,16 @@ class VectorField:
         # single-term mode consumes 64 k per stage).  'f16' without split I/O falls back to the fp32 kernels.
         il = self.split_il.get
         if self.precision == "f16":
-            split_io = Bt * T > 64 and dim % 64 == 0
+            split_io = M > 64 and dim % 64 == 0
             sp = self.split.get if split_io else (lambda k: None)
         else:
-            split_io = self.precision == "f16x3" and Bt * T > 64 and dim % 32 == 0
+            split_io = self.precision == "f16x3" and M > 64 and dim % 32 == 0
             sp = self.split.get
 
         h0 = take()
         ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
         h = take()
-        ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T)
+        ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
         free.append(h0)
         # residual-stream tensors that later feed a skip combiner (as x or as the popped skip) also get a split
         # twin, so that GEMM takes both operands pre-split (all-DMA kernel) instead of splitting on the fly
@@ -351,7 +386,7 @@ class VectorField:
                          w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
                          write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
                 ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16,
-                                    qk_scale=s_qk, v_scale=s_v, out_scale=s_at)
+                                    qk_scale=s_qk, v_scale=s_v, out_scale=s_at, ragged=rg)
                 h_att = take() if keep_input else h
                 ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
                          a_split=a16, a_scale=s_at)
@@ -368,7 +403,7 @@ class VectorField:
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])
             ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
                      w_split=sp(p + ".2.to_qkv.weight"))
-            ops.attention(ws["qkv"], ws["att"], Bt, T, d["heads"], 64 ** -0.5)
+            ops.attention(ws["qkv"], ws["att"], Bt, T, d["heads"], 64 ** -0.5, ragged=rg)
             h_att = take() if keep_input else h
             ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"))
             h = h_att
@@ -419,10 +454,10 @@ class FlowMatchingSampler:
     # batch size it applies to; large batches are GPU-bound and stay eager).
     GRAPH_CACHE = 4
 
-    def _integrate(self, phoneme_ids, cond, y, times_dev, dts, s: float, use_null: bool) -> None:
-        """prepare() + the fixed-grid loop; advances `y` in place."""
+    def _integrate(self, phoneme_ids, cond, y, times_dev, dts, s: float, use_null: bool, lengths=None) -> None:
+        """prepare() + the fixed-grid loop; advances `y` in place (ragged batch: y, cond, ids packed, see prepare)."""
         f = self.field
-        ctx = f.prepare(phoneme_ids, cond, times_dev, use_null)
+        ctx = f.prepare(phoneme_ids, cond, times_dev, use_null, lengths=lengths)
         ws, M1 = ctx["ws"], ctx["M1"]
         xin = ws["xin"]
         x_c = xin[:M1]
@@ -435,7 +470,8 @@ class FlowMatchingSampler:
         # under the other's matrix work instead of every CU hitting the same phase at the same time.
         Bt = ctx["Bt"]
         chains = int(os.environ.get("CVX_CHAINS", "1"))
-        if chains == 2 and Bt % 2 == 0 and (Bt // 2) * ctx["T"] >= 2048 and not torch.cuda.is_current_stream_capturing():
+        if (chains == 2 and ctx["ragged"] is None and Bt % 2 == 0 and (Bt // 2) * ctx["T"] >= 2048
+                and not torch.cuda.is_current_stream_capturing()):
             ctx["parts"] = [(0, Bt // 2), (Bt // 2, Bt)]
             main = torch.cuda.current_stream()
             if self._side is None:
@@ -515,3 +551,38 @@ class FlowMatchingSampler:
         st["y"].copy_(y)
         g.replay()
         return st["y"].clone()
+
+    @torch.no_grad()
+    def sample_ragged(self, *, phoneme_ids: List[torch.Tensor], cond: List[torch.Tensor], cond_scale: float = 1.0,
+                      y0: Optional[List[torch.Tensor]] = None) -> List[torch.Tensor]:
+        """The same solve for several utterances of DIFFERENT length in one launch sequence: utterance i is
+        phoneme_ids[i] [T_i(, streams)], cond[i] [T_i, dim_cond] (y0[i] [T_i, dim_out]); returns the list of [T_i, dim_out]
+        results.  The reference runs such utterances one at a time (monologue_generation.py:259-304) and its network has
+        no padding mask (acoustic.py:313), so they are PACKED back to back - M = sum T_i rows - and the three operators
+        that look along time (attention, rotary positions, ConvPositionEmbed) work per sequence (include/covomix_hip.h,
+        RAGGED BATCHES); every utterance gets the result of its own B = 1 run up to fp32 summation order."""
+        f, d = self.field, self.field.d
+        dev = f.device
+        n = len(cond)
+        if n == 0:
+            return []
+        lengths = [int(c.shape[0]) for c in cond]
+        for i in range(n):
+            if cond[i].ndim != 2 or cond[i].shape[1] != d["dim_cond"] or lengths[i] < 1:
+                raise AssertionError(f"cond[{i}] must be [T,{d['dim_cond']}] with T >= 1, got {tuple(cond[i].shape)}")
+            expect = (lengths[i],) + ((d["streams"],) if d["streams"] > 1 else ())
+            if tuple(phoneme_ids[i].shape) != expect:
+                raise AssertionError(f"phoneme_ids[{i}] must be {expect}, got {tuple(phoneme_ids[i].shape)}")
+            if y0 is not None and tuple(y0[i].shape) != (lengths[i], d["dim_out"]):
+                raise AssertionError(f"y0[{i}] must be {(lengths[i], d['dim_out'])}, got {tuple(y0[i].shape)}")
+        cond_p = torch.cat([c.to(device=dev, dtype=torch.float32) for c in cond]).contiguous()
+        ids_p = torch.cat([p.to(device=dev, dtype=torch.int64) for p in phoneme_ids]).contiguous()
+        if y0 is None:                       # acoustic.py:647-650, one draw per utterance
+            y = torch.randn(cond_p.shape[0], d["dim_out"], device=dev, dtype=torch.float32)
+        else:
+            y = torch.cat([t.to(device=dev, dtype=torch.float32) for t in y0]).contiguous().clone()
+        use_null = float(cond_scale) != 1.0          # acoustic.py:423
+        times, dts = evaluation_times(self.nfe, self.method)
+        self._integrate(ids_p, cond_p, y, times.to(dev), dts, float(cond_scale), use_null, lengths=lengths)
+        return list(torch.split(y, lengths))
+

@@ -160,8 +160,15 @@ class CoVoMixModel:
     def synthesis_sample(self, phoneme_ids, cond, mask, cond_scale, y0=None):
         """reference conditional_model.py:295-302 -> ConditionalFlowMatcherWrapper.sample.
         `mask` is accepted and unused, exactly as in the reference (acoustic.py:597-688).
-        `y0` (optional) fixes the initial noise; parity is defined given y0."""
+        `y0` (optional) fixes the initial noise; parity is defined given y0.
+        Extension: LISTS of per-utterance tensors (phoneme_ids[i] [T_i(, streams)], cond[i] [T_i, C], y0[i] [T_i, dim_out],
+        lengths may differ) run as one packed ragged batch and return a list; each result equals that utterance's B = 1
+        call up to fp32 summation order (the reference loops over utterances, monologue_generation.py:259-304)."""
         sampler = FlowMatchingSampler(self._get_field(), nfe=self.nfe, method=self.ode_method)
+        if isinstance(cond, (list, tuple)):          # extension: utterances of different length in one packed launch
+            outs = sampler.sample_ragged(phoneme_ids=list(phoneme_ids), cond=list(cond), cond_scale=cond_scale,
+                                         y0=None if y0 is None else list(y0))
+            return [o.to(c.device) if c.device != o.device else o for o, c in zip(outs, cond)]
         out = sampler.sample(phoneme_ids=phoneme_ids, cond=cond, mask=mask, cond_scale=cond_scale, y0=y0)
         return out.to(cond.device) if cond.device != out.device else out
 

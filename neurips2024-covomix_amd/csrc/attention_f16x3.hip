@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
                                                                 int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
                                                                 const float* __restrict__ qk_scale, const float* __restrict__ v_scale,
-                                                                const float* __restrict__ out_scale)
+                                                                const float* __restrict__ out_scale, const int* __restrict__ cu_seqlens)
 {
     // activation pre-scales (device scalars, powers of two): scores carry qk_scale^2, O carries v_scale
     if (qk_scale) { const float q = *qk_scale; scale_log2e /= q * q; }
@@ -81,14 +81,28 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
     const int head = grp % H, b = grp / H;
     const int q_blk = ((blockIdx.x >> 3) % n_qt) * QB;
     const int64_t ldqk = (int64_t)2 * H * HD;
+    // Key window [kc0, kc1) in V^T COLUMN coordinates; the q|k row of column c is c + roff.
+    //   equal-length batch: every (sequence, head) has its own V^T rows, columns 0 .. T-1 (+ zero padding up to Tp);
+    //   ragged batch (cu_seqlens): ONE V^T row set per head over all M packed rows (the to_qkv epilogue ran with
+    //     rope_T = M), sequence b = columns [cu[b], cu[b+1]).  Key tiles stay aligned to 32 GLOBAL columns (16-byte DMA
+    //     pieces, frame-slot groups of 16), so the first and the last tile of a sequence may contain a neighbour's keys:
+    //     they are masked like the keys >= T of the last tile (acoustic.py:313: an utterance only ever sees itself).
+    int kc0 = 0, kc1 = T, vt_grp = b * H + head;
+    int64_t roff = (int64_t)b * T;
+    if (cu_seqlens) {
+        kc0 = cu_seqlens[b]; kc1 = cu_seqlens[b + 1]; roff = 0; vt_grp = head;
+        if (q_blk >= kc1 - kc0) return;            // block-uniform: the grid is sized for the longest sequence
+    }
+    const int Tb = kc1 - kc0;
 
     // ---- Q fragments (B operand of S^T): lane (q = l31, g) holds d = 16s + 8g .. +7 for s = 0..3, hi and lo
     int qrow = q_blk + wid * 32 + l31;
-    const bool q_valid = qrow < T;
-    if (!q_valid) qrow = T - 1;
+    const bool q_valid = qrow < Tb;
+    if (!q_valid) qrow = Tb - 1;
+    const int64_t q_grow = roff + kc0 + qrow;      // row of this lane's query in the packed tensors
     f16x8 qh[4], ql[4];
     {
-        const int64_t off = ((int64_t)b * T + qrow) * ldqk + head * HD + 8 * g;
+        const int64_t off = q_grow * ldqk + head * HD + 8 * g;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             qh[s] = gload8h(qk_hi + off + 16 * s);
@@ -102,11 +116,11 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
     const int64_t k_col = (int64_t)H * HD + head * HD + 8 * k_c;
     const int v_r = 16 * wid + (lane >> 2);                                 // head-dim row inside the tile
     const int v_c = (lane & 3) ^ ((v_r >> 2) & 3);
-    const int64_t v_row = ((int64_t)(b * H + head) * HD + v_r) * Tp + 8 * v_c;
+    const int64_t v_row = ((int64_t)vt_grp * HD + v_r) * Tp + 8 * v_c;
     auto issue = [&](int key0, int stage) {
         f16* S = smem + stage * STAGE;
-        const int key = min(key0 + k_r, T - 1);
-        const int64_t ko = ((int64_t)b * T + key) * ldqk + k_col;
+        const int key = min(max(key0 + k_r, kc0), kc1 - 1);
+        const int64_t ko = (roff + key) * ldqk + k_col;
         glds16(qk_hi + ko, S + 8 * wid * HD);
         if constexpr (NT == 3) glds16(qk_lo + ko, S + TILE + 8 * wid * HD);
         const int64_t vo = v_row + key0;
@@ -134,8 +148,8 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
     // (a stage of two key tiles - one barrier per 64 keys - was measured slower: 64 KiB of LDS drops the kernel
     //  from 3 to 2 blocks per CU)
     // (a 3-stage ring - tiles requested two ahead - measured the same: the loop is not DMA-latency bound)
-    const int ntiles = (T + KT - 1) / KT;
-    issue(0, 0);
+    const int tile0 = kc0 / KT, ntiles = (kc1 + KT - 1) / KT - tile0;
+    issue(tile0 * KT, 0);
 #ifdef CVX_ATT_TRACE
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
 #define TSTAMP(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); tr[i] += now_ - tlast_; tlast_ = now_; }
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
 #define TSTAMP(i)
 #endif
     for (int it = 0; it < ntiles; ++it) {
-        const int cur = it & 1, key0 = it * KT;
+        const int cur = it & 1, key0 = (tile0 + it) * KT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // tile `it` landed everywhere; stage cur^1 is free
         TSTAMP(0)
@@ -180,12 +194,14 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
         TSTAMP(1)
         // ---- online softmax (this lane: 16 keys of query l31; partner lane^32 holds the other 16).
         // The running max m_run is kept in the scaled log2 domain; scores stay raw and the scale is folded into one
-        // fma per element: p = exp2(s*c - m).  Only the last tile can contain keys >= T (wave-uniform branch), and
+        // fma per element: p = exp2(s*c - m).  Only the last tile (ragged batches: and the first) can contain keys outside the sequence (wave-uniform branch), and
         // the 32 accumulator rescales are skipped when no lane's max moved (alpha == 1 exactly - also wave-uniform).
-        if (key0 + KT > T) {
+        if (key0 + KT > kc1 || key0 < kc0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (key0 + mfma32_row(r, lane) >= T) sacc[r] = -1e30f;
+            for (int r = 0; r < 16; ++r) {
+                const int kk = key0 + mfma32_row(r, lane);
+                if (kk >= kc1 || kk < kc0) sacc[r] = -1e30f;
+            }
         }
         float mx = sacc[0];
 #pragma unroll
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
     const float inv = 1.0f / l_tot / (v_scale ? *v_scale : 1.f);        // fp32 output: the true value
     const float osc = out_scale ? *out_scale : 1.f;                        // split output: times the consumer's pre-scale
     if (q_valid) {
-        const int64_t o_off = ((int64_t)b * T + qrow) * (H * HD) + head * HD + 4 * g;
+        const int64_t o_off = q_grow * (H * HD) + head * HD + 4 * g;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             f32x4 a, c;
@@ -291,17 +307,18 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
 
 }  // namespace
 
-extern "C" int cvx_attention_f16x3_scaled(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
-                                          float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                          int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale,
-                                          const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s)
+static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                                  float* out, uint16_t* out_hi, uint16_t* out_lo, const int32_t* cu_seqlens_dev,
+                                  int32_t Bt, int32_t T, int64_t cols, int32_t Tp, int32_t H, float scale,
+                                  const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s)
 {
+    // T: frames per sequence (equal-length batch) or the LONGEST sequence (ragged batch); cols: V^T columns in use
     const bool single = (qk_lo == nullptr);        // hi halves only: plain fp16 operands, one product
     CVX_REQUIRE(qk_hi && vt_hi && ((qk_lo == nullptr) == (vt_lo == nullptr)) && (out || out_hi) &&
                 (out_hi || !out_lo) && (single || (out_hi == nullptr) == (out_lo == nullptr)),
                 "attention_f16x3: null pointer");
-    CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0 && Tp % 8 == 0 && Tp >= ((T + KT - 1) / KT) * KT,
-                "attention_f16x3: bad shape Bt=%d T=%d Tp=%d H=%d (Tp must be a multiple of 8 and >= T rounded up to 32)", Bt, T, Tp, H);
+    CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0 && Tp % 8 == 0 && Tp >= ((cols + KT - 1) / KT) * KT,
+                "attention_f16x3: bad shape Bt=%d T=%d Tp=%d H=%d (Tp must be a multiple of 8 and >= the V^T columns in use rounded up to 32)", Bt, T, Tp, H);
     CVX_REQUIRE((((uintptr_t)qk_hi | (uintptr_t)qk_lo | (uintptr_t)vt_hi | (uintptr_t)vt_lo) & 15) == 0,
                 "attention_f16x3: inputs must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;
@@ -312,15 +329,34 @@ extern "C" int cvx_attention_f16x3_scaled(const uint16_t* qk_hi, const uint16_t*
                            reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
                            reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
                            out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev);
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev);
     else
         hipLaunchKernelGGL(attention_f16x3_kernel<3>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                            reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
                            reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
                            out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev);
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev);
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;
+}
+
+extern "C" int cvx_attention_f16x3_scaled(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                                          float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                          int32_t Bt, int32_t T, int32_t Tp, int32_t H, float scale,
+                                          const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s)
+{
+    return launch_attention_f16x3(qk_hi, qk_lo, vt_hi, vt_lo, out, out_hi, out_lo, nullptr, Bt, T, T, Tp, H, scale,
+                                  qk_scale_dev, v_scale_dev, out_scale_dev, s);
+}
+
+extern "C" int cvx_attention_f16x3_varlen(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,
+                                          float* out, uint16_t* out_hi, uint16_t* out_lo, const int32_t* cu_seqlens_dev,
+                                          int32_t n_seq, int32_t max_T, int64_t M, int32_t vt_ld, int32_t H, float scale,
+                                          const float* qk_scale_dev, const float* v_scale_dev, const float* out_scale_dev, cvx_stream_t s)
+{
+    CVX_REQUIRE(cu_seqlens_dev && M >= 0 && max_T <= M, "attention_f16x3_varlen: needs cu_seqlens and max_T <= M");
+    return launch_attention_f16x3(qk_hi, qk_lo, vt_hi, vt_lo, out, out_hi, out_lo, cu_seqlens_dev, n_seq, max_T, M, vt_ld, H, scale,
+                                  qk_scale_dev, v_scale_dev, out_scale_dev, s);
 }
 
 extern "C" int cvx_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, const uint16_t* vt_hi, const uint16_t* vt_lo,

@@ -46,7 +46,8 @@ __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t
 
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
-                                                              int T, int H, int n_groups, int n_qt, float scale_log2e)
+                                                              int T, int H, int n_groups, int n_qt, float scale_log2e,
+                                                              const int* __restrict__ cu_seqlens)
 {
     __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
@@ -60,7 +61,15 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
     const int head = grp % H, b = grp / H;
     const int q_blk = ((blockIdx.x >> 3) % n_qt) * QB;
     const int64_t row_stride = (int64_t)3 * H * HD;
-    const float* qbase = qkv + (int64_t)b * T * row_stride + head * HD;
+    // ragged batch (cu_seqlens != NULL): sequence b owns rows [cu[b], cu[b+1]) of the packed [M, 3*H*64] tensor and only
+    // attends to its own keys (acoustic.py:313 runs every utterance alone: no padding mask, no cross-utterance keys)
+    int64_t row0 = (int64_t)b * T;
+    if (cu_seqlens) {
+        row0 = cu_seqlens[b];
+        T = cu_seqlens[b + 1] - (int)row0;
+        if (q_blk >= T) return;                 // block-uniform: the grid is sized for the longest sequence
+    }
+    const float* qbase = qkv + row0 * row_stride + head * HD;
     const float* kbase = qbase + H * HD;
     const float* vbase = qbase + 2 * H * HD;
 
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_valid) {
-        const int64_t o_off = ((int64_t)b * T + qrow) * (H * HD) + head * HD + 4 * half;
+        const int64_t o_off = (row0 + qrow) * (H * HD) + head * HD + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 a, c;
@@ -188,18 +197,24 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int cvx_attention_f32(const float* qkv, float* out, uint16_t* out_hi, uint16_t* out_lo,
-                                 int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s)
+extern "C" int cvx_attention_varlen_f32(const float* qkv, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                        const int32_t* cu_seqlens_dev, int32_t Bt, int32_t max_T, int32_t H, float scale, cvx_stream_t s)
 {
     CVX_REQUIRE(qkv && (out || out_hi) && (out_hi || !out_lo), "attention: null pointer");      // out_lo == NULL: hi halves only
-    CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0, "attention: bad shape Bt=%d T=%d H=%d", Bt, T, H);
+    CVX_REQUIRE(Bt >= 0 && max_T > 0 && H > 0, "attention: bad shape Bt=%d T=%d H=%d", Bt, max_T, H);
     CVX_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attention: pointers must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;
-    const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
+    const int n_qt = (max_T + QB - 1) / QB, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                        qkv, out, reinterpret_cast<_Float16*>(out_hi), reinterpret_cast<_Float16*>(out_lo),
-                       T, H, n_groups, n_qt, scale * 1.44269504088896340736f);
+                       max_T, H, n_groups, n_qt, scale * 1.44269504088896340736f, cu_seqlens_dev);
     CVX_CHECK_LAUNCH("cvx_attention_f32");
     return CVX_OK;
+}
+
+extern "C" int cvx_attention_f32(const float* qkv, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                 int32_t Bt, int32_t T, int32_t H, float scale, cvx_stream_t s)
+{
+    return cvx_attention_varlen_f32(qkv, out, out_hi, out_lo, nullptr, Bt, T, H, scale, s);
 }

@@ -176,12 +176,18 @@ constexpr int DW_K = 31;
 constexpr int DW_TT = 16;
 __global__ __launch_bounds__(256) void dwconv31_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                      int T, int C)
+                                                      int T, int C, const int* __restrict__ cu_seqlens)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int t0 = blockIdx.y * DW_TT;
-    const int64_t base = (int64_t)blockIdx.z * T * C;
+    int64_t base = (int64_t)blockIdx.z * T * C;
+    if (cu_seqlens) {                 // ragged batch: sequence z = rows [cu[z], cu[z+1]) of the packed tensor, zero-padded at ITS ends
+        const int r0 = cu_seqlens[blockIdx.z];
+        T = cu_seqlens[blockIdx.z + 1] - r0;
+        base = (int64_t)r0 * C;
+        if (t0 >= T) return;          // block-uniform: the grid is sized for the longest sequence
+    }
     float wk[DW_K];
 #pragma unroll
     for (int k = 0; k < DW_K; ++k) wk[k] = w[c * DW_K + k];
@@ -392,17 +398,23 @@ extern "C" int cvx_pow2_scale_from_amax_f32(uint32_t* amax_bits_dev, float targe
     return CVX_OK;
 }
 
+extern "C" int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, const float* bias, float* y,
+                                                const int32_t* cu_seqlens_dev, int32_t Bt, int32_t max_T, int32_t C, cvx_stream_t s)
+{
+    CVX_REQUIRE(x && w && bias && y, "dwconv31: null pointer");
+    CVX_REQUIRE(Bt >= 0 && max_T > 0 && C > 0 && Bt <= 65535, "dwconv31: bad shape");
+    CVX_REQUIRE(x != y, "dwconv31: in-place operation is not supported");
+    if (Bt == 0) return CVX_OK;
+    dim3 grid((C + 255) / 256, (max_T + DW_TT - 1) / DW_TT, Bt);
+    hipLaunchKernelGGL(dwconv31_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, w, bias, y, max_T, C, cu_seqlens_dev);
+    CVX_CHECK_LAUNCH("cvx_dwconv31_gelu_res_f32");
+    return CVX_OK;
+}
+
 extern "C" int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias, float* y,
                                          int32_t Bt, int32_t T, int32_t C, cvx_stream_t s)
 {
-    CVX_REQUIRE(x && w && bias && y, "dwconv31: null pointer");
-    CVX_REQUIRE(Bt >= 0 && T > 0 && C > 0, "dwconv31: bad shape");
-    CVX_REQUIRE(x != y, "dwconv31: in-place operation is not supported");
-    if (Bt == 0) return CVX_OK;
-    dim3 grid((C + 255) / 256, (T + DW_TT - 1) / DW_TT, Bt);
-    hipLaunchKernelGGL(dwconv31_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, w, bias, y, T, C);
-    CVX_CHECK_LAUNCH("cvx_dwconv31_gelu_res_f32");
-    return CVX_OK;
+    return cvx_dwconv31_gelu_res_varlen_f32(x, w, bias, y, nullptr, Bt, T, C, s);
 }
 
 extern "C" int cvx_cfg_combine_axpy_f32(const float* f_c, const float* f_n, const float* y, float cond_scale,

@@ -93,6 +93,25 @@ def batch_equal_length(indices: Sequence[int], lengths: Sequence[int], max_batch
     return out
 
 
+def batch_by_frames(indices: Sequence[int], lengths: Sequence[int], max_batch: int, max_frames: int) -> List[List[int]]:
+    """Group a rank's utterances into ragged batches: in the given order, up to max_batch utterances and max_frames frames
+    per batch (an utterance longer than max_frames runs alone).  Packed batches have no padding, so the grouping does not
+    change the work - only how much of it one launch sequence carries."""
+    out: List[List[int]] = []
+    cur: List[int] = []
+    frames = 0
+    for i in indices:
+        t = int(lengths[i])
+        if cur and (len(cur) >= max_batch or frames + t > max_frames):
+            out.append(cur)
+            cur, frames = [], 0
+        cur.append(i)
+        frames += t
+    if cur:
+        out.append(cur)
+    return out
+
+
 def broadcast_state_dict(sd: Dict[str, torch.Tensor], device: torch.device, src: int = 0,
                          bucket_bytes: int = 256 << 20) -> Dict[str, torch.Tensor]:
     """Make every rank hold rank `src`'s tensors.  All ranks must pass dicts with identical

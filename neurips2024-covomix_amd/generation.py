@@ -54,7 +54,8 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--saved_dir", type=str, default=".saved_dir", help="target directory")
     p.add_argument("--seed", type=int, default=30, help="random seed")
     p.add_argument("--mode", type=str, choices=["covosingle", "covosinx", "covomix"], default="covosingle")
-    p.add_argument("--max_batch", type=int, default=8, help="equal-length utterances per launch")
+    p.add_argument("--max_batch", type=int, default=8, help="utterances per launch (any lengths: they are packed back to back)")
+    p.add_argument("--max_frames", type=int, default=10240, help="frames per launch (sum over its utterances)")
     p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
                    "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
     p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
@@ -303,23 +304,31 @@ def run(dialogue: bool, argv=None) -> int:
     done, frames = 0, 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for batch in dp.batch_equal_length(list(range(len(items))), lengths, args.max_batch):
-        ids = torch.stack([items[i][0] for i in batch]).to(device)
-        cond = torch.stack([items[i][1] for i in batch]).to(device)
-        mask = torch.stack([items[i][2] for i in batch]).to(device)
-        T = ids.shape[1]
-        y0 = torch.stack([torch.randn(T, n_out, device=device, generator=torch.Generator(device=device).manual_seed(
-            _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch])      # acoustic.py:647-650, per utterance
-        sampled = model.synthesis_sample(phoneme_ids=ids, cond=cond, mask=mask, cond_scale=COND_SCALE, y0=y0)
+    # The reference generates one utterance at a time (monologue_generation.py:259-304); here up to --max_batch utterances
+    # of ANY lengths share a launch sequence: packed back to back (no padding), every utterance attending to itself only
+    # (sample_ragged), so each gets the result of its own B = 1 run.  Longest first: neighbours in the order have similar
+    # lengths, which keeps the vocoder groups below large.
+    order = sorted(range(len(items)), key=lambda i: (-lengths[i], i))
+    for batch in dp.batch_by_frames(order, lengths, args.max_batch, args.max_frames):
+        y0 = [torch.randn(lengths[i], n_out, device=device, generator=torch.Generator(device=device).manual_seed(
+            _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch]        # acoustic.py:647-650, per utterance
+        if len(set(lengths[i] for i in batch)) == 1:                                     # equal lengths: the plain [B, T, .] call
+            sampled = list(model.synthesis_sample(phoneme_ids=torch.stack([items[i][0] for i in batch]).to(device),
+                                                  cond=torch.stack([items[i][1] for i in batch]).to(device),
+                                                  mask=torch.stack([items[i][2] for i in batch]).to(device),
+                                                  cond_scale=COND_SCALE, y0=torch.stack(y0)))
+        else:
+            sampled = model.synthesis_sample(phoneme_ids=[items[i][0].to(device) for i in batch], cond=[items[i][1].to(device) for i in batch],
+                                             mask=[items[i][2] for i in batch], cond_scale=COND_SCALE, y0=y0)
         # vocoder: utterances of the batch with the same number of generated frames go through HiFi-GAN together; one
         # device-to-host copy per group
         n_prompt = [int((~items[i][2]).sum()) for i in batch]
         groups = {}
         for j, i in enumerate(batch):
-            if T - n_prompt[j] > 0:
-                groups.setdefault(n_prompt[j], []).append(j)
-        for npmt, js in groups.items():
-            mel = sampled[js, npmt:, :].permute(0, 2, 1).contiguous()                   # [g, 80, Tgen] (:299-300: mask is a suffix)
+            if lengths[i] - n_prompt[j] > 0:
+                groups.setdefault(lengths[i] - n_prompt[j], []).append(j)
+        for tgen, js in groups.items():
+            mel = torch.stack([sampled[j][n_prompt[j]:, :].T for j in js]).contiguous()   # [g, 80, Tgen] (:299-300: mask is a suffix)
             pcm = ops.wav_to_int16(generator(mel).squeeze(1).contiguous()).cpu().numpy()   # mel_decode_to_wav (:52-59), batched
             frames += mel.shape[0] * mel.shape[2]
             for r, j in enumerate(js):

@@ -246,16 +246,46 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     return out if out is not None else out_split
 
 
-def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None):
+class Ragged:
+    """A packed batch of sequences of different length: sequence i owns rows [cu[i], cu[i+1]) of every [M, width] tensor.
+    cu: int32 CUDA tensor [n + 1]; lengths: the python list (host side: grid sizes, slicing)."""
+
+    def __init__(self, lengths, device, repeat: int = 1):
+        """repeat = 2: the same sequences twice (conditional rows, then the null-branch rows of CFG)."""
+        self.lengths = [int(t) for t in lengths] * repeat
+        assert self.lengths and min(self.lengths) > 0
+        self.n, self.max_T, self.M = len(self.lengths), max(self.lengths), sum(self.lengths)
+        cu = [0]
+        for t in self.lengths:
+            cu.append(cu[-1] + t)
+        self.cu_host = cu
+        self.cu = torch.tensor(cu, dtype=torch.int32, device=device)
+
+    def positions(self) -> torch.Tensor:
+        """Position of every packed row inside its own sequence (fp32, on the device)."""
+        cu = self.cu.to(torch.int64)
+        rows = torch.arange(self.M, device=self.cu.device)
+        seq = torch.searchsorted(cu[1:], rows, right=True)
+        return (rows - cu[seq]).to(torch.float32)
+
+
+def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None,
+              ragged: Optional[Ragged] = None):
+    """ragged: packed batch (Bt, T are then ignored: rows = ragged.M, keys restricted to the own sequence)."""
     _chk_f32(qkv, out)
+    rows = ragged.M if ragged is not None else Bt * T
     assert qkv.is_contiguous() and (out is None or out.is_contiguous())
-    assert qkv.numel() == Bt * T * 3 * H * 64 and (out is None or out.numel() == Bt * T * H * 64)
+    assert qkv.numel() == rows * 3 * H * 64 and (out is None or out.numel() == rows * H * 64)
     oh, ol = (None, None)
     if out_split is not None:
-        oh, ol, _ = _pair(out_split, Bt * T if isinstance(out_split, SplitIL) else None, H * 64)
-        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == Bt * T * H * 64)
-    _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), oh, ol, Bt, T, H, scale, _stream()),
-               "cvx_attention_f32")
+        oh, ol, _ = _pair(out_split, rows if isinstance(out_split, SplitIL) else None, H * 64)
+        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == rows * H * 64)
+    if ragged is not None:
+        _lib.check(_lib.load().cvx_attention_varlen_f32(qkv.data_ptr(), _p(out), oh, ol, ragged.cu.data_ptr(), ragged.n, ragged.max_T,
+                                                        H, scale, _stream()), "cvx_attention_varlen_f32")
+    else:
+        _lib.check(_lib.load().cvx_attention_f32(qkv.data_ptr(), _p(out), oh, ol, Bt, T, H, scale, _stream()),
+                   "cvx_attention_f32")
     return out if out is not None else out_split
 
 
@@ -267,25 +297,33 @@ def vt_frame_slots(T: int, device=None) -> torch.Tensor:
 
 
 def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T: int, H: int, scale: float, out_split=None,
-                    qk_scale=None, v_scale=None, out_scale=None):
+                    qk_scale=None, v_scale=None, out_scale=None, ragged: Optional[Ragged] = None):
     """Split-precision attention on the pairs written by gemm(..., out_split=qk_split, vt_split=vt_split).
     (hi, None) pairs select the single-term fp16 kernel.  qk_scale / v_scale: the pre-scales the producer applied to the
-    pairs (c_scale / vt_scale of the to_qkv GEMM); out_scale: pre-scale of out_split (a_scale of the to_out GEMM)."""
+    pairs (c_scale / vt_scale of the to_qkv GEMM); out_scale: pre-scale of out_split (a_scale of the to_out GEMM).
+    ragged: packed batch - qk pairs [M, 2*H*64], vt pairs [H*64, >= M rounded up to 32] written by a to_qkv GEMM that ran
+    with per-row RoPE tables [M, 32] (rope_T = M); Bt, T are ignored."""
     qh, ql = qk_split
     vh, vl = vt_split
     assert (ql is None) == (vl is None)
     for t in (qh, ql, vh, vl):
         assert t is None or (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous())
-    assert qh.shape == (Bt * T, 2 * H * 64) and vh.shape[0] == Bt * H * 64
+    rows = ragged.M if ragged is not None else Bt * T
+    assert qh.shape == (rows, 2 * H * 64) and vh.shape[0] == (H * 64 if ragged is not None else Bt * H * 64)
     Tp = vh.shape[1]
     _chk_f32(out)
     oh, ol = (None, None)
     if out_split is not None:
-        oh, ol, _ = _pair(out_split, Bt * T if isinstance(out_split, SplitIL) else None, H * 64)
-        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == Bt * T * H * 64)
-    _lib.check(_lib.load().cvx_attention_f16x3_scaled(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), oh, ol,
-                                                      Bt, T, Tp, H, scale, _sp(qk_scale), _sp(v_scale), _sp(out_scale), _stream()),
-               "cvx_attention_f16x3")
+        oh, ol, _ = _pair(out_split, rows if isinstance(out_split, SplitIL) else None, H * 64)
+        assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == rows * H * 64)
+    if ragged is not None:
+        _lib.check(_lib.load().cvx_attention_f16x3_varlen(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), oh, ol, ragged.cu.data_ptr(),
+                                                          ragged.n, ragged.max_T, ragged.M, Tp, H, scale, _sp(qk_scale), _sp(v_scale),
+                                                          _sp(out_scale), _stream()), "cvx_attention_f16x3_varlen")
+    else:
+        _lib.check(_lib.load().cvx_attention_f16x3_scaled(qh.data_ptr(), _p(ql), vh.data_ptr(), _p(vl), _p(out), oh, ol,
+                                                          Bt, T, Tp, H, scale, _sp(qk_scale), _sp(v_scale), _sp(out_scale), _stream()),
+                   "cvx_attention_f16x3")
     return out if out is not None else out_split
 
 
@@ -298,10 +336,16 @@ def geglu(h: torch.Tensor, out: torch.Tensor, F: int) -> torch.Tensor:
 
 
 def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor,
-                      Bt: int, T: int) -> torch.Tensor:
+                      Bt: int, T: int, ragged: Optional[Ragged] = None) -> torch.Tensor:
     _chk_f32(x, w, bias, out)
     C_ = x.shape[-1]
     assert x.is_contiguous() and out.is_contiguous() and w.is_contiguous() and w.numel() == C_ * 31
+    if ragged is not None:
+        assert x.numel() == ragged.M * C_
+        _lib.check(_lib.load().cvx_dwconv31_gelu_res_varlen_f32(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                                ragged.cu.data_ptr(), ragged.n, ragged.max_T, C_, _stream()),
+                   "cvx_dwconv31_gelu_res_varlen_f32")
+        return out
     _lib.check(_lib.load().cvx_dwconv31_gelu_res_f32(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                                      Bt, T, C_, _stream()), "cvx_dwconv31_gelu_res_f32")
     return out

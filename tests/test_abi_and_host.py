@@ -169,6 +169,13 @@ def test_sharding_plan():
     assert shard_utterances([], 4) == [[], [], [], []]
     batches = batch_equal_length([0, 4, 5, 1, 8], ragged, max_batch=2)
     assert batches == [[0, 4], [5], [1, 8]]
+    # ragged batches: in the given order, bounded by utterance count and by frames; an over-long utterance runs alone
+    from covomix_amd.dp import batch_by_frames
+    assert batch_by_frames([2, 7, 0, 4, 5, 1, 8, 6, 3], ragged, max_batch=3, max_frames=1500) == [[2], [7, 0], [4, 5, 1], [8, 6, 3]]
+    assert batch_by_frames([2, 7], ragged, max_batch=8, max_frames=100) == [[2], [7]]
+    assert batch_by_frames([], ragged, 8, 1000) == []
+    every = batch_by_frames(list(range(9)), ragged, max_batch=8, max_frames=10 ** 9)
+    assert every == [list(range(8)), [8]]
 
 
 def test_two_rank_gloo_broadcast_and_shard(tmp_path):

@@ -51,32 +51,46 @@ def test_cli_end_to_end(tmp_path, mode, dialogue, monkeypatch):
         k = npred[n]
         np.save(os.path.join(tdir, f"{n}.semantic.npy"),
                 g.randint(0, 510, size=(2, k)) if mode == "covomix" else g.randint(0, 510, size=k))
-    captured = {}
+    captured = []                                    # one (ids, cond, mask, y0) per utterance, whatever the batching
     real = generation.CoVoMixModel.synthesis_sample
 
     def spy(self, phoneme_ids, cond, mask, cond_scale, y0=None):
-        y0 = torch.randn(cond.shape[0], cond.shape[1], 80, generator=torch.Generator().manual_seed(int(cond.shape[1])))
-        captured[int(cond.shape[1])] = (phoneme_ids.cpu(), cond.cpu(), mask.cpu(), y0)
-        return real(self, phoneme_ids, cond, mask, cond_scale, y0=y0)
+        ragged = isinstance(cond, (list, tuple))
+        ids_l, cond_l, mask_l = list(phoneme_ids), list(cond), list(mask)
+        y0_l = [torch.randn(c.shape[0], 80, generator=torch.Generator().manual_seed(1000 * int(c.shape[0]) + len(captured) + j))
+                for j, c in enumerate(cond_l)]
+        for i_, c_, m_, y_ in zip(ids_l, cond_l, mask_l, y0_l):
+            captured.append((i_.cpu(), c_.cpu(), m_.cpu(), y_))
+        return real(self, phoneme_ids, cond, mask, cond_scale, y0=y0_l if ragged else torch.stack(y0_l))
     monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample", spy)
     n = generation.run(dialogue, ["--acous_ckpt", os.path.join(tmp, "acous.ckpt"), "--hifigan_ckpt",
                                   os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir, "--prompt_dir", pdir,
                                   "--saved_dir", sdir, "--mode", mode, "--seed", "30"])
-    assert n == 3 and os.path.isfile(os.path.join(sdir, "config.txt"))
+    assert n == 3 and os.path.isfile(os.path.join(sdir, "config.txt")) and len(captured) == 3
     from scipy.io.wavfile import read
     folded = orc.fold_weight_norm(vsd)
     model_nfe = 32
-    for T, (ids, cond, mask, y0) in captured.items():
+    pcms = {nm: read(os.path.join(sdir, nm + ".wav")) for nm in names}
+    matched = set()
+    for ids, cond, mask, y0 in captured:
+        T = int(ids.shape[0])
         assert ids.dtype == torch.int64 and int(ids.max()) <= 501
-        ref_mel = orc.sample(ema, ids, cond, y0, 0.7, nfe=model_nfe)             # EMA weights are what run
-        for j in range(ids.shape[0]):
-            valid = assembly.select_generated_frames(ref_mel[j:j + 1], mask[j])
-            ref_pcm = orc.wav_to_int16(orc.hifigan_forward(folded, h, valid))
-            name = [nm for nm in names if 30 + npred[nm] == T][j]
-            sr, pcm = read(os.path.join(sdir, name + ".wav"))
+        ref_mel = orc.sample(ema, ids[None], cond[None], y0[None], 0.7, nfe=model_nfe)   # EMA weights are what run
+        valid = assembly.select_generated_frames(ref_mel, mask)
+        ref_pcm = orc.wav_to_int16(orc.hifigan_forward(folded, h, valid))
+        ok = None
+        for nm in names:                              # (two utterances share a length: match by content)
+            sr, pcm = pcms[nm]
+            if nm in matched or 30 + npred[nm] != T:
+                continue
             assert sr == 8000 and pcm.dtype == np.int16 and pcm.shape == ref_pcm.shape == (160 * (T - 30) + 32,)
             err = np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32))
-            assert err.max() <= 64 and (err > 2).mean() < 0.01, (err.max(), (err > 2).mean())
+            if err.max() <= 64 and (err > 2).mean() < 0.01:
+                ok = nm
+                break
+        assert ok is not None, (T, "no written file matches the oracle for this utterance")
+        matched.add(ok)
+    assert matched == set(names)
 
 
 def test_cli_full_pipeline_with_text2semantic(tmp_path, monkeypatch):
@@ -113,7 +127,7 @@ def test_cli_full_pipeline_with_text2semantic(tmp_path, monkeypatch):
     real_syn = generation.CoVoMixModel.synthesis_sample
 
     def spy_syn(self, phoneme_ids, cond, mask, cond_scale, y0=None):
-        seen_ids.append(phoneme_ids.cpu())
+        seen_ids.append([p.cpu() for p in phoneme_ids])       # per utterance: [B, T, .] tensor or a ragged list
         return real_syn(self, phoneme_ids, cond, mask, cond_scale, y0=y0)
     monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample_text2semantic", spy_t2s)
     monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample", spy_syn)
@@ -252,14 +266,15 @@ def test_cli_dialogue_turn_modes(tmp_path, mode, monkeypatch):
     real = generation.CoVoMixModel.synthesis_sample
 
     def spy(self, phoneme_ids, cond, mask, cond_scale, y0=None):
-        seen.append((phoneme_ids.cpu(), cond.cpu(), mask.cpu()))
+        for i_, c_, m_ in zip(phoneme_ids, cond, mask):          # per utterance (equal-length [B, T, .] call or ragged lists)
+            seen.append((i_.cpu(), c_.cpu(), m_.cpu()))
         return real(self, phoneme_ids, cond, mask, cond_scale, y0=y0)
     monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample", spy)
     n = generation.run(True, ["--acous_ckpt", os.path.join(tmp, "acous.ckpt"), "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"),
                               "--text_dir", tdir, "--prompt_dir", pdir, "--saved_dir", sdir, "--mode", mode, "--seed", "30"])
     assert n == 2
     from scipy.io.wavfile import read
-    rows = [(ids[j], cond[j], mask[j]) for ids, cond, mask in seen for j in range(ids.shape[0])]
+    rows = seen
     for name in ("dlg_a", "dlg_b"):
         sr, pcm = read(os.path.join(sdir, name + ".wav"))
         assert sr == 8000 and pcm.dtype == np.int16
@@ -338,3 +353,74 @@ def test_cli_rate_matches_bench_path(tmp_path):
         bench_rate = max(bench_rate, 2 * 8 * (T - P) / (time.perf_counter() - t0))
     print(f"CLI {cli_rate:.0f} generated frames/s vs bench-style loop {bench_rate:.0f}: ratio {cli_rate / bench_rate:.3f}")
     assert cli["frames"] == N * (T - P) and cli_rate >= 0.85 * bench_rate
+
+
+
+def test_cli_rate_on_ragged_directory(tmp_path):
+    """Round-2 verdict item 2: a REAL directory has utterances of all different lengths.  16 utterances of distinct
+    T in [400, 1200] (40 % prompt, like the bench shape) through generation.run on the full-width VoMix + config_covomix
+    HiFi-GAN must generate frames at >= 85 % of the rate of the bench-style loop on 8 x 1000 equal-length frames (with
+    equal-length-only batching this directory ran at the B = 1 rate, about 0.4)."""
+    import time
+    import covomix_amd.synthetic as syn
+    from covomix_amd import generation, ops
+    from covomix_amd.conditional_model import CoVoMixModel
+    from covomix_amd.vocoder import AttrDict, Generator
+    tmp = str(tmp_path)
+    shapes = syn.acoustic_param_shapes()
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
+    full = {"cfm_wrapper.CoVoMix." + k: v for k, v in sd.items()}
+    torch.save({"state_dict": full, "hyper_parameters": {"twocondition_oneoutput": True}}, os.path.join(tmp, "acous.ckpt"))
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    os.makedirs(os.path.join(tmp, "voc"))
+    torch.save({"generator": vsd}, os.path.join(tmp, "voc", "g_00000001"))
+    json.dump(h, open(os.path.join(tmp, "voc", "vocoder_config.json"), "w"))
+    tdir, pdir, sdir = (os.path.join(tmp, d) for d in ("text", "prompt", "out"))
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(7)
+    lengths = [400, 1200, 451, 1149, 503, 1097, 555, 1044, 607, 993, 659, 941, 711, 889, 763, 837]
+    gen_frames = 0
+    for i, T in enumerate(lengths):
+        P = int(0.4 * T)
+        for suf in ("_1", "_2"):
+            np.save(os.path.join(pdir, f"u{i:02d}{suf}.hubert_code.npy"), g.randint(0, 500, size=P))
+            np.save(os.path.join(pdir, f"u{i:02d}{suf}.mel.npy"), (g.randn(80, P) * 2 - 6).astype(np.float32))
+        np.save(os.path.join(tdir, f"u{i:02d}.semantic.npy"), g.randint(0, 500, size=(2, T - P)))
+        gen_frames += T - P
+    argv = ["--acous_ckpt", os.path.join(tmp, "acous.ckpt"), "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"),
+            "--text_dir", tdir, "--prompt_dir", pdir, "--saved_dir", sdir, "--mode", "covomix", "--seed", "1"]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.cuda.empty_cache()
+        assert generation.run(True, argv) == len(lengths)         # first pass also pays packing / first-launch costs
+        cli_rate = 0.0
+        for _ in range(3):                                       # best of three: a wall-clock ratio on a shared host
+            assert generation.run(True, argv) == len(lengths)
+            cli = generation.run.last_stats
+            cli_rate = max(cli_rate, cli["frames"] / cli["seconds"])
+    from scipy.io.wavfile import read
+    for i, T in enumerate(lengths):
+        sr, pcm = read(os.path.join(sdir, f"u{i:02d}.wav"))
+        assert sr == 8000 and pcm.shape == (160 * (T - int(0.4 * T)) + 32,)
+    model = CoVoMixModel.from_state_dict(sd, nfe=32).eval().to("cuda:0")
+    gen = Generator(AttrDict(h)).to("cuda:0"); gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
+    T, P = 1000, 400
+    inp = syn.synthetic_inputs("vomix", 8, T, P, seed=3)
+    ids, cond, mask = inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda()
+
+    def step():
+        mel = model.synthesis_sample(ids, cond, mask, 0.7, y0=torch.randn(8, T, 80, device="cuda"))
+        return ops.wav_to_int16(gen(mel[:, P:].permute(0, 2, 1).contiguous()).squeeze(1).contiguous()).cpu()
+    step()
+    bench_rate = 0.0
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        bench_rate = max(bench_rate, 2 * 8 * (T - P) / (time.perf_counter() - t0))
+    print(f"ragged directory: CLI {cli_rate:.0f} generated frames/s vs bench-style loop {bench_rate:.0f}: ratio {cli_rate / bench_rate:.3f}")
+    assert cli["frames"] == gen_frames and cli_rate >= 0.85 * bench_rate
+
