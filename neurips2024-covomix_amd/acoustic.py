@@ -57,6 +57,9 @@ class VectorField:
         if precision not in ("f16x3", "fp32", "f16"):
             raise ValueError(f"precision must be 'f16x3', 'f16' or 'fp32', got {precision!r}")
         self.precision = precision
+        if torch.device(device).type == "cuda":
+            with torch.cuda.device(device):
+                ops.saturation_reset()      # (allocates the device's saturation flag now, outside any stream capture)
         sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()}
         self.device = device
         self.d = d = _dims_from_state(sd)

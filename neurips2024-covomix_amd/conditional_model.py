@@ -96,6 +96,7 @@ class CoVoMixModel:
         self.nfe, self.ode_method = nfe, ode_method
         self.precision = precision or os.environ.get("CVX_PRECISION", "f16x3")
         self._field: Optional[VectorField] = None
+        self._field_fp32: Optional[VectorField] = None      # built only if a split-precision call ever saturates
         self._t2s = None
 
     # ---- construction ---------------------------------------------------------------------
@@ -128,6 +129,7 @@ class CoVoMixModel:
         if use != self._use_ema:
             self._use_ema = use
             self._field = None
+            self._field_fp32 = None
             self._t2s = None
         return self
 
@@ -139,6 +141,7 @@ class CoVoMixModel:
         if device != self.device:
             self.device = device
             self._field = None
+            self._field_fp32 = None
             self._t2s = None
         return self
 
@@ -164,13 +167,47 @@ class CoVoMixModel:
         Extension: LISTS of per-utterance tensors (phoneme_ids[i] [T_i(, streams)], cond[i] [T_i, C], y0[i] [T_i, dim_out],
         lengths may differ) run as one packed ragged batch and return a list; each result equals that utterance's B = 1
         call up to fp32 summation order (the reference loops over utterances, monologue_generation.py:259-304)."""
-        sampler = FlowMatchingSampler(self._get_field(), nfe=self.nfe, method=self.ode_method)
-        if isinstance(cond, (list, tuple)):          # extension: utterances of different length in one packed launch
-            outs = sampler.sample_ragged(phoneme_ids=list(phoneme_ids), cond=list(cond), cond_scale=cond_scale,
-                                         y0=None if y0 is None else list(y0))
-            return [o.to(c.device) if c.device != o.device else o for o, c in zip(outs, cond)]
-        out = sampler.sample(phoneme_ids=phoneme_ids, cond=cond, mask=mask, cond_scale=cond_scale, y0=y0)
+        from . import ops
+        field = self._get_field()
+        ragged = isinstance(cond, (list, tuple))     # extension: utterances of different length in one packed launch
+
+        def run(f):
+            sampler = FlowMatchingSampler(f, nfe=self.nfe, method=self.ode_method)
+            if ragged:
+                return sampler.sample_ragged(phoneme_ids=list(phoneme_ids), cond=list(cond), cond_scale=cond_scale,
+                                             y0=None if y0 is None else list(y0))
+            return sampler.sample(phoneme_ids=phoneme_ids, cond=cond, mask=mask, cond_scale=cond_scale, y0=y0)
+        # Split-precision activations live in a window of 2^12 around the RMS the gain model predicts (acoustic.py,
+        # _activation_scales).  A checkpoint with an outlier row / channel can leave it: the kernels then clamp and raise the
+        # device's sticky saturation flag (include/covomix_hip.h).  One flag read per call (the only host synchronisation of
+        # the solve); a flagged call is re-run on the exact-fp32 kernels (or raises: CVX_ON_SATURATION=raise) - never
+        # returned as is.
+        checked = field.precision != "fp32" and os.environ.get("CVX_SAT_CHECK", "1") == "1" and (not ragged or len(cond) > 0)
+        if ragged and y0 is None and checked:       # a re-run must see the same noise
+            y0 = [torch.randn(c.shape[0], field.d["dim_out"], device=self.device) for c in cond]
+        elif not ragged and y0 is None and checked:
+            y0 = torch.randn(cond.shape[0], cond.shape[1], field.d["dim_out"], device=self.device)
+        if checked:
+            ops.saturation_reset()
+        out = run(field)
+        if checked and ops.saturation_query():
+            out = run(self._saturated(field.precision))
+        if ragged:
+            return [o.to(c.device) if c.device != o.device else o for o, c in zip(out, cond)]
         return out.to(cond.device) if cond.device != out.device else out
+
+    def _saturated(self, precision: str) -> VectorField:
+        """Called when a split-precision solve raised the saturation flag: warn (or raise) and hand back the exact-fp32
+        field (built on first use: one more device copy of the weights)."""
+        msg = (f"covomix_amd: split-precision ('{precision}') activations left the fp16 window (saturating store): this "
+               "checkpoint has outlier weights the gain model does not predict")
+        if os.environ.get("CVX_ON_SATURATION", "fp32") == "raise":
+            from ._lib import CovomixHipError
+            raise CovomixHipError(msg + " (CVX_ON_SATURATION=raise)")
+        warnings.warn(msg + "; re-running this call on the exact-fp32 kernels (construct the model with precision='fp32' to avoid the double work)")
+        if self._field_fp32 is None:
+            self._field_fp32 = VectorField(self.active_state_dict(), self.device, precision="fp32")
+        return self._field_fp32
 
     def _get_t2s(self):
         """The device-resident text2semantic decoder (built on first use)."""

@@ -42,8 +42,9 @@ __device__ __forceinline__ f16x8 gload8h(const f16* p)
     return *reinterpret_cast<gp>(reinterpret_cast<uintptr_t>(p));
 }
 
-__device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, const f32x4 o)
+__device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, const f32x4 o, float& amax)
 {
+    amax = cvx_amax4(amax, o);
     // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
     // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
     if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
                                                                 int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
                                                                 const float* __restrict__ qk_scale, const float* __restrict__ v_scale,
-                                                                const float* __restrict__ out_scale, const int* __restrict__ cu_seqlens)
+                                                                const float* __restrict__ out_scale, const int* __restrict__ cu_seqlens,
+                                                                uint32_t* __restrict__ sat)
 {
     // activation pre-scales (device scalars, powers of two): scores carry qk_scale^2, O carries v_scale
     if (qk_scale) { const float q = *qk_scale; scale_log2e /= q * q; }
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot / (v_scale ? *v_scale : 1.f);        // fp32 output: the true value
     const float osc = out_scale ? *out_scale : 1.f;                        // split output: times the consumer's pre-scale
+    float amax = 0.f;
     if (q_valid) {
         const int64_t o_off = q_grow * (H * HD) + head * HD + 4 * g;
 #pragma unroll
@@ -298,11 +301,14 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
             if (out_hi) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { a[e] *= osc; c[e] *= osc; }
-                store_split4(out_hi, out_lo, o_off + 8 * gq, a);
-                store_split4(out_hi, out_lo, o_off + 32 + 8 * gq, c);
+                store_split4(out_hi, out_lo, o_off + 8 * gq, a, amax);
+                store_split4(out_hi, out_lo, o_off + 32 + 8 * gq, c, amax);
             }
         }
     }
+    // a non-finite normaliser (overflowed scores, all-masked row) also means the result cannot be trusted: flag it
+    if (!(l_tot > 0.f && l_tot < __builtin_inff())) amax = __builtin_inff();
+    cvx_sat_commit(sat, amax);
 }
 
 }  // namespace
@@ -324,18 +330,19 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
     if (Bt == 0) return CVX_OK;
     const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
+    uint32_t* sat = cvx_sat_flag_dev();
     if (single)
         hipLaunchKernelGGL(attention_f16x3_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                            reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
                            reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
                            out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev);
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat);
     else
         hipLaunchKernelGGL(attention_f16x3_kernel<3>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                            reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
                            reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
                            out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev);
+                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat);
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;
 }

@@ -28,8 +28,9 @@ constexpr int K_LD = HD + 4;    // padded K row in LDS (floats): conflict-free d
 constexpr int V_LD = HD;
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, float& amax)
 {
+    amax = cvx_amax4(amax, o);
     // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
     // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
     if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
@@ -47,7 +48,7 @@ __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t
 __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
                                                               int T, int H, int n_groups, int n_qt, float scale_log2e,
-                                                              const int* __restrict__ cu_seqlens)
+                                                              const int* __restrict__ cu_seqlens, uint32_t* __restrict__ sat)
 {
     __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
     __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
     // ---- normalise and store: lane holds O[q][d] for d = dt*32 + (r&3) + 8*(r>>2) + 4*half
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    float amax = 0.f;
     if (q_valid) {
         const int64_t o_off = (row0 + qrow) * (H * HD) + head * HD + 4 * half;
 #pragma unroll
@@ -188,11 +190,12 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
                 *reinterpret_cast<f32x4*>(out + o_off + 32 + 8 * g) = c;
             }
             if (out_hi) {     // split copy for the to_out GEMM's pre-split A operand
-                store_split4(out_hi, out_lo, o_off + 8 * g, a);
-                store_split4(out_hi, out_lo, o_off + 32 + 8 * g, c);
+                store_split4(out_hi, out_lo, o_off + 8 * g, a, amax);
+                store_split4(out_hi, out_lo, o_off + 32 + 8 * g, c, amax);
             }
         }
     }
+    cvx_sat_commit(sat, amax);
 }
 
 }  // namespace
@@ -208,7 +211,8 @@ extern "C" int cvx_attention_varlen_f32(const float* qkv, float* out, uint16_t* 
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                        qkv, out, reinterpret_cast<_Float16*>(out_hi), reinterpret_cast<_Float16*>(out_lo),
-                       max_T, H, n_groups, n_qt, scale * 1.44269504088896340736f, cu_seqlens_dev);
+                       max_T, H, n_groups, n_qt, scale * 1.44269504088896340736f, cu_seqlens_dev,
+                       out_hi ? cvx_sat_flag_dev() : nullptr);
     CVX_CHECK_LAUNCH("cvx_attention_f32");
     return CVX_OK;
 }

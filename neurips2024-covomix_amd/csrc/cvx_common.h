@@ -15,6 +15,12 @@ void cvx_set_error(const char* fmt, ...);
 void cvx_allow_dynamic_lds(const void* kernel, int bytes);
 // compute units of the current device (cached per device)
 int cvx_device_cus();
+// Sticky saturation flag: one uint32 per device, owned by the library (cvx_saturation_flag_* in the header).  Every kernel
+// that writes (fp16 hi, fp16 lo) split pairs clamps to +-65504 and ORs bit 0 into the flag when a value it stored was
+// larger than that - the pair then no longer represents the fp32 value and the caller must not trust the result.
+// Returns the device pointer for the current device (allocated and zeroed on first use; NULL if that failed, e.g. first
+// use inside a stream capture - the kernels then skip the bookkeeping).
+uint32_t* cvx_sat_flag_dev();
 
 #define CVX_REQUIRE(cond, ...)                       \
     do {                                             \
@@ -42,6 +48,16 @@ __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 
 // wait for HBM); this keeps them global_load_dwordx4.
 typedef const f32x4 __attribute__((address_space(1)))* cvx_gptr4;
 __device__ __forceinline__ f32x4 gload4(const float* p) { return *reinterpret_cast<cvx_gptr4>(reinterpret_cast<uintptr_t>(p)); }
+
+// max |.| bookkeeping of the values a lane stores as split pairs, and the commit (one atomic, only when saturated)
+__device__ __forceinline__ float cvx_amax4(float m, const f32x4 v)
+{
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, float amax)
+{
+    if (flag && amax > 65504.f) atomicOr(flag, 1u);
+}
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }

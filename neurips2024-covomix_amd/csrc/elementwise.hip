@@ -53,7 +53,39 @@ int cvx_device_cus()
     }
     return n_cu[dev];
 }
-extern "C" int cvx_version(void) { return 100; }
+uint32_t* cvx_sat_flag_dev()
+{
+    static std::mutex mu;
+    static uint32_t* flag[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!flag[dev]) {
+        uint32_t* p = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+        flag[dev] = p;
+    }
+    return flag[dev];
+}
+extern "C" int cvx_saturation_flag_reset(cvx_stream_t s)
+{
+    uint32_t* f = cvx_sat_flag_dev();
+    CVX_REQUIRE(f, "saturation_flag: could not allocate the device flag");
+    if (hipMemsetAsync(f, 0, sizeof(uint32_t), reinterpret_cast<hipStream_t>(s)) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
+    return CVX_OK;
+}
+extern "C" int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t s)
+{
+    uint32_t* f = cvx_sat_flag_dev();
+    CVX_REQUIRE(f && host_out, "saturation_flag: no device flag / null output");
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    if (hipMemcpyAsync(host_out, f, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { cvx_set_error("saturation_flag: read failed: %s", hipGetErrorString(hipGetLastError())); return CVX_EHIP; }
+    if (reset && hipMemsetAsync(f, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
+    return CVX_OK;
+}
+extern "C" int cvx_version(void) { return 101; }
 
 namespace {
 
@@ -66,8 +98,9 @@ __device__ __forceinline__ float wave_sum(float v)
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 // split 4 floats into fp16 (hi, lo) and store 8 bytes each (for GEMMs that take their A operand pre-split)
-__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, float& amax)
 {
+    amax = cvx_amax4(amax, o);
     // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
     // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
     if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
@@ -89,11 +122,12 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
                                                         int64_t rows, int D, int64_t rows_per_group, float scale, float eps,
-                                                        const float* __restrict__ split_scale)
+                                                        const float* __restrict__ split_scale, uint32_t* __restrict__ sat)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    float amax = 0.f;
     const float ssc = split_scale ? *split_scale : 1.f;      // power-of-two pre-scale of the split copy (device scalar)
     const float* xr = x + row * D;
     const int64_t g = row / rows_per_group;
@@ -128,9 +162,10 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
                 for (int e = 0; e < 4; ++e) o[e] += bb[e];
             }
             if (y) *reinterpret_cast<f32x4*>(yr + 4 * j) = o;
-            if (y_hi) { const f32x4 os = {o[0] * ssc, o[1] * ssc, o[2] * ssc, o[3] * ssc}; store_split4(y_hi, y_lo, row * D + 4 * j, os); }
+            if (y_hi) { const f32x4 os = {o[0] * ssc, o[1] * ssc, o[2] * ssc, o[3] * ssc}; store_split4(y_hi, y_lo, row * D + 4 * j, os, amax); }
         }
     }
+    cvx_sat_commit(sat, amax);
 }
 
 // generic-D fallback: two passes over the row (second pass hits L1/L2)
@@ -138,11 +173,12 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
                                                                 const float* __restrict__ beta, float* __restrict__ y,
                                                                 _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
                                                                 int64_t rows, int D, int64_t rows_per_group, float scale, float eps,
-                                                                const float* __restrict__ split_scale)
+                                                                const float* __restrict__ split_scale, uint32_t* __restrict__ sat)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    float amax = 0.f;
     const float ssc = split_scale ? *split_scale : 1.f;
     const float* xr = x + row * D;
     const int64_t g = row / rows_per_group;
@@ -165,8 +201,9 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
             for (int e = 0; e < 4; ++e) o[e] += bb[e];
         }
         if (y) *reinterpret_cast<f32x4*>(y + row * D + 4 * j) = o;
-        if (y_hi) { const f32x4 os = {o[0] * ssc, o[1] * ssc, o[2] * ssc, o[3] * ssc}; store_split4(y_hi, y_lo, row * D + 4 * j, os); }
+        if (y_hi) { const f32x4 os = {o[0] * ssc, o[1] * ssc, o[2] * ssc, o[3] * ssc}; store_split4(y_hi, y_lo, row * D + 4 * j, os, amax); }
     }
+    cvx_sat_commit(sat, amax);
 }
 
 // ---------------------------------------------------------------- depthwise conv k=31 + GELU + residual
@@ -332,10 +369,11 @@ extern "C" int cvx_adarmsnorm_scaled_f32(const float* x, const float* gamma, con
     if (rows == 0) return CVX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
-    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
-    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
-    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev);
+    uint32_t* sat = y_hi ? cvx_sat_flag_dev() : nullptr;
+    if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
+    else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
+    else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
+    else                hipLaunchKernelGGL(adarmsnorm_generic_kernel, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
     CVX_CHECK_LAUNCH("cvx_adarmsnorm_scaled_f32");
     return CVX_OK;
 }

@@ -40,7 +40,8 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int map_
 struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
                   _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld;
                   const float* c_scale; const float* vt_scale; const float* a_scale;
-                  int dbg; unsigned long long* trace; };   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
+                  int dbg; unsigned long long* trace;
+                  uint32_t* sat; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
 
 // accumulator factor: 1 / (weight pre-scale) / (activation pre-scale); both powers of two, so the division is exact
 __device__ __forceinline__ float total_acc_scale(float acc_scale, const SplitOut& so)
@@ -57,6 +58,7 @@ __device__ __forceinline__ int il_col(int c) { return ((c >> 5) << 6) | (c & 31)
 __device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v)
 {
     const float x = fminf(fmaxf(v, -65504.f), 65504.f);
+    cvx_sat_commit(so.sat, fabsf(v));
     const _Float16 h = (_Float16)x;
     so.hi[idx] = h;
     if (so.lo) so.lo[idx] = (_Float16)(x - (float)h);      // lo == NULL: single-term fp16 consumer
@@ -118,6 +120,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
         const float b_lo_v = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
         const float b_hi_v = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
         const float vs = so.vt_scale ? *so.vt_scale : 1.f;
+        float amax = 0.f;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -132,7 +135,9 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                     cvx_f16x4 vh, vl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = fminf(fmaxf((acc[mi][hsel][4 * rg + e] + bias) * vs, -65504.f), 65504.f);
+                        const float xr = (acc[mi][hsel][4 * rg + e] + bias) * vs;
+                        amax = fmaxf(amax, fabsf(xr));
+                        const float x = fminf(fmaxf(xr, -65504.f), 65504.f);
                         vh[e] = (_Float16)x;
                         vl[e] = (_Float16)(x - (float)vh[e]);
                     }
@@ -154,6 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                 }
             }
         }
+        cvx_sat_commit(so.sat, amax);
         return;
     }
     const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
@@ -169,6 +175,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                         (!p.residual || (((uintptr_t)p.residual & 15) == 0 && (p.ldr & 3) == 0)) &&
                         (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0)));
     if (vec_ok) {
+        float amax = 0.f;
         const int q = lane & 3;
         const int c4_lo = colw + 4 * ((lane & 31) >> 2);          // this lane's 4 columns after the transpose
 #pragma unroll
@@ -219,6 +226,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                     cvx_f16x4 h0, l0, h1, l1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        amax = fmaxf(amax, fmaxf(fabsf(vlo[e] * cs), fabsf(vhi[e] * cs)));
                         const float x0 = fminf(fmaxf(vlo[e] * cs, -65504.f), 65504.f);
                         const float x1 = fminf(fmaxf(vhi[e] * cs, -65504.f), 65504.f);
                         h0[e] = (_Float16)x0; l0[e] = (_Float16)(x0 - (float)h0[e]);
@@ -233,6 +241,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                 }
             }
         }
+        cvx_sat_commit(so.sat, amax);
         return;
     }
 #pragma unroll

@@ -24,10 +24,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int TILE_H = 128 * BK;            // halves per operand tile (8 KiB)
 constexpr float F16_MAX = 65504.f;
 
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo, float pre = 1.0f)
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo, float pre, float& amax)
 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        amax = fmaxf(amax, fabsf(v[e] * pre));
         const float x = fminf(fmaxf(v[e] * pre, -F16_MAX), F16_MAX);     // saturate instead of inf - inf
         const f16 h = (f16)x;
         hi[e] = h;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
     f32x4 ra[4];
     const int nk = p.K / BK;
     const float a_pre = so.a_scale ? *so.a_scale : 1.0f;      // activation pre-scale applied while splitting on the fly
+    float a_amax = 0.f;
     {   // prologue: tile 0 -> stage 0
         const bool sw = (0 == switch_tile);
 #pragma unroll
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 hi, lo;
-            split4(ra[i], hi, lo, a_pre);
+            split4(ra[i], hi, lo, a_pre, a_amax);
             *reinterpret_cast<f16x4*>(S0 + a_st[i]) = hi;
             *reinterpret_cast<f16x4*>(S0 + TILE_H + a_st[i]) = lo;
         }
@@ -180,12 +182,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f16x4 hi, lo;
-            split4(ra[i], hi, lo, a_pre);
+            split4(ra[i], hi, lo, a_pre, a_amax);
             *reinterpret_cast<f16x4*>(Sn + a_st[i]) = hi;
             *reinterpret_cast<f16x4*>(Sn + TILE_H + a_st[i]) = lo;
         }
         __syncthreads();
     }
+    cvx_sat_commit(so.sat, a_amax);
     acc_scale = total_acc_scale(acc_scale, so);
     if (acc_scale != 1.0f) {        // undo the power-of-two weight (and activation) pre-scale (exact)
 #pragma unroll
@@ -577,11 +580,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
 }
 
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ w, f16* __restrict__ hi,
-                                                       f16* __restrict__ lo, int64_t n, float scale, const float* __restrict__ scale_dev)
+                                                       f16* __restrict__ lo, int64_t n, float scale, const float* __restrict__ scale_dev,
+                                                       uint32_t* __restrict__ sat)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     if (scale_dev) scale *= *scale_dev;
+    cvx_sat_commit(sat, fabsf(w[i] * scale));
     const float x = fminf(fmaxf(w[i] * scale, -F16_MAX), F16_MAX);
     const f16 h = (f16)x;
     const int64_t o = (lo == hi + 32) ? (((i >> 5) << 6) | (i & 31)) : i;      // interleaved pair: [hi 32 | lo 32] blocks
@@ -597,7 +602,7 @@ extern "C" int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int
     CVX_REQUIRE(w && hi && n >= 0, "split_f16: bad arguments");      // lo == NULL: plain fp16 cast (saturating)
     if (n == 0) return CVX_OK;
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale, scale_dev);
+                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale, scale_dev, cvx_sat_flag_dev());
     CVX_CHECK_LAUNCH("cvx_split_f16");
     return CVX_OK;
 }
@@ -696,6 +701,7 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
                     "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
     SplitOut so{nullptr, nullptr, 0, 1, nullptr, nullptr, 0};
+    so.sat = cvx_sat_flag_dev();
     PreSplitA A{nullptr, nullptr, 0, nullptr, nullptr, 0};
     if (io) {
         if (io->C_hi || io->C_lo) {

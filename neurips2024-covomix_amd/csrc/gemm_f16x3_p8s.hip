@@ -51,8 +51,9 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
 #define CVX_P8_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions, exact residual by v_fma_mix
-__device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo)
+__device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, float& amax)
 {
+    amax = cvx_amax4(amax, v);
     float x[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
@@ -109,6 +110,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);          // wave-uniform (64-column wave tile = one head)
     const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
     const bool il = so.hi && so.lo == so.hi + 32;
+    float amax = 0.f;
     f32x4 bias[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -165,12 +167,13 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 const int c = col0 + 16 * ni + lc;
                 const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
                 f16x4 h, l;
-                split4_pk(f32x4{v[ni][0] * cs, v[ni][1] * cs, v[ni][2] * cs, v[ni][3] * cs}, h, l);
+                split4_pk(f32x4{v[ni][0] * cs, v[ni][1] * cs, v[ni][2] * cs, v[ni][3] * cs}, h, l, amax);
                 *reinterpret_cast<f16x4*>(so.hi + o) = h;
                 if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = l;
             }
         }
     }
+    cvx_sat_commit(so.sat, amax);
 }
 
 // ---- epilogue of a V block of a to_qkv projection, UN-swapped layout:
@@ -183,6 +186,7 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
     const int H = p.rope_cols / 128, T = p.rope_T;
     const int head = (col0 - p.rope_cols) / 64;
     const float vs = (so.vt_scale ? *so.vt_scale : 1.f) * acc_scale;
+    float amax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int r0 = row0 + 16 * mi + 4 * (lane >> 4);
@@ -194,7 +198,7 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
             const int d = 16 * ni + (lane & 15);
             const float bv = p.bias ? p.bias[col0 + d] * (so.vt_scale ? *so.vt_scale : 1.f) : 0.f;
             f16x4 h, l;
-            split4_pk(f32x4{fmaf(acc[mi][ni][0], vs, bv), fmaf(acc[mi][ni][1], vs, bv), fmaf(acc[mi][ni][2], vs, bv), fmaf(acc[mi][ni][3], vs, bv)}, h, l);
+            split4_pk(f32x4{fmaf(acc[mi][ni][0], vs, bv), fmaf(acc[mi][ni][1], vs, bv), fmaf(acc[mi][ni][2], vs, bv), fmaf(acc[mi][ni][3], vs, bv)}, h, l, amax);
             if (vec) {
                 const int64_t o = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld + vt_slot(t0);
                 *reinterpret_cast<f16x4*>(so.vt_hi + o) = h;
@@ -212,6 +216,7 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
             }
         }
     }
+    cvx_sat_commit(so.sat, amax);
 }
 
 // the main loop for one output tile; SWAP selects the operand order of every MFMA (see the header)

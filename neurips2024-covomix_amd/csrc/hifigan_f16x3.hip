@@ -46,6 +46,7 @@ struct Conv16Args {
     int L, Lp, Cp_in, Np, ksize, dil, pad, halo_l;
     float acc_scale, out_scale, z_slope;
     const float* z_scale;              // device scalar (power of two) carried by z and applied to out_z, or NULL = 1
+    uint32_t* sat;                     // sticky saturation flag of the device (cvx_common.h) or NULL
 };
 
 template <int TMI, int TNI, int WN>
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     const int wm = wid / WN, wn = wid % WN;
     const float zs = p.z_scale ? *p.z_scale : 1.f;          // activation pre-scale of this stage's split pairs
     const float a_sc = p.acc_scale / zs;                    // (exact: both are powers of two)
+    float amax = 0.f;
     const int l0 = blockIdx.x * TMB;
     const int b = blockIdx.y;
     const int n_chunks = p.Cp_in / CK;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float z = (v[e] > 0.f ? v[e] : v[e] * p.z_slope) * zs;
+                        amax = fmaxf(amax, fabsf(z));
                         z = fminf(fmaxf(z, -65504.f), 65504.f);
                         zh[e] = (_Float16)z;
                         zl[e] = (_Float16)(z - (float)zh[e]);
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
             }
         }
     }
+    cvx_sat_commit(p.sat, amax);
 }
 
 // ---------------------------------------------------------------- fused ResBlock pair (narrow stages: Np = 32 / 64)
@@ -247,11 +251,13 @@ struct PairArgs {
     int B, L, Lp, ksize, dil, halo_l, tiles_per_seq, n_tiles;
     float acc1, acc2, out_scale, slope;
     const float* z_scale;
+    uint32_t* sat;                     // sticky saturation flag of the device or NULL
 };
 
 // (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions
-__device__ __forceinline__ void pair_split4(const f32x4 v, cvx_f16x4& hi, cvx_f16x4& lo)
+__device__ __forceinline__ void pair_split4(const f32x4 v, cvx_f16x4& hi, cvx_f16x4& lo, float& amax)
 {
+    amax = cvx_amax4(amax, v);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     float x[4];
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
     const int wm = wid;                                   // 8 x 1 waves: 32 rows x all NP channels each
     const float zs = p.z_scale ? *p.z_scale : 1.f;
     const float a1 = p.acc1 / zs, a2 = p.acc2 / zs;       // (exact: powers of two)
+    float amax = 0.f;
     const int k = p.ksize, h2 = (k - 1) / 2, pad1 = (k - 1) * p.dil / 2;
     const int tm_out = ROWS - 2 * h2;
     const int n_groups = (k + TS - 1) / TS;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = xr[i][e] * (xr[i][e] > 0.f ? zs : zs_neg);
             cvx_f16x4 zh, zl;
-            pair_split4(z, zh, zl);
+            pair_split4(z, zh, zl, amax);
             const int off = ((c4 >> 3) * 2 * ZR + row) * CK + 8 * (((c4 & 7) >> 1) ^ ((row >> 2) & 3)) + 4 * (c4 & 1);
             *reinterpret_cast<cvx_f16x4*>(Zs + off) = zh;
             *reinterpret_cast<cvx_f16x4*>(Zs + off + A_TILE) = zl;
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= v[e] > 0.f ? sp : sn;
                 cvx_f16x4 zh, zl;
-                pair_split4(v, zh, zl);
+                pair_split4(v, zh, zl, amax);
                 const int off = (ni * 2 * ZR + row) * CK + 8 * ((c4e >> 3) ^ ((row >> 2) & 3)) + (c4e & 7);
                 *reinterpret_cast<cvx_f16x4*>(Zs + off) = zh;
                 *reinterpret_cast<cvx_f16x4*>(Zs + off + A_TILE) = zl;
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
         }
         PSTAMP(5)
     }
+    cvx_sat_commit(p.sat, amax);
 #ifdef CVX_PAIR_TRACE
     if (lane == 0 && p.accum == nullptr && p.out_scale == 0.f) {      // (trace build: out_scale 0 makes the output all zero; stamps go on top)
         unsigned long long* tb = reinterpret_cast<unsigned long long*>(p.out) + ((size_t)blockIdx.x * 8 + wid) * 8;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
 __global__ __launch_bounds__(256) void cm_to_cl_kernel(const float* __restrict__ x, float* __restrict__ x_cl,
                                                       f16* __restrict__ z_hi, f16* __restrict__ z_lo,
                                                       int C, int L, int Lp, int Cp, int halo_l, float slope,
-                                                      const float* __restrict__ z_scale)
+                                                      const float* __restrict__ z_scale, uint32_t* __restrict__ sat)
 {
     __shared__ float tile[32][65];
     const float zs = z_scale ? *z_scale : 1.f;
@@ -516,6 +524,7 @@ __global__ __launch_bounds__(256) void cm_to_cl_kernel(const float* __restrict__
         if (x_cl) x_cl[o] = v;
         if (z_hi) {
             float z = (v > 0.f ? v : v * slope) * zs;
+            cvx_sat_commit(sat, fabsf(z));
             z = fminf(fmaxf(z, -65504.f), 65504.f);
             const f16 h = (f16)z;
             z_hi[o] = h;
@@ -577,7 +586,8 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
     Conv16Args k{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
                  reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
-                 a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev};
+                 a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev,
+                 a->out_zhi ? cvx_sat_flag_dev() : nullptr};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     if (a->Np == 256) {
         // one block per CU: when the 256-position tiles leave more than a quarter of the chip idle in their last (or only)
@@ -618,7 +628,7 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
     PairArgs k{a->x, reinterpret_cast<const f16*>(a->c1.w_hi), reinterpret_cast<const f16*>(a->c1.w_lo),
                reinterpret_cast<const f16*>(a->c2.w_hi), reinterpret_cast<const f16*>(a->c2.w_lo), a->c1.bias, a->c2.bias,
                a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
-               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev};
+               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_dev()};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const int cus = cvx_device_cus();
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU
@@ -651,7 +661,8 @@ extern "C" int cvx_hifigan_to_channels_last_scaled(const float* x, float* x_cl, 
     if (B == 0) return CVX_OK;
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
     hipLaunchKernelGGL(cm_to_cl_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, x_cl,
-                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope, z_scale_dev);
+                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope, z_scale_dev,
+                       z_hi ? cvx_sat_flag_dev() : nullptr);
     CVX_CHECK_LAUNCH("cvx_hifigan_to_channels_last");
     return CVX_OK;
 }

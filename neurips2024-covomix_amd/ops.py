@@ -246,6 +246,20 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     return out if out is not None else out_split
 
 
+def saturation_reset() -> None:
+    """Clear the device's sticky saturation flag (enqueued on the current stream; no host synchronisation)."""
+    _lib.check(_lib.load().cvx_saturation_flag_reset(_stream()), "cvx_saturation_flag_reset")
+
+
+def saturation_query(reset: bool = True) -> int:
+    """The sticky saturation flag after everything enqueued so far on the current stream (synchronises that stream):
+    non-zero = some split-pair store since the last reset had to clamp (or a softmax normaliser was not finite) - the
+    split-precision result must not be trusted."""
+    v = C.c_uint32(0)
+    _lib.check(_lib.load().cvx_saturation_flag_query(C.byref(v), 1 if reset else 0, _stream()), "cvx_saturation_flag_query")
+    return int(v.value)
+
+
 class Ragged:
     """A packed batch of sequences of different length: sequence i owns rows [cu[i], cu[i+1]) of every [M, width] tensor.
     cu: int32 CUDA tensor [n + 1]; lengths: the python list (host side: grid sizes, slicing)."""

@@ -79,12 +79,14 @@ class Generator:
         self._sd: Optional[Dict[str, torch.Tensor]] = None
         self._has_weight_norm = False
         self._packed = None
+        self._fp32_twin: Optional["Generator"] = None       # built only if a split-precision call ever saturates
 
     # ---- nn.Module-like surface used by the reference scripts -------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         self._sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self._has_weight_norm = any(k.endswith(".weight_g") for k in self._sd)
         self._packed = None
+        self._fp32_twin = None
         return self
 
     def state_dict(self):
@@ -98,6 +100,7 @@ class Generator:
         if device != self.device:
             self.device = device
             self._packed = None
+            self._fp32_twin = None
         return self
 
     def remove_weight_norm(self):
@@ -106,6 +109,7 @@ class Generator:
             self._sd = fold_weight_norm(self._sd)
             self._has_weight_norm = False
             self._packed = None
+            self._fp32_twin = None
         return self
 
     # ---- weight packing -----------------------------------------------------------------
@@ -169,6 +173,31 @@ class Generator:
 
     @torch.no_grad()
     def __call__(self, mel: torch.Tensor) -> torch.Tensor:
+        """The split-precision stages keep their activations within 2^6 of the measured max|x| of the stage input; when a
+        ResBlock intermediate outgrows that, the kernels clamp and raise the device's sticky saturation flag
+        (include/covomix_hip.h).  One flag read per call; a flagged call is re-run on the all-fp32 kernels (or raises:
+        CVX_ON_SATURATION=raise) - never returned as is."""
+        checked = self.precision != "fp32" and os.environ.get("CVX_SAT_CHECK", "1") == "1" and self.device.type == "cuda"
+        if not checked:
+            return self._forward(mel)
+        with torch.cuda.device(self.device):
+            ops.saturation_reset()
+            y = self._forward(mel)
+            if not ops.saturation_query():
+                return y
+        msg = ("covomix_amd: the split-precision vocoder stages saturated (an intermediate left the fp16 window around the "
+               "measured stage input)")
+        if os.environ.get("CVX_ON_SATURATION", "fp32") == "raise":
+            raise ops._lib.CovomixHipError(msg + " (CVX_ON_SATURATION=raise)")
+        import warnings
+        warnings.warn(msg + "; re-running this call on the all-fp32 kernels")
+        if self._fp32_twin is None:
+            twin = Generator(self.h, precision="fp32").to(self.device)
+            twin._sd, twin._has_weight_norm = self._sd, self._has_weight_norm
+            self._fp32_twin = twin
+        return self._fp32_twin._forward(mel)
+
+    def _forward(self, mel: torch.Tensor) -> torch.Tensor:
         if self._packed is None:
             self._pack()
         pk = self._packed

@@ -1,0 +1,204 @@
+"""Parity robustness of the split-precision path (round-2 verdict, "What's weak" #2 / next-round item 3a).
+
+Split activations are stored as (fp16 hi, fp16 lo) pairs times a power-of-two pre-scale from a weights-only gain model
+(transformer) or from the measured stage input (vocoder); every such store clamps to +-65504.  Before this round a
+checkpoint or an input outside the model's window gave a wrong result with rc 0.  Now every saturating store raises the
+device's sticky flag (cvx_saturation_flag_*), the host reads it once per call and re-runs a flagged call on the exact-fp32
+kernels (or raises, CVX_ON_SATURATION=raise).  Checked here:
+  * kernel level: each family of split stores raises the flag when (and only when) it clamps;
+  * outlier checkpoints - ONE to_embed row / FF channel / to_qkv row / HiFi-GAN conv_pre channel times 2^14 - stay
+    <= 1e-5 from the CPU oracle (flagged or not: never a silent 1e-2);
+  * inputs / weights that do leave the window: warning + fp32 re-run <= 1e-5, or a loud error under CVX_ON_SATURATION=raise.
+"""
+import math
+import warnings
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    import covomix_amd.ops as o
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_flag_is_raised_by_every_family_of_split_stores(ops):
+    dev_ = dev()
+    g = torch.Generator().manual_seed(0)
+    one = lambda v: torch.tensor([v], dtype=torch.float32, device=dev_)
+
+    def flagged(fn):
+        ops.saturation_reset()
+        fn()
+        return ops.saturation_query()
+    x = torch.randn(300, 256, generator=g).to(dev_)
+    # cvx_split_f16_dev
+    assert flagged(lambda: ops.split_act_f16(x)) == 0
+    assert flagged(lambda: ops.split_act_f16(x, scale=one(2.0 ** 15))) != 0
+    big = x.clone(); big[7, 3] = 1e5
+    assert flagged(lambda: ops.split_act_f16(big)) != 0
+    # sticky: stays up across later clean launches until it is reset; query(reset=True) clears it
+    ops.saturation_reset(); ops.split_act_f16(big); ops.split_act_f16(x)
+    assert ops.saturation_query(reset=False) != 0 and ops.saturation_query() != 0 and ops.saturation_query() == 0
+    # AdaRMSNorm split output
+    gam, bet = torch.ones(256, device=dev_), torch.zeros(256, device=dev_)
+    pair = (torch.empty(300, 256, dtype=torch.float16, device=dev_), torch.empty(300, 256, dtype=torch.float16, device=dev_))
+    assert flagged(lambda: ops.adarmsnorm(x, gam, bet, None, out_split=pair, split_scale=one(16.0))) == 0
+    assert flagged(lambda: ops.adarmsnorm(x, gam, bet, None, out_split=pair, split_scale=one(2.0 ** 15))) != 0
+    # GEMM epilogues (small-problem kernel and large-problem kernel): split output and transposed V^T
+    for M in (300, 2304):
+        a = torch.randn(M, 256, generator=g).to(dev_)
+        w = (torch.randn(512, 256, generator=g) / 16).to(dev_)
+        ws = ops.split_f16(w)
+        kw = dict(w_split=ws, a_split=ops.split_act_f16(a))
+        if M >= 2048:
+            il = ops.SplitIL(M, 256, dev_); ops.split_act_f16(a, il)
+            kw = dict(w_split=ws, w_il=ops.split_f16_interleaved(ws), a_split=il)
+        o = (torch.empty(M, 512, dtype=torch.float16, device=dev_), torch.empty(M, 512, dtype=torch.float16, device=dev_))
+        c = torch.empty(M, 512, device=dev_)
+        assert flagged(lambda: ops.gemm(a, w, c, out_split=o, **kw)) == 0
+        assert flagged(lambda: ops.gemm(a, w, c, out_split=o, c_scale=one(2.0 ** 17), **kw)) != 0
+        assert torch.isfinite(o[0].float()).all() and float(o[0].float().abs().max()) == 65504.0      # clamped, not inf
+    # attention split output
+    Bt, T, H = 1, 64, 1
+    qkv = (torch.randn(T, 192, generator=g) * 0.5).to(dev_)
+    ah, al = ops.split_act_f16(qkv.contiguous())
+    qk = (ah[:, :128].contiguous(), al[:, :128].contiguous())
+    vt = (torch.zeros(64, 64, dtype=torch.float16, device=dev_), torch.zeros(64, 64, dtype=torch.float16, device=dev_))
+    slots = ops.vt_frame_slots(T, dev_)
+    vt[0][:, slots] = ah[:, 128:].T; vt[1][:, slots] = al[:, 128:].T
+    op = (torch.empty(T, 64, dtype=torch.float16, device=dev_), torch.empty(T, 64, dtype=torch.float16, device=dev_))
+    assert flagged(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=op)) == 0
+    assert flagged(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=op, out_scale=one(2.0 ** 18))) != 0
+
+
+def _full_width_state(kind="vomix"):
+    import covomix_amd.synthetic as syn
+    two = kind == "vomix"
+    shapes = syn.acoustic_param_shapes(dim_cond=160 if two else 80, streams=2 if two else 1)
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
+    sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
+    return sd
+
+
+OUTLIERS = {
+    "to_embed_row": ("to_embed.weight", 77),
+    "ff1_channel": ("transformer.layers.3.4.0.weight", 1234),
+    "to_qkv_v_row": ("transformer.layers.5.2.to_qkv.weight", 2 * 1024 + 99),
+    "to_out_row": ("transformer.layers.2.2.to_out.weight", 500),
+}
+
+
+@pytest.mark.parametrize("which", list(OUTLIERS))
+def test_single_outlier_row_times_2_14_is_never_silently_wrong(which):
+    """Full-width VoMix, one weight ROW (= one output channel) times 2^14: the gain model only sees the Frobenius norm move.
+    The result must be fp32-class against the CPU oracle - by staying inside the window or by the flagged fp32 re-run."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _full_width_state()
+    key, row = OUTLIERS[which]
+    sd[key] = sd[key].clone()
+    sd[key][row] *= 2.0 ** 14
+    inp = syn.synthetic_inputs("vomix", 2, 96, 40, seed=21)
+    model = CoVoMixModel.from_state_dict(sd, nfe=2).eval().to("cuda:0")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = model.synthesis_sample(inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda(), 0.7, y0=inp["y0"])
+    rerun = any("saturat" in str(w.message) for w in rec)
+    ref = orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2)
+    e = rel_l2(out, ref)
+    print(f"outlier {which}: rel-L2 vs oracle {e:.3e} ({'flagged -> fp32 re-run' if rerun else 'inside the window'})")
+    assert torch.isfinite(out).all() and e < 1e-5
+
+
+def test_input_outside_the_window_is_rerun_in_fp32_or_raises(monkeypatch):
+    """The gain model takes the prompt mel at RMS 4; a cond tensor 4000x that leaves the residual stream's window.  Default:
+    warning + the exact-fp32 result; CVX_ON_SATURATION=raise: CovomixHipError; CVX_SAT_CHECK=0 shows what the unguarded path
+    would have returned."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd._lib import CovomixHipError
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _full_width_state()
+    inp = syn.synthetic_inputs("vomix", 1, 80, 40, seed=5)
+    cond = inp["cond"] * 4000.0
+    model = CoVoMixModel.from_state_dict(sd, nfe=2).eval().to("cuda:0")
+    args = (inp["phoneme_ids"].cuda(), cond.cuda(), inp["mask"].cuda(), 0.7)
+    ref = orc.sample(sd, inp["phoneme_ids"], cond, inp["y0"], 0.7, nfe=2)
+    with pytest.warns(UserWarning, match="saturat"):
+        out = model.synthesis_sample(*args, y0=inp["y0"])
+    assert rel_l2(out, ref) < 1e-5
+    # ragged call, same mechanism
+    with pytest.warns(UserWarning, match="saturat"):
+        outs = model.synthesis_sample([inp["phoneme_ids"][0].cuda()], [cond[0].cuda()], None, 0.7, y0=[inp["y0"][0]])
+    assert rel_l2(outs[0], ref[0]) < 1e-5
+    monkeypatch.setenv("CVX_ON_SATURATION", "raise")
+    with pytest.raises(CovomixHipError, match="saturat"):
+        model.synthesis_sample(*args, y0=inp["y0"])
+    monkeypatch.delenv("CVX_ON_SATURATION")
+    monkeypatch.setenv("CVX_SAT_CHECK", "0")
+    silent = model.synthesis_sample(*args, y0=inp["y0"])
+    print("unguarded split-precision result on the out-of-window input: rel-L2", rel_l2(silent, ref))
+    monkeypatch.delenv("CVX_SAT_CHECK")
+    # a normal input right afterwards is neither flagged nor re-run
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ok = model.synthesis_sample(inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda(), 0.7, y0=inp["y0"])
+    assert rel_l2(ok, orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2)) < 1e-5
+
+
+def _vocoder(h, vsd, precision=None):
+    from covomix_amd.vocoder import AttrDict, Generator
+    gen = Generator(AttrDict(h), precision=precision).to("cuda:0")
+    gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
+    return gen
+
+
+def test_vocoder_conv_pre_channel_times_2_14():
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    vsd["conv_pre.weight_g"] = vsd["conv_pre.weight_g"].clone()
+    vsd["conv_pre.weight_g"][123] *= 2.0 ** 14                     # weight-norm gain of ONE output channel
+    mel = (torch.randn(2, 80, 60, generator=torch.Generator().manual_seed(2)) * 2 - 6).clamp(-11.52, 2.0)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        wav = _vocoder(h, vsd)(mel.cuda())
+    ref = orc.hifigan_forward(orc.fold_weight_norm(vsd), h, mel)
+    e = rel_l2(wav, ref)
+    print(f"vocoder conv_pre channel x 2^14: rel-L2 vs oracle {e:.3e} (re-run: {any('saturat' in str(w.message) for w in rec)})")
+    assert torch.isfinite(wav).all() and e < 1e-5
+
+
+def test_vocoder_resblock_gain_outside_the_window_is_rerun_or_raises(monkeypatch):
+    """First convolutions of one stage-1 ResBlock times 2^10: its intermediates sit 2^10 above the measured stage input,
+    outside the 2^6 headroom of that stage's pre-scale -> flag -> all-fp32 re-run (<= 1e-5 vs the oracle) / loud error."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd._lib import CovomixHipError
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    for m in range(3):
+        k = f"resblocks.3.convs1.{m}.weight_g"
+        vsd[k] = vsd[k] * 2.0 ** 10
+    mel = (torch.randn(1, 80, 50, generator=torch.Generator().manual_seed(3)) * 2 - 6).clamp(-11.52, 2.0)
+    gen = _vocoder(h, vsd)
+    ref = orc.hifigan_forward(orc.fold_weight_norm(vsd), h, mel)
+    with pytest.warns(UserWarning, match="saturat"):
+        wav = gen(mel.cuda())
+    assert rel_l2(wav, ref) < 1e-5
+    monkeypatch.setenv("CVX_ON_SATURATION", "raise")
+    with pytest.raises(CovomixHipError, match="saturat"):
+        gen(mel.cuda())
