@@ -243,6 +243,14 @@ int cvx_time_fourier_f32(const float* times, const float* w, float* out, int32_t
  * Covers conv_pre (:81), ups[i] preceded by leaky_relu (:102-103), every ResBlock1
  * conv with its preceding leaky_relu and residual add (:35-42) and the
  * xs accumulate / divide by num_kernels (:104-110). */
+/* Ragged batches in the vocoder (items of different length in one launch; the reference vocodes utterances one by
+ * one, monologue_generation.py:52-59, :299-304): all tensors are sized for the LONGEST item and item b is valid on its
+ * first  item_len_dev[b] * mul + add  OUTPUT positions (the lengths of a stage are an affine function of the item's
+ * mel frames: item_len_dev holds the frames, the caller supplies the stage's mul / add).  A kernel given this table
+ * writes ZEROS behind an item's last valid position (up to the common length), which is exactly the zero padding the
+ * next convolution of a B = 1 run sees there; inputs must obey the same rule (zero-padded mel).  item_len_dev == NULL:
+ * every item has the common length. */
+typedef struct { const int32_t* item_len_dev; int32_t mul, add; } cvx_item_lengths;
 typedef struct {
     const float* x;  int32_t B, Cin, Lin;
     const float* Wp; const float* bias;
@@ -250,6 +258,7 @@ typedef struct {
     int32_t ksize, dil, pad, up;
     float in_slope;
     const float* res; const float* accum; float out_scale;
+    cvx_item_lengths items;                      /* ragged batch (valid OUTPUT positions per item) or {NULL, 0, 0} */
 } cvx_conv_args;
 int     cvx_hifigan_conv1d_f32(const cvx_conv_args* a, cvx_stream_t s);
 /* number of floats of the packed weight for (Cout, Cin, ksize) */
@@ -311,6 +320,7 @@ typedef struct {
      * it; res / accum / out_x are true fp32 values.  Keeps the split pairs inside fp16's full-precision window whatever
      * the magnitude of the stage's activations (cvx_amax_pow2_scale_f32 measures it from the stage input). */
     const float* z_scale_dev;
+    cvx_item_lengths items;                      /* ragged batch (valid positions per item, of L) or {NULL, 0, 0} */
 } cvx_conv16_args;
 int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s);
 
@@ -335,6 +345,7 @@ typedef struct {
     float* xb; uint16_t *zb_hi, *zb_lo;
     const float* accum; float* out; float out_scale;
     const float* z_scale_dev;
+    cvx_item_lengths items;                      /* ragged batch (valid positions per item, of L) or {NULL, 0, 0} */
 } cvx_resblock16_args;
 int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stream_t s);
 
@@ -353,6 +364,7 @@ typedef struct {
     const float* accum; float* out; float out_scale;
     const float* z_scale_dev;
     int32_t flags;      /* 0; bit 0 (dev A/B): Np = 64 on 128-row tiles, two blocks per CU, instead of 256-row tiles, one per CU */
+    cvx_item_lengths items;                      /* ragged batch (valid positions per item, of L) or {NULL, 0, 0} */
 } cvx_respair16_args;
 int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_stream_t s);
 

@@ -46,6 +46,10 @@ class GemmSplitIO(C.Structure):
     ]
 
 
+class ItemLengths(C.Structure):
+    _fields_ = [("item_len_dev", C.c_void_p), ("mul", C.c_int32), ("add", C.c_int32)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("B", C.c_int32), ("Cin", C.c_int32), ("Lin", C.c_int32),
@@ -54,6 +58,7 @@ class ConvArgs(C.Structure):
         ("ksize", C.c_int32), ("dil", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32),
         ("in_slope", C.c_float),
         ("res", C.c_void_p), ("accum", C.c_void_p), ("out_scale", C.c_float),
+        ("items", ItemLengths),
     ]
 
 
@@ -66,6 +71,7 @@ class Conv16Args(C.Structure):
         ("res", C.c_void_p), ("accum", C.c_void_p), ("out_x", C.c_void_p), ("out_scale", C.c_float),
         ("out_zhi", C.c_void_p), ("out_zlo", C.c_void_p), ("z_slope", C.c_float),
         ("z_scale_dev", C.c_void_p),
+        ("items", ItemLengths),
     ]
 
 
@@ -82,7 +88,7 @@ class Resblock16Args(C.Structure):
                 ("xa", C.c_void_p), ("za_hi", C.c_void_p), ("za_lo", C.c_void_p),
                 ("xb", C.c_void_p), ("zb_hi", C.c_void_p), ("zb_lo", C.c_void_p),
                 ("accum", C.c_void_p), ("out", C.c_void_p), ("out_scale", C.c_float),
-                ("z_scale_dev", C.c_void_p)]
+                ("z_scale_dev", C.c_void_p), ("items", ItemLengths)]
 
 
 class Respair16Args(C.Structure):
@@ -91,7 +97,7 @@ class Respair16Args(C.Structure):
                 ("c1", Conv16Weights), ("c2", Conv16Weights),
                 ("ksize", C.c_int32), ("dil", C.c_int32),
                 ("accum", C.c_void_p), ("out", C.c_void_p), ("out_scale", C.c_float),
-                ("z_scale_dev", C.c_void_p), ("flags", C.c_int32)]
+                ("z_scale_dev", C.c_void_p), ("flags", C.c_int32), ("items", ItemLengths)]
 
 
 class T2SLayer(C.Structure):

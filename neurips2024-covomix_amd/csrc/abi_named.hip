@@ -87,7 +87,7 @@ extern "C" int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stre
         for (int m = 0; m < 3; ++m) {
             cvx_respair16_args r{};
             r.x = cur; r.B = a->B; r.L = a->L; r.Lp = a->Lp; r.Np = a->Np; r.halo_l = a->halo_l;
-            r.c1 = a->c1[m]; r.c2 = a->c2[m]; r.ksize = a->ksize; r.dil = a->dil[m]; r.z_scale_dev = a->z_scale_dev;
+            r.c1 = a->c1[m]; r.c2 = a->c2[m]; r.ksize = a->ksize; r.dil = a->dil[m]; r.z_scale_dev = a->z_scale_dev; r.items = a->items;
             r.out_scale = 1.0f;
             if (m < 2) r.out = (m == 0) ? a->xa : a->xb;
             else { r.out = a->out; r.accum = a->accum; r.out_scale = a->out_scale; }
@@ -105,7 +105,7 @@ extern "C" int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stre
         CVX_REQUIRE(a->c1[m].w_hi && a->c2[m].w_hi && a->dil[m] > 0, "hifigan_resblock_f16x3: missing weights / dilation of pair %d", m);
         cvx_conv16_args c{};
         c.B = a->B; c.L = a->L; c.Lp = a->Lp; c.Cp_in = a->Np; c.halo_l = a->halo_l; c.Np = a->Np; c.ksize = a->ksize;
-        c.z_slope = 0.1f; c.out_scale = 1.0f; c.z_scale_dev = a->z_scale_dev;
+        c.z_slope = 0.1f; c.out_scale = 1.0f; c.z_scale_dev = a->z_scale_dev; c.items = a->items;
         // t = split(leaky_relu(c1(z)))                                     models.py:36-38
         c.z_hi = cur_zh; c.z_lo = cur_zl; c.dil = a->dil[m];
         c.w_hi = a->c1[m].w_hi; c.w_lo = a->c1[m].w_lo; c.acc_scale = a->c1[m].acc_scale; c.bias = a->c1[m].bias;

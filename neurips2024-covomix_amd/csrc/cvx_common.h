@@ -49,6 +49,12 @@ __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 
 typedef const f32x4 __attribute__((address_space(1)))* cvx_gptr4;
 __device__ __forceinline__ f32x4 gload4(const float* p) { return *reinterpret_cast<cvx_gptr4>(reinterpret_cast<uintptr_t>(p)); }
 
+// valid positions of item b in a ragged vocoder batch (cvx_item_lengths in the header), at most the common length L
+__device__ __forceinline__ int cvx_item_len(const cvx_item_lengths& it, int b, int L)
+{
+    return it.item_len_dev ? min(L, max(0, it.item_len_dev[b] * it.mul + it.add)) : L;
+}
+
 // max |.| bookkeeping of the values a lane stores as split pairs, and the commit (one atomic, only when saturated)
 __device__ __forceinline__ float cvx_amax4(float m, const f32x4 v)
 {

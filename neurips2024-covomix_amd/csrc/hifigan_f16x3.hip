@@ -47,6 +47,7 @@ struct Conv16Args {
     float acc_scale, out_scale, z_slope;
     const float* z_scale;              // device scalar (power of two) carried by z and applied to out_z, or NULL = 1
     uint32_t* sat;                     // sticky saturation flag of the device (cvx_common.h) or NULL
+    cvx_item_lengths items;            // ragged batch: valid positions per item (zeros are written behind them)
 };
 
 template <int TMI, int TNI, int WN>
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     float amax = 0.f;
     const int l0 = blockIdx.x * TMB;
     const int b = blockIdx.y;
+    const int Lb = cvx_item_len(p.items, b, p.L);
     const int n_chunks = p.Cp_in / CK;
     const int n_groups = (p.ksize + TS - 1) / TS;
     const int steps = n_chunks * n_groups;
@@ -194,6 +196,8 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += r4[e];
                 }
+                if (l >= Lb) v = f32x4{0.f, 0.f, 0.f, 0.f};      // behind a shorter item's end: the zero padding a B = 1 run sees
+
                 if (p.out_x) {
                     f32x4 w = v;
                     if (p.accum) {
@@ -252,6 +256,7 @@ struct PairArgs {
     float acc1, acc2, out_scale, slope;
     const float* z_scale;
     uint32_t* sat;                     // sticky saturation flag of the device or NULL
+    cvx_item_lengths items;            // ragged batch: valid positions per item (zeros are written behind them)
 };
 
 // (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
     PSTAMP(0)
     for (; tile < p.n_tiles; tile += gridDim.x) {
         const int b = tile / p.tiles_per_seq, l0 = (tile - b * p.tiles_per_seq) * tm_out;
+        const int Lb = cvx_item_len(p.items, b, p.L);
         const int next_tile = tile + gridDim.x;
         const bool has_next = next_tile < p.n_tiles;
 
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
                 quad_transpose(v0, v1, v2, v3, lane);
                 const int row = wm * 32 + 8 * rg + 4 * g + q;
                 const int pos = l0 - h2 + row;
-                const bool inside = pos >= 0 && pos < p.L;
+                const bool inside = pos >= 0 && pos < Lb;
                 const float sp = inside ? zs : 0.f, sn = inside ? zs_neg : 0.f;
                 f32x4 v = {fmaf(v0, a1, bv[0]), fmaf(v1, a1, bv[1]), fmaf(v2, a1, bv[2]), fmaf(v3, a1, bv[3])};
 #pragma unroll
@@ -478,6 +484,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += a4[e];
                 }
+                if (l >= Lb) v = f32x4{0.f, 0.f, 0.f, 0.f};      // behind a shorter item's end
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
                 *reinterpret_cast<f32x4*>(p.out + o) = v;
@@ -587,7 +594,7 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
                  reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
                  a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev,
-                 a->out_zhi ? cvx_sat_flag_dev() : nullptr};
+                 a->out_zhi ? cvx_sat_flag_dev() : nullptr, a->items};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     if (a->Np == 256) {
         // one block per CU: when the 256-position tiles leave more than a quarter of the chip idle in their last (or only)
@@ -628,7 +635,7 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
     PairArgs k{a->x, reinterpret_cast<const f16*>(a->c1.w_hi), reinterpret_cast<const f16*>(a->c1.w_lo),
                reinterpret_cast<const f16*>(a->c2.w_hi), reinterpret_cast<const f16*>(a->c2.w_lo), a->c1.bias, a->c2.bias,
                a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
-               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_dev()};
+               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_dev(), a->items};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const int cus = cvx_device_cus();
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU

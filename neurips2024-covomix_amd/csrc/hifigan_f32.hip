@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const cvx_conv_args
     const int l0 = blockIdx.x * LT;
     const int b = blockIdx.z;
     if (l0 >= Lm) return;
+    const int Lvalid = cvx_item_len(pin.items, b, pin.Lout);    // ragged batch: zeros behind this item's last output
     const int halo = (p.ksize - 1) * p.dil;
     const int xw = LT + halo;                                   // staged positions per channel
     const int64_t Lv = (int64_t)(p.Lin - 1) * p.up + 1;         // virtual (zero-stuffed) length
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const cvx_conv_args
                 if (p.res) v += p.res[o];
                 if (p.accum) v += p.accum[o];
                 v *= p.out_scale;
+                if (l * ostride + ooff >= Lvalid) v = 0.f;
                 p.out[o] = v;
                 vmax = fmaxf(vmax, fabsf(v));
             }

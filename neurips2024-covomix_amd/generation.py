@@ -320,20 +320,22 @@ def run(dialogue: bool, argv=None) -> int:
         else:
             sampled = model.synthesis_sample(phoneme_ids=[items[i][0].to(device) for i in batch], cond=[items[i][1].to(device) for i in batch],
                                              mask=[items[i][2] for i in batch], cond_scale=COND_SCALE, y0=y0)
-        # vocoder: utterances of the batch with the same number of generated frames go through HiFi-GAN together; one
-        # device-to-host copy per group
+        # vocoder: the generated frames of every utterance of the batch (:299-300: mask is a suffix) go through HiFi-GAN in
+        # ONE ragged call (zero-padded to the longest, per-item lengths: every item gets its B = 1 waveform); one int16 cast
+        # and one device-to-host copy per batch, sliced per utterance on the host
         n_prompt = [int((~items[i][2]).sum()) for i in batch]
-        groups = {}
-        for j, i in enumerate(batch):
-            if lengths[i] - n_prompt[j] > 0:
-                groups.setdefault(lengths[i] - n_prompt[j], []).append(j)
-        for tgen, js in groups.items():
-            mel = torch.stack([sampled[j][n_prompt[j]:, :].T for j in js]).contiguous()   # [g, 80, Tgen] (:299-300: mask is a suffix)
-            pcm = ops.wav_to_int16(generator(mel).squeeze(1).contiguous()).cpu().numpy()   # mel_decode_to_wav (:52-59), batched
-            frames += mel.shape[0] * mel.shape[2]
+        js = [j for j, i in enumerate(batch) if lengths[i] - n_prompt[j] > 0]
+        if js:
+            tgen = [lengths[batch[j]] - n_prompt[j] for j in js]
+            mel = torch.zeros(len(js), n_out, max(tgen), dtype=torch.float32, device=device)
+            for r, j in enumerate(js):
+                mel[r, :, : tgen[r]] = sampled[j][n_prompt[j]:, :].T
+            wav = generator(mel, lengths=tgen) if len(set(tgen)) > 1 else generator(mel)
+            pcm = ops.wav_to_int16(wav.squeeze(1).contiguous()).cpu().numpy()              # mel_decode_to_wav (:52-59), batched
+            frames += sum(tgen)
             for r, j in enumerate(js):
                 n, seg = owner[batch[j]]
-                segments[n][seg] = pcm[r]
+                segments[n][seg] = pcm[r, : generator.output_length(tgen[r])].copy()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     for n in mine:

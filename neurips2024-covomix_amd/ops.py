@@ -398,9 +398,19 @@ def time_fourier(times: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> tor
     return out
 
 
+def _items(dst, items) -> None:
+    """Fill a cvx_item_lengths field: items = (int32 CUDA tensor of per-item mel frames, mul, add) or None."""
+    if items is None:
+        dst.item_len_dev, dst.mul, dst.add = None, 0, 0
+        return
+    t, mul, add = items
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    dst.item_len_dev, dst.mul, dst.add = t.data_ptr(), int(mul), int(add)
+
+
 def hifigan_conv1d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
                    cout: int, ksize: int, dil: int = 1, pad: int = 0, up: int = 1, in_slope: float = 1.0,
-                   res=None, accum=None, out_scale: float = 1.0) -> torch.Tensor:
+                   res=None, accum=None, out_scale: float = 1.0, items=None) -> torch.Tensor:
     _chk_f32(x, wp, bias, out, res, accum)
     B, Cin, Lin = x.shape
     assert x.is_contiguous() and out.is_contiguous() and out.shape[0] == B and out.shape[1] == cout
@@ -411,6 +421,7 @@ def hifigan_conv1d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tenso
     a.ksize, a.dil, a.pad, a.up = ksize, dil, pad, up
     a.in_slope = in_slope
     a.res, a.accum, a.out_scale = _p(res), _p(accum), out_scale
+    _items(a.items, items)
     _lib.check(_lib.load().cvx_hifigan_conv1d_f32(C.byref(a), _stream()), "cvx_hifigan_conv1d_f32")
     return out
 
@@ -442,7 +453,8 @@ def hifigan_pack_conv_transpose1d(w: torch.Tensor, stride: int, padding: int) ->
 
 
 def hifigan_conv_transpose1d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, cout: int, ksize: int,
-                             stride: int, padding: int, in_slope: float = 1.0, amax_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             stride: int, padding: int, in_slope: float = 1.0, amax_bits: Optional[torch.Tensor] = None,
+                             items=None) -> torch.Tensor:
     """out = ConvTranspose1d(leaky_relu(x, in_slope)) in polyphase form; amax_bits (int32[1] on the device, zero): receives the
     bit pattern of max|out| (pow2_scale_from_amax turns it into an activation pre-scale and zeroes it)."""
     _chk_f32(x, wp, bias, out)
@@ -454,6 +466,7 @@ def hifigan_conv_transpose1d(x: torch.Tensor, wp: torch.Tensor, bias: Optional[t
     a.out, a.Cout, a.Lout = out.data_ptr(), cout, out.shape[2]
     a.ksize, a.dil, a.pad, a.up = ksize, 1, ksize - 1 - padding, stride
     a.in_slope, a.out_scale = in_slope, 1.0
+    _items(a.items, items)
     _lib.check(_lib.load().cvx_hifigan_conv_transpose1d_f32(C.byref(a), _p(amax_bits), _stream()), "cvx_hifigan_conv_transpose1d_f32")
     return out
 
@@ -498,7 +511,7 @@ def amax_pow2_scale(x: torch.Tensor, target: float, scale: torch.Tensor, scratch
 
 
 def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, res=None, accum=None, out_x=None,
-                         out_scale: float = 1.0, out_z=None, z_slope: float = 0.1, z_scale=None) -> None:
+                         out_scale: float = 1.0, out_z=None, z_slope: float = 0.1, z_scale=None, items=None) -> None:
     """z = (hi, lo) channels-last [B, Lp, Cp_in]; wpk from hifigan_pack_weight_f16x3; bias [Np] (zero padded)."""
     zh, zl = z
     w_hi, w_lo, inv, np_, cp = wpk
@@ -520,10 +533,12 @@ def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, 
         a.out_zhi, a.out_zlo = None, None
     a.z_slope = z_slope
     a.z_scale_dev = _sp(z_scale)
+    _items(a.items, items)
     _lib.check(_lib.load().cvx_hifigan_conv1d_f16x3(C.byref(a), _stream()), "cvx_hifigan_conv1d_f16x3")
 
 
-def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, accum=None, out=None, out_scale: float = 1.0, z_scale=None) -> None:
+def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, accum=None, out=None, out_scale: float = 1.0, z_scale=None,
+                           items=None) -> None:
     """One ResBlock1 (three conv pairs) through the operator-level C entry point cvx_hifigan_resblock_f16x3.
     block: list of 3 (c1, c2) pairs of objects with .w16 = hifigan_pack_weight_f16x3(...), .bias16, .k, .dil;
     scratch: dict with t, rz0, rz1 (split pairs) and r0, r1 (fp32), all [B, Lp, Np] like x_cl / z."""
@@ -548,10 +563,12 @@ def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, acc
         a.zb_hi, a.zb_lo = scratch["rz1"][0].data_ptr(), scratch["rz1"][1].data_ptr()
     a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
     a.z_scale_dev = _sp(z_scale)
+    _items(a.items, items)
     _lib.check(_lib.load().cvx_hifigan_resblock_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_f16x3")
 
 
-def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None, out_scale: float = 1.0, z_scale=None, flags: int = 0) -> None:
+def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None, out_scale: float = 1.0, z_scale=None, flags: int = 0,
+                                items=None) -> None:
     """out = (c2(lrelu(c1(lrelu(x)))) + x (+ accum)) * out_scale as one kernel (cvx_hifigan_resblock_pair_f16x3; Np = 32 / 64).
     x_cl / out / accum: fp32 channels-last [B, Lp, Np]; c1, c2: objects with .w16, .bias16, .k, .dil (c2.dil == 1)."""
     a = _lib.Respair16Args()
@@ -566,6 +583,7 @@ def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None
     a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
     a.z_scale_dev = _sp(z_scale)
     a.flags = flags
+    _items(a.items, items)
     _lib.check(_lib.load().cvx_hifigan_resblock_pair_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_pair_f16x3")
 
 

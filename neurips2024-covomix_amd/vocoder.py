@@ -163,26 +163,46 @@ class Generator:
 
     # ---- forward ------------------------------------------------------------------------
     def _run(self, c: _Conv, x: torch.Tensor, out: Optional[torch.Tensor] = None, *, in_slope=1.0, res=None,
-             accum=None, out_scale=1.0) -> torch.Tensor:
+             accum=None, out_scale=1.0, items=None) -> torch.Tensor:
         B, _, lin = x.shape
         lout = (lin - 1) * c.up + 1 + 2 * c.pad - (c.k - 1) * c.dil
         if out is None:
             out = torch.empty(B, c.cout, lout, dtype=torch.float32, device=x.device)
         return ops.hifigan_conv1d(x, c.wp, c.bias, out, cout=c.cout, ksize=c.k, dil=c.dil, pad=c.pad, up=c.up,
-                                  in_slope=in_slope, res=res, accum=accum, out_scale=out_scale)
+                                  in_slope=in_slope, res=res, accum=accum, out_scale=out_scale, items=items)
+
+    @staticmethod
+    def _affine(c: _Conv, mul: int, add: int) -> tuple:
+        """Output length of convolution c as a function of the item's mel frames T, given its input length mul * T + add."""
+        # lout = (lin - 1) * up + 1 + 2 * pad - (k - 1) * dil
+        return mul * c.up, (add - 1) * c.up + 1 + 2 * c.pad - (c.k - 1) * c.dil
+
+    def output_length(self, frames: int) -> int:
+        """Samples the generator returns for a mel of `frames` frames."""
+        if self._packed is None:
+            self._pack()
+        mul, add = 1, 0
+        for c in [self._packed["pre"]] + self._packed["ups"]:
+            mul, add = self._affine(c, mul, add)
+        return mul * frames + add
 
     @torch.no_grad()
-    def __call__(self, mel: torch.Tensor) -> torch.Tensor:
-        """The split-precision stages keep their activations within 2^6 of the measured max|x| of the stage input; when a
+    def __call__(self, mel: torch.Tensor, lengths=None) -> torch.Tensor:
+        """mel [B, 80, T] -> [B, 1, L]  ([80, T] -> [1, L]), models.py:100-116.
+        lengths (extension, ragged batch): item b only has lengths[b] <= T valid frames (the rest of its mel must be zero
+        padding); its first output_length(lengths[b]) samples are then exactly what a B = 1 call on its own frames returns
+        (every kernel writes zeros behind a shorter item's end - the zero padding the B = 1 run sees there), the samples
+        behind them are unspecified.  `ragged()` wraps the padding and slicing.
+        The split-precision stages keep their activations within 2^6 of the measured max|x| of the stage input; when a
         ResBlock intermediate outgrows that, the kernels clamp and raise the device's sticky saturation flag
         (include/covomix_hip.h).  One flag read per call; a flagged call is re-run on the all-fp32 kernels (or raises:
         CVX_ON_SATURATION=raise) - never returned as is."""
         checked = self.precision != "fp32" and os.environ.get("CVX_SAT_CHECK", "1") == "1" and self.device.type == "cuda"
         if not checked:
-            return self._forward(mel)
+            return self._forward(mel, lengths)
         with torch.cuda.device(self.device):
             ops.saturation_reset()
-            y = self._forward(mel)
+            y = self._forward(mel, lengths)
             if not ops.saturation_query():
                 return y
         msg = ("covomix_amd: the split-precision vocoder stages saturated (an intermediate left the fp16 window around the "
@@ -195,9 +215,22 @@ class Generator:
             twin = Generator(self.h, precision="fp32").to(self.device)
             twin._sd, twin._has_weight_norm = self._sd, self._has_weight_norm
             self._fp32_twin = twin
-        return self._fp32_twin._forward(mel)
+        return self._fp32_twin._forward(mel, lengths)
 
-    def _forward(self, mel: torch.Tensor) -> torch.Tensor:
+    @torch.no_grad()
+    def ragged(self, mels) -> list:
+        """mels: list of [80, T_b] tensors of different length -> list of [1, L_b] waveforms from ONE batched call (each
+        equal to generator(mels[b]) up to fp32 summation order)."""
+        if not mels:
+            return []
+        T = [int(m.shape[-1]) for m in mels]
+        pad = torch.zeros(len(mels), mels[0].shape[0], max(T), dtype=torch.float32, device=self.device)
+        for b, m in enumerate(mels):
+            pad[b, :, : T[b]] = m
+        y = self(pad, lengths=T) if len(set(T)) > 1 else self(pad)
+        return [y[b, :, : self.output_length(T[b])] for b in range(len(mels))]
+
+    def _forward(self, mel: torch.Tensor, lengths=None) -> torch.Tensor:
         if self._packed is None:
             self._pack()
         pk = self._packed
@@ -206,9 +239,17 @@ class Generator:
         if unbatched:
             x = x.unsqueeze(0)
         x = x.contiguous()
-        x = self._run(pk["pre"], x)
+        lens, mul, add = None, 1, 0               # ragged batch: item b is valid on mul * lens[b] + add positions of x
+        if lengths is not None:
+            if len(lengths) != x.shape[0] or min(lengths) < 1 or max(lengths) > x.shape[2]:
+                raise ValueError(f"lengths must hold one frame count in [1, {x.shape[2]}] per batch item")
+            lens = torch.tensor([int(t) for t in lengths], dtype=torch.int32, device=self.device)
+        it = lambda: None if lens is None else (lens, mul, add)
+        mul, add = self._affine(pk["pre"], mul, add)
+        x = self._run(pk["pre"], x, items=it())
         for i in range(self.num_upsamples):
             up = pk["ups"][i]
+            mul, add = self._affine(up, mul, add)
             split = all(c.w16 is not None for block in pk["res"][i] for pair in block for c in pair)
             if up.wp_poly is not None:                                      # leaky_relu + ConvTranspose1d (polyphase)
                 B, _, lin = x.shape
@@ -216,14 +257,14 @@ class Generator:
                 buf = self._cl_buffers(B, up.cout, lout) if split and self.act_scales else None
                 y = torch.empty(B, up.cout, lout, dtype=torch.float32, device=x.device)
                 x = ops.hifigan_conv_transpose1d(x, up.wp_poly, up.bias, y, cout=up.cout, ksize=up.k, stride=up.up, padding=up.padding,
-                                                 in_slope=LRELU_SLOPE, amax_bits=buf["zs_scratch"] if buf is not None else None)
+                                                 in_slope=LRELU_SLOPE, amax_bits=buf["zs_scratch"] if buf is not None else None, items=it())
                 if split:
-                    x = self._resblocks_f16x3(pk["res"][i], x, measured=buf is not None)
+                    x = self._resblocks_f16x3(pk["res"][i], x, measured=buf is not None, items=it())
                     continue
             else:
-                x = self._run(up, x, in_slope=LRELU_SLOPE)
+                x = self._run(up, x, in_slope=LRELU_SLOPE, items=it())
                 if split:
-                    x = self._resblocks_f16x3(pk["res"][i], x)
+                    x = self._resblocks_f16x3(pk["res"][i], x, items=it())
                     continue
             t = torch.empty_like(x)
             r = torch.empty_like(x)
@@ -232,13 +273,13 @@ class Generator:
             for j, block in enumerate(pk["res"][i]):
                 cur = x
                 for m, (c1, c2) in enumerate(block):
-                    self._run(c1, cur, t, in_slope=LRELU_SLOPE)
+                    self._run(c1, cur, t, in_slope=LRELU_SLOPE, items=it())
                     if m + 1 < len(block):
-                        self._run(c2, t, r, in_slope=LRELU_SLOPE, res=cur)
+                        self._run(c2, t, r, in_slope=LRELU_SLOPE, res=cur, items=it())
                         cur = r
                     else:                                                    # last pair: fold into xs
                         self._run(c2, t, xs, in_slope=LRELU_SLOPE, res=cur, accum=xs if j > 0 else None,
-                                  out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0)
+                                  out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, items=it())
             x = xs
         B, _, L = x.shape
         y = torch.empty(B, 1, L, dtype=torch.float32, device=x.device)
@@ -271,7 +312,7 @@ class Generator:
             self._cl[key] = buf
         return buf
 
-    def _resblocks_f16x3(self, blocks, x: torch.Tensor, measured: bool = False) -> torch.Tensor:
+    def _resblocks_f16x3(self, blocks, x: torch.Tensor, measured: bool = False, items=None) -> torch.Tensor:
         """xs = sum_j ResBlock1_j(x) / num_kernels  (models.py:104-110, :35-42) for one upsampling stage."""
         B, C, L = x.shape
         buf = self._cl_buffers(B, C, L)
@@ -290,31 +331,31 @@ class Generator:
         for j, block in enumerate(blocks):
             if len(block) == 3:                   # one C call per ResBlock: cvx_hifigan_resblock_f16x3 (6 launches, or 3 fused pairs)
                 ops.hifigan_resblock_f16x3(buf["x0"], buf.get("z0"), block, B, L, buf, accum=buf["xs"] if j > 0 else None, out=buf["xs"],
-                                           out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
+                                           out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs, items=items)
                 continue
             if narrow:                            # other dilation counts: pair by pair
                 cur = buf["x0"]
                 for m, (c1, c2) in enumerate(block):
                     if m + 1 < len(block):
                         nxt = buf["r0"] if m % 2 == 0 else buf["r1"]
-                        ops.hifigan_resblock_pair_f16x3(cur, c1, c2, B, L, nxt, z_scale=zs)
+                        ops.hifigan_resblock_pair_f16x3(cur, c1, c2, B, L, nxt, z_scale=zs, items=items)
                         cur = nxt
                     else:
                         ops.hifigan_resblock_pair_f16x3(cur, c1, c2, B, L, buf["xs"], accum=buf["xs"] if j > 0 else None,
-                                                        out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
+                                                        out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs, items=items)
                 continue
             cur_x, cur_z = buf["x0"], buf["z0"]   # other dilation counts: convolution by convolution
             for m, (c1, c2) in enumerate(block):
-                ops.hifigan_conv1d_f16x3(cur_z, c1.w16, c1.bias16, B, L, ksize=c1.k, dil=c1.dil, out_z=buf["t"], z_slope=LRELU_SLOPE, z_scale=zs)
+                ops.hifigan_conv1d_f16x3(cur_z, c1.w16, c1.bias16, B, L, ksize=c1.k, dil=c1.dil, out_z=buf["t"], z_slope=LRELU_SLOPE, z_scale=zs, items=items)
                 if m + 1 < len(block):
                     ox, oz = (buf["r0"], buf["rz0"]) if m % 2 == 0 else (buf["r1"], buf["rz1"])
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x, out_x=ox,
-                                             out_z=oz, z_slope=LRELU_SLOPE, z_scale=zs)
+                                             out_z=oz, z_slope=LRELU_SLOPE, z_scale=zs, items=items)
                     cur_x, cur_z = ox, oz
                 else:
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x,
                                              accum=buf["xs"] if j > 0 else None, out_x=buf["xs"],
-                                             out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs)
+                                             out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs, items=items)
         out = torch.empty_like(x)
         return ops.hifigan_from_channels_last(buf["xs"], out)
 

@@ -225,3 +225,32 @@ def test_ragged_full_width_16_utterances_vs_b1_and_oracle():
         e = rel_l2(o, ref)
         print(f"  T = {lengths[i]}: rel-L2 vs the oracle (4 NFE) {e:.3e}")
         assert e < 1e-5
+
+
+@pytest.mark.parametrize("c0,precision", [(500, "f16x3"), (64, "f16x3"), (64, "fp32")])
+def test_vocoder_ragged_batch_vs_b1_and_oracle(c0, precision):
+    """HiFi-GAN on items of different length in ONE batched call (per-item lengths: every kernel writes zeros behind a shorter
+    item's end, the zero padding its B = 1 run sees there): each waveform against its own B = 1 call and the CPU oracle."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    from covomix_amd.vocoder import AttrDict, Generator
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    h["upsample_initial_channel"] = c0
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    gen = Generator(AttrDict(h), precision=precision).to("cuda:0")
+    gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
+    folded = orc.fold_weight_norm(vsd)
+    T = [57, 120, 3, 88, 119]
+    g = torch.Generator().manual_seed(c0)
+    mels = [(torch.randn(80, t, generator=g) * 2 - 6).clamp(-11.52, 2.0) for t in T]
+    # a longer call first: the cached channels-last buffers then hold stale rows behind every item's end
+    gen((torch.randn(len(T), 80, max(T), generator=g) * 2 - 6).cuda())
+    wavs = gen.ragged([m.cuda() for m in mels])
+    for t, m, w in zip(T, mels, wavs):
+        single = gen(m.cuda())
+        ref = orc.hifigan_forward(folded, h, m[None])[0]
+        assert w.shape == single.shape == ref.shape == (1, gen.output_length(t))
+        e1, e2 = rel_l2(w, single), rel_l2(w, ref)
+        assert e1 < 1e-6 and e2 < 1e-5, (c0, precision, t, e1, e2)
+    with pytest.raises(ValueError):
+        gen(torch.zeros(2, 80, 10).cuda(), lengths=[10, 11])

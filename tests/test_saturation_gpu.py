@@ -79,7 +79,7 @@ def test_flag_is_raised_by_every_family_of_split_stores(ops):
     vt[0][:, slots] = ah[:, 128:].T; vt[1][:, slots] = al[:, 128:].T
     op = (torch.empty(T, 64, dtype=torch.float16, device=dev_), torch.empty(T, 64, dtype=torch.float16, device=dev_))
     assert flagged(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=op)) == 0
-    assert flagged(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=op, out_scale=one(2.0 ** 18))) != 0
+    assert flagged(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=op, out_scale=one(2.0 ** 26))) != 0
 
 
 def _full_width_state(kind="vomix"):
