@@ -446,6 +446,14 @@ typedef struct {
 } cvx_t2s_decoder;
 
 int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream_t stream);
+/* The same n_steps token steps as ONE persistent launch (one block per CU): phase boundaries are grid barriers instead of
+ * kernel boundaries and every wave requests the weight rows of its next phase before it waits, so a step no longer pays
+ * 8 * depth + 2 launch gaps and exposed weight round trips.  Same device code per phase: logits and tokens are
+ * bit-identical to cvx_t2s_decode_steps.  sync_ws_dev: 2 uint32 of DEVICE memory owned by the caller for the duration of
+ * the launch (zeroed by the call): [0] barrier counter, [1] error word - non-zero after the launch means a barrier timed
+ * out (some block was not resident: another kernel held its CU for > 0.1 s) and the step results are invalid; the kernel
+ * always terminates.  Needs heads * batch <= the device's CU count. */
+int cvx_t2s_decode_persistent(const cvx_t2s_decoder* dec, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t stream);
 
 /* out[r, c] = h[r, c] * gelu(h[r, F + c]) for c < F, 0 for F <= c < ld_out   (GEGLU, text2semantic.py:154-157;
  * the encoder's feed-forward; ld_out >= F pads the K dimension of the following GEMM). */

@@ -60,58 +60,64 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <int MODE, int BQ>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float xs[];         // [BQ][Kin] (Kin a multiple of 4)
-    __shared__ float red[BQ][4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per utterance
+constexpr int PF = 4;                                      // 4 x 256 floats per row in flight (K <= 1024 entirely)
 
-    // ---- the two rows of this wave
-    const int pair = blockIdx.x * 4 + wid;
-    int r0, r1, sidx = 0;
-    bool valid;
+// the two rows of row-pair `pair` (the pairs are chosen so that the epilogue has both members of a RoPE pair / a GEGLU
+// (value, gate) pair in one wave)
+template <int MODE>
+__device__ __forceinline__ bool pair_rows(const GemvArgs& a, int pair, int& r0, int& r1, int& sidx)
+{
+    sidx = 0;
     if (MODE == MODE_QKV) {
         // pair p -> head-local (h, i): rows base + h*64 + i and + 32 for i in [0, 32); 3*inner/2 pairs in total
         const int per = a.inner / 2;
         const int sec = pair / per, q = pair - sec * per;             // 0 q, 1 k, 2 v
         r0 = sec * a.inner + (q >> 5) * 64 + (q & 31);
         r1 = r0 + 32;
-        valid = pair < 3 * per;
+        return pair < 3 * per;
     } else if (MODE == MODE_GEGLU) {
         const int F = a.N / 2;
         r0 = pair; r1 = pair + F;
-        valid = pair < F;
+        return pair < F;
     } else if (MODE == MODE_LOGITS) {
         const int per = (a.N + 1) / 2;
         sidx = pair / per;
         r0 = 2 * (pair - sidx * per); r1 = r0 + 1;
-        valid = sidx < a.streams;
-    } else {
-        r0 = 2 * pair; r1 = r0 + 1;
-        valid = r0 < a.N;
+        return sidx < a.streams;
     }
+    r0 = 2 * pair; r1 = r0 + 1;
+    return r0 < a.N;
+}
+
+// the first PF chunks of the two weight rows of a pair: they do not depend on the input vector, so their HBM / MALL round
+// trip can overlap whatever precedes the dot product (staging of x; in the persistent kernel: the grid barrier)
+struct RowPrefetch { f32x4 pa[PF], pb[PF]; };
+template <int MODE>
+__device__ __forceinline__ void prefetch_pair(const GemvArgs& a, int pair, int lane, RowPrefetch& pf)
+{
+    int r0, r1, sidx;
+    const bool valid = pair_rows<MODE>(a, pair, r0, r1, sidx);
     const bool has1 = valid && r1 < a.N;
     const float* w0 = a.W + (int64_t)(valid ? r0 : 0) * a.ldw;
     const float* w1 = a.W + (int64_t)(has1 ? r1 : (valid ? r0 : 0)) * a.ldw;
     const int K4 = a.K & ~3;
-
-    // ---- weights first: they do not depend on the input vector, so their HBM / MALL round trip overlaps the
-    // staging of x below (the step is a chain of 34 dependent launches; every microsecond of latency counts)
-    constexpr int PF = 4;                                  // 4 x 256 floats per row in flight (K <= 1024 entirely)
-    f32x4 pa[PF], pb[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
         const int k = 4 * lane + 256 * i;
-        if (k < K4) { pa[i] = gload4(w0 + k); pb[i] = gload4(w1 + k); }
+        if (k < K4) { pf.pa[i] = gload4(w0 + k); pf.pb[i] = gload4(w1 + k); }
     }
+}
 
-    // ---- stage (and normalise) the input vectors (k outer, utterances inner: the loads of one k are independent)
-    float inv[BQ], ss[BQ];
+// stage (and RMS-normalise) the input vectors of a GEMV into LDS: xs[b][k] = x[b][k] * gamma[k]; inv[b] = the per-vector
+// normalisation factor (1 without gamma).  All threads of the block; contains block barriers.
+template <int BQ>
+__device__ __forceinline__ void stage_input(const GemvArgs& a, int Kin, float* xs, float (*red)[4], float (&inv)[BQ])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float ss[BQ];
 #pragma unroll
     for (int b = 0; b < BQ; ++b) ss[b] = 0.f;
-    for (int k = tid; k < Kin; k += 256) {
+    for (int k = tid; k < Kin; k += 256) {      // (k outer, utterances inner: the loads of one k are independent)
         const float gk = a.gamma ? a.gamma[k] : 1.f;
         float v[BQ];
 #pragma unroll
@@ -136,6 +142,17 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             inv[b] = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize(eps = 1e-12) * sqrt(dim)
         }
     }
+}
+
+// one row pair: dot products with every staged vector (fixed summation order: lane-strided 4-vectors, then the wave
+// reduction - independent of the batch size and of which kernel runs it) + the MODE epilogue (lane 0)
+template <int MODE, int BQ, bool PRE>
+__device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const float* xs, int Kin, const float (&inv)[BQ],
+                                          const RowPrefetch& pf)
+{
+    const int lane = threadIdx.x & 63;
+    int r0, r1, sidx;
+    const bool valid = pair_rows<MODE>(a, pair, r0, r1, sidx);
     if (!valid) {
         if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
             const int F = a.N / 2;
@@ -144,6 +161,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         }
         return;
     }
+    const bool has1 = r1 < a.N;
+    const float* w0 = a.W + (int64_t)r0 * a.ldw;
+    const float* w1 = a.W + (int64_t)(has1 ? r1 : r0) * a.ldw;
+    const int K4 = a.K & ~3;
     const float* xv = xs + ((MODE == MODE_LOGITS) ? sidx * a.K : 0);
     float acc0[BQ], acc1[BQ];
 #pragma unroll
@@ -152,11 +173,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     for (int i = 0; i < PF; ++i) {
         const int k = 4 * lane + 256 * i;
         if (k < K4) {
+            const f32x4 a0 = PRE ? pf.pa[i] : gload4(w0 + k);
+            const f32x4 a1 = PRE ? pf.pb[i] : gload4(w1 + k);
 #pragma unroll
             for (int b = 0; b < BQ; ++b) {
                 const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { acc0[b] = fmaf(pa[i][e], xw[e], acc0[b]); acc1[b] = fmaf(pb[i][e], xw[e], acc1[b]); }
+                for (int e = 0; e < 4; ++e) { acc0[b] = fmaf(a0[e], xw[e], acc0[b]); acc1[b] = fmaf(a1[e], xw[e], acc1[b]); }
             }
         }
     }
@@ -180,33 +203,50 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     const int pos = (MODE == MODE_QKV) ? min(a.state[0], a.max_len - 1) : 0;
 #pragma unroll
     for (int b = 0; b < BQ; ++b) {
-    float s0 = acc0[b], s1 = acc1[b];
-    float* const yb = a.y + (int64_t)b * a.y_stride;
-    if (a.bias) { s0 += a.bias[r0]; if (has1) s1 += a.bias[r1]; }
+        float s0 = acc0[b], s1 = acc1[b];
+        float* const yb = a.y + (int64_t)b * a.y_stride;
+        if (a.bias) { s0 += a.bias[r0]; if (has1) s1 += a.bias[r1]; }
 
-    if (MODE == MODE_QKV) {
-        const int sec = r0 / a.inner, c0 = r0 - sec * a.inner;        // column inside q / k / v
-        if (sec < 2) {                                                // half-split RoPE on the (i, i+32) pair
-            const float c = a.rope_cos[pos * 32 + (c0 & 31)], s = a.rope_sin[pos * 32 + (c0 & 31)];
-            const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
-            s0 = n0; s1 = n1;
+        if (MODE == MODE_QKV) {
+            const int sec = r0 / a.inner, c0 = r0 - sec * a.inner;        // column inside q / k / v
+            if (sec < 2) {                                                // half-split RoPE on the (i, i+32) pair
+                const float c = a.rope_cos[pos * 32 + (c0 & 31)], s = a.rope_sin[pos * 32 + (c0 & 31)];
+                const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
+                s0 = n0; s1 = n1;
+            }
+            float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + b * a.cache_stride + (int64_t)pos * a.inner;
+            dst[c0] = s0;
+            dst[c0 + 32] = s1;
+        } else if (MODE == MODE_RES) {
+            yb[r0] += s0;
+            if (has1) yb[r1] += s1;
+        } else if (MODE == MODE_GEGLU) {
+            yb[r0] = s0 * gelu_erf(s1);                                   // F.gelu(gate) * x, text2semantic.py:154-157
+        } else if (MODE == MODE_LOGITS) {
+            yb[sidx * a.N + r0] = s0;
+            if (has1) yb[sidx * a.N + r1] = s1;
+        } else {
+            yb[r0] = s0;
+            if (has1) yb[r1] = s1;
         }
-        float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + b * a.cache_stride + (int64_t)pos * a.inner;
-        dst[c0] = s0;
-        dst[c0 + 32] = s1;
-    } else if (MODE == MODE_RES) {
-        yb[r0] += s0;
-        if (has1) yb[r1] += s1;
-    } else if (MODE == MODE_GEGLU) {
-        yb[r0] = s0 * gelu_erf(s1);                                   // F.gelu(gate) * x, text2semantic.py:154-157
-    } else if (MODE == MODE_LOGITS) {
-        yb[sidx * a.N + r0] = s0;
-        if (has1) yb[sidx * a.N + r1] = s1;
-    } else {
-        yb[r0] = s0;
-        if (has1) yb[r1] = s1;
     }
-    }
+}
+
+template <int MODE, int BQ>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];         // [BQ][Kin] (Kin a multiple of 4)
+    __shared__ float red[BQ][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per utterance
+    const int pair = blockIdx.x * 4 + wid;                              // every wave owns TWO output rows
+    // weights first: their HBM / MALL round trip overlaps the staging of x below (the step is a chain of 34 dependent
+    // launches; every microsecond of latency counts)
+    RowPrefetch pf;
+    prefetch_pair<MODE>(a, pair, lane, pf);
+    float inv[BQ];
+    stage_input<BQ>(a, Kin, xs, red, inv);
+    gemv_pair<MODE, BQ, true>(a, pair, xs, Kin, inv, pf);
 }
 
 // ---------------------------------------------------------------- attention of ONE query over n cached keys
@@ -222,13 +262,11 @@ struct AttnArgs {
     int max_len;
 };
 
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
+// sc: T2S_MAX_KEYS floats, red: 4 floats, part: 16 x 64 floats (16-byte aligned) of LDS; all 256 threads of the block
+__device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int heads, float* sc, float* red, float (*part)[64])
 {
-    __shared__ float sc[T2S_MAX_KEYS];
-    __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float part[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int h = blockIdx.x, b = blockIdx.y, HD64 = gridDim.x * 64;
+    const int HD64 = heads * 64;
     const int n = a.n_fixed >= 0 ? a.n_fixed
                                  : (a.n_fixed == -1 ? min(a.state[0] + 1, a.max_len) : min(a.state[4 * b + 3], T2S_MAX_KEYS));
     const float* const kb = a.k + b * a.batch_stride;
@@ -277,6 +315,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
+{
+    __shared__ float sc[T2S_MAX_KEYS];
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float part[16][64];
+    attn_body(a, blockIdx.x, blockIdx.y, gridDim.x, sc, red, part);
+}
+
 // ---------------------------------------------------------------- top-k + Gumbel argmax, eos bookkeeping, next input
 struct SampleArgs {
     const float* logits;     // [batch][streams, V]
@@ -290,34 +336,34 @@ struct SampleArgs {
     float inv_temp;
 };
 
-__global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
+// NT threads (a multiple of 64, <= 1024); every thread owns the vocabulary entries tid, tid + NT, ...  The selection is an
+// exact function of the logits and the uniforms (rank counting, then argmax with the lowest index on ties), so it does not
+// depend on NT.  lg: 1024 floats, bv / bi: 16 entries, chosen: one int of LDS.
+template <int NT>
+__device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* lg, float* bv, int* bi, int* chosen)
 {
-    __shared__ float lg[1024];
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    __shared__ int chosen;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int b = blockIdx.x;
     int* const state = a.state + 4 * b;
     const int pos = state[0];
-    if (pos >= a.max_len) return;
+    if (pos >= a.max_len) return;                   // (block-uniform)
     bool eos = false;
     for (int s = 0; s < a.streams; ++s) {
-        if (tid < a.V) lg[tid] = a.logits[((int64_t)b * a.streams + s) * a.V + tid];
+        for (int i = tid; i < a.V; i += NT) lg[i] = a.logits[((int64_t)b * a.streams + s) * a.V + i];
         __syncthreads();
         float val = -INFINITY;
-        if (tid < a.V) {
-            const float me = lg[tid];
+        int idx = tid;
+        for (int i = tid; i < a.V; i += NT) {
+            const float me = lg[i];
             int cnt = 0;
             for (int j = 0; j < a.V; ++j) cnt += (lg[j] > me) ? 1 : 0;
             if (cnt < a.top_k) {
-                const float u = a.uniforms[(((int64_t)pos * a.batch + b) * a.streams + s) * a.V + tid];
+                const float u = a.uniforms[(((int64_t)pos * a.batch + b) * a.streams + s) * a.V + i];
                 const float g = -logf(fmaxf(-logf(fmaxf(u, 1e-20f)), 1e-20f));
-                val = me * a.inv_temp + g;
+                const float v = me * a.inv_temp + g;
+                if (v > val) { val = v; idx = i; }   // (ascending i: the lowest index wins ties)
             }
         }
         // argmax, lowest index on ties (torch.argmax)
-        int idx = tid;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(val, o, 64);
@@ -328,15 +374,15 @@ __global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
         __syncthreads();
         if (tid == 0) {
             float best = bv[0]; int bt = bi[0];
-            for (int w = 1; w < 16; ++w)
+            for (int w = 1; w < NT / 64; ++w)
                 if (bv[w] > best || (bv[w] == best && bi[w] < bt)) { best = bv[w]; bt = bi[w]; }
-            chosen = bt;
+            *chosen = bt;
             a.tokens[((int64_t)b * a.streams + s) * a.max_len + pos] = bt;
         }
         __syncthreads();
-        const int tok = chosen;
+        const int tok = *chosen;
         eos = eos || (tok == a.eos_id);
-        for (int d = tid; d < a.dim_emb; d += 1024)
+        for (int d = tid; d < a.dim_emb; d += NT)
             a.x[((int64_t)b * a.streams + s) * a.dim_emb + d] = a.emb[(int64_t)tok * a.dim_emb + d];
         __syncthreads();
     }
@@ -344,6 +390,15 @@ __global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
         if (eos && state[1] == 0) { state[1] = 1; state[2] = pos + 1; }
         state[0] = pos + 1;
     }
+}
+
+__global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
+{
+    __shared__ float lg[1024];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int chosen;
+    sample_body<1024>(a, blockIdx.x, lg, bv, bi, &chosen);
 }
 
 __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h, float* __restrict__ out, int64_t rows,
@@ -354,6 +409,182 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h,
     const int64_t r = i / ld_out;
     const int c = (int)(i - r * ld_out);
     out[i] = c < F ? h[r * 2 * F + c] * gelu_erf(h[r * 2 * F + F + c]) : 0.f;
+}
+
+
+// ================================================================ persistent decode kernel
+// The per-launch path above is a chain of 8 * depth + 2 dependent launches per token; each costs ~5.7 us on the device
+// (launch gap + one exposed HBM / MALL round trip for the weights + the staging of the input vector), 34 x 5.7 = 194 of
+// the 213 us a CoSingle step takes, for 15 us worth of weight streaming.  Here ONE launch of one block per CU walks all
+// phases of n_steps token steps:
+//   * a phase boundary is a GRID BARRIER (one device-scope atomic per block on a monotonically increasing counter, then a
+//     spin on an acquire load) instead of a kernel boundary;
+//   * before it arrives at the barrier a wave requests the weight rows of ITS first row pair of the NEXT phase
+//     (prefetch_pair: registers), so the weight round trip runs under the barrier wait instead of behind it;
+//   * row pairs are dealt round-robin over all waves of the grid; attention phases run on heads x batch blocks, the sampler
+//     on `batch` blocks; every phase runs the same device code as the per-launch kernels (gemv_pair, attn_body, sample_body),
+//     so logits and tokens are BIT-IDENTICAL to that path (tests/test_t2s_gpu.py).
+// All blocks must be co-resident (the launcher sizes the grid to the CU count; 256 threads and < 64 KiB of LDS per block
+// always fit).  A barrier that is not satisfied within ~2^22 polls raises the error word next to the counter and lets the
+// block run on: the kernel terminates with garbage and the launcher's caller sees the flag - never a hung GPU.
+constexpr int T2S_MAX_DEPTH = 16;
+struct PersistArgs {
+    cvx_t2s_decoder d;
+    cvx_t2s_layer layers[T2S_MAX_DEPTH];
+    unsigned* sync;          // [0] barrier counter (zero at launch), [1] error word
+    int n_steps;
+    int lds_x_floats;        // floats of the staged-input region
+};
+
+struct GridBarrier {
+    unsigned* ctr;
+    unsigned target, nblocks;
+    bool dead;               // a wait timed out: the launch is lost (error word set); stop waiting so that it ends quickly
+    __device__ __forceinline__ void arrive_and_wait()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this thread's global writes -> visible device-wide
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            target += nblocks;
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (!dead && __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22) || ((spins & 1023u) == 0 && __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_fetch_or(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // drop stale L1 / non-local L2 lines before the next phase reads
+    }
+};
+
+template <int MODE, int BQ>
+__device__ __forceinline__ void phase_gemv(const GemvArgs& a, int n_pairs, float* xs, float (*red)[4], int gwave, int n_gwaves,
+                                           const RowPrefetch& pf)
+{
+    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;
+    if (gwave - (int)(threadIdx.x >> 6) >= n_pairs) return;            // no wave of this block has a pair (block-uniform)
+    float inv[BQ];
+    stage_input<BQ>(a, Kin, xs, red, inv);
+    if (gwave < n_pairs) gemv_pair<MODE, BQ, true>(a, gwave, xs, Kin, inv, pf);
+    for (int pair = gwave + n_gwaves; pair < n_pairs; pair += n_gwaves) gemv_pair<MODE, BQ, false>(a, pair, xs, Kin, inv, pf);
+}
+
+template <int BQ>
+__global__ __launch_bounds__(256) void t2s_persistent_kernel(const PersistArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const xs = lds;                                             // [BQ][Kin] of the running GEMV phase
+    float* const sc = lds;                                             // attention: scores (T2S_MAX_KEYS floats) ...
+    float (*const part)[64] = reinterpret_cast<float (*)[64]>(lds + T2S_MAX_KEYS);      // ... + 16 x 64 partial outputs
+    float* const lg = lds;                                             // sampler: 1024 logits
+    __shared__ float red[BQ][4];
+    __shared__ float red4[4];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int chosen;
+
+    const cvx_t2s_decoder& d = P.d;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    const int gwave = bid * 4 + wid, n_gwaves = nblk * 4;
+    GridBarrier bar{P.sync, 0u, (unsigned)nblk, false};
+    const float scale = 0.125f;        // dim_head ** -0.5
+    const int nb = d.batch;
+    const int64_t cache_stride = (int64_t)d.max_len * d.inner;
+
+    auto qkv_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.wqkv_s; g.ldw = d.dim; g.x = d.x; g.x_stride = d.dim; g.gamma = L.gamma_s; g.y = d.q; g.y_stride = d.inner;
+        g.N = 3 * d.inner; g.K = d.dim;
+        g.inner = d.inner; g.rope_cos = d.rope_cos; g.rope_sin = d.rope_sin; g.k_cache = L.k_cache; g.v_cache = L.v_cache;
+        g.cache_stride = cache_stride; g.state = d.state; g.max_len = d.max_len;
+        return g;
+    };
+    auto out_args = [&](const float* W) {                              // to_out of either attention: att -> x (+=)
+        GemvArgs g{};
+        g.W = W; g.ldw = d.inner; g.x = d.att; g.x_stride = d.inner; g.y = d.x; g.y_stride = d.dim; g.N = d.dim; g.K = d.inner;
+        return g;
+    };
+    auto qc_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.wq_c; g.ldw = d.dim; g.x = d.x; g.x_stride = d.dim; g.gamma = L.gamma_c; g.y = d.q; g.y_stride = d.inner;
+        g.N = d.inner; g.K = d.dim;
+        return g;
+    };
+    auto ff1_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.w1; g.ldw = d.dim; g.x = d.x; g.x_stride = d.dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d.h;
+        g.y_stride = d.ff_inner_pad; g.N = 2 * d.ff_inner; g.K = d.dim; g.y_pad = d.ff_inner_pad;
+        return g;
+    };
+    auto ff2_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.w2; g.ldw = d.ff_inner_pad; g.x = d.h; g.x_stride = d.ff_inner_pad; g.bias = L.b2; g.y = d.x; g.y_stride = d.dim;
+        g.N = d.dim; g.K = d.ff_inner_pad;
+        return g;
+    };
+    auto logit_args = [&]() {
+        GemvArgs g{};
+        g.W = d.emb; g.ldw = d.dim_emb; g.x = d.x; g.x_stride = d.dim; g.gamma = d.final_gamma; g.y = d.logits;
+        g.y_stride = d.streams * d.vocab; g.N = d.vocab; g.K = d.dim_emb; g.streams = d.streams;
+        return g;
+    };
+    const int p_qkv = 3 * d.inner / 2, p_out = (d.dim + 1) / 2, p_qc = d.inner / 2, p_ff1 = d.ff_inner_pad,
+              p_logit = d.streams * ((d.vocab + 1) / 2);
+
+    RowPrefetch pf;
+    { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
+    for (int step = 0; step < P.n_steps; ++step) {
+        for (int l = 0; l < d.depth; ++l) {
+            const cvx_t2s_layer& L = P.layers[l];
+            // ---- self-attention: q | k | v with RoPE; k, v appended to the cache at position pos
+            { const GemvArgs g = qkv_args(L); phase_gemv<MODE_QKV, BQ>(g, p_qkv, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = out_args(L.wo_s); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            if (bid < d.heads * nb) {
+                const AttnArgs at{d.q, L.k_cache, L.v_cache, d.inner, cache_stride, d.att, d.state, -1, scale, d.max_len};
+                attn_body(at, bid % d.heads, bid / d.heads, d.heads, sc, red4, part);
+            }
+            bar.arrive_and_wait();
+            { const GemvArgs g = out_args(L.wo_s); phase_gemv<MODE_RES, BQ>(g, p_out, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = qc_args(L); if (gwave < p_qc) prefetch_pair<MODE_PLAIN>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            // ---- cross-attention over [null kv | encoder context]
+            { const GemvArgs g = qc_args(L); phase_gemv<MODE_PLAIN, BQ>(g, p_qc, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = out_args(L.wo_c); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            if (bid < d.heads * nb) {
+                const AttnArgs ac{d.q, L.kv_c, L.kv_c + d.inner, 2 * (int64_t)d.inner, (int64_t)d.ctx_rows * 2 * d.inner, d.att, d.state,
+                                  d.n_ctx > 0 ? d.n_ctx : -2, scale, d.max_len};
+                attn_body(ac, bid % d.heads, bid / d.heads, d.heads, sc, red4, part);
+            }
+            bar.arrive_and_wait();
+            { const GemvArgs g = out_args(L.wo_c); phase_gemv<MODE_RES, BQ>(g, p_out, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = ff1_args(L); if (gwave < p_ff1) prefetch_pair<MODE_GEGLU>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            // ---- GEGLU feed-forward
+            { const GemvArgs g = ff1_args(L); phase_gemv<MODE_GEGLU, BQ>(g, p_ff1, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = ff2_args(L); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            { const GemvArgs g = ff2_args(L); phase_gemv<MODE_RES, BQ>(g, p_out, xs, red, gwave, n_gwaves, pf); }
+            if (l + 1 < d.depth) { const GemvArgs g = qkv_args(P.layers[l + 1]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
+            else { const GemvArgs g = logit_args(); if (gwave < p_logit) prefetch_pair<MODE_LOGITS>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+        }
+        { const GemvArgs g = logit_args(); phase_gemv<MODE_LOGITS, BQ>(g, p_logit, xs, red, gwave, n_gwaves, pf); }
+        bar.arrive_and_wait();
+        if (bid < nb) {
+            const SampleArgs sa{d.logits, d.uniforms, d.emb, d.x, d.tokens, d.state, nb, d.vocab, d.dim_emb, d.streams, d.max_len,
+                                d.top_k, d.vocab - 1, 1.0f / fmaxf(d.temperature, 1e-10f)};
+            sample_body<256>(sa, bid, lg, bv, bi, &chosen);
+        }
+        if (step + 1 < P.n_steps) { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
+        bar.arrive_and_wait();
+    }
 }
 
 template <int MODE, int BQ>
@@ -388,7 +619,7 @@ extern "C" int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F
     return CVX_OK;
 }
 
-extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, cvx_stream_t s)
+static int t2s_validate(const cvx_t2s_decoder* d, int32_t n_steps)
 {
     CVX_REQUIRE(d && d->layers && n_steps >= 0, "t2s_decode: null decoder");
     CVX_REQUIRE(d->dim > 0 && d->dim % 4 == 0 && d->dim <= T2S_MAX_DIM && d->inner == d->heads * 64 && d->depth > 0 &&
@@ -402,6 +633,53 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
                 d->max_len, d->batch);
     CVX_REQUIRE(d->final_gamma && d->emb && d->rope_cos && d->rope_sin && d->uniforms && d->x && d->q && d->att && d->h &&
                 d->logits && d->tokens && d->state, "t2s_decode: null buffer");
+    for (int l = 0; l < d->depth; ++l) {
+        const cvx_t2s_layer& L = d->layers[l];
+        CVX_REQUIRE(L.gamma_s && L.wqkv_s && L.wo_s && L.gamma_c && L.wq_c && L.wo_c && L.kv_c && L.gamma_f && L.w1 && L.b1 &&
+                    L.w2 && L.b2 && L.k_cache && L.v_cache, "t2s_decode: null pointer in layer %d", l);
+    }
+    return CVX_OK;
+}
+
+extern "C" int cvx_t2s_decode_persistent(const cvx_t2s_decoder* d, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t s)
+{
+    const int rc = t2s_validate(d, n_steps);
+    if (rc != CVX_OK) return rc;
+    CVX_REQUIRE(sync_ws_dev && d->depth <= T2S_MAX_DEPTH, "t2s_decode_persistent: needs a 2-word device workspace and depth <= %d", T2S_MAX_DEPTH);
+    if (n_steps == 0) return CVX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    const int grid = cvx_device_cus();                 // one block per CU: all co-resident (grid barrier)
+    CVX_REQUIRE(d->heads * d->batch <= grid, "t2s_decode_persistent: heads x batch = %d exceeds the %d blocks of the grid", d->heads * d->batch, grid);
+    PersistArgs P{};
+    P.d = *d;
+    for (int l = 0; l < d->depth; ++l) P.layers[l] = d->layers[l];
+    P.d.layers = nullptr;                               // (a host pointer: the kernel uses the by-value copy)
+    P.sync = sync_ws_dev;
+    P.n_steps = n_steps;
+    int kin = d->dim > d->inner ? d->dim : d->inner;
+    if (d->ff_inner_pad > kin) kin = d->ff_inner_pad;
+    const int bq = d->batch <= 1 ? 1 : d->batch <= 2 ? 2 : d->batch <= 4 ? 4 : 8;
+    size_t floats = (size_t)bq * kin;
+    if (floats < (size_t)T2S_MAX_KEYS + 16 * 64) floats = (size_t)T2S_MAX_KEYS + 16 * 64;
+    P.lds_x_floats = (int)floats;
+    const size_t lds = floats * sizeof(float);
+    CVX_REQUIRE(lds <= 150 * 1024, "t2s_decode_persistent: %zu bytes of LDS per block", lds);
+    if (hipMemsetAsync(sync_ws_dev, 0, 2 * sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("t2s_decode_persistent: memset failed"); return CVX_EHIP; }
+#define CVX_T2S_PERSIST(BQ_)                                                                                              \
+    do {                                                                                                                  \
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&t2s_persistent_kernel<BQ_>), (int)lds);                      \
+        hipLaunchKernelGGL((t2s_persistent_kernel<BQ_>), dim3((unsigned)grid), dim3(256), lds, st, P);                    \
+    } while (0)
+    if (bq == 1) CVX_T2S_PERSIST(1); else if (bq == 2) CVX_T2S_PERSIST(2); else if (bq == 4) CVX_T2S_PERSIST(4); else CVX_T2S_PERSIST(8);
+#undef CVX_T2S_PERSIST
+    CVX_CHECK_LAUNCH("cvx_t2s_decode_persistent");
+    return CVX_OK;
+}
+
+extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, cvx_stream_t s)
+{
+    const int rc = t2s_validate(d, n_steps);
+    if (rc != CVX_OK) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const float scale = 0.125f;        // dim_head ** -0.5
     const int nb = d->batch;
@@ -409,8 +687,6 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < d->depth; ++l) {
             const cvx_t2s_layer& L = d->layers[l];
-            CVX_REQUIRE(L.gamma_s && L.wqkv_s && L.wo_s && L.gamma_c && L.wq_c && L.wo_c && L.kv_c && L.gamma_f && L.w1 && L.b1 &&
-                        L.w2 && L.b2 && L.k_cache && L.v_cache, "t2s_decode: null pointer in layer %d", l);
             GemvArgs g{};
             // self-attention: q | k | v with RoPE; k, v appended to the cache at position pos
             g.W = L.wqkv_s; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_s; g.y = d->q; g.y_stride = d->inner;

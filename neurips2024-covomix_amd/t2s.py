@@ -7,8 +7,11 @@ forwards to (covomix/conditional_model.py:313-321).  Only what the generation sc
 
   encoder  (source transformer, once per utterance): the full-sequence kernels of the acoustic path - fp32 GEMM with
            the RoPE epilogue, flash attention, RMSNorm - plus a GEGLU kernel;
-  decoder  (one token per step): csrc/t2s_decode.hip through cvx_t2s_decode_steps, 34 launches per step, replayed
-           from a HIP graph of CHUNK steps; the host only looks at the eos flags between chunks.  `generate_batch`
+  decoder  (one token per step): csrc/t2s_decode.hip.  Default: cvx_t2s_decode_persistent - CHUNK token steps as ONE
+           persistent launch (one block per CU, grid barriers between the 34 phases of a step, next-phase weights requested
+           before every barrier wait).  CVX_T2S_PERSISTENT=0: cvx_t2s_decode_steps, 34 launches per step replayed from a HIP
+           graph of CHUNK steps (the same device code per phase: bit-identical logits and tokens).  The host only looks at
+           the eos flags (and the persistent kernel's barrier-timeout word) between chunks.  `generate_batch`
            advances up to MAX_BATCH utterances together (the reference decodes them one by one): a token step is
            bound by streaming the decoder weights, which a batch shares, and the per-utterance arithmetic does not
            depend on the batch size - the tokens are bit-identical to the one-by-one decode.
@@ -117,8 +120,12 @@ class TextToSemanticDecoder:
         self.top_k = math.ceil(TOP_K_THRES * V)
         self.buf = dict(x=f32(MAX_BATCH, d["dim_target"]), q=f32(MAX_BATCH, I), att=f32(MAX_BATCH, I), h=f32(MAX_BATCH, self.Fp),
                         logits=f32(MAX_BATCH, S, V), uniforms=f32(self.max_length * MAX_BATCH * S * V),
-                        tokens=torch.zeros(MAX_BATCH, S, self.max_length, dtype=torch.int64, device=device),
-                        state=torch.zeros(MAX_BATCH, 4, dtype=torch.int32, device=device))
+                        tokens=torch.zeros(MAX_BATCH, S, self.max_length, dtype=torch.int64, device=device))
+        # decode state [MAX_BATCH, 4] + one more row = the persistent kernel's workspace (barrier counter, error word): one
+        # device-to-host copy per chunk brings both
+        self._stsync = torch.zeros(MAX_BATCH + 1, 4, dtype=torch.int32, device=device)
+        self.buf["state"] = self._stsync[:MAX_BATCH]
+        self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "1") == "1
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
             for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
@@ -174,8 +181,30 @@ class TextToSemanticDecoder:
             setattr(dec, n, b[n].data_ptr())
         return dec
 
+    def _steps(self, temperature: float, batch: int, n: int) -> None:
+        """n token steps on the current stream without a graph."""
+        st = torch.cuda.current_stream().cuda_stream
+        if self.persistent:
+            _lib.check(_lib.load().cvx_t2s_decode_persistent(C.byref(self._descriptor(temperature, batch)), n,
+                                                             self._stsync[MAX_BATCH].data_ptr(), st), "cvx_t2s_decode_persistent")
+        else:
+            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch)), n, st), "cvx_t2s_decode_steps")
+
+    def _read_state(self, nb: int) -> list:
+        """state rows of the first nb utterances (the one host sync per chunk); raises if the persistent kernel reported a
+        barrier timeout."""
+        rows = self._stsync.tolist()
+        if self.persistent and rows[MAX_BATCH][1] != 0:
+            raise _lib.CovomixHipError("cvx_t2s_decode_persistent: a grid barrier timed out (a block was not resident); the decoded "
+                                       "tokens of this chunk are invalid - set CVX_T2S_PERSISTENT=0 to use the per-launch path")
+        return rows[:nb]
+
     def _run_chunk(self, temperature: float, batch: int = 1) -> None:
-        """CHUNK token steps on the current stream (graph replay when enabled)."""
+        """CHUNK token steps on the current stream (one persistent launch, or a graph replay of the per-launch path)."""
+        if self.persistent:
+            self._steps(temperature, batch, CHUNK)
+            return
+
         def launch():
             _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch)), CHUNK,
                                                         torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
@@ -241,17 +270,16 @@ class TextToSemanticDecoder:
         logits = []
         while steps < max_len:
             if collect_logits:
-                _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(float(temperature), nb)), 1,
-                                                            torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+                self._steps(float(temperature), nb, 1)
                 logits.append(b["logits"][:nb].clone())
                 steps += 1
             else:
                 self._run_chunk(float(temperature), nb)
                 steps += CHUNK
-            st = b["state"][:nb].tolist()                               # the only host sync: once per CHUNK tokens
+            st = self._read_state(nb)                                   # the only host sync: once per CHUNK tokens
             if all(row[1] for row in st):
                 break
-        st = b["state"][:nb].tolist()
+        st = self._read_state(nb)
         eos = V - 1
         out = []
         for i in range(nb):

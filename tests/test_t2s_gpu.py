@@ -135,3 +135,34 @@ def test_batched_decode_is_bit_identical_to_one_by_one(case):
     res8 = model.generate_batch([src] * 8, [uni] * 8)
     for r in res8:
         assert torch.equal(r[0].cpu(), torch.from_numpy(g["tokens"]))
+
+
+def test_persistent_kernel_is_bit_identical_to_per_launch_path(case):
+    """cvx_t2s_decode_persistent (one launch per CHUNK steps, grid barriers, next-phase weight prefetch: the default) against
+    cvx_t2s_decode_steps (34 launches per step): same device code per phase, so step logits and tokens must agree BITWISE -
+    batch 1 (stepwise with logits, and chunked) and a full batch of 8 with different texts."""
+    name, g, model = case
+    src, uni = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
+    S, V = uni.shape[1], uni.shape[-1]
+    gen = torch.Generator().manual_seed(23)
+    texts = [src, src[:, :5], torch.cat((src, src[:, :7]), dim=1), src[:, 2:9], src[:, 1:], src[:, :3], src, src[:, 4:]]
+    unis = [uni] + [torch.rand(uni.shape[0], S, V, generator=gen) for _ in texts[1:]]
+    assert model.persistent
+    out = {}
+    try:
+        for mode in (True, False):
+            model.persistent = mode
+            out[mode] = (model.generate(src, uniforms=uni, collect_logits=True),        # single steps
+                         model.generate(src, uniforms=uni, return_streams=True),         # chunks of 16 steps
+                         model.generate_batch(texts, unis),
+                         model.generate_batch(texts[:3], unis[:3], collect_logits=True))
+    finally:
+        model.persistent = True
+    p, q = out[True], out[False]
+    assert torch.equal(p[0][2], q[0][2]) and torch.equal(p[0][0], q[0][0])             # logits and tokens, step by step
+    assert torch.equal(p[0][0].cpu(), torch.from_numpy(g["tokens"]))
+    assert torch.equal(p[1][0], q[1][0]) and torch.equal(p[1][1], q[1][1])
+    for a, b in zip(p[2], q[2]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for a, b in zip(p[3], q[3]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
