@@ -125,7 +125,7 @@ class TextToSemanticDecoder:
         # device-to-host copy per chunk brings both
         self._stsync = torch.zeros(MAX_BATCH + 1, 4, dtype=torch.int32, device=device)
         self.buf["state"] = self._stsync[:MAX_BATCH]
-        self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "1") == "1
+        self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "1") == "1"
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
             for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",

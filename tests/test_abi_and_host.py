@@ -337,3 +337,14 @@ torch.distributed.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); from covomix_amd import dp; dp.init_from_env('gloo')"],
                        env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True)
     assert r.returncode != 0 and "MASTER_PORT" in r.stderr
+
+
+def test_every_python_source_compiles():
+    """Host modules that only run on a GPU box (t2s, hubert, generation, tools) are still byte-compiled here, so a syntax
+    error cannot reach the GPU tier unnoticed."""
+    import compileall
+    for sub in ("neurips2024-covomix_amd", "tools", "tests", "oracle"):
+        assert compileall.compile_dir(os.path.join(ROOT, sub), quiet=1, force=False, maxlevels=2), sub
+    for f in ("bench.py", "__graft_entry__.py", "monologue_generation.py", "dialogue_generation.py", "covomix_amd.py"):
+        assert compileall.compile_file(os.path.join(ROOT, f), quiet=1), f
+    import covomix_amd.t2s, covomix_amd.generation, covomix_amd.hubert, covomix_amd.mel, covomix_amd.vocoder  # noqa: F401,E401
