@@ -22,6 +22,11 @@
 // Positions: the device counter state[0]; every kernel reads it, so a captured HIP graph of N steps replays as is.
 #include "cvx_common.h"
 
+// No implicit a * b + c -> fma contraction in this file: the per-launch kernels and the persistent kernel instantiate the
+// same device functions in different contexts, and their results are REQUIRED to agree bitwise (tests/test_t2s_gpu.py);
+// every fused multiply-add below is an explicit fmaf.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int T2S_MAX_KEYS = 4096;
@@ -440,24 +445,28 @@ struct GridBarrier {
     unsigned* ctr;
     unsigned target, nblocks;
     bool dead;               // a wait timed out: the launch is lost (error word set); stop waiting so that it ends quickly
+    // The cache maintenance is per CACHE, not per thread: one L2 write-back (release fence) after every wave of the block
+    // has drained its stores (__syncthreads waits for vmcnt(0)), one L1 / L2 invalidate (acquire fence) after the wait, both
+    // by thread 0 (one block per CU: its fence covers the CU's L1).  The spin polls with RELAXED device-scope loads: an
+    // acquire load per poll would invalidate the XCD's L2 on every iteration of every block.
     __device__ __forceinline__ void arrive_and_wait()
     {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this thread's global writes -> visible device-wide
         __syncthreads();
         if (threadIdx.x == 0) {
             target += nblocks;
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the block's global writes -> visible device-wide
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
-            while (!dead && __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 22) || ((spins & 1023u) == 0 && __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     __hip_atomic_fetch_or(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     dead = true;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale L1 / non-local L2 lines before the next phase reads
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // drop stale L1 / non-local L2 lines before the next phase reads
     }
 };
 

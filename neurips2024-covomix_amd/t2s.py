@@ -7,11 +7,14 @@ forwards to (covomix/conditional_model.py:313-321).  Only what the generation sc
 
   encoder  (source transformer, once per utterance): the full-sequence kernels of the acoustic path - fp32 GEMM with
            the RoPE epilogue, flash attention, RMSNorm - plus a GEGLU kernel;
-  decoder  (one token per step): csrc/t2s_decode.hip.  Default: cvx_t2s_decode_persistent - CHUNK token steps as ONE
-           persistent launch (one block per CU, grid barriers between the 34 phases of a step, next-phase weights requested
-           before every barrier wait).  CVX_T2S_PERSISTENT=0: cvx_t2s_decode_steps, 34 launches per step replayed from a HIP
-           graph of CHUNK steps (the same device code per phase: bit-identical logits and tokens).  The host only looks at
-           the eos flags (and the persistent kernel's barrier-timeout word) between chunks.  `generate_batch`
+  decoder  (one token per step): csrc/t2s_decode.hip.  Default: cvx_t2s_decode_steps, 34 launches per step replayed from a
+           HIP graph of CHUNK steps.  CVX_T2S_PERSISTENT=1 (opt-in, measured 2.7x SLOWER: 524 vs 195 us per CoSingle step):
+           cvx_t2s_decode_persistent - CHUNK token steps as ONE persistent launch (one block per CU, grid barriers between
+           the 34 phases of a step, next-phase weights requested before every barrier wait; the same device code per phase:
+           bit-identical logits and tokens).  On MI355X a grid barrier with the L2 write-back / invalidate that cross-XCD
+           visibility needs costs 4-7 us (MI355X_MICROARCH.md, barrier-counter / barrier-xcd) against 1.2-1.5 us for a
+           dependent kernel boundary, so the launch chain wins; the kernel is kept as the measured negative result.  The host
+           only looks at the eos flags (and the persistent kernel's barrier-timeout word) between chunks.  `generate_batch`
            advances up to MAX_BATCH utterances together (the reference decodes them one by one): a token step is
            bound by streaming the decoder weights, which a batch shares, and the per-utterance arithmetic does not
            depend on the batch size - the tokens are bit-identical to the one-by-one decode.
@@ -125,7 +128,7 @@ class TextToSemanticDecoder:
         # device-to-host copy per chunk brings both
         self._stsync = torch.zeros(MAX_BATCH + 1, 4, dtype=torch.int32, device=device)
         self.buf["state"] = self._stsync[:MAX_BATCH]
-        self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "1") == "1"
+        self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "0") == "1"
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
             for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
