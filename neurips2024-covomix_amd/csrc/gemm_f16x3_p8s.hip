@@ -50,44 +50,76 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
 #define CVX_P8_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define CVX_P8_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-// (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions, exact residual by v_fma_mix
+// ---- packed fp32 helpers.  The epilogues are VALU-issue bound (ff1: ~30 VALU instructions per output element, two waves per
+// SIMD in their epilogue at the same time = 19 us of an 83 us tile): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two
+// elements per issue slot, and an MFMA accumulator block of four registers is two aligned register pairs, so the whole
+// element-wise chain is written on pairs.  Per element the same IEEE operations in the same order as the scalar form.
+__device__ __forceinline__ f32x2 fma2(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(const float x) { return f32x2{x, x}; }
+// a * b with NO licence to be fused into a neighbouring add (the RoPE rotation fixes its rounding points)
+#pragma clang fp contract(off)
+__device__ __forceinline__ f32x2 mul2_rn(const f32x2 a, const f32x2 b) { return a * b; }
+#pragma clang fp contract(fast)
+
+// max(m, |a|, |b|) in one instruction (the saturation bookkeeping of cvx_common.h; fmaxf would add a canonicalising
+// v_max per operand in IEEE mode)
+__device__ __forceinline__ float amax3(float m, const float a, const float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+    return m;
+}
+
+// (hi, lo) fp16 halves of two fp32 values, saturating: v_med3 clamp, packed RNE conversion, exact residual x - hi by
+// v_fma_mix_f32 straight from the packed halves, packed conversion of the residuals
+__device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, float& amax)
+{
+    amax = amax3(amax, v[0], v[1]);
+    const float x0 = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), x1 = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
+    hi = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    const unsigned int hb = __builtin_bit_cast(unsigned int, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+    lo = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+}
 __device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, float& amax)
 {
-    amax = cvx_amax4(amax, v);
-    float x[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-    const f16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2), h23 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
-    const f16x2 l01 = __builtin_convertvector(f32x2{x[0] - (float)h01[0], x[1] - (float)h01[1]}, f16x2);
-    const f16x2 l23 = __builtin_convertvector(f32x2{x[2] - (float)h23[0], x[3] - (float)h23[1]}, f16x2);
+    f16x2 h01, h23, l01, l23;
+    split2_pk(f32x2{v[0], v[1]}, h01, l01, amax);
+    split2_pk(f32x2{v[2], v[3]}, h23, l23, amax);
     hi = f16x4{h01[0], h01[1], h23[0], h23[1]};
     lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
 }
 
 // erf to ~1 ulp without branches (both polynomial pieces, one select): |x| <= 0.927734375: x + x * P(x^2); beyond:
 // 1 - exp(Q(|x|)).  The library erff is several times longer and branchy; GELU runs on 4096 columns of every row.
-__device__ __forceinline__ float erf_fast(float a)
+__device__ __forceinline__ f32x2 erf_fast2(const f32x2 a)
 {
-    const float t = fabsf(a), s = a * a;
-    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-    r = fmaf(r, s, u);
-    r = fmaf(r, t, -1.06777877e-1f);
-    r = fmaf(r, t, -6.34846687e-1f);
-    r = fmaf(r, t, -1.28717512e-1f);
-    r = fmaf(r, t, -t);
-    r = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f);
-    r = copysignf(r, a);
-    float q = -5.96761703e-4f;
-    q = fmaf(q, s, 4.99119423e-3f);
-    q = fmaf(q, s, -2.67681349e-2f);
-    q = fmaf(q, s, 1.12819925e-1f);
-    q = fmaf(q, s, -3.76125336e-1f);
-    q = fmaf(q, s, 1.28379166e-1f);
-    q = fmaf(q, a, a);
-    return t > 0.927734375f ? r : q;
+    const f32x2 t = __builtin_elementwise_abs(a), s = a * a;
+    f32x2 r = fma2(splat2(-1.72853470e-5f), t, splat2(3.83197126e-4f));
+    const f32x2 u = fma2(splat2(-3.88396438e-3f), t, splat2(2.42546219e-2f));
+    r = fma2(r, s, u);
+    r = fma2(r, t, splat2(-1.06777877e-1f));
+    r = fma2(r, t, splat2(-6.34846687e-1f));
+    r = fma2(r, t, splat2(-1.28717512e-1f));
+    r = fma2(r, t, -t);
+    const f32x2 e = r * splat2(1.44269504088896340736f);
+    r = splat2(1.0f) - f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    r = f32x2{copysignf(r[0], a[0]), copysignf(r[1], a[1])};
+    f32x2 q = splat2(-5.96761703e-4f);
+    q = fma2(q, s, splat2(4.99119423e-3f));
+    q = fma2(q, s, splat2(-2.67681349e-2f));
+    q = fma2(q, s, splat2(1.12819925e-1f));
+    q = fma2(q, s, splat2(-3.76125336e-1f));
+    q = fma2(q, s, splat2(1.28379166e-1f));
+    q = fma2(q, a, a);
+    return f32x2{t[0] > 0.927734375f ? r[0] : q[0], t[1] > 0.927734375f ? r[1] : q[1]};
 }
-__device__ __forceinline__ float gelu_fast(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ f32x2 gelu_fast2(const f32x2 v)
+{
+    return (splat2(0.5f) * v) * (splat2(1.0f) + erf_fast2(v * splat2(0.70710678118654752440f)));
+}
+__device__ __forceinline__ f32x2 silu2(const f32x2 v) { return f32x2{silu(v[0]), silu(v[1])}; }
 
 // ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]
 template <int EPI>
@@ -111,26 +143,28 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
     const bool il = so.hi && so.lo == so.hi + 32;
     float amax = 0.f;
-    f32x4 bias[4];
+    const f32x2 sc2 = splat2(acc_scale), cs2 = splat2(cs);
+    f32x2 bias[4][2];                           // [ni][pair]: columns col0 + 16 ni + lc + 2 pair + {0, 1}
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-        if (p.bias) bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
-        else bias[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+        bias[ni][0] = f32x2{b4[0], b4[1]}; bias[ni][1] = f32x2{b4[2], b4[3]};
     }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int row = row0 + 16 * mi + lr;
         const bool live = row < p.M;
         const int rr = live ? row : p.M - 1;
-        f32x4 v[4];
+        f32x2 v[4][2];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = fmaf(acc[mi][ni][e], acc_scale, bias[ni][e]);
-                if (p.act == CVX_ACT_GELU) x = gelu_fast(x);
-                else if (p.act == CVX_ACT_SILU) x = silu(x);
-                v[ni][e] = x;
+            for (int h = 0; h < 2; ++h) {
+                f32x2 x = fma2(f32x2{acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]}, sc2, bias[ni][h]);
+                if (p.act == CVX_ACT_GELU) x = gelu_fast2(x);
+                else if (p.act == CVX_ACT_SILU) x = silu2(x);
+                v[ni][h] = x;
             }
         }
         if (do_rope) {      // half-split rotation: column j of the head pairs with j + 32 = tile ni + 2, same lane, same register
@@ -140,10 +174,11 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
                 const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = v[ni][e], hi = v[ni + 2][e];
-                    v[ni][e] = __builtin_fmaf(lo, c[e], -__fmul_rn(hi, s[e]));          // fixed contraction, as in the 32x32 epilogue
-                    v[ni + 2][e] = __builtin_fmaf(hi, c[e], __fmul_rn(lo, s[e]));
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 c2 = f32x2{c[2 * h], c[2 * h + 1]}, s2 = f32x2{s[2 * h], s[2 * h + 1]};
+                    const f32x2 lo = v[ni][h], hi = v[ni + 2][h];
+                    v[ni][h] = fma2(lo, c2, -mul2_rn(hi, s2));          // fixed contraction, as in the 32x32 epilogue
+                    v[ni + 2][h] = fma2(hi, c2, mul2_rn(lo, s2));
                 }
             }
         }
@@ -151,25 +186,26 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[ni][e] += r[e];
+                v[ni][0] += f32x2{r[0], r[1]};
+                v[ni][1] += f32x2{r[2], r[3]};
             }
         }
         if (!live) continue;
         if (so.write_f32) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + 16 * ni + lc) = v[ni];
+                *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + 16 * ni + lc) = f32x4{v[ni][0][0], v[ni][0][1], v[ni][1][0], v[ni][1][1]};
         }
         if (so.hi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int c = col0 + 16 * ni + lc;
                 const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
-                f16x4 h, l;
-                split4_pk(f32x4{v[ni][0] * cs, v[ni][1] * cs, v[ni][2] * cs, v[ni][3] * cs}, h, l, amax);
-                *reinterpret_cast<f16x4*>(so.hi + o) = h;
-                if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = l;
+                f16x2 h01, h23, l01, l23;
+                split2_pk(v[ni][0] * cs2, h01, l01, amax);
+                split2_pk(v[ni][1] * cs2, h23, l23, amax);
+                *reinterpret_cast<f16x4*>(so.hi + o) = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = f16x4{l01[0], l01[1], l23[0], l23[1]};
             }
         }
     }
