@@ -65,5 +65,9 @@ __device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, float amax)
     if (flag && amax > 65504.f) atomicOr(flag, 1u);
 }
 
+// the same, NON-TEMPORAL (global_load_dwordx4 ... nt): for weight rows that ONE CU reads once per pass (batch-1 decode GEMVs) -
+// MI355X_MICROARCH.md `nt-weights`: issued -> landed -18 %, a decode layer -5...10 %
+__device__ __forceinline__ f32x4 gload4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<cvx_gptr4>(reinterpret_cast<uintptr_t>(p))); }
+
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }

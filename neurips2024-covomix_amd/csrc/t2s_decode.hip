@@ -66,6 +66,11 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 constexpr int PF = 4;                                      // 4 x 256 floats per row in flight (K <= 1024 entirely)
+#ifndef CVX_T2S_NT
+#define CVX_T2S_NT 1
+#endif
+// weight rows: streamed once per token step by one wave each -> non-temporal loads (A/B: -DCVX_T2S_NT=0)
+__device__ __forceinline__ f32x4 wload4(const float* p) { return CVX_T2S_NT ? gload4_nt(p) : gload4(p); }
 
 // the two rows of row-pair `pair` (the pairs are chosen so that the epilogue has both members of a RoPE pair / a GEGLU
 // (value, gate) pair in one wave)
@@ -109,7 +114,7 @@ __device__ __forceinline__ void prefetch_pair(const GemvArgs& a, int pair, int l
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
         const int k = 4 * lane + 256 * i;
-        if (k < K4) { pf.pa[i] = gload4(w0 + k); pf.pb[i] = gload4(w1 + k); }
+        if (k < K4) { pf.pa[i] = wload4(w0 + k); pf.pb[i] = wload4(w1 + k); }
     }
 }
 
@@ -178,8 +183,8 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
     for (int i = 0; i < PF; ++i) {
         const int k = 4 * lane + 256 * i;
         if (k < K4) {
-            const f32x4 a0 = PRE ? pf.pa[i] : gload4(w0 + k);
-            const f32x4 a1 = PRE ? pf.pb[i] : gload4(w1 + k);
+            const f32x4 a0 = PRE ? pf.pa[i] : wload4(w0 + k);
+            const f32x4 a1 = PRE ? pf.pb[i] : wload4(w1 + k);
 #pragma unroll
             for (int b = 0; b < BQ; ++b) {
                 const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);
@@ -189,8 +194,8 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
         }
     }
     for (int k = 4 * lane + 256 * PF; k < K4; k += 256) {
-        const f32x4 a0 = gload4(w0 + k);
-        const f32x4 a1 = gload4(w1 + k);
+        const f32x4 a0 = wload4(w0 + k);
+        const f32x4 a1 = wload4(w1 + k);
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
             const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);

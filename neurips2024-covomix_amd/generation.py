@@ -59,6 +59,8 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
                    "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
     p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
+    p.add_argument("--nfe", type=int, default=32, help="extension: CFG-combined field evaluations of the midpoint solver (32 = the "
+                   "reference's ode_step_size 0.0625, acoustic.py:586-591; 64 = BASELINE config 5's 64-step setting)")
     p.add_argument("--gpus", type=int, default=1, help="extension: from a plain shell, start this many ranks (one per GPU, "
                    "utterances sharded; under torch.distributed.run the launcher's WORLD_SIZE is used instead)")
     return p
@@ -267,6 +269,7 @@ def run(dialogue: bool, argv=None) -> int:
     model = CoVoMixModel.load_from_checkpoint(args.acous_ckpt, base_dir="", batch_size=16, num_workers=0)
     model.eval()
     model = model.to(device)
+    model.nfe = int(args.nfe)
     if rank == 0:
         with open(os.path.join(args.saved_dir, "config.txt"), "w") as f:
             f.write("Vocoder: " + str(dict(h)) + "\n")

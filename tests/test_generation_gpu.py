@@ -424,3 +424,87 @@ def test_cli_rate_on_ragged_directory(tmp_path):
     print(f"ragged directory: CLI {cli_rate:.0f} generated frames/s vs bench-style loop {bench_rate:.0f}: ratio {cli_rate / bench_rate:.3f}")
     assert cli["frames"] == gen_frames and cli_rate >= 0.85 * bench_rate
 
+
+
+def test_c5_pipeline_eight_dialogues_64nfe(tmp_path, monkeypatch):
+    """BASELINE config 5 through the CLI: 8 dialogues of different text / prompt length, CoMix text2semantic (one batched
+    decode) -> token assembly -> VoMix at 64 NFE (ragged batch) -> HiFi-GAN (ragged batch) -> int16 wav.  Reduced-width
+    models so that the CPU oracles can follow: every dialogue's semantic tokens BIT-EXACT vs the text2semantic oracle, three
+    dialogues' audio against the oracle's 64-NFE rollout + vocoder from the captured noise."""
+    import covomix_oracle as orc
+    import t2s_oracle as torc
+    import covomix_amd.synthetic as syn
+    from covomix_amd import assembly, generation
+    from scipy.io.wavfile import read
+    tmp = str(tmp_path)
+    ema, vsd, h = _write_fixture(tmp, "vomix")
+    shapes = syn.t2s_param_shapes(two_output=True, dim=64, dim_target=128, source_depth=2, target_depth=2, heads=1, num_text=200)
+    tsd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(shapes, seed=0).items()}
+    torch.save({"state_dict": {"cfm_wrapper.model." + k: v for k, v in tsd.items()},
+                "hyper_parameters": {"text2semantic": True, "text2semantic_two_output": True}}, os.path.join(tmp, "t2s.ckpt"))
+    tdir, pdir, sdir = (os.path.join(tmp, d) for d in ("text", "prompt", "out"))
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(8)
+    names = [f"dlg{i}" for i in range(8)]
+    text = {}
+    for i, n in enumerate(names):
+        for suf in ("_1", "_2"):
+            plen = 14 + 3 * i + (2 if suf == "_2" else 0)
+            np.save(os.path.join(pdir, f"{n}{suf}.hubert_code.npy"), g.randint(0, 510, size=plen))
+            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), (g.randn(80, plen) * 2 - 6).astype(np.float32))
+        text[n] = g.randint(1, 199, size=(1, 5 + i)).astype(np.int64)
+        np.save(os.path.join(tdir, f"{n}.text_ids.npy"), text[n])
+    uni = {n: torch.from_numpy(g.uniform(1e-6, 1 - 1e-6, size=(24, 2, 502)).astype(np.float32)) for n in names}
+    real_t2s = generation.CoVoMixModel.synthesis_sample_text2semantic
+    real_syn = generation.CoVoMixModel.synthesis_sample
+    seen, order = [], []
+
+    def spy_t2s(self, ids, **kw):                     # all 8 dialogues decode as ONE batch
+        assert isinstance(ids, list) and len(ids) == 8
+        by_len = {int(t.shape[1]): n for n, t in ((n, torch.from_numpy(text[n])) for n in names)}
+        order[:] = [by_len[int(i.shape[1])] for i in ids]
+        return real_t2s(self, ids, uniforms=[uni[n] for n in order], max_length=24)
+
+    def spy_syn(self, phoneme_ids, cond, mask, cond_scale, y0=None):
+        assert self.nfe == 64
+        for i_, c_, m_, y_ in zip(phoneme_ids, cond, mask, y0):
+            seen.append((i_.cpu(), c_.cpu(), m_.cpu(), y_.cpu()))
+        return real_syn(self, phoneme_ids, cond, mask, cond_scale, y0=y0)
+    monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample_text2semantic", spy_t2s)
+    monkeypatch.setattr(generation.CoVoMixModel, "synthesis_sample", spy_syn)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        n = generation.run(True, ["--t2s_ckpt", os.path.join(tmp, "t2s.ckpt"), "--acous_ckpt", os.path.join(tmp, "acous.ckpt"),
+                                  "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir,
+                                  "--prompt_dir", pdir, "--saved_dir", sdir, "--mode", "covomix", "--seed", "30", "--nfe", "64"])
+    assert len(seen) == 8 and sorted(order) == sorted(names)
+    folded = orc.fold_weight_norm(vsd)
+    checked, written = 0, 0
+    for k, nm in enumerate(names):
+        o = torc.generate(tsd, torch.from_numpy(text[nm]), uni[nm][:, :, None, :], max_length=24)
+        flat = o["tokens"]
+        half = flat.shape[0] // 2
+        sa, ma = assembly.truncate_prompt(torch.from_numpy(np.load(os.path.join(pdir, nm + "_1.hubert_code.npy")).astype(np.int64)),
+                                          torch.from_numpy(np.load(os.path.join(pdir, nm + "_1.mel.npy"))))
+        sb, mb = assembly.truncate_prompt(torch.from_numpy(np.load(os.path.join(pdir, nm + "_2.hubert_code.npy")).astype(np.int64)),
+                                          torch.from_numpy(np.load(os.path.join(pdir, nm + "_2.mel.npy"))))
+        want_ids, want_cond, want_mask = assembly.build_dialogue_inputs(sa, sb, flat[:half], flat[half:], ma, mb)
+        hit = [r for r in seen if r[0].shape == want_ids.shape and torch.equal(r[0], want_ids)]
+        assert len(hit) == 1, (nm, "semantic tokens / assembly differ from the oracle's")
+        ids, cond, mask, y0 = hit[0]
+        assert torch.equal(mask, want_mask) and torch.allclose(cond, want_cond)
+        n_gen = int(mask.sum())
+        if n_gen == 0:                                  # (an eos as the very first token: nothing to synthesise, no file)
+            assert not os.path.isfile(os.path.join(sdir, nm + ".wav"))
+            continue
+        written += 1
+        sr, pcm = read(os.path.join(sdir, nm + ".wav"))
+        assert sr == 8000 and pcm.dtype == np.int16 and pcm.shape == (160 * n_gen + 32,)
+        if checked < 3 and k in (0, 3, 5, 7):
+            ref_mel = orc.sample(ema, ids[None], cond[None], y0[None], 0.7, nfe=64)
+            ref_pcm = orc.wav_to_int16(orc.hifigan_forward(folded, h, assembly.select_generated_frames(ref_mel, mask)))
+            err = np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32))
+            assert err.max() <= 64 and (err > 2).mean() < 0.01, (nm, err.max(), (err > 2).mean())
+            checked += 1
+    assert checked == 3 and n == written and written >= 6

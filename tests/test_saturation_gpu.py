@@ -166,6 +166,9 @@ def _vocoder(h, vsd, precision=None):
 
 
 def test_vocoder_conv_pre_channel_times_2_14():
+    """One conv_pre output channel times 2^14.  The problem itself becomes ill-conditioned in fp32 (the CPU oracle sits 7.5e-6
+    from an fp64 evaluation, 5e-7 without the outlier), so the yardstick is fp64: the GPU result must be fp32-class, i.e. no
+    further from fp64 than twice the fp32 oracle is."""
     import covomix_oracle as orc
     import covomix_amd.synthetic as syn
     h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
@@ -176,10 +179,13 @@ def test_vocoder_conv_pre_channel_times_2_14():
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         wav = _vocoder(h, vsd)(mel.cuda())
-    ref = orc.hifigan_forward(orc.fold_weight_norm(vsd), h, mel)
-    e = rel_l2(wav, ref)
-    print(f"vocoder conv_pre channel x 2^14: rel-L2 vs oracle {e:.3e} (re-run: {any('saturat' in str(w.message) for w in rec)})")
-    assert torch.isfinite(wav).all() and e < 1e-5
+    folded = orc.fold_weight_norm(vsd)
+    ref32 = orc.hifigan_forward(folded, h, mel)
+    ref64 = orc.hifigan_forward({k: v.double() for k, v in folded.items()}, h, mel.double())
+    e_gpu, e_cpu = rel_l2(wav, ref64), rel_l2(ref32, ref64)
+    print(f"vocoder conv_pre channel x 2^14: rel-L2 vs fp64 {e_gpu:.3e} (fp32 CPU oracle: {e_cpu:.3e}; "
+          f"re-run: {any('saturat' in str(w.message) for w in rec)})")
+    assert torch.isfinite(wav).all() and e_gpu < max(1e-5, 2 * e_cpu)
 
 
 def test_vocoder_resblock_gain_outside_the_window_is_rerun_or_raises(monkeypatch):
