@@ -97,6 +97,9 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+#ifndef CVX_NORM_NT
+#define CVX_NORM_NT 0          // dev A/B: bit 0 = non-temporal loads of x, bit 1 = non-temporal stores of the split pair (AdaRMSNorm)
+#endif
 // split 4 floats into fp16 (hi, lo) and store 8 bytes each (for GEMMs that take their A operand pre-split)
 __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, float& amax)
 {
@@ -110,6 +113,11 @@ __device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t
         const float x = fminf(fmaxf(o[e], -65504.f), 65504.f);
         h[e] = (_Float16)x;
         l[e] = (_Float16)(x - (float)h[e]);
+    }
+    if (CVX_NORM_NT & 2) {
+        __builtin_nontemporal_store(h, reinterpret_cast<f16x4_t*>(hi + off));
+        if (lo) __builtin_nontemporal_store(l, reinterpret_cast<f16x4_t*>(lo + off));
+        return;
     }
     *reinterpret_cast<f16x4_t*>(hi + off) = h;
     if (lo) *reinterpret_cast<f16x4_t*>(lo + off) = l;      // lo == NULL: hi halves only
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
     for (int i = 0; i < NV; ++i) {
         const int j = lane + 64 * i;
         if (j < nvec) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+            v[i] = (CVX_NORM_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * j)) : *reinterpret_cast<const f32x4*>(xr + 4 * j);
             ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
         }
     }
