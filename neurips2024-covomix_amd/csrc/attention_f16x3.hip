@@ -26,7 +26,7 @@ typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int HD = 64, QB = 128, KT = 32;
+constexpr int HD = 64, KT = 32;             // queries per block: 32 per wave, NW waves (128 or 256)
 constexpr int TILE = KT * HD;                 // halves per operand tile (4 KiB)
 constexpr int STAGE = 4 * TILE;               // Khi | Klo | Vthi | Vtlo
 
@@ -63,8 +63,20 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 #ifndef CVX_ATT_WAVES
 #define CVX_ATT_WAVES 2
 #endif
-template <int NT>
-__global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
+// ENERGY ABLATIONS (dev builds only, results are WRONG by construction; tools/attn_ablate.py): which part of the loop the
+// power-capped launch pays for.  bit 0: no L2 -> LDS DMA after the first tile (tiles stay resident); bit 1: no LDS fragment
+// reads after the first tile (K / V^T fragments stay in registers); bit 2: no v_exp_f32 (p = its argument); bit 3: no P.V
+// MFMAs; bit 4: no K.Q MFMAs.
+#ifndef CVX_ATT_ABLATE
+#define CVX_ATT_ABLATE 0
+#endif
+// NW = waves per block (4 or 8), 32 queries each.  The K / V^T tiles a block streams through LDS are shared by its waves:
+// with 8 waves (256 queries) the L2 -> LDS DMA bytes per score halve.  Round-3 ablations (tools/attn_ablate.py, Bt = 16,
+// T = 1000, H = 16, NW = 4): DMA switched off after the first tile 177 instead of 211 us and 0.233
+// instead of 0.286 J (on zero operands, i.e. at full clock, 130 instead of 159 us); no LDS fragment reads -7 %; no
+// v_exp_f32 -1 %; no P.V MFMAs 140 us; no K.Q MFMAs 134 us.  Halving the DMA BYTES (NW = 8) does not buy the DMA-off time.
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
                                                                 const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
                                                                 int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
@@ -81,6 +93,7 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
     const int grp = (blockIdx.x / (8 * n_qt)) * 8 + (blockIdx.x & 7);      // same (batch, head) -> same XCD
     if (grp >= n_groups) return;
     const int head = grp % H, b = grp / H;
+    constexpr int QB = 32 * NW;
     const int q_blk = ((blockIdx.x >> 3) % n_qt) * QB;
     const int64_t ldqk = (int64_t)2 * H * HD;
     // Key window [kc0, kc1) in V^T COLUMN coordinates; the q|k row of column c is c + roff.
@@ -112,22 +125,29 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
         }
     }
 
-    // ---- DMA sources.  wave w: K rows [8w, 8w+8) (hi, lo) and V^T rows [16w, 16w+16) (hi, lo): 4 pieces per tile
-    const int k_r = 8 * wid + (lane >> 3);                                  // key row inside the tile
+    // ---- DMA sources.  NW = 4: wave w fetches K rows [8w, 8w+8) (hi, lo) and V^T rows [16w, 16w+16) (hi, lo): 4 pieces per
+    // tile and wave.  NW = 8: waves 0-3 fetch the K pieces, waves 4-7 the V^T pieces (2 per tile and wave).
+    const int wq = wid & 3;
+    const bool dma_k = NW == 4 || wid < 4, dma_v = NW == 4 || wid >= 4;
+    const int k_r = 8 * wq + (lane >> 3);                                   // key row inside the tile
     const int k_c = (lane & 7) ^ ((k_r >> 1) & 7);                          // source chunk for LDS chunk (lane & 7)
     const int64_t k_col = (int64_t)H * HD + head * HD + 8 * k_c;
-    const int v_r = 16 * wid + (lane >> 2);                                 // head-dim row inside the tile
+    const int v_r = 16 * wq + (lane >> 2);                                  // head-dim row inside the tile
     const int v_c = (lane & 3) ^ ((v_r >> 2) & 3);
     const int64_t v_row = ((int64_t)vt_grp * HD + v_r) * Tp + 8 * v_c;
     auto issue = [&](int key0, int stage) {
         f16* S = smem + stage * STAGE;
-        const int key = min(max(key0 + k_r, kc0), kc1 - 1);
-        const int64_t ko = (roff + key) * ldqk + k_col;
-        glds16(qk_hi + ko, S + 8 * wid * HD);
-        if constexpr (NT == 3) glds16(qk_lo + ko, S + TILE + 8 * wid * HD);
-        const int64_t vo = v_row + key0;
-        glds16(vt_hi + vo, S + 2 * TILE + 16 * wid * KT);
-        if constexpr (NT == 3) glds16(vt_lo + vo, S + 3 * TILE + 16 * wid * KT);
+        if (dma_k) {                                                        // (wave-uniform)
+            const int key = min(max(key0 + k_r, kc0), kc1 - 1);
+            const int64_t ko = (roff + key) * ldqk + k_col;
+            glds16(qk_hi + ko, S + 8 * wq * HD);
+            if constexpr (NT == 3) glds16(qk_lo + ko, S + TILE + 8 * wq * HD);
+        }
+        if (dma_v) {
+            const int64_t vo = v_row + key0;
+            glds16(vt_hi + vo, S + 2 * TILE + 16 * wq * KT);
+            if constexpr (NT == 3) glds16(vt_lo + vo, S + 3 * TILE + 16 * wq * KT);
+        }
     };
 
     // ---- fragment offsets (halves)
@@ -159,12 +179,14 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
 #else
 #define TSTAMP(i)
 #endif
+    f16x8 kfh[4], kfl[4];                         // K fragments of the running tile
+    f16x8 vfh[2][2], vfl[2][2];                   // V^T fragments [s][dt]
     for (int it = 0; it < ntiles; ++it) {
         const int cur = it & 1, key0 = (tile0 + it) * KT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // tile `it` landed everywhere; stage cur^1 is free
         TSTAMP(0)
-        if (it + 1 < ntiles) issue(key0 + KT, cur ^ 1);
+        if (it + 1 < ntiles && !((CVX_ATT_ABLATE & 1) && it > 0)) issue(key0 + KT, cur ^ 1);
         const f16* S = smem + cur * STAGE;
 
         // ---- S^T = K . Q^T  (3 products per 16-wide d slice), ONE accumulator: the matrix pipe forwards the result of an
@@ -172,12 +194,17 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
         // per-term accumulators disappear (measured: 1 accumulator 260 us, 3 accumulators 272 us, 2: 285 us).
         // The first MFMA of the chain takes its C operand from a zero register block kept live over the loop.
         f32x16 sacc;
-        f16x8 kfh[4], kfl[4];                     // all K fragments first (8 reads in flight), then the MFMA chain
+        if (!((CVX_ATT_ABLATE & 2) && it > 0)) {  // all K fragments first (8 reads in flight), then the MFMA chain
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kfh[s] = *reinterpret_cast<const f16x8*>(S + koff[s]);
-            if constexpr (NT == 3) kfl[s] = *reinterpret_cast<const f16x8*>(S + TILE + koff[s]);
+            for (int s = 0; s < 4; ++s) {
+                kfh[s] = *reinterpret_cast<const f16x8*>(S + koff[s]);
+                if constexpr (NT == 3) kfl[s] = *reinterpret_cast<const f16x8*>(S + TILE + koff[s]);
+            }
         }
+        if (CVX_ATT_ABLATE & 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = (float)(r + it) * 0.01f;
+        } else
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if constexpr (NT == 3) {
@@ -224,8 +251,9 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
             u32x4 hw[2], lw[2];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[2 * j], scale_log2e, -m_new));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[2 * j + 1], scale_log2e, -m_new));
+                const float a0 = fmaf(sacc[2 * j], scale_log2e, -m_new), a1 = fmaf(sacc[2 * j + 1], scale_log2e, -m_new);
+                const float p0 = (CVX_ATT_ABLATE & 4) ? a0 : __builtin_amdgcn_exp2f(a0);
+                const float p1 = (CVX_ATT_ABLATE & 4) ? a1 : __builtin_amdgcn_exp2f(a1);
                 psum += p0 + p1;                 // (pairs first: 8 dependent adds instead of 16)
                 const f16x2 h2 = __builtin_convertvector(f32x2{p0, p1}, f16x2);
                 const unsigned int hb = __builtin_bit_cast(unsigned int, h2);
@@ -253,12 +281,16 @@ __global__ __launch_bounds__(256, CVX_ATT_WAVES) void attention_f16x3_kernel(con
         const f16* Vl = S + 3 * TILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f16x8 vhh[2], vll[2];
+            f16x8 (&vhh)[2] = vfh[s];
+            f16x8 (&vll)[2] = vfl[s];
+            if (!((CVX_ATT_ABLATE & 2) && it > 0)) {
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                vhh[dt] = *reinterpret_cast<const f16x8*>(Vh + dt * 32 * KT + voff[s]);
-                if constexpr (NT == 3) vll[dt] = *reinterpret_cast<const f16x8*>(Vl + dt * 32 * KT + voff[s]);
+                for (int dt = 0; dt < 2; ++dt) {
+                    vhh[dt] = *reinterpret_cast<const f16x8*>(Vh + dt * 32 * KT + voff[s]);
+                    if constexpr (NT == 3) vll[dt] = *reinterpret_cast<const f16x8*>(Vl + dt * 32 * KT + voff[s]);
+                }
             }
+            if (CVX_ATT_ABLATE & 8) continue;
             // interleave the two O^T tiles: consecutive MFMAs alternate accumulators
             if constexpr (NT == 3) {
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vll[0], ph[s], o0, 0, 0, 0);
@@ -328,21 +360,27 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
     CVX_REQUIRE((((uintptr_t)qk_hi | (uintptr_t)qk_lo | (uintptr_t)vt_hi | (uintptr_t)vt_lo) & 15) == 0,
                 "attention_f16x3: inputs must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;
-    const int n_qt = (T + QB - 1) / QB, n_groups = Bt * H;
+    // 128-query blocks (4 waves, three blocks per CU).  256-query blocks (8 waves: half the L2 -> LDS tile traffic per score,
+    // one block per CU) are built and correct but measured 3 % SLOWER (218.6 vs 212.5 us, same joules; on zero operands
+    // 182 vs 159 us: the schedule loses what the traffic saves) - opt-in for A/B runs: -DCVX_ATT_QB256.
+#ifdef CVX_ATT_QB256
+    const int nw = T >= 384 ? 8 : 4;
+#else
+    const int nw = 4;
+#endif
+    const int qb = 32 * nw;
+    const int n_qt = (T + qb - 1) / qb, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     uint32_t* sat = cvx_sat_flag_dev();
-    if (single)
-        hipLaunchKernelGGL(attention_f16x3_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                           reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
-                           reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
-                           out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat);
-    else
-        hipLaunchKernelGGL(attention_f16x3_kernel<3>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                           reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),
-                           reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),
-                           out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),
-                           T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat);
+#define CVX_ATT_LAUNCH(NT_, NW_)                                                                                                          \
+    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_>), grid, dim3(64 * NW_), 0, reinterpret_cast<hipStream_t>(s),                       \
+                       reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
+                       reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
+                       out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
+                       T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
+    if (single) { if (nw == 8) CVX_ATT_LAUNCH(1, 8); else CVX_ATT_LAUNCH(1, 4); }
+    else { if (nw == 8) CVX_ATT_LAUNCH(3, 8); else CVX_ATT_LAUNCH(3, 4); }
+#undef CVX_ATT_LAUNCH
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;
 }
