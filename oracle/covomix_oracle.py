@@ -241,9 +241,13 @@ def hifigan_forward(sd: SD, h: dict, mel: Tensor) -> Tensor:
         # config_covomix, Cin 500 -> Cout 250, k 8, stride 5, 88 or 120 input frames: max error 0.9 of max |y| 3.9 against the
         # fp64 evaluation; 1 thread or the native kernel: 1e-6).  The oracle is the yardstick, so the transposed convolutions run
         # on the native kernel (tools/voc_flaky_probe.py found it: the HIP path agreed with fp64, the fp32 oracle did not).
-        with torch.backends.mkldnn.flags(enabled=False):
+        prev = torch._C._get_mkldnn_enabled()                          # (torch.backends.mkldnn.flags warns about Intel GPUs on every entry)
+        torch._C._set_mkldnn_enabled(False)
+        try:
             x = F.conv_transpose1d(x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=u,
                                    padding=(k - u) // 2)
+        finally:
+            torch._C._set_mkldnn_enabled(prev)
         xs = None
         for j, (rk, dil) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
             r = x
