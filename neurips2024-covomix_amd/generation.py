@@ -54,8 +54,9 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--saved_dir", type=str, default=".saved_dir", help="target directory")
     p.add_argument("--seed", type=int, default=30, help="random seed")
     p.add_argument("--mode", type=str, choices=["covosingle", "covosinx", "covomix"], default="covosingle")
-    p.add_argument("--max_batch", type=int, default=8, help="utterances per launch (any lengths: they are packed back to back)")
-    p.add_argument("--max_frames", type=int, default=10240, help="frames per launch (sum over its utterances)")
+    p.add_argument("--max_batch", type=int, default=32, help="utterances per launch at most (any lengths: they are packed back to back)")
+    p.add_argument("--max_frames", type=int, default=8192, help="frames per launch (sum over its utterances): 8192 frames = 64 row "
+                   "panels of 256 rows with both CFG branches, whole rounds of GEMM tiles on 256 CUs")
     p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
                    "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
     p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
@@ -309,10 +310,9 @@ def run(dialogue: bool, argv=None) -> int:
     t0 = time.perf_counter()
     # The reference generates one utterance at a time (monologue_generation.py:259-304); here up to --max_batch utterances
     # of ANY lengths share a launch sequence: packed back to back (no padding), every utterance attending to itself only
-    # (sample_ragged), so each gets the result of its own B = 1 run.  Longest first: neighbours in the order have similar
-    # lengths, which keeps the vocoder groups below large.
-    order = sorted(range(len(items)), key=lambda i: (-lengths[i], i))
-    for batch in dp.batch_by_frames(order, lengths, args.max_batch, args.max_frames):
+    # (sample_ragged), so each gets the result of its own B = 1 run.  Batches are FILLED to --max_frames (first-fit decreasing,
+    # dp.pack_by_frames): the frames of a launch decide how many whole rounds of GEMM tiles it runs.
+    for batch in dp.pack_by_frames(list(range(len(items))), lengths, args.max_frames, args.max_batch):
         y0 = [torch.randn(lengths[i], n_out, device=device, generator=torch.Generator(device=device).manual_seed(
             _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch]        # acoustic.py:647-650, per utterance
         if len(set(lengths[i] for i in batch)) == 1:                                     # equal lengths: the plain [B, T, .] call

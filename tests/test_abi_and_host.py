@@ -176,6 +176,16 @@ def test_sharding_plan():
     assert batch_by_frames([], ragged, 8, 1000) == []
     every = batch_by_frames(list(range(9)), ragged, max_batch=8, max_frames=10 ** 9)
     assert every == [list(range(8)), [8]]
+    # first-fit decreasing into bins of max_frames (what the CLI uses): bins are filled, every index exactly once, deterministic
+    from covomix_amd.dp import pack_by_frames
+    bins = pack_by_frames(list(range(9)), ragged, max_frames=1000, max_batch=32)
+    assert sorted(sum(bins, [])) == list(range(9)) and all(sum(ragged[i] for i in b) <= 1000 for b in bins)
+    assert bins == [[2], [7, 1, 6], [0, 4], [5, 8, 3]] and bins == pack_by_frames(list(range(9))[::-1], ragged, 1000, 32)
+    assert pack_by_frames([2, 7], ragged, max_frames=100, max_batch=32) == [[2], [7]]         # longer than a bin: alone
+    assert pack_by_frames(list(range(9)), ragged, max_frames=10 ** 9, max_batch=4) == [[2, 7, 0, 4], [5, 1, 8, 6], [3]]
+    lens16 = [400, 1200, 451, 1149, 503, 1097, 555, 1044, 607, 993, 659, 941, 711, 889, 763, 837]
+    b16 = pack_by_frames(list(range(16)), lens16, 8192, 32)
+    assert len(b16) == 2 and sum(lens16[i] for i in b16[0]) >= 8000
 
 
 def test_two_rank_gloo_broadcast_and_shard(tmp_path):
