@@ -55,11 +55,22 @@ __device__ __forceinline__ int cvx_item_len(const cvx_item_lengths& it, int b, i
     return it.item_len_dev ? min(L, max(0, it.item_len_dev[b] * it.mul + it.add)) : L;
 }
 
+// max(m, |a|, |b|) in ONE instruction (fmaxf would add a canonicalising v_max per operand in IEEE mode and, in the big unrolled
+// GEMM epilogues, enough live values to spill)
+__device__ __forceinline__ float cvx_amax3(float m, const float a, const float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+    return m;
+}
 // max |.| bookkeeping of the values a lane stores as split pairs, and the commit (one atomic, only when saturated)
 __device__ __forceinline__ float cvx_amax4(float m, const f32x4 v)
 {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    return cvx_amax3(cvx_amax3(m, v[0], v[1]), v[2], v[3]);
 }
+// the same in plain C for the 32 x 32 GEMM epilogues of gemm_common.h: there the inline asm (opaque to the optimiser) made the
+// compiler keep a 576-byte copy of the accumulator block in scratch in every kernel that carries the generic epilogue
+// (round 3: the opt-in f16 mode lost 22 % to it before this was found)
+__device__ __forceinline__ float cvx_amax3_c(float m, const float a, const float b) { return fmaxf(m, fmaxf(fabsf(a), fabsf(b))); }
 __device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, float amax)
 {
     if (flag && amax > 65504.f) atomicOr(flag, 1u);

@@ -55,10 +55,12 @@ __device__ __forceinline__ int vt_slot(int t) { return (t & ~12) | ((t & 4) << 1
 // column -> position inside a row of an INTERLEAVED split pair ([hi 32 | lo 32] per block of 32 columns; lo == hi + 32)
 __device__ __forceinline__ int il_col(int c) { return ((c >> 5) << 6) | (c & 31); }
 
-__device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v)
+// (amax: the caller's running max |v| for the saturation flag - committed once per row block, not per element: an atomic
+//  inside the scalar path's 16 x TM unrolled stores made the compiler give up unrolling and index the accumulators from scratch)
+__device__ __forceinline__ void store_split(const SplitOut& so, int64_t idx, float v, float& amax)
 {
     const float x = fminf(fmaxf(v, -65504.f), 65504.f);
-    cvx_sat_commit(so.sat, fabsf(v));
+    amax = cvx_amax3_c(amax, v, v);
     const _Float16 h = (_Float16)x;
     so.hi[idx] = h;
     if (so.lo) so.lo[idx] = (_Float16)(x - (float)h);      // lo == NULL: single-term fp16 consumer
@@ -120,7 +122,6 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
         const float b_lo_v = (p.bias && c_lo < p.N) ? p.bias[c_lo] : 0.f;
         const float b_hi_v = (p.bias && c_hi < p.N) ? p.bias[c_hi] : 0.f;
         const float vs = so.vt_scale ? *so.vt_scale : 1.f;
-        float amax = 0.f;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -133,14 +134,16 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                     const int d = (lane & 31) + 32 * hsel;
                     const float bias = hsel ? b_hi_v : b_lo_v;
                     cvx_f16x4 vh, vl;
+                    float amax = 0.f;               // committed per store group: no value kept live across the unrolled epilogue
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float xr = (acc[mi][hsel][4 * rg + e] + bias) * vs;
-                        amax = fmaxf(amax, fabsf(xr));
+                        amax = cvx_amax3_c(amax, xr, xr);
                         const float x = fminf(fmaxf(xr, -65504.f), 65504.f);
                         vh[e] = (_Float16)x;
                         vl[e] = (_Float16)(x - (float)vh[e]);
                     }
+                    cvx_sat_commit(so.sat, amax);
                     const int64_t base = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld;
                     if ((t0 & 3) == 0 && t0 + 3 < T && row0 + 3 < p.M) {
                         *reinterpret_cast<cvx_f16x4*>(so.vt_hi + base + vt_slot(t0)) = vh;
@@ -159,7 +162,6 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                 }
             }
         }
-        cvx_sat_commit(so.sat, amax);
         return;
     }
     const bool do_rope = (p.rope_cos != nullptr) && (colw < p.rope_cols);   // wave-uniform
@@ -175,7 +177,6 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                         (!p.residual || (((uintptr_t)p.residual & 15) == 0 && (p.ldr & 3) == 0)) &&
                         (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0)));
     if (vec_ok) {
-        float amax = 0.f;
         const int q = lane & 3;
         const int c4_lo = colw + 4 * ((lane & 31) >> 2);          // this lane's 4 columns after the transpose
 #pragma unroll
@@ -224,14 +225,17 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                     const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c4_lo) : c4_lo);
                     const int64_t o32 = il ? 64 : 32;              // the partner columns c4_lo + 32 are the next block
                     cvx_f16x4 h0, l0, h1, l1;
+                    float amax = 0.f;               // committed per store group: no value kept live across the unrolled epilogue
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        amax = fmaxf(amax, fmaxf(fabsf(vlo[e] * cs), fabsf(vhi[e] * cs)));
-                        const float x0 = fminf(fmaxf(vlo[e] * cs, -65504.f), 65504.f);
-                        const float x1 = fminf(fmaxf(vhi[e] * cs, -65504.f), 65504.f);
+                        const float s0 = vlo[e] * cs, s1 = vhi[e] * cs;
+                        amax = cvx_amax3_c(amax, s0, s1);
+                        const float x0 = fminf(fmaxf(s0, -65504.f), 65504.f);
+                        const float x1 = fminf(fmaxf(s1, -65504.f), 65504.f);
                         h0[e] = (_Float16)x0; l0[e] = (_Float16)(x0 - (float)h0[e]);
                         h1[e] = (_Float16)x1; l1[e] = (_Float16)(x1 - (float)h1[e]);
                     }
+                    cvx_sat_commit(so.sat, amax);
                     *reinterpret_cast<cvx_f16x4*>(so.hi + o) = h0;
                     *reinterpret_cast<cvx_f16x4*>(so.hi + o + o32) = h1;
                     if (so.lo) {
@@ -241,9 +245,9 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                 }
             }
         }
-        cvx_sat_commit(so.sat, amax);
         return;
     }
+    float amax_s = 0.f;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -272,11 +276,12 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
             }
             if (so.hi) {
                 const bool il = so.lo == so.hi + 32;
-                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_lo) : c_lo), lo * cs);
-                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_hi) : c_hi), hi * cs);
+                if (c_lo < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_lo) : c_lo), lo * cs, amax_s);
+                if (c_hi < p.N) store_split(so, (int64_t)row * so.ldc_h + (il ? il_col(c_hi) : c_hi), hi * cs, amax_s);
             }
         }
     }
+    cvx_sat_commit(so.sat, amax_s);
 }
 
 // global -> LDS DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane*16

@@ -637,8 +637,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (so.write_f32) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
     if (so.hi) {
         const float cs = so.c_scale ? *so.c_scale : 1.f;
+        float amax = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + ((so.lo == so.hi + 32) ? il_col(col + e) : col + e), v[e] * cs);
+        for (int e = 0; e < 4; ++e) store_split(so, (int64_t)row * so.ldc_h + ((so.lo == so.hi + 32) ? il_col(col + e) : col + e), v[e] * cs, amax);
+        cvx_sat_commit(so.sat, amax);
     }
 }
 

@@ -61,19 +61,12 @@ __device__ __forceinline__ f32x2 splat2(const float x) { return f32x2{x, x}; }
 __device__ __forceinline__ f32x2 mul2_rn(const f32x2 a, const f32x2 b) { return a * b; }
 #pragma clang fp contract(fast)
 
-// max(m, |a|, |b|) in one instruction (the saturation bookkeeping of cvx_common.h; fmaxf would add a canonicalising
-// v_max per operand in IEEE mode)
-__device__ __forceinline__ float amax3(float m, const float a, const float b)
-{
-    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
-    return m;
-}
 
 // (hi, lo) fp16 halves of two fp32 values, saturating: v_med3 clamp, packed RNE conversion, exact residual x - hi by
 // v_fma_mix_f32 straight from the packed halves, packed conversion of the residuals
 __device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, float& amax)
 {
-    amax = amax3(amax, v[0], v[1]);
+    amax = cvx_amax3(amax, v[0], v[1]);
     const float x0 = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), x1 = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
     hi = __builtin_convertvector(f32x2{x0, x1}, f16x2);
     const unsigned int hb = __builtin_bit_cast(unsigned int, hi);
