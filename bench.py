@@ -196,6 +196,8 @@ def main():
 
     from covomix_amd import dp, ops
     import covomix_amd.synthetic as syn
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False): covomix_amd has no CPU path")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started from a plain shell: become the launcher of N ranks (one process per GPU, free rendezvous port) - the
         # reference's own multi-GPU entry point spawns its ranks itself too (hifi-gan/train.py:268-278)
