@@ -150,6 +150,27 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
         }
     };
 
+#ifdef CVX_ATT_REGSTAGE
+    // A/B variant (T14 of the guide, "issue early / write late"): the next tile goes global -> VGPR while the current one is
+    // computed and VGPR -> LDS (same swizzled layout) behind its last MFMA, instead of by LDS-DMA.  NW = 4 only.
+    f16x8 st_kh, st_kl, st_vh, st_vl;
+    auto fetch = [&](int key0) {
+        const int key = min(max(key0 + k_r, kc0), kc1 - 1);
+        const int64_t ko = (roff + key) * ldqk + k_col;
+        st_kh = gload8h(qk_hi + ko);
+        if constexpr (NT == 3) st_kl = gload8h(qk_lo + ko);
+        const int64_t vo = v_row + key0;
+        st_vh = gload8h(vt_hi + vo);
+        if constexpr (NT == 3) st_vl = gload8h(vt_lo + vo);
+    };
+    auto commit = [&](int stage) {
+        f16* S = smem + stage * STAGE;
+        *reinterpret_cast<f16x8*>(S + 8 * wq * HD + lane * 8) = st_kh;
+        if constexpr (NT == 3) *reinterpret_cast<f16x8*>(S + TILE + 8 * wq * HD + lane * 8) = st_kl;
+        *reinterpret_cast<f16x8*>(S + 2 * TILE + 16 * wq * KT + lane * 8) = st_vh;
+        if constexpr (NT == 3) *reinterpret_cast<f16x8*>(S + 3 * TILE + 16 * wq * KT + lane * 8) = st_vl;
+    };
+#endif
     // ---- fragment offsets (halves)
     int koff[4];                                   // K rows are 64 halves; chunk (2s+g) ^ ((row>>1)&7)
 #pragma unroll
@@ -171,7 +192,12 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
     //  from 3 to 2 blocks per CU)
     // (a 3-stage ring - tiles requested two ahead - measured the same: the loop is not DMA-latency bound)
     const int tile0 = kc0 / KT, ntiles = (kc1 + KT - 1) / KT - tile0;
+#ifdef CVX_ATT_REGSTAGE
+    fetch(tile0 * KT);
+    commit(0);
+#else
     issue(tile0 * KT, 0);
+#endif
 #ifdef CVX_ATT_TRACE
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
 #define TSTAMP(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); tr[i] += now_ - tlast_; tlast_ = now_; }
@@ -183,10 +209,15 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
     f16x8 vfh[2][2], vfl[2][2];                   // V^T fragments [s][dt]
     for (int it = 0; it < ntiles; ++it) {
         const int cur = it & 1, key0 = (tile0 + it) * KT;
+#ifdef CVX_ATT_REGSTAGE
+        __syncthreads();                                    // every wave's ds_writes of tile `it` are visible; stage cur^1 is free
+        if (it + 1 < ntiles) fetch(key0 + KT);
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // tile `it` landed everywhere; stage cur^1 is free
         TSTAMP(0)
         if (it + 1 < ntiles && !((CVX_ATT_ABLATE & 1) && it > 0)) issue(key0 + KT, cur ^ 1);
+#endif
         const f16* S = smem + cur * STAGE;
 
         // ---- S^T = K . Q^T  (3 products per 16-wide d slice), ONE accumulator: the matrix pipe forwards the result of an
@@ -301,6 +332,9 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[0], ph[s], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhh[1], ph[s], o1, 0, 0, 0);
         }
+#ifdef CVX_ATT_REGSTAGE
+        if (it + 1 < ntiles) commit(cur ^ 1);
+#endif
 #ifdef CVX_ATT_TRACE
         asm volatile("" : "+v"(o0), "+v"(o1));
         { float t_ = o0[0] + o1[0]; asm volatile("s_nop 0" : "+v"(t_)); }
