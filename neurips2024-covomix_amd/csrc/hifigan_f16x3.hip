@@ -34,6 +34,12 @@ constexpr int A_ROWS = 320;            // TMB + halo (<= 50) rounded up to the 1
 constexpr int A_TILE = A_ROWS * CK;    // halves of one (hi or lo) activation tile: 20 KiB
 constexpr int W_TILE = 256 * CK;       // halves of one (hi or lo) weight stage (TS taps x Np rows = 256 rows): 16 KiB
 constexpr int LDS_HALVES = 2 * 2 * A_TILE + 2 * 2 * W_TILE;      // 144 KiB
+#ifndef CVX_PAIR_PIPE
+#define CVX_PAIR_PIPE 1                 // dev A/B: 0 = the plain loop of the fused pair kernel (lgkmcnt(0) in front of every step)
+#endif
+#ifndef CVX_CONV_PIPE
+#define CVX_CONV_PIPE 0                 // dev A/B: 1 = fragment reads software-pipelined across steps (measured: no change)
+#endif
 
 struct Conv16Args {
     const f16* z_hi; const f16* z_lo;  // [B][Lp][Cp_in]
@@ -49,6 +55,14 @@ struct Conv16Args {
     uint32_t* sat;                     // sticky saturation flag of the device (cvx_common.h) or NULL
     cvx_item_lengths items;            // ragged batch: valid positions per item (zeros are written behind them)
 };
+
+// ds_read_b128 with an immediate byte offset, issued from asm: the compiler does not count it, the waits are explicit
+__device__ __forceinline__ f16x8 lds_read16(uint32_t addr, const int off)
+{
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
 
 template <int TMI, int TNI, int WN>
 __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
@@ -66,6 +80,9 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
+#ifdef CVX_CONV_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const float zs = p.z_scale ? *p.z_scale : 1.f;          // activation pre-scale of this stage's split pairs
     const float a_sc = p.acc_scale / zs;                    // (exact: both are powers of two)
     float amax = 0.f;
@@ -119,6 +136,101 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     for (int s = 0; s < 2; ++s) woff[s] = (wn * TNI * 32 + i31) * CK + 8 * ((2 * s + g) ^ wswz);
     const int arow_base = wm * TMI * 32 + i31;
 
+#if CVX_CONV_PIPE
+    // ---- main loop, software pipelined.  A STEP = (tap, 16-channel half s) = TMI*TNI*3 MFMAs on 2*(TMI + TNI) fragment reads.
+    // Fragments live in two register sets: F1 (s = 1 of the tap) is requested before the MFMAs of F0 (s = 0) issue, and F0 of
+    // the NEXT tap before the MFMAs of F1 - a ds_read always has one step of matrix work to land under (the plain loop
+    // waited lgkmcnt(0) in front of every step with only two waves per SIMD to cover it: MFMA busy 0.3).
+    // Stage hand-over: the barrier sits between the two steps of a stage's LAST tap.  By then every wave has all of the
+    // stage's fragments in registers (lgkmcnt(0)), so the stage's weight buffer (and, with one group per chunk, its
+    // activation tile) may be refilled: the DMA of stage st + 2 is issued right behind the barrier, and vmcnt(0) in front of
+    // it retires the DMA of stage st + 1 (issued one stage earlier), whose first fragments are requested next.
+    struct Frags { f16x8 ah[TMI], al[TMI], wh[TNI], wl[TNI]; };
+    constexpr int NFR = 2 * (TMI + TNI);                              // ds_read_b128 per fragment set
+    static_assert(NFR <= 15, "counted lgkmcnt wait: 4-bit field");
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_c;
+    auto issue_stage = [&](int st_) {
+        issue_w(st_);
+        const int chunk_ = st_ / n_groups;
+        if (st_ == chunk_ * n_groups) issue_a(chunk_);
+    };
+    // The reads are inline asm and the waits are ours: left to itself hipcc waits lgkmcnt(0) in front of mma(F0) - one path
+    // into the loop header carries the barrier - which would also wait for the F1 requests issued just above it.
+    auto load_frags = [&](Frags& F, int chunk_, int st_, int tap_abs, int tl_, const int s_) {
+        const int arow = arow_base + tap_abs * p.dil;                  // tile row of output row i31 for this tap
+        const int aoff = arow * CK + 8 * ((2 * s_ + g) ^ ((arow >> 2) & 3));
+        const uint32_t wa = lds0 + 2u * (uint32_t)(4 * A_TILE + (st_ & 1) * 2 * W_TILE + tl_ * NP * CK + woff[s_]);
+        const uint32_t aa = lds0 + 2u * (uint32_t)((chunk_ & 1) * 2 * A_TILE + aoff);
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) {
+            F.wh[ni] = lds_read16(wa, ni * 32 * CK * 2);
+            F.wl[ni] = lds_read16(wa, (W_TILE + ni * 32 * CK) * 2);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TMI; ++mi) {
+            F.ah[mi] = lds_read16(aa, mi * 32 * CK * 2);
+            F.al[mi] = lds_read16(aa, (A_TILE + mi * 32 * CK) * 2);
+        }
+    };
+    // every request up to and including F's has landed (the NFR requests issued after them may still be in flight); the
+    // empty asm statements tie F's registers to the wait so that no MFMA on them is scheduled above it
+    auto wait_frags = [&](Frags& F) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NFR));
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) { asm volatile("" : "+v"(F.wh[ni])); asm volatile("" : "+v"(F.wl[ni])); }
+#pragma unroll
+        for (int mi = 0; mi < TMI; ++mi) { asm volatile("" : "+v"(F.ah[mi])); asm volatile("" : "+v"(F.al[mi])); }
+    };
+    auto mma = [&](const Frags& F) {
+#pragma unroll
+        for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[mi], F.wh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[mi], F.wl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < TMI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[mi], F.wh[ni], acc[mi][ni], 0, 0, 0);
+    };
+
+    issue_stage(0);
+    if (steps > 1) issue_stage(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags F0, F1;
+    load_frags(F0, 0, 0, 0, 0, 0);
+    {
+        int chunk = 0, grp = 0;
+        for (int st = 0; st < steps; ++st) {
+            const int t0 = grp * TS, nt = min(TS, p.ksize - t0);
+            for (int tl = 0; tl < nt; ++tl) {
+                load_frags(F1, chunk, st, t0 + tl, tl, 1);
+                wait_frags(F0);
+                mma(F0);
+                const bool last = tl + 1 == nt;
+                if (last && st + 1 < steps) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (st + 2 < steps) issue_stage(st + 2);
+                }
+                // the next step's s = 0 fragments - requested on ONE control path, so that the wait in front of mma(F1) can
+                // be a counted one (behind the very last step: a dummy read of the other buffers, never used)
+                const bool wrap = last && grp + 1 == n_groups;
+                load_frags(F0, wrap ? chunk + 1 : chunk, last ? st + 1 : st, wrap ? 0 : t0 + tl + 1, last ? 0 : tl + 1, 0);
+                wait_frags(F1);
+                mma(F1);
+            }
+            if (++grp == n_groups) { grp = 0; ++chunk; }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the dummy request behind the last step: its registers are reused below
+#else
     issue_a(0);
     issue_w(0);
     for (int st = 0; st < steps; ++st) {
@@ -172,12 +284,39 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
         }
     }
 
+#endif
+
+#ifdef CVX_CONV_TRACE
+    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- epilogue.  acc register 4*rg + e of lane (i31, g): position 8*rg + 4*g + e, channel i31.  After the quad
     // transpose lane q = lane & 3 holds position 8*rg + 4*g + q and the 4 channels 4*(i31 >> 2) .. +3.
     const int q = lane & 3;
     const int c4 = 4 * (i31 >> 2);
+    // The residual / accumulate rows of one 32-position slice (TNI x 4 vectors each) are requested TOGETHER, ahead of the
+    // slice's arithmetic: with a load in front of every store group the epilogue was a chain of 16-24 exposed HBM round
+    // trips per wave (tools/conv_trace.py: 22-28 us per block, as long as the k = 3 main loop).  Rows behind L are inside
+    // the allocation (Lp >= halo + roundup(L, 256) + 64), so the loads need no predicate; the stores keep theirs.
 #pragma unroll
     for (int mi = 0; mi < TMI; ++mi) {
+        const int lrow = l0 + wm * TMI * 32 + mi * 32 + 4 * g + q;              // + 8 * rg
+        const int ccol = wn * TNI * 32 + c4;
+        const int64_t grow = (int64_t)b * p.Lp + p.halo_l + lrow;
+        const int64_t orow = grow * NP + ccol;                                   // + 8 * rg * NP + ni * 32
+        auto ldrow = [&](int rg) { return min(grow + 8 * rg, last_row); };      // (192-row tiles of the last item may reach past the buffer)
+        f32x4 rres[TNI][4], racc[TNI][4];
+        if (p.res) {
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) rres[ni][rg] = gload4(p.res + ldrow(rg) * NP + ccol + ni * 32);
+        }
+        if (p.accum) {
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) racc[ni][rg] = gload4(p.accum + ldrow(rg) * NP + ccol + ni * 32);
+        }
 #pragma unroll
         for (int ni = 0; ni < TNI; ++ni) {
             const int co = wn * TNI * 32 + ni * 32 + c4;
@@ -187,23 +326,21 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
                 float v0 = acc[mi][ni][4 * rg + 0], v1 = acc[mi][ni][4 * rg + 1];
                 float v2 = acc[mi][ni][4 * rg + 2], v3 = acc[mi][ni][4 * rg + 3];
                 quad_transpose(v0, v1, v2, v3, lane);
-                const int l = l0 + wm * TMI * 32 + mi * 32 + 8 * rg + 4 * g + q;
+                const int l = lrow + 8 * rg;
                 if (l >= p.L) continue;
-                const int64_t o = ((int64_t)b * p.Lp + p.halo_l + l) * NP + co;
+                const int64_t o = orow + (int64_t)8 * rg * NP + ni * 32;
                 f32x4 v = {v0 * a_sc + bv[0], v1 * a_sc + bv[1], v2 * a_sc + bv[2], v3 * a_sc + bv[3]};
                 if (p.res) {
-                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                    for (int e = 0; e < 4; ++e) v[e] += rres[ni][rg][e];
                 }
                 if (l >= Lb) v = f32x4{0.f, 0.f, 0.f, 0.f};      // behind a shorter item's end: the zero padding a B = 1 run sees
 
                 if (p.out_x) {
                     f32x4 w = v;
                     if (p.accum) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.accum + o);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] += a4[e];
+                        for (int e = 0; e < 4; ++e) w[e] += racc[ni][rg][e];
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] *= p.out_scale;
@@ -226,6 +363,19 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
         }
     }
     cvx_sat_commit(p.sat, amax);
+#ifdef CVX_CONV_TRACE
+    // trace build (tools/conv_trace.py): with out_scale = 0 the fp32 output is all zero; the block leaves its 100 MHz stamps
+    // (start, end of the main loop, end) and its CU in its own first output row
+    __syncthreads();
+    if (tid == 0 && p.out_x && p.out_scale == 0.f && l0 < p.L) {
+        unsigned long long* tb = reinterpret_cast<unsigned long long*>(p.out_x + ((int64_t)b * p.Lp + p.halo_l + l0) * NP);
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tb[0] = tr0; tb[1] = tr1; tb[2] = __builtin_amdgcn_s_memrealtime(); tb[3] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- fused ResBlock pair (narrow stages: Np = 32 / 64)
@@ -370,7 +520,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
     int seq = 0;                                          // weight stages issued so far by the block (buffer = seq & 1)
     // One pass: acc = sum over (chunk, tap) of A[row + tap*dil] . W[tap].  (nwh, nwl): weights of the pass that follows
     // (nullptr: none); prefetch_x: request the next tile's x rows behind the first weight stage.
-    auto run_pass = [&](const f16* wh, const f16* wl, const f16* nwh, const f16* nwl, int dil, bool prefetch_x, int next_tile) {
+    auto run_pass_plain = [&](const f16* wh, const f16* wl, const f16* nwh, const f16* nwl, int dil, bool prefetch_x, int next_tile) {
 #pragma unroll
         for (int ni = 0; ni < TNI; ++ni)
 #pragma unroll
@@ -414,6 +564,82 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // every wave is done reading the tile: it may be overwritten
+    };
+
+    // Software-pipelined form (see conv_f16x3_kernel; used at Np = 64 - measured 8-10 % faster at k = 7 / 11 - and not at Np = 32,
+    // whose 128-register budget it overflows: 10 % slower there): a step = (tap, 16-channel half) = 3 TNI MFMAs on 2 + 2 TNI fragment
+    // reads; the reads of step i + 1 are in flight while the MFMAs of step i issue (two register sets, inline-asm reads,
+    // counted lgkmcnt waits).  The stage barrier sits between the two steps of a stage's last tap: every wave then holds all
+    // of the stage's fragments, so its weight buffer is refilled with stage st + 2 (or stage 0 of the pass that follows).
+    struct PFrags { f16x8 ah, al, wh[TNI], wl[TNI]; };
+    constexpr int NFR = 2 + 2 * TNI;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_c;
+    auto load_frags = [&](PFrags& F, int chunk_, int par, int tap_abs, int tl_, int dil_, const int s_) {
+        const int arow = arow_base + tap_abs * dil_;
+        const uint32_t aa = lds0 + 2u * (uint32_t)(chunk_ * 2 * A_TILE + arow * CK + 8 * ((2 * s_ + g) ^ ((arow >> 2) & 3)));
+        const uint32_t wa = lds0 + 2u * (uint32_t)(NCH * 2 * A_TILE + par * 2 * W_ST + tl_ * NP * CK + woff[s_]);
+        F.ah = lds_read16(aa, 0);
+        F.al = lds_read16(aa, A_TILE * 2);
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) {
+            F.wh[ni] = lds_read16(wa, ni * 32 * CK * 2);
+            F.wl[ni] = lds_read16(wa, (W_ST + ni * 32 * CK) * 2);
+        }
+    };
+    auto wait_frags = [&](PFrags& F) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NFR));
+        asm volatile("" : "+v"(F.ah)); asm volatile("" : "+v"(F.al));
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) { asm volatile("" : "+v"(F.wh[ni])); asm volatile("" : "+v"(F.wl[ni])); }
+    };
+    auto mma = [&](const PFrags& F) {
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al, F.wh[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah, F.wl[ni], acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah, F.wh[ni], acc[ni], 0, 0, 0);
+    };
+    auto run_pass_pipe = [&](const f16* wh, const f16* wl, const f16* nwh, const f16* nwl, int dil, bool prefetch_x, int next_tile) {
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // stage 0 of the pass landed, the tile written before the pass is visible
+        if (S > 1) issue_w(wh, wl, 1, (seq + 1) & 1);
+        else if (nwh) issue_w(nwh, nwl, 0, (seq + 1) & 1);
+        if (prefetch_x) load_x(next_tile);
+        PFrags F0, F1;
+        load_frags(F0, 0, seq & 1, 0, 0, dil, 0);
+        int chunk = 0, grp = 0;
+        for (int st = 0; st < S; ++st, ++seq) {
+            const int t0 = grp * TS, nt = min(TS, k - t0);
+            for (int tl = 0; tl < nt; ++tl) {
+                load_frags(F1, chunk, seq & 1, t0 + tl, tl, dil, 1);
+                wait_frags(F0);
+                mma(F0);
+                const bool last = tl + 1 == nt;
+                if (last && st + 1 < S) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();  // stage st + 1 landed; every wave holds the rest of stage st in registers
+                    if (st + 2 < S) issue_w(wh, wl, st + 2, seq & 1);
+                    else if (nwh) issue_w(nwh, nwl, 0, seq & 1);
+                }
+                const bool wrap = last && grp + 1 == n_groups;
+                // (behind the pass's last step: a dummy read of valid LDS, never used)
+                load_frags(F0, wrap ? (chunk + 1 < NCH ? chunk + 1 : 0) : chunk, last ? (seq + 1) & 1 : seq & 1, wrap ? 0 : t0 + tl + 1, last ? 0 : tl + 1, dil, 0);
+                wait_frags(F1);
+                mma(F1);
+            }
+            if (++grp == n_groups) { grp = 0; ++chunk; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // every wave is done reading the tile: it may be overwritten
+    };
+    auto run_pass = [&](const f16* wh, const f16* wl, const f16* nwh, const f16* nwl, int dil, bool prefetch_x, int next_tile) {
+        if constexpr (CVX_PAIR_PIPE && TNI == 2) run_pass_pipe(wh, wl, nwh, nwl, dil, prefetch_x, next_tile);
+        else run_pass_plain(wh, wl, nwh, nwl, dil, prefetch_x, next_tile);
     };
 
     int tile = blockIdx.x;
@@ -464,7 +690,25 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
         PSTAMP(3)
         if (has_next) store_z();                   // the next tile's z (its x rows arrived during pass 2)
         PSTAMP(4)
-        // ---- epilogue 2: x' = acc*a2 + b2 + x   (rows r < tm_out, positions < L)
+        // ---- epilogue 2: x' = acc*a2 + b2 + x   (rows r < tm_out, positions < L).  The residual (and accumulate) vectors of the
+        // wave's whole slice are requested first, unpredicated (rows clamped to the allocation): one exposed round trip to
+        // the Infinity Cache per tile instead of one per store group (4 - 8 per tile).
+        f32x4 rres[TNI][4], racc[TNI][4];
+        const uint32_t grow0 = (uint32_t)(b * p.Lp + p.halo_l + l0 + wm * 32 + 4 * g + q);
+        constexpr int RG_AHEAD = TNI == 2 ? 4 : 3;    // (<1, 8> lives under a 128-register cap: 3 of its 4 vectors ahead, no spill)
+#pragma unroll
+        for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+            for (int rg = 0; rg < RG_AHEAD; ++rg)
+                rres[ni][rg] = gload4(p.x + (min(grow0 + 8u * rg, last_row) * (uint32_t)NP + (uint32_t)(ni * 32 + c4e)));
+        constexpr bool BATCH_ACC = TNI == 2;       // (<1, 8>: the accumulate loads stay in the store loop)
+        if (BATCH_ACC && has_accum) {
+#pragma unroll
+            for (int ni = 0; ni < TNI; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    racc[ni][rg] = gload4(p.accum + (min(grow0 + 8u * rg, last_row) * (uint32_t)NP + (uint32_t)(ni * 32 + c4e)));
+        }
 #pragma unroll
         for (int ni = 0; ni < TNI; ++ni) {
             const int co = ni * 32 + c4e;
@@ -477,10 +721,10 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
                 const int l = l0 + row;
                 if (row >= tm_out || l >= p.L) continue;
                 const uint32_t o = (uint32_t)(b * p.Lp + p.halo_l + l) * (uint32_t)NP + (uint32_t)co;
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.x + o);
+                const f32x4 r4 = rg < RG_AHEAD ? rres[ni][rg] : gload4(p.x + o);
                 f32x4 v = {fmaf(v0, a2, bv[0]) + r4[0], fmaf(v1, a2, bv[1]) + r4[1], fmaf(v2, a2, bv[2]) + r4[2], fmaf(v3, a2, bv[3]) + r4[3]};
                 if (has_accum) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.accum + o);
+                    const f32x4 a4 = BATCH_ACC ? racc[ni][rg] : gload4(p.accum + o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += a4[e];
                 }

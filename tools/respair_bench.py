@@ -21,13 +21,14 @@ for C_, L in ((31, 160032), (62, 80016)):
     np_ = 32 if C_ <= 32 else 64
     Lp = ops.hifigan_cl_rows(L)
     x0 = torch.zeros(B, Lp, np_, device=dev); o = torch.zeros_like(x0)
-    x0[:, ops.HIFI_HALO_L:ops.HIFI_HALO_L + L, :C_] = torch.randn(B, L, C_, device=dev)
+    if not os.environ.get("ZERO"):          # ZERO=1: all-zero operands (no switching power in the matrix pipe): what the schedule alone costs
+        x0[:, ops.HIFI_HALO_L:ops.HIFI_HALO_L + L, :C_] = torch.randn(B, L, C_, device=dev)
     scale = torch.full((1,), 256.0, device=dev)
     for k in (3, 7, 11):
         for dil in (1, 3, 5):
             def conv(d):
                 c = SimpleNamespace(k=k, dil=d)
-                c.w16 = ops.hifigan_pack_weight_f16x3((torch.randn(C_, C_, k) / (C_ * k) ** 0.5).to(dev))
+                c.w16 = ops.hifigan_pack_weight_f16x3((torch.randn(C_, C_, k) / (C_ * k) ** 0.5).to(dev) * (0.0 if os.environ.get("ZERO") else 1.0))
                 c.bias16 = torch.zeros(np_, device=dev)
                 return c
             c1, c2 = conv(dil), conv(1)
