@@ -379,6 +379,46 @@ int cvx_hifigan_to_channels_last_scaled(const float* x, float* x_cl, uint16_t* z
                                         cvx_stream_t s);
 int cvx_hifigan_from_channels_last(const float* x_cl, float* x, int32_t B, int32_t C, int32_t L, int32_t Lp,
                                    int32_t Cp, int32_t halo_l, cvx_stream_t s);
+/* leaky_relu + ConvTranspose1d (the upsamplers, covomix/vocoder/models.py:85-88, :102-103) on the split-precision pipe,
+ * channels-last in and out (round 3; the fp32 form is cvx_hifigan_conv_transpose1d_f32, channel-major).
+ * Stride-1 form: output position stride * m + r only sees the kernel taps c_r + stride * j (c_r = (r + padding) mod stride) at the inputs m + a_r - j
+ * (a_r = (r + padding) div stride): the layer is ONE stride-1 convolution over the input with stride * Np_out output
+ * columns - column r * Np_out + co of row m is channel co of position stride * m + r, which is exactly the channels-last
+ * output buffer read as rows of `stride` positions.  The columns are cut into n_tiles tiles of tile_np (a whole number of
+ * phases); tile t runs tile_taps[t] taps, tap kk reading input row m + kk - tile_pad[t], from the packed weights at
+ * w_hi/w_lo + tile_w_off[t] (layout [Cp_in/32][tile_taps[t]][tile_np][32 ci], pre-scaled by 1/acc_scale and split, taps a
+ * phase does not see are zero).  covomix_amd.ops.hifigan_pack_conv_transpose1d_f16x3 builds weights, bias and table.
+ *   z_hi/z_lo : split(leaky_relu(x) * *z_scale_dev) of the input, [B][Lp_in][Cp_in], layout rules of cvx_conv16_args
+ *   bias      : [stride * Np_out], bias[co] repeated per phase (zero in the padded channels)
+ *   out       : fp32 [B][Lp_out][Np_out], rows halo_out + l for l < L_out = (L_in - 1) * stride + kernel size - 2 * padding are
+ *               written (zeros behind an item's end when `items` - lengths in OUTPUT positions - is set); rows m >= L_in of
+ *               the stride-1 form (config_covomix's first upsampler: L_out = 5 L_in + 1) read the zero rows behind the input:
+ *               ceil(L_out / stride) <= L_in + 32; Lp_out >= halo_out + L_out
+ *   amax_bits_dev : optional; receives the bit pattern of max |out| (atomicMax; feed cvx_pow2_scale_from_amax_f32) */
+typedef struct {
+    const uint16_t *z_hi, *z_lo;
+    int32_t B, L_in, Lp_in, Cp_in, halo_in;
+    const uint16_t *w_hi, *w_lo;
+    float acc_scale;
+    const float* bias;
+    int32_t Np_out, stride, n_tiles, tile_np;
+    int32_t tile_taps[8], tile_pad[8];
+    int64_t tile_w_off[8];                       /* in halves */
+    float* out;
+    int32_t L_out, Lp_out, halo_out;
+    const float* z_scale_dev;
+    uint32_t* amax_bits_dev;
+    cvx_item_lengths items;
+} cvx_convt16_args;
+int cvx_hifigan_conv_transpose1d_f16x3(const cvx_convt16_args* a, cvx_stream_t s);
+/* z = split(leaky_relu(x, slope) * *z_scale_dev) over n floats of a channels-last fp32 buffer (n % 4 == 0; the whole
+ * buffer: zero rows and channels stay zero) - the input pair of the call above / of cvx_hifigan_conv1d_f16x3. */
+int cvx_hifigan_split_channels_last(const float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int64_t n, float slope,
+                                    const float* z_scale_dev, cvx_stream_t s);
+/* cvx_hifigan_post_f32 (leaky_relu + conv_post + tanh, models.py:112-114) reading the channels-last stage output
+ * [B][Lp][Np] (Np <= 64, halo_l >= 3, zero rows around the signal): same summation order, same bits. y: [B][L]. */
+int cvx_hifigan_post_channels_last_f32(const float* x_cl, const float* w, float bias, float* y, int32_t B, int32_t C, int32_t Np,
+                                       int32_t L, int32_t Lp, int32_t halo_l, float slope, cvx_stream_t s);
 /* *scale_dev = 2^round(log2(target / max|x|)) (1 when x is all zero; exponent clamped to +-40): the power-of-two factor that
  * brings the largest magnitude of x to about `target`.  Everything stays on the device (scratch_dev: one uint32 of
  * caller-owned scratch), so a consumer kernel can use the scale without a host round trip. */

@@ -75,6 +75,19 @@ class Conv16Args(C.Structure):
     ]
 
 
+class ConvT16Args(C.Structure):
+    _fields_ = [
+        ("z_hi", C.c_void_p), ("z_lo", C.c_void_p),
+        ("B", C.c_int32), ("L_in", C.c_int32), ("Lp_in", C.c_int32), ("Cp_in", C.c_int32), ("halo_in", C.c_int32),
+        ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("bias", C.c_void_p),
+        ("Np_out", C.c_int32), ("stride", C.c_int32), ("n_tiles", C.c_int32), ("tile_np", C.c_int32),
+        ("tile_taps", C.c_int32 * 8), ("tile_pad", C.c_int32 * 8), ("tile_w_off", C.c_int64 * 8),
+        ("out", C.c_void_p), ("L_out", C.c_int32), ("Lp_out", C.c_int32), ("halo_out", C.c_int32),
+        ("z_scale_dev", C.c_void_p), ("amax_bits_dev", C.c_void_p),
+        ("items", ItemLengths),
+    ]
+
+
 class Conv16Weights(C.Structure):
     _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("acc_scale", C.c_float), ("bias", C.c_void_p)]
 
@@ -146,6 +159,10 @@ class HubertModel(C.Structure):
 SIGNATURES = {
     "cvx_version": (C.c_int, []),
     "cvx_hifigan_conv1d_f16x3": (C.c_int, [C.POINTER(Conv16Args), C.c_void_p]),
+    "cvx_hifigan_conv_transpose1d_f16x3": (C.c_int, [C.POINTER(ConvT16Args), C.c_void_p]),
+    "cvx_hifigan_split_channels_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_hifigan_post_channels_last_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_hifigan_to_channels_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "cvx_hifigan_from_channels_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

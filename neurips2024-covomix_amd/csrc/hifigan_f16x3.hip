@@ -54,6 +54,17 @@ struct Conv16Args {
     const float* z_scale;              // device scalar (power of two) carried by z and applied to out_z, or NULL = 1
     uint32_t* sat;                     // sticky saturation flag of the device (cvx_common.h) or NULL
     cvx_item_lengths items;            // ragged batch: valid positions per item (zeros are written behind them)
+    // Output-column tiles (blockIdx.z), each with its own taps.  A "same" convolution has ONE (ksize, pad, offset 0).
+    // ConvTranspose1d in stride-1 form has stride * Np_out output columns - column r * Np_out + co of row m is channel co of
+    // output position stride * m + r - and phase r only sees the taps kk = c_r + stride * j of the kernel, so every tile of
+    // NP columns (a group of phases) carries its own tap count, its own "pad" and its own packed weights.
+    int zk[8], zpad[8];
+    long long zw[8];                   // offset of the tile's packed weights, in halves
+    // out row l, tile column n  ->  out_x[b * out_bs + out_base + l * ldo + zt * NP + n]; it is position
+    // l * ostride + ((zt * NP + n) >> ph_shift) of the signal, stored when < L_out (and < the item's length)
+    long long out_bs, out_base;
+    int ldo, ostride, ph_shift, L_out;
+    uint32_t* amax_out;                // receives the bit pattern of max |out_x| (atomicMax) or NULL
 };
 
 // ds_read_b128 with an immediate byte offset, issued from asm: the compiler does not count it, the waits are explicit
@@ -88,14 +99,18 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     float amax = 0.f;
     const int l0 = blockIdx.x * TMB;
     const int b = blockIdx.y;
-    const int Lb = cvx_item_len(p.items, b, p.L);
+    const int zt = blockIdx.z;
+    const int ksize = p.zk[zt], pad = p.zpad[zt];
+    const f16* const w_hi = p.w_hi + p.zw[zt];
+    const f16* const w_lo = p.w_lo + p.zw[zt];
+    const int Lb = cvx_item_len(p.items, b, p.L_out);
     const int n_chunks = p.Cp_in / CK;
-    const int n_groups = (p.ksize + TS - 1) / TS;
+    const int n_groups = (ksize + TS - 1) / TS;
     const int steps = n_chunks * n_groups;
 
     // ---- DMA addressing: a piece = 16 rows x 64 bytes; lane -> (row = lane >> 2, 16-byte chunk = lane & 3, swizzled)
     const int prow = lane >> 2;
-    const int64_t a_row0 = (int64_t)b * p.Lp + p.halo_l + l0 - p.pad;            // global row of tile row 0 (>= 0)
+    const int64_t a_row0 = (int64_t)b * p.Lp + p.halo_l + l0 - pad;            // global row of tile row 0 (>= 0)
     const int64_t last_row = (int64_t)gridDim.y * p.Lp - 1;
     auto issue_a = [&](int chunk) {
         f16* dst = As + (chunk & 1) * 2 * A_TILE;
@@ -109,15 +124,15 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     };
     auto issue_w = [&](int st) {
         const int chunk = st / n_groups, grp = st - chunk * n_groups;
-        const int t0 = grp * TS, nt = min(TS, p.ksize - t0);
+        const int t0 = grp * TS, nt = min(TS, ksize - t0);
         f16* dst = Ws + (st & 1) * 2 * W_TILE;
-        const int64_t base = ((int64_t)chunk * p.ksize + t0) * NP * CK;
+        const int64_t base = ((int64_t)chunk * ksize + t0) * NP * CK;
         for (int pc = wid; pc < nt * NP / 16; pc += 8) {
             const int r = 16 * pc + prow;
             const int c4 = (lane & 3) ^ ((r >> 2) & 3);
             const int64_t src = base + (int64_t)r * CK + 8 * c4;
-            glds16(p.w_hi + src, dst + 16 * pc * CK);
-            glds16(p.w_lo + src, dst + W_TILE + 16 * pc * CK);
+            glds16(w_hi + src, dst + 16 * pc * CK);
+            glds16(w_lo + src, dst + W_TILE + 16 * pc * CK);
         }
     };
 
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     {
         int chunk = 0, grp = 0;
         for (int st = 0; st < steps; ++st) {
-            const int t0 = grp * TS, nt = min(TS, p.ksize - t0);
+            const int t0 = grp * TS, nt = min(TS, ksize - t0);
             for (int tl = 0; tl < nt; ++tl) {
                 load_frags(F1, chunk, st, t0 + tl, tl, 1);
                 wait_frags(F0);
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     issue_w(0);
     for (int st = 0; st < steps; ++st) {
         const int chunk = st / n_groups, grp = st - chunk * n_groups;
-        const int t0 = grp * TS, nt = min(TS, p.ksize - t0);
+        const int t0 = grp * TS, nt = min(TS, ksize - t0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // stage st (and its activation tile) landed; the other buffers are free
         if (st + 1 < steps) {
@@ -293,6 +308,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     // transpose lane q = lane & 3 holds position 8*rg + 4*g + q and the 4 channels 4*(i31 >> 2) .. +3.
     const int q = lane & 3;
     const int c4 = 4 * (i31 >> 2);
+    float omax = 0.f;
     // The residual / accumulate rows of one 32-position slice (TNI x 4 vectors each) are requested TOGETHER, ahead of the
     // slice's arithmetic: with a load in front of every store group the epilogue was a chain of 16-24 exposed HBM round
     // trips per wave (tools/conv_trace.py: 22-28 us per block, as long as the k = 3 main loop).  Rows behind L are inside
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
         const int lrow = l0 + wm * TMI * 32 + mi * 32 + 4 * g + q;              // + 8 * rg
         const int ccol = wn * TNI * 32 + c4;
         const int64_t grow = (int64_t)b * p.Lp + p.halo_l + lrow;
-        const int64_t orow = grow * NP + ccol;                                   // + 8 * rg * NP + ni * 32
+        const int64_t orow = (int64_t)b * p.out_bs + p.out_base + (int64_t)lrow * p.ldo + zt * NP + ccol;       // + 8 * rg * ldo + ni * 32
         auto ldrow = [&](int rg) { return min(grow + 8 * rg, last_row); };      // (192-row tiles of the last item may reach past the buffer)
         f32x4 rres[TNI][4], racc[TNI][4];
         if (p.res) {
@@ -327,14 +343,15 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
                 float v2 = acc[mi][ni][4 * rg + 2], v3 = acc[mi][ni][4 * rg + 3];
                 quad_transpose(v0, v1, v2, v3, lane);
                 const int l = lrow + 8 * rg;
-                if (l >= p.L) continue;
-                const int64_t o = orow + (int64_t)8 * rg * NP + ni * 32;
+                const int lpos = l * p.ostride + ((zt * NP + ccol + ni * 32) >> p.ph_shift);       // position of the signal (= l for a plain convolution)
+                if (l >= p.L || lpos >= p.L_out) continue;
+                const int64_t o = orow + (int64_t)8 * rg * p.ldo + ni * 32;
                 f32x4 v = {v0 * a_sc + bv[0], v1 * a_sc + bv[1], v2 * a_sc + bv[2], v3 * a_sc + bv[3]};
                 if (p.res) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rres[ni][rg][e];
                 }
-                if (l >= Lb) v = f32x4{0.f, 0.f, 0.f, 0.f};      // behind a shorter item's end: the zero padding a B = 1 run sees
+                if (lpos >= Lb) v = f32x4{0.f, 0.f, 0.f, 0.f};   // behind a shorter item's end: the zero padding a B = 1 run sees
 
                 if (p.out_x) {
                     f32x4 w = v;
@@ -345,6 +362,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] *= p.out_scale;
                     *reinterpret_cast<f32x4*>(p.out_x + o) = w;
+                    omax = cvx_amax3_c(cvx_amax3_c(omax, w[0], w[1]), w[2], w[3]);
                 }
                 if (p.out_zhi) {
                     cvx_f16x4 zh, zl;
@@ -363,6 +381,12 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
         }
     }
     cvx_sat_commit(p.sat, amax);
+    if (p.amax_out) {                       // max |out_x| of the launch (non-negative floats order like their bits)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
+        if (lane == 0 && omax > 0.f && omax < __builtin_inff() && __float_as_uint(omax) > __atomic_load_n(p.amax_out, __ATOMIC_RELAXED))
+            atomicMax(p.amax_out, __float_as_uint(omax));        // (most waves cannot raise the maximum: no atomic)
+    }
 #ifdef CVX_CONV_TRACE
     // trace build (tools/conv_trace.py): with out_scale = 0 the fp32 output is all zero; the block leaves its 100 MHz stamps
     // (start, end of the main loop, end) and its CU in its own first output row
@@ -809,13 +833,81 @@ __global__ __launch_bounds__(256) void cl_to_cm_kernel(const float* __restrict__
 }
 
 template <int TMI, int TNI, int WN>
-void launch_conv16(const Conv16Args& a, int B, hipStream_t st)
+void launch_conv16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
 {
     constexpr int tmb = (8 / WN) * TMI * 32;
     const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
     cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN>), (int)lds);
-    dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B);
+    dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
     hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN>), grid, dim3(512), lds, st, a);
+}
+
+// kernel instance by output tile width; Np = 256: one block per CU - when the 256-position tiles leave more than a quarter of
+// the chip idle in their last (or only) round and 192-position tiles fit in fewer block-rows of work, take those (stage 0 of
+// the bench shape: 160 -> 216 blocks of 3/4 the work each on 256 CUs)
+void dispatch_conv16(const Conv16Args& k, int B, int n_ztiles, hipStream_t st)
+{
+    if (k.Np == 256) {
+        const int cus = cvx_device_cus();
+        const int64_t n256 = (int64_t)((k.L + 255) / 256) * B * n_ztiles, n192 = (int64_t)((k.L + 191) / 192) * B * n_ztiles;
+        const int64_t t256 = (n256 + cus - 1) / cus * 4, t192 = (n192 + cus - 1) / cus * 3;      // rounds x tile size
+        if (t192 < t256) launch_conv16<3, 2, 4>(k, B, n_ztiles, st);
+        else launch_conv16<4, 2, 4>(k, B, n_ztiles, st);
+    }
+    else if (k.Np == 128) launch_conv16<2, 2, 2>(k, B, n_ztiles, st);
+    else if (k.Np == 64) launch_conv16<1, 2, 1>(k, B, n_ztiles, st);
+    else launch_conv16<1, 1, 1>(k, B, n_ztiles, st);
+}
+
+// ---------------------------------------------------------------- fp32 channels-last -> split pair; conv_post on channels-last
+// z = split(leaky_relu(x, slope) * *z_scale) over a whole channels-last buffer (zero rows / channels stay zero)
+__global__ __launch_bounds__(256) void cl_split_kernel(const float* __restrict__ x, f16* __restrict__ z_hi, f16* __restrict__ z_lo,
+                                                       int64_t n4, float slope, const float* __restrict__ z_scale, uint32_t* __restrict__ sat)
+{
+    const float zs = z_scale ? *z_scale : 1.f;
+    float amax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = gload4(x + 4 * i);
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = (v[e] > 0.f ? v[e] : v[e] * slope) * zs;
+        cvx_f16x4 zh, zl;
+        pair_split4(z, zh, zl, amax);
+        *reinterpret_cast<cvx_f16x4*>(z_hi + 4 * i) = zh;
+        *reinterpret_cast<cvx_f16x4*>(z_lo + 4 * i) = zl;
+    }
+    cvx_sat_commit(sat, amax);
+}
+
+// conv_post (Conv1d(C, 1, 7, padding 3) on leaky_relu(x)) + tanh (models.py:112-114) reading the channels-last stage output:
+// a block stages its 256 + 6 rows (leaky_relu applied; halo rows are zero in the buffer) in LDS and every thread sums its
+// position in the order of the channel-major kernel (bias first, channels outer, taps inner) - the same bits.
+constexpr int POST_ROWS = 256 + 6;
+__global__ __launch_bounds__(256) void post_cl_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
+                                                      float* __restrict__ y, int C, int Np, int L, int Lp, int halo_l, float slope)
+{
+    extern __shared__ __attribute__((aligned(16))) float post_tile[];          // [POST_ROWS][Np + 1]
+    const int l0 = blockIdx.x * 256, b = blockIdx.y, ld = Np + 1;
+    const float* xb = x + ((int64_t)b * Lp + halo_l + l0 - 3) * Np;           // halo_l >= 3: row -3 exists
+    const int64_t lim = ((int64_t)gridDim.y * Lp - ((int64_t)b * Lp + halo_l + l0 - 3)) * Np;      // floats left in the buffer
+    for (int i = threadIdx.x; i < POST_ROWS * Np / 4; i += 256) {
+        const int r = (4 * i) / Np, c = (4 * i) % Np;
+        f32x4 v = (int64_t)4 * i + 3 < lim ? gload4(xb + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) post_tile[r * ld + c + e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    }
+    __syncthreads();
+    const int l = l0 + threadIdx.x;
+    if (l >= L) return;
+    float acc = bias;
+    for (int ci = 0; ci < C; ++ci) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int pidx = l + k - 3;
+            if (pidx >= 0 && pidx < L) acc = fmaf(w[ci * 7 + k], post_tile[(threadIdx.x + k) * ld + ci], acc);
+        }
+    }
+    y[(int64_t)b * L + l] = tanhf(acc);
 }
 
 }  // namespace
@@ -838,22 +930,74 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
                  reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
                  a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev,
-                 a->out_zhi ? cvx_sat_flag_dev() : nullptr, a->items};
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    if (a->Np == 256) {
-        // one block per CU: when the 256-position tiles leave more than a quarter of the chip idle in their last (or only)
-        // round and 192-position tiles fit in fewer block-rows of work, take those (stage 0 of the bench shape: 160 -> 216
-        // blocks of 3/4 the work each on 256 CUs)
-        const int cus = cvx_device_cus();
-        const int64_t n256 = (int64_t)((a->L + 255) / 256) * a->B, n192 = (int64_t)((a->L + 191) / 192) * a->B;
-        const int64_t t256 = (n256 + cus - 1) / cus * 4, t192 = (n192 + cus - 1) / cus * 3;      // rounds x tile size
-        if (t192 < t256) launch_conv16<3, 2, 4>(k, a->B, st);
-        else launch_conv16<4, 2, 4>(k, a->B, st);
-    }
-    else if (a->Np == 128) launch_conv16<2, 2, 2>(k, a->B, st);
-    else if (a->Np == 64) launch_conv16<1, 2, 1>(k, a->B, st);
-    else launch_conv16<1, 1, 1>(k, a->B, st);
+                 a->out_zhi ? cvx_sat_flag_dev() : nullptr, a->items, {}, {}, {}, 0, 0, 0, 0, 0, 0, nullptr};
+    k.zk[0] = a->ksize; k.zpad[0] = pad; k.zw[0] = 0;                  // one output-column tile, the plain layout
+    k.out_bs = (long long)a->Lp * a->Np; k.out_base = (long long)a->halo_l * a->Np;
+    k.ldo = a->Np; k.ostride = 1; k.ph_shift = 31; k.L_out = a->L;
+    dispatch_conv16(k, a->B, 1, reinterpret_cast<hipStream_t>(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_f16x3");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_conv_transpose1d_f16x3(const cvx_convt16_args* a, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && a->z_hi && a->z_lo && a->w_hi && a->w_lo && a->bias && a->out, "conv_transpose1d_f16x3: null pointer");
+    CVX_REQUIRE(a->B >= 0 && a->L_in > 0 && a->Cp_in > 0 && a->Cp_in % 32 == 0 && a->stride >= 1 && a->stride <= 8 &&
+                (a->Np_out == 32 || a->Np_out == 64 || a->Np_out == 128 || a->Np_out == 256),
+                "conv_transpose1d_f16x3: bad shape (L_in=%d Cp_in=%d Np_out=%d stride=%d)", a->L_in, a->Cp_in, a->Np_out, a->stride);
+    CVX_REQUIRE((a->tile_np == 32 || a->tile_np == 64 || a->tile_np == 128 || a->tile_np == 256) && a->tile_np % a->Np_out == 0 &&
+                a->n_tiles >= 1 && a->n_tiles <= 8 && (int64_t)a->n_tiles * a->tile_np == (int64_t)a->stride * a->Np_out,
+                "conv_transpose1d_f16x3: %d tiles of %d columns do not cover stride * Np_out = %d x %d", a->n_tiles, a->tile_np, a->stride, a->Np_out);
+    const int M = a->L_out > 0 ? (a->L_out + a->stride - 1) / a->stride : 0;       // rows of `stride` output positions
+    CVX_REQUIRE(a->L_out > 0 && M <= a->L_in + 32 && a->halo_out >= 0 && a->Lp_out >= a->halo_out + a->L_out,
+                "conv_transpose1d_f16x3: L_out = %d needs ceil(L_out / stride) <= L_in + 32 (the zero rows behind the input) and "
+                "Lp_out >= halo_out + L_out (L_in=%d Lp_out=%d)", a->L_out, a->L_in, a->Lp_out);
+    int max_up = 0;
+    for (int t = 0; t < a->n_tiles; ++t) {
+        CVX_REQUIRE(a->tile_taps[t] >= 1 && a->tile_taps[t] <= 8 && a->tile_pad[t] <= a->halo_in && a->tile_pad[t] >= -8 && a->tile_w_off[t] >= 0 &&
+                    a->tile_w_off[t] % 8 == 0, "conv_transpose1d_f16x3: bad tap table entry %d", t);
+        max_up = std::max(max_up, a->tile_taps[t] - 1 - a->tile_pad[t]);
+    }
+    CVX_REQUIRE(a->Lp_in >= a->halo_in + ((a->L_in + TMB - 1) / TMB) * TMB + (A_ROWS - TMB) && max_up <= A_ROWS - TMB - 14,
+                "conv_transpose1d_f16x3: the input buffer needs Lp_in >= halo_in + roundup(L_in, 256) + 64 (halo_in=%d Lp_in=%d)", a->halo_in, a->Lp_in);
+    if (a->B == 0) return CVX_OK;
+    Conv16Args k{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
+                 reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, nullptr, nullptr, a->out,
+                 nullptr, nullptr, M, a->Lp_in, a->Cp_in, a->tile_np, 1, 1, 0, a->halo_in, a->acc_scale, 1.f, 0.f, a->z_scale_dev,
+                 nullptr, a->items, {}, {}, {}, 0, 0, 0, 0, 0, 0, nullptr};
+    for (int t = 0; t < a->n_tiles; ++t) { k.zk[t] = a->tile_taps[t]; k.zpad[t] = a->tile_pad[t]; k.zw[t] = a->tile_w_off[t]; }
+    k.out_bs = (long long)a->Lp_out * a->Np_out; k.out_base = (long long)a->halo_out * a->Np_out;
+    k.ldo = a->stride * a->Np_out; k.ostride = a->stride; k.ph_shift = __builtin_ctz((unsigned)a->Np_out); k.L_out = a->L_out;
+    k.amax_out = a->amax_bits_dev;
+    dispatch_conv16(k, a->B, a->n_tiles, reinterpret_cast<hipStream_t>(s));
+    CVX_CHECK_LAUNCH("cvx_hifigan_conv_transpose1d_f16x3");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_split_channels_last(const float* x_cl, uint16_t* z_hi, uint16_t* z_lo, int64_t n, float slope,
+                                               const float* z_scale_dev, cvx_stream_t s)
+{
+    CVX_REQUIRE(x_cl && z_hi && z_lo && n >= 0 && n % 4 == 0, "split_channels_last: bad arguments (n must be a multiple of 4)");
+    if (n == 0) return CVX_OK;
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)cvx_device_cus() * 16);
+    hipLaunchKernelGGL(cl_split_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(s), x_cl,
+                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), n4, slope, z_scale_dev, cvx_sat_flag_dev());
+    CVX_CHECK_LAUNCH("cvx_hifigan_split_channels_last");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_post_channels_last_f32(const float* x_cl, const float* w, float bias, float* y, int32_t B, int32_t C, int32_t Np,
+                                                  int32_t L, int32_t Lp, int32_t halo_l, float slope, cvx_stream_t s)
+{
+    CVX_REQUIRE(x_cl && w && y && B >= 0 && C > 0 && Np >= C && Np % 4 == 0 && Np <= 64 && L > 0 && halo_l >= 3 && Lp >= halo_l + L + 3,
+                "post_channels_last: bad arguments (C=%d Np=%d L=%d Lp=%d halo_l=%d; Np <= 64)", C, Np, L, Lp, halo_l);
+    if (B == 0) return CVX_OK;
+    const size_t lds = (size_t)POST_ROWS * (Np + 1) * sizeof(float);
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&post_cl_kernel), (int)lds);
+    hipLaunchKernelGGL(post_cl_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), lds, reinterpret_cast<hipStream_t>(s),
+                       x_cl, w, bias, y, C, Np, L, Lp, halo_l, slope);
+    CVX_CHECK_LAUNCH("cvx_hifigan_post_channels_last_f32");
     return CVX_OK;
 }
 

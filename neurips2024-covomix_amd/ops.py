@@ -501,6 +501,95 @@ def hifigan_pack_weight_f16x3(w: torch.Tensor):
     return hi, lo, inv, np_, cp
 
 
+def hifigan_pack_conv_transpose1d_f16x3(w: torch.Tensor, bias: torch.Tensor, stride: int, padding: int, cp_in: Optional[int] = None):
+    """ConvTranspose1d weight [Cin, Cout, K] (fp32, on the GPU) -> the stride-1 form of cvx_hifigan_conv_transpose1d_f16x3
+    (include/covomix_hip.h): dict(w_hi, w_lo, acc_scale, bias [stride * Np_out], np_out, cp_in, stride, tile_np, taps, pad,
+    w_off).  Output position stride*m + r sees kernel taps c + stride*j (c = (r + padding) % stride) at inputs m + a - j
+    (a = (r + padding) // stride).  Phases are grouped into column tiles (<= 256 columns, a whole number of phases) so that
+    the taps a tile runs but a phase does not see - zero weights, wasted MFMAs - are fewest.  Load-time plumbing."""
+    cin, cout, K = w.shape
+    s = int(stride)
+    tile = lambda c: 32 if c <= 32 else 64 if c <= 64 else 128 if c <= 128 else 256
+    assert cout <= 256 and 1 <= s <= 8
+    np_out, cp = tile(cout), cp_in or (cin + 31) // 32 * 32          # cp_in: channel count of the input buffers (>= cin, x32)
+    assert cp >= cin and cp % 32 == 0
+    ph = []                                               # per phase: (c, a, J) - J taps, input offsets a - J + 1 .. a
+    for r in range(s):
+        q = r + padding
+        c, a = q % s, q // s
+        ph.append((c, a, max(0, -(-(K - c) // s))))
+    def plan(ppt):                                        # tiles of ppt phases: (first phase, lowest offset, taps)
+        tiles = []
+        for r0 in range(0, s, ppt):
+            live = [(a - J + 1, a) for (c, a, J) in ph[r0:r0 + ppt] if J > 0] or [(0, 0)]
+            lo, hi = min(l for l, _ in live), max(h for _, h in live)
+            tiles.append((r0, lo, hi - lo + 1))
+        return tiles
+    cands = [ppt for ppt in range(1, s + 1) if s % ppt == 0 and ppt * np_out in (32, 64, 128, 256) and s // ppt <= 8]
+    # matrix work of a plan (taps x columns, summed over its tiles) plus a per-tile term for what every extra tile costs
+    # whatever its width (its own activation tiles, blocks and epilogues): the narrow layers prefer ONE tile with a zero tap
+    ppt = min(cands, key=lambda n: (sum(t[2] * n * np_out + 256 for t in plan(n)), n))
+    tiles, tile_np = plan(ppt), ppt * np_out
+    blocks, w_off, taps, pads, off = [], [], [], [], 0
+    for r0, lo, nt in tiles:
+        full = torch.zeros(tile_np, cp, nt, dtype=torch.float32, device=w.device)      # conv1d weight [co, ci, tap]
+        for rl in range(ppt):
+            c, a, J = ph[r0 + rl]
+            for t in range(nt):
+                j = a - (lo + t)
+                if 0 <= j < J:
+                    full[rl * np_out: rl * np_out + cout, :cin, t] = w[:, :, s * j + c].t()
+        blocks.append(full.reshape(tile_np, cp // 32, 32, nt).permute(1, 3, 0, 2).contiguous().reshape(-1))   # [chunk][tap][co][ci]
+        w_off.append(off); taps.append(nt); pads.append(-lo)
+        off += blocks[-1].numel()
+    hi, lo_, inv = split_f16(torch.cat(blocks))
+    b = torch.zeros(s, np_out, dtype=torch.float32, device=w.device)
+    b[:, :cout] = bias.to(w.device).float()
+    return dict(w_hi=hi, w_lo=lo_, acc_scale=inv, bias=b.reshape(-1).contiguous(), np_out=np_out, cp_in=cp, stride=s, tile_np=tile_np,
+                taps=taps, pad=pads, w_off=w_off, ksize=K, padding=padding)
+
+
+def hifigan_conv_transpose1d_f16x3(z, pk: dict, B: int, L_in: int, out: torch.Tensor, L_out: int, *, z_scale=None, amax_bits=None,
+                                   items=None) -> torch.Tensor:
+    """out (fp32 channels-last [B, Lp_out, Np_out]) = ConvTranspose1d of the activation whose split(leaky_relu(.) * z_scale) pair is
+    z = (hi, lo) [B, Lp_in, Cp_in]; pk from hifigan_pack_conv_transpose1d_f16x3.  items: valid OUTPUT positions per item."""
+    zh, zl = z
+    assert zh.dtype == torch.float16 and zh.is_contiguous() and zl.is_contiguous() and zh.shape == zl.shape
+    assert zh.shape[0] == B and zh.shape[2] == pk["cp_in"], (tuple(zh.shape), pk["cp_in"])
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == B and out.shape[2] == pk["np_out"]
+    a = _lib.ConvT16Args()
+    a.z_hi, a.z_lo = zh.data_ptr(), zl.data_ptr()
+    a.B, a.L_in, a.Lp_in, a.Cp_in, a.halo_in = B, L_in, zh.shape[1], pk["cp_in"], HIFI_HALO_L
+    a.w_hi, a.w_lo, a.acc_scale, a.bias = pk["w_hi"].data_ptr(), pk["w_lo"].data_ptr(), pk["acc_scale"], pk["bias"].data_ptr()
+    a.Np_out, a.stride, a.n_tiles, a.tile_np = pk["np_out"], pk["stride"], len(pk["taps"]), pk["tile_np"]
+    for t in range(len(pk["taps"])):
+        a.tile_taps[t], a.tile_pad[t], a.tile_w_off[t] = pk["taps"][t], pk["pad"][t], pk["w_off"][t]
+    a.out, a.L_out, a.Lp_out, a.halo_out = out.data_ptr(), L_out, out.shape[1], HIFI_HALO_L
+    a.z_scale_dev, a.amax_bits_dev = _sp(z_scale), _p(amax_bits)
+    _items(a.items, items)
+    _lib.check(_lib.load().cvx_hifigan_conv_transpose1d_f16x3(C.byref(a), _stream()), "cvx_hifigan_conv_transpose1d_f16x3")
+    return out
+
+
+def hifigan_split_channels_last(x_cl: torch.Tensor, z, slope: float, z_scale=None) -> None:
+    """z = split(leaky_relu(x_cl, slope) * z_scale) over a whole fp32 channels-last buffer."""
+    zh, zl = z
+    assert x_cl.dtype == torch.float32 and x_cl.is_contiguous() and zh.dtype == torch.float16 and zh.is_contiguous() and zl.is_contiguous()
+    assert zh.shape == x_cl.shape and zl.shape == x_cl.shape and x_cl.numel() % 4 == 0
+    _lib.check(_lib.load().cvx_hifigan_split_channels_last(x_cl.data_ptr(), zh.data_ptr(), zl.data_ptr(), x_cl.numel(), slope,
+                                                           _sp(z_scale), _stream()), "cvx_hifigan_split_channels_last")
+
+
+def hifigan_post_channels_last(x_cl: torch.Tensor, C_: int, L: int, w: torch.Tensor, bias: float, out: torch.Tensor, slope: float = 0.01) -> torch.Tensor:
+    """hifigan_post reading the channels-last stage output [B, Lp, Np] (C_ valid channels, L valid positions); out [B, 1, L]."""
+    _chk_f32(x_cl, w, out)
+    B, Lp, np_ = x_cl.shape
+    assert x_cl.is_contiguous() and out.is_contiguous() and out.numel() == B * L and w.numel() == C_ * 7
+    _lib.check(_lib.load().cvx_hifigan_post_channels_last_f32(x_cl.data_ptr(), w.data_ptr(), float(bias), out.data_ptr(), B, C_, np_, L, Lp,
+                                                              HIFI_HALO_L, slope, _stream()), "cvx_hifigan_post_channels_last_f32")
+    return out
+
+
 def amax_pow2_scale(x: torch.Tensor, target: float, scale: torch.Tensor, scratch: torch.Tensor) -> torch.Tensor:
     """scale[0] = 2^round(log2(target / max|x|)) computed on the device (scratch: one int32 element)."""
     _chk_f32(x, scale)

@@ -60,7 +60,7 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 class _Conv:
-    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn", "w16", "bias16", "wp_poly", "padding")
+    __slots__ = ("wp", "bias", "cout", "cin", "k", "dil", "pad", "up", "lout_fn", "w16", "bias16", "wp_poly", "padding", "w16t")
 
 
 class Generator:
@@ -72,6 +72,9 @@ class Generator:
             raise ValueError(f"vocoder precision must be 'f16x3' or 'fp32', got {self.precision!r}")
         self._cl: Dict[tuple, dict] = {}
         self.act_scales = os.environ.get("CVX_ACT_SCALES", "1") == "1"
+        # channels-last pipeline (round 3): the upsamplers on the split pipe too, no layout converters between the stages
+        # (CVX_VOCODER_CL=0: ConvTranspose1d on the fp32 kernel, channel-major between the stages - the round-2 flow)
+        self.cl_pipeline = os.environ.get("CVX_VOCODER_CL", "1") == "1"
         self.h = h
         self.num_kernels = len(h["resblock_kernel_sizes"])
         self.num_upsamples = len(h["upsample_rates"])
@@ -129,7 +132,10 @@ class Generator:
         if transposed and up > 1:                 # polyphase form: 1/stride of the zero-stuffed form's matrix work
             c.wp_poly = ops.hifigan_pack_conv_transpose1d(w, up, pad).to(self.device)
         c.bias = sd[name + ".bias"].float().to(self.device).contiguous()
-        c.w16 = c.bias16 = None
+        c.w16 = c.bias16 = c.w16t = None
+        if self.precision == "f16x3" and transposed and 1 <= c.k - 2 * pad <= 2 * up and c.cout <= 256 and up <= 8:
+            cp_in = (32 if c.cin <= 32 else 64 if c.cin <= 64 else 128 if c.cin <= 128 else 256) if c.cin <= 256 else (c.cin + 31) // 32 * 32
+            c.w16t = ops.hifigan_pack_conv_transpose1d_f16x3(w.to(self.device), c.bias, up, pad, cp_in)   # (input = a stage's Np-wide buffers)
         if (self.precision == "f16x3" and not transposed and up == 1 and name.startswith("resblocks.") and c.cout <= 256
                 and (c.k - 1) * dil <= 50 and (c.k - 1) * dil % 2 == 0):
             c.w16 = ops.hifigan_pack_weight_f16x3(w.to(self.device))
@@ -247,6 +253,10 @@ class Generator:
         it = lambda: None if lens is None else (lens, mul, add)
         mul, add = self._affine(pk["pre"], mul, add)
         x = self._run(pk["pre"], x, items=it())
+        if (self.cl_pipeline and self.precision == "f16x3" and all(u.w16t is not None for u in pk["ups"]) and pk["ups"][-1].cout <= 64
+                and all(c.w16 is not None and len(block) == 3 for blocks in pk["res"] for block in blocks for pair in block for c in pair)):
+            y = self._forward_channels_last(pk, x, lens, mul, add)
+            return y.squeeze(0) if unbatched else y
         for i in range(self.num_upsamples):
             up = pk["ups"][i]
             mul, add = self._affine(up, mul, add)
@@ -307,7 +317,7 @@ class Generator:
             buf["zs_scratch"] = torch.zeros(1, dtype=torch.int32, device=self.device)
             if Cp > 64:                           # (the narrow stages run one kernel per conv pair: no split pairs in HBM)
                 buf.update(z0=f16(), t=f16(), rz0=f16(), rz1=f16())
-            if len(self._cl) >= 8:
+            if len(self._cl) >= 12:
                 self._cl.clear()
             self._cl[key] = buf
         return buf
@@ -325,8 +335,15 @@ class Generator:
             zs = ops.pow2_scale_from_amax(buf["zs_scratch"], 1024.0, buf["zs"])
         else:
             zs = ops.amax_pow2_scale(x, 1024.0, buf["zs"], buf["zs_scratch"])
-        narrow = "z0" not in buf
         ops.hifigan_to_channels_last(x, buf["x0"], buf.get("z0"), LRELU_SLOPE, z_scale=zs)
+        self._resblocks_cl(blocks, buf, B, L, zs, items)
+        out = torch.empty_like(x)
+        return ops.hifigan_from_channels_last(buf["xs"], out)
+
+    def _resblocks_cl(self, blocks, buf: dict, B: int, L: int, zs, items=None) -> None:
+        """buf["xs"] = sum_j ResBlock1_j(x) / num_kernels from buf["x0"] (fp32) and, on the wide stages, buf["z0"] =
+        split(leaky_relu(x0) * zs): all channels-last."""
+        narrow = "z0" not in buf
         nblk = len(blocks)
         for j, block in enumerate(blocks):
             if len(block) == 3:                   # one C call per ResBlock: cvx_hifigan_resblock_f16x3 (6 launches, or 3 fused pairs)
@@ -356,8 +373,47 @@ class Generator:
                     ops.hifigan_conv1d_f16x3(buf["t"], c2.w16, c2.bias16, B, L, ksize=c2.k, dil=c2.dil, res=cur_x,
                                              accum=buf["xs"] if j > 0 else None, out_x=buf["xs"],
                                              out_scale=(1.0 / self.num_kernels) if j == nblk - 1 else 1.0, z_scale=zs, items=items)
-        out = torch.empty_like(x)
-        return ops.hifigan_from_channels_last(buf["xs"], out)
+
+    def _forward_channels_last(self, pk, x: torch.Tensor, lens, mul: int, add: int) -> torch.Tensor:
+        """Everything behind conv_pre on channels-last buffers: per stage
+            ConvTranspose1d on the split pipe (stride-1 form; leaves max|out| on the device) -> fp32 x0
+            -> [wide stages] z0 = split(leaky_relu(x0) * zs)  -> the ResBlocks -> xs
+            -> max|xs| -> the next upsampler's input pair split(leaky_relu(xs) * zs'),
+        then conv_post + tanh straight from the last xs.  No channel-major tensor exists between conv_pre and the waveform
+        (round 2 converted twice per stage and ran the upsamplers on the fp32 pipe: 1.9 of 11.4 ms)."""
+        B, C, L = x.shape
+        it = lambda: None if lens is None else (lens, mul, add)
+        up0 = pk["ups"][0].w16t
+        key = ("in", B, up0["cp_in"], L)
+        zin = self._cl.get(key)
+        if zin is None:
+            shape = (B, ops.hifigan_cl_rows(L), up0["cp_in"])
+            zin = dict(z=(torch.zeros(shape, dtype=torch.float16, device=self.device), torch.zeros(shape, dtype=torch.float16, device=self.device)),
+                       zs=torch.ones(1, dtype=torch.float32, device=self.device), scr=torch.zeros(1, dtype=torch.int32, device=self.device))
+            self._cl[key] = zin
+        cur_zs = ops.amax_pow2_scale(x, 1024.0, zin["zs"], zin["scr"]) if self.act_scales else None
+        ops.hifigan_to_channels_last(x, None, zin["z"], LRELU_SLOPE, z_scale=cur_zs)
+        cur_z, lin = zin["z"], L
+        for i in range(self.num_upsamples):
+            up = pk["ups"][i]
+            mul, add = self._affine(up, mul, add)
+            lout = (lin - 1) * up.up + up.k - 2 * up.padding
+            buf = self._cl_buffers(B, up.cout, lout)
+            ops.hifigan_conv_transpose1d_f16x3(cur_z, up.w16t, B, lin, buf["x0"], lout, z_scale=cur_zs,
+                                               amax_bits=buf["zs_scratch"] if self.act_scales else None, items=it())
+            zs = ops.pow2_scale_from_amax(buf["zs_scratch"], 1024.0, buf["zs"]) if self.act_scales else None
+            if "z0" in buf:
+                ops.hifigan_split_channels_last(buf["x0"], buf["z0"], LRELU_SLOPE, z_scale=zs)
+            self._resblocks_cl(pk["res"][i], buf, B, lout, zs, it())
+            if i + 1 < self.num_upsamples:
+                if "zn" not in buf:                   # the next upsampler's input pair (the wide stages lend their t pair)
+                    buf["zn"] = buf["t"] if "t" in buf else (torch.zeros_like(buf["xs"], dtype=torch.float16), torch.zeros_like(buf["xs"], dtype=torch.float16))
+                    buf["zs_out"] = torch.ones(1, dtype=torch.float32, device=self.device)
+                cur_zs = ops.amax_pow2_scale(buf["xs"], 1024.0, buf["zs_out"], buf["zs_scratch"]) if self.act_scales else None
+                ops.hifigan_split_channels_last(buf["xs"], buf["zn"], LRELU_SLOPE, z_scale=cur_zs)
+                cur_z, lin = buf["zn"], lout
+        y = torch.empty(B, 1, lout, dtype=torch.float32, device=x.device)
+        return ops.hifigan_post_channels_last(buf["xs"], pk["ups"][-1].cout, lout, pk["post_w"], pk["post_b"], y, slope=0.01)
 
 
 def mel_decode_to_wav(generator: Generator, mel: torch.Tensor):

@@ -230,6 +230,69 @@ def test_hifigan_conv_transpose(ops, Cin, Cout, L, k, u):
     assert rel_l2(out, ref) < TOL
 
 
+def _to_cl(ops, x, cp, scale=1.0, slope=None):
+    """[B, C, L] (CPU/GPU fp32) -> zero-haloed channels-last fp32 [B, Lp, cp] (leaky_relu * scale applied when slope is given)."""
+    B, C_, L = x.shape
+    buf = torch.zeros(B, ops.hifigan_cl_rows(L), cp, device=dev())
+    v = x if slope is None else F.leaky_relu(x, slope) * scale
+    buf[:, ops.HIFI_HALO_L:ops.HIFI_HALO_L + L, :C_] = v.transpose(1, 2)
+    return buf
+
+
+@pytest.mark.parametrize("Cin,Cout,L,k,u", [(500, 250, 50, 8, 5), (250, 125, 301, 8, 4), (125, 62, 256, 4, 4), (62, 31, 700, 4, 2),
+                                            (500, 250, 512, 11, 5), (64, 40, 130, 3, 3), (33, 31, 77, 2, 2), (96, 128, 260, 16, 8)])
+def test_conv_transpose1d_f16x3(ops, Cin, Cout, L, k, u):
+    """leaky_relu + ConvTranspose1d on the split pipe (stride-1 form, channels-last in and out) vs fp64 conv_transpose1d: the four
+    upsamplers of config_covomix (the first has kernel - 2 padding = stride + 1: one output more than stride * L), a kernel as
+    long as its stride (one tap per phase), stride 8, L a multiple of the tile; with a measured pre-scale on
+    inputs 2^12 times larger, the fused max|out|, and a ragged batch (zeros behind the shorter item)."""
+    B = 2
+    p = (k - u) // 2
+    x = randn(B, Cin, L, seed=70) * 4096.0
+    w = randn(Cin, Cout, k, seed=71) / math.sqrt(Cin * k / u)
+    b = randn(Cout, seed=72)
+    pk = ops.hifigan_pack_conv_transpose1d_f16x3(w, b, u, p)
+    zs = torch.empty(1, device=dev()); scr = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.amax_pow2_scale(x, 1024.0, zs, scr)
+    xin = _to_cl(ops, x, pk["cp_in"])
+    z = (torch.empty_like(xin, dtype=torch.float16), torch.empty_like(xin, dtype=torch.float16))
+    ops.hifigan_split_channels_last(xin, z, 0.1, z_scale=zs)
+    lout = (L - 1) * u + k - 2 * p
+    out = torch.zeros(B, ops.hifigan_cl_rows(lout), pk["np_out"], device=dev())
+    amax = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.hifigan_conv_transpose1d_f16x3(z, pk, B, L, out, lout, z_scale=zs, amax_bits=amax)
+    ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=p)
+    assert ref.shape[2] == lout
+    got = out[:, ops.HIFI_HALO_L:ops.HIFI_HALO_L + lout, :Cout].transpose(1, 2)
+    assert rel_l2(got, ref) < 2e-6
+    assert float((got.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    assert float(out[:, :ops.HIFI_HALO_L].abs().max()) == 0.0 and float(out[:, ops.HIFI_HALO_L + lout:].abs().max()) == 0.0
+    assert Cout == pk["np_out"] or float(out[:, :, Cout:].abs().max()) == 0.0              # padded channels stay zero
+    assert abs(float(amax.view(torch.float32)) - float(got.abs().max())) == 0.0
+    # ragged: item 1 is valid on L - 7 input positions -> u * (L - 7) outputs, zeros behind them, item 0 untouched
+    lens = torch.tensor([L, L - 7], dtype=torch.int32, device=dev())
+    x2 = x.clone(); x2[1, :, L - 7:] = 0.0
+    xin2 = _to_cl(ops, x2, pk["cp_in"])
+    ops.hifigan_split_channels_last(xin2, z, 0.1, z_scale=zs)
+    out2 = torch.zeros_like(out)
+    ops.hifigan_conv_transpose1d_f16x3(z, pk, B, L, out2, lout, z_scale=zs, items=(lens, u, k - 2 * p - u))
+    l1 = (L - 7 - 1) * u + k - 2 * p
+    assert torch.equal(out2[0], out[0])
+    assert float(out2[1, ops.HIFI_HALO_L + l1:].abs().max()) == 0.0
+    one = F.conv_transpose1d(F.leaky_relu(x2[1:, :, :L - 7].double(), 0.1), w.double(), b.double(), stride=u, padding=p)
+    assert one.shape[2] == l1
+    assert rel_l2(out2[1, ops.HIFI_HALO_L:ops.HIFI_HALO_L + l1, :Cout].t(), one[0]) < 2e-6
+
+
+def test_hifigan_post_channels_last_same_bits(ops):
+    B, C, L = 3, 31, 1000
+    x, w = randn(B, C, L, seed=80), randn(1, C, 7, seed=81) / 10
+    y0, y1 = torch.empty(B, 1, L, device=dev()), torch.empty(B, 1, L, device=dev())
+    ops.hifigan_post(x, w.reshape(C, 7).contiguous(), 0.05, y0)
+    ops.hifigan_post_channels_last(_to_cl(ops, x, 32), C, L, w.reshape(C, 7).contiguous(), 0.05, y1)
+    assert torch.equal(y0, y1)
+
+
 def test_hifigan_post(ops):
     B, C, L = 2, 31, 999
     x, w = randn(B, C, L, seed=80), randn(1, C, 7, seed=81) / 10
