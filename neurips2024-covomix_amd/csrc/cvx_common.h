@@ -59,7 +59,9 @@ __device__ __forceinline__ int cvx_item_len(const cvx_item_lengths& it, int b, i
 // GEMM epilogues, enough live values to spill)
 __device__ __forceinline__ float cvx_amax3(float m, const float a, const float b)
 {
+#ifndef CVX_NO_SAT_TRACK                      // (dev A/B: what the bookkeeping costs)
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+#endif
     return m;
 }
 // max |.| bookkeeping of the values a lane stores as split pairs, and the commit (one atomic, only when saturated)
@@ -70,7 +72,11 @@ __device__ __forceinline__ float cvx_amax4(float m, const f32x4 v)
 // the same in plain C for the 32 x 32 GEMM epilogues of gemm_common.h: there the inline asm (opaque to the optimiser) made the
 // compiler keep a 576-byte copy of the accumulator block in scratch in every kernel that carries the generic epilogue
 // (round 3: the opt-in f16 mode lost 22 % to it before this was found)
+#ifndef CVX_NO_SAT_TRACK
 __device__ __forceinline__ float cvx_amax3_c(float m, const float a, const float b) { return fmaxf(m, fmaxf(fabsf(a), fabsf(b))); }
+#else
+__device__ __forceinline__ float cvx_amax3_c(float m, const float, const float) { return m; }
+#endif
 __device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, float amax)
 {
     if (flag && amax > 65504.f) atomicOr(flag, 1u);

@@ -46,6 +46,12 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
                  : "memory");
 }
 
+#ifndef CVX_P8S_RES_AHEAD
+#define CVX_P8S_RES_AHEAD 2
+#endif
+#ifndef CVX_P8S_AMAX
+#define CVX_P8S_AMAX 0
+#endif
 #define CVX_P8_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define CVX_P8_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define CVX_P8_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -66,7 +72,13 @@ __device__ __forceinline__ f32x2 mul2_rn(const f32x2 a, const f32x2 b) { return 
 // v_fma_mix_f32 straight from the packed halves, packed conversion of the residuals
 __device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, float& amax)
 {
+#if CVX_P8S_AMAX == 1                          // dev A/B of the saturation bookkeeping: plain C
+    amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+#elif CVX_P8S_AMAX == 2                        // on the clamped values' bit patterns (integer max of the magnitudes)
+    amax = __builtin_bit_cast(float, max(__builtin_bit_cast(unsigned, amax), max(__builtin_bit_cast(unsigned, v[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[1]) & 0x7fffffffu)));
+#else
     amax = cvx_amax3(amax, v[0], v[1]);
+#endif
     const float x0 = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), x1 = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
     hi = __builtin_convertvector(f32x2{x0, x1}, f16x2);
     const unsigned int hb = __builtin_bit_cast(unsigned int, hi);
@@ -144,11 +156,26 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
         if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
         bias[ni][0] = f32x2{b4[0], b4[1]}; bias[ni][1] = f32x2{b4[2], b4[3]};
     }
+    // residual rows are requested CVX_P8S_RES_AHEAD row groups before they are added (explicitly: where hipcc puts these loads
+    // on its own moves with unrelated changes of the epilogue - the saturation bookkeeping cost 0.65 % of the step that way)
+    constexpr int RA = CVX_P8S_RES_AHEAD;
+    f32x4 rbuf[RA + 1][4];
+    auto load_res = [&](int mi_, f32x4 (&r)[4]) {
+        const int row_ = row0 + 16 * mi_ + lr;
+        const int rr_ = row_ < p.M ? row_ : p.M - 1;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) r[ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr_ * p.ldr + col0 + 16 * ni + lc);
+    };
+    if (RA > 0 && p.residual) {
+#pragma unroll
+        for (int a = 0; a < RA; ++a) load_res(a, rbuf[a]);
+    }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int row = row0 + 16 * mi + lr;
         const bool live = row < p.M;
         const int rr = live ? row : p.M - 1;
+        if (RA > 0 && p.residual && mi + RA < 8) load_res(mi + RA, rbuf[(mi + RA) % (RA + 1)]);
         f32x2 v[4][2];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -178,7 +205,8 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
         if (p.residual) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
+                const f32x4 r = RA > 0 ? rbuf[mi % (RA + 1)][ni]
+                                       : *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
                 v[ni][0] += f32x2{r[0], r[1]};
                 v[ni][1] += f32x2{r[2], r[3]};
             }
