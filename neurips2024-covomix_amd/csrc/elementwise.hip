@@ -144,15 +144,27 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
     float* yr = y ? y + row * D : nullptr;
     const int nvec = D >> 2;
 
-    f32x4 v[NV];
-    float ss = 0.f;
+    // every load of the row's pass is requested up front - x, and the item's gamma / beta rows (L2 hits) that used to be
+    // requested only behind the wave reduction, one exposed round trip per row later
+    f32x4 v[NV], gv[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) v[i] = (CVX_NORM_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * j)) : gload4(xr + 4 * j);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int j = lane + 64 * i;
         if (j < nvec) {
-            v[i] = (CVX_NORM_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * j)) : *reinterpret_cast<const f32x4*>(xr + 4 * j);
-            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            gv[i] = gload4(gr + 4 * j);
+            if (br) bv[i] = gload4(br + 4 * j);
         }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nvec) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
     }
     ss = wave_sum(ss);
     const float inv = scale / fmaxf(sqrtf(ss), eps);
@@ -160,12 +172,12 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
     for (int i = 0; i < NV; ++i) {
         const int j = lane + 64 * i;
         if (j < nvec) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(gr + 4 * j);
+            const f32x4 gg = gv[i];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[i][e] * inv * gg[e];
             if (br) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(br + 4 * j);
+                const f32x4 bb = bv[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += bb[e];
             }
