@@ -96,6 +96,10 @@ class VectorField:
                     self.split[k] = ops.split_f16(v, with_lo=(precision == "f16x3"))
             # the step-invariant columns of to_embed (phoneme embeddings | conditioning mel: one [2BT, 2208] x [2208, 1024] product
             # per solve) - 0.74 ms on the fp32 pipe at the bench shape
+            # the adaptive-norm table GEMM ([n evaluation times, dim] x the packed [4 depth dim, dim] matrix: weight streaming,
+            # 0.66 ms per solve on the fp32 kernel at 32 rows)
+            if precision == "f16x3" and self.ada_w.shape[1] % 32 == 0:
+                self.split["ada"] = ops.split_f16(self.ada_w)
             w_rest = sd["to_embed.weight"][:, d["dim_out"]:]
             if precision == "f16x3" and w_rest.shape[1] % 32 == 0:
                 self.w_rest = w_rest.contiguous()
@@ -272,7 +276,10 @@ class VectorField:
         temb = torch.empty(n, d["time_hidden"], dtype=torch.float32, device=self.device)
         ops.gemm(four, sd["sinu_pos_emb.1.weight"], temb, bias=sd["sinu_pos_emb.1.bias"], act=ops.ACT_SILU)
         table = torch.empty(n, self.ada_w.shape[0], dtype=torch.float32, device=self.device)
-        ops.gemm(temb, self.ada_w, table, bias=self.ada_b)
+        if "ada" in self.split:
+            ops.gemm(temb, self.ada_w, table, bias=self.ada_b, w_split=self.split["ada"], a_split=ops.split_act_f16(temb))
+        else:
+            ops.gemm(temb, self.ada_w, table, bias=self.ada_b)
         # step-invariant to_embed columns: rows [0, M1) conditional, rows [M1, 2*M1) null branch
         g = ws["gathered"]
         ids = phoneme_ids.to(torch.int64).contiguous()
