@@ -211,6 +211,16 @@ int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias,
 /* ragged batch (see RAGGED BATCHES above): x, y [M, C] packed */
 int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, const float* bias, float* y,
                                      const int32_t* cu_seqlens_dev, int32_t n_seq, int32_t max_T, int32_t C, cvx_stream_t s);
+/* to_embed's state columns + ConvPositionEmbed in one launch (acoustic.py:174-176, :60-68; round 3):
+ *     h0 = x . W[:, :K]^T + base;      y = h0 + gelu(dwconv31(h0) + dw_b)
+ * x [rows, K] (K % 8 == 0, K <= 80: the ODE state), w_embed [C, ldw] (its first K columns are used), base [rows, C] (the
+ * step-invariant part of to_embed, bias included), dw_w [C, 31], y [rows, C], C % 64 == 0.  Sequences as in
+ * cvx_dwconv31_gelu_res_varlen_f32 (cu_seqlens_dev NULL: Bt sequences of max_T rows).  Exact fp32 products on the fp32 matrix
+ * pipe; the depthwise taps in the order of cvx_dwconv31_gelu_res_f32.  Replaces a GEMM that writes h0 and a convolution
+ * that reads it back. */
+int cvx_embed_conv31_f32(const float* x, int32_t K, const float* w_embed, int32_t ldw, const float* base, const float* dw_w,
+                         const float* dw_b, float* y, const int32_t* cu_seqlens_dev, int32_t Bt, int32_t max_T, int32_t C,
+                         cvx_stream_t s);
 
 /* v = f_c*(1+s) - s*f_n   (f_n == NULL: v = f_c)        CFG combine, acoustic.py:428
  * out = y + coef*v ; out2, out3 = optional extra copies  ODE stage update (torchdiffeq midpoint:

@@ -104,6 +104,11 @@ class VectorField:
             if precision == "f16x3" and w_rest.shape[1] % 32 == 0:
                 self.w_rest = w_rest.contiguous()
                 self.split["to_embed.rest"] = ops.split_f16(self.w_rest)
+        # one launch for to_embed's state columns + ConvPositionEmbed: built, bit-identical, and SLOWER than the two launches it
+        # replaces (155 vs 101 us at the bench shape: load / matrix / convolution phases of a block do not overlap with two
+        # blocks per CU) - opt-in
+        self.fused_embed = (os.environ.get("CVX_FUSED_EMBED", "0") == "1" and d["dim_out"] % 8 == 0 and d["dim_out"] <= 80
+                            and d["dim"] % 64 == 0 and sd["to_embed.weight"].stride(0) % 4 == 0)
         self._init_gain_model()
         # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
         self.split_il: Dict[str, tuple] = {}
@@ -358,11 +363,14 @@ class VectorField:
             split_io = self.precision == "f16x3" and M > 64 and dim % 32 == 0
             sp = self.split.get
 
-        h0 = take()
-        ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
         h = take()
-        ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
-        free.append(h0)
+        if self.fused_embed:                 # state columns of to_embed + ConvPositionEmbed in one launch (h0 never reaches HBM)
+            ops.embed_conv31(ws["xin"], sd["to_embed.weight"], ws["base"], self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
+        else:
+            h0 = take()
+            ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
+            ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
+            free.append(h0)
         # residual-stream tensors that later feed a skip combiner (as x or as the popped skip) also get a split
         # twin, so that GEMM takes both operands pre-split (all-DMA kernel) instead of splitting on the fly
         twin = {id(b): pr for b, pr in zip(ws["h"], ws["h16"])} if split_io else None

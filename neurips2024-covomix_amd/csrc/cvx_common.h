@@ -86,5 +86,37 @@ __device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, float amax)
 // MI355X_MICROARCH.md `nt-weights`: issued -> landed -18 %, a decode layer -5...10 %
 __device__ __forceinline__ f32x4 gload4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<cvx_gptr4>(reinterpret_cast<uintptr_t>(p))); }
 
+// packed-pair fp32 helpers (v_pk_fma_f32 / v_pk_mul_f32)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(const float x) { return f32x2{x, x}; }
+// erf to ~1 ulp without branches (both polynomial pieces, one select): |x| <= 0.927734375: x + x * P(x^2); beyond:
+// 1 - exp(Q(|x|)).  The library erff is several times longer and branchy; GELU runs on 4096 columns of every row.
+__device__ __forceinline__ f32x2 erf_fast2(const f32x2 a)
+{
+    const f32x2 t = __builtin_elementwise_abs(a), s = a * a;
+    f32x2 r = fma2(splat2(-1.72853470e-5f), t, splat2(3.83197126e-4f));
+    const f32x2 u = fma2(splat2(-3.88396438e-3f), t, splat2(2.42546219e-2f));
+    r = fma2(r, s, u);
+    r = fma2(r, t, splat2(-1.06777877e-1f));
+    r = fma2(r, t, splat2(-6.34846687e-1f));
+    r = fma2(r, t, splat2(-1.28717512e-1f));
+    r = fma2(r, t, -t);
+    const f32x2 e = r * splat2(1.44269504088896340736f);
+    r = splat2(1.0f) - f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    r = f32x2{copysignf(r[0], a[0]), copysignf(r[1], a[1])};
+    f32x2 q = splat2(-5.96761703e-4f);
+    q = fma2(q, s, splat2(4.99119423e-3f));
+    q = fma2(q, s, splat2(-2.67681349e-2f));
+    q = fma2(q, s, splat2(1.12819925e-1f));
+    q = fma2(q, s, splat2(-3.76125336e-1f));
+    q = fma2(q, s, splat2(1.28379166e-1f));
+    q = fma2(q, a, a);
+    return f32x2{t[0] > 0.927734375f ? r[0] : q[0], t[1] > 0.927734375f ? r[1] : q[1]};
+}
+__device__ __forceinline__ f32x2 gelu_fast2(const f32x2 v)
+{
+    return (splat2(0.5f) * v) * (splat2(1.0f) + erf_fast2(v * splat2(0.70710678118654752440f)));
+}
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }

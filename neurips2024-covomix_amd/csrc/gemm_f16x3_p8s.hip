@@ -60,8 +60,6 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
 // SIMD in their epilogue at the same time = 19 us of an 83 us tile): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two
 // elements per issue slot, and an MFMA accumulator block of four registers is two aligned register pairs, so the whole
 // element-wise chain is written on pairs.  Per element the same IEEE operations in the same order as the scalar form.
-__device__ __forceinline__ f32x2 fma2(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(const float x) { return f32x2{x, x}; }
 // a * b with NO licence to be fused into a neighbouring add (the RoPE rotation fixes its rounding points)
 #pragma clang fp contract(off)
 __device__ __forceinline__ f32x2 mul2_rn(const f32x2 a, const f32x2 b) { return a * b; }
@@ -96,34 +94,6 @@ __device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, f
     lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
 }
 
-// erf to ~1 ulp without branches (both polynomial pieces, one select): |x| <= 0.927734375: x + x * P(x^2); beyond:
-// 1 - exp(Q(|x|)).  The library erff is several times longer and branchy; GELU runs on 4096 columns of every row.
-__device__ __forceinline__ f32x2 erf_fast2(const f32x2 a)
-{
-    const f32x2 t = __builtin_elementwise_abs(a), s = a * a;
-    f32x2 r = fma2(splat2(-1.72853470e-5f), t, splat2(3.83197126e-4f));
-    const f32x2 u = fma2(splat2(-3.88396438e-3f), t, splat2(2.42546219e-2f));
-    r = fma2(r, s, u);
-    r = fma2(r, t, splat2(-1.06777877e-1f));
-    r = fma2(r, t, splat2(-6.34846687e-1f));
-    r = fma2(r, t, splat2(-1.28717512e-1f));
-    r = fma2(r, t, -t);
-    const f32x2 e = r * splat2(1.44269504088896340736f);
-    r = splat2(1.0f) - f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-    r = f32x2{copysignf(r[0], a[0]), copysignf(r[1], a[1])};
-    f32x2 q = splat2(-5.96761703e-4f);
-    q = fma2(q, s, splat2(4.99119423e-3f));
-    q = fma2(q, s, splat2(-2.67681349e-2f));
-    q = fma2(q, s, splat2(1.12819925e-1f));
-    q = fma2(q, s, splat2(-3.76125336e-1f));
-    q = fma2(q, s, splat2(1.28379166e-1f));
-    q = fma2(q, a, a);
-    return f32x2{t[0] > 0.927734375f ? r[0] : q[0], t[1] > 0.927734375f ? r[1] : q[1]};
-}
-__device__ __forceinline__ f32x2 gelu_fast2(const f32x2 v)
-{
-    return (splat2(0.5f) * v) * (splat2(1.0f) + erf_fast2(v * splat2(0.70710678118654752440f)));
-}
 __device__ __forceinline__ f32x2 silu2(const f32x2 v) { return f32x2{silu(v[0]), silu(v[1])}; }
 
 // ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]

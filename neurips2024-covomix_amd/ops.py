@@ -365,6 +365,21 @@ def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out:
     return out
 
 
+def embed_conv31(x: torch.Tensor, w_embed: torch.Tensor, base: torch.Tensor, dw_w: torch.Tensor, dw_b: torch.Tensor, out: torch.Tensor,
+                 Bt: int, T: int, ragged: Optional[Ragged] = None) -> torch.Tensor:
+    """out = h0 + gelu(dwconv31(h0) + dw_b) with h0 = x @ w_embed[:, :K].T + base, one launch (cvx_embed_conv31_f32).
+    x [rows, K]; w_embed [C, >= K] (row stride = its own, a column slice of to_embed.weight is fine); base / out [rows, C]."""
+    _chk_f32(x, w_embed, base, dw_w, dw_b, out)
+    K, C_ = x.shape[-1], base.shape[-1]
+    assert x.is_contiguous() and base.is_contiguous() and out.is_contiguous() and dw_w.is_contiguous() and dw_w.numel() == C_ * 31
+    assert w_embed.shape[0] == C_ and w_embed.shape[1] >= K and w_embed.stride(1) == 1
+    cu, n, mt = (ragged.cu.data_ptr(), ragged.n, ragged.max_T) if ragged is not None else (None, Bt, T)
+    assert x.numel() == (ragged.M if ragged is not None else Bt * T) * K
+    _lib.check(_lib.load().cvx_embed_conv31_f32(x.data_ptr(), K, w_embed.data_ptr(), w_embed.stride(0), base.data_ptr(), dw_w.data_ptr(),
+                                                dw_b.data_ptr(), out.data_ptr(), cu, n, mt, C_, _stream()), "cvx_embed_conv31_f32")
+    return out
+
+
 def cfg_combine_axpy(f_c, f_n, y, cond_scale: float, coef: float, out, out2=None, out3=None) -> None:
     _chk_f32(f_c, f_n, y, out, out2, out3)
     n = y.numel()

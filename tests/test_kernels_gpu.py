@@ -161,6 +161,41 @@ def test_dwconv31(ops, Bt, T, C):
     assert rel_l2(y, ref) < TOL
 
 
+@pytest.mark.parametrize("Bt,T,C,K", [(2, 1000, 1024, 80), (3, 97, 128, 80), (1, 31, 64, 80), (2, 300, 256, 64), (1, 5, 64, 8)])
+def test_embed_conv31_fused(ops, Bt, T, C, K):
+    """to_embed's state columns + ConvPositionEmbed in one launch vs fp64 and vs the two-launch form it replaces (GEMM with the
+    base as residual, then the depthwise convolution); w_embed is a column slice of a wider matrix, as in the model."""
+    x, base = randn(Bt * T, K, seed=43), randn(Bt * T, C, seed=44)
+    w_full = randn(C, K + 48, seed=45) / math.sqrt(K)
+    dw, db = randn(C, 31, seed=46) / 5, randn(C, seed=47)
+    y = torch.full((Bt * T, C), float("nan"), device=dev())
+    ops.embed_conv31(x, w_full, base, dw, db, y, Bt, T)
+    h0 = (x.double() @ w_full[:, :K].double().t() + base.double()).view(Bt, T, C)
+    ref = F.gelu(F.conv1d(h0.transpose(1, 2), dw.double()[:, None, :], db.double(), padding=15, groups=C)).transpose(1, 2) + h0
+    assert rel_l2(y.view(Bt, T, C), ref) < TOL
+    h0f, y2 = torch.empty(Bt * T, C, device=dev()), torch.empty(Bt * T, C, device=dev())
+    ops.gemm(x, w_full[:, :K], h0f, residual=base)
+    ops.dwconv31_gelu_res(h0f, dw, db, y2, Bt, T)
+    assert rel_l2(y, y2.double()) < 1e-6
+
+
+def test_embed_conv31_fused_ragged(ops):
+    """Packed sequences of different length: each equals its own single-sequence call (zero padding at ITS ends)."""
+    C, K, lens = 128, 80, [130, 7, 98, 99, 260]
+    rg = ops.Ragged(lens, dev())
+    M = sum(lens)
+    x, base = randn(M, K, seed=48), randn(M, C, seed=49)
+    w, dw, db = randn(C, K, seed=45) / math.sqrt(K), randn(C, 31, seed=46) / 5, randn(C, seed=47)
+    y = torch.full((M, C), float("nan"), device=dev())
+    ops.embed_conv31(x, w, base, dw, db, y, len(lens), max(lens), ragged=rg)
+    r = 0
+    for L in lens:
+        one = torch.empty(L, C, device=dev())
+        ops.embed_conv31(x[r:r + L].contiguous(), w, base[r:r + L].contiguous(), dw, db, one, 1, L)
+        assert torch.equal(y[r:r + L], one)
+        r += L
+
+
 def test_cfg_axpy_gather_fourier_int16(ops):
     n = 12345
     fc, fn, y = randn(n, seed=50), randn(n, seed=51), randn(n, seed=52)
