@@ -179,10 +179,26 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
     if (vec_ok) {
         const int q = lane & 3;
         const int c4_lo = colw + 4 * ((lane & 31) >> 2);          // this lane's 4 columns after the transpose
+        // residual vectors are requested two store groups ahead, unpredicated (row clamped): a load in front of every group's
+        // add was an exposed round trip per group (the same change as in the eight-phase kernel's epilogue)
+        constexpr int RA = 2, NG = TM * 4;
+        f32x4 rb[RA + 1][2];
+        auto load_res = [&](int gi, f32x4 (&r)[2]) {
+            const int row_ = min(m0 + wm * TM * 32 + (gi >> 2) * 32 + 8 * (gi & 3) + 4 * (lane >> 5) + q, p.M - 1);
+            const float* rp = p.residual + (int64_t)row_ * p.ldr + c4_lo;
+            r[0] = *reinterpret_cast<const f32x4*>(rp);
+            r[1] = *reinterpret_cast<const f32x4*>(rp + 32);
+        };
+        if (p.residual) {
+#pragma unroll
+            for (int a = 0; a < RA && a < NG; ++a) load_res(a, rb[a]);
+        }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
+                const int gi = mi * 4 + rg;
+                if (p.residual && gi + RA < NG) load_res(gi + RA, rb[(gi + RA) % (RA + 1)]);
                 const int row0 = m0 + wm * TM * 32 + mi * 32 + 8 * rg + 4 * (lane >> 5);
                 float lo[4], hi[4];
 #pragma unroll
@@ -209,9 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 
                 if (row >= p.M) continue;
                 f32x4 vlo = {lo[0], lo[1], lo[2], lo[3]}, vhi = {hi[0], hi[1], hi[2], hi[3]};
                 if (p.residual) {
-                    const float* rp = p.residual + (int64_t)row * p.ldr + c4_lo;
-                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
-                    const f32x4 r1 = *reinterpret_cast<const f32x4*>(rp + 32);
+                    const f32x4 r0 = rb[gi % (RA + 1)][0], r1 = rb[gi % (RA + 1)][1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vlo[e] += r0[e]; vhi[e] += r1[e]; }
                 }
