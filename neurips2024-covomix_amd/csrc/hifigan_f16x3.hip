@@ -37,9 +37,6 @@ constexpr int LDS_HALVES = 2 * 2 * A_TILE + 2 * 2 * W_TILE;      // 144 KiB
 #ifndef CVX_PAIR_PIPE
 #define CVX_PAIR_PIPE 1                 // dev A/B: 0 = the plain loop of the fused pair kernel (lgkmcnt(0) in front of every step)
 #endif
-#ifndef CVX_CONV_PIPE
-#define CVX_CONV_PIPE 0                 // dev A/B: 1 = fragment reads software-pipelined across steps (measured: no change)
-#endif
 
 struct Conv16Args {
     const f16* z_hi; const f16* z_lo;  // [B][Lp][Cp_in]
@@ -151,101 +148,6 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     for (int s = 0; s < 2; ++s) woff[s] = (wn * TNI * 32 + i31) * CK + 8 * ((2 * s + g) ^ wswz);
     const int arow_base = wm * TMI * 32 + i31;
 
-#if CVX_CONV_PIPE
-    // ---- main loop, software pipelined.  A STEP = (tap, 16-channel half s) = TMI*TNI*3 MFMAs on 2*(TMI + TNI) fragment reads.
-    // Fragments live in two register sets: F1 (s = 1 of the tap) is requested before the MFMAs of F0 (s = 0) issue, and F0 of
-    // the NEXT tap before the MFMAs of F1 - a ds_read always has one step of matrix work to land under (the plain loop
-    // waited lgkmcnt(0) in front of every step with only two waves per SIMD to cover it: MFMA busy 0.3).
-    // Stage hand-over: the barrier sits between the two steps of a stage's LAST tap.  By then every wave has all of the
-    // stage's fragments in registers (lgkmcnt(0)), so the stage's weight buffer (and, with one group per chunk, its
-    // activation tile) may be refilled: the DMA of stage st + 2 is issued right behind the barrier, and vmcnt(0) in front of
-    // it retires the DMA of stage st + 1 (issued one stage earlier), whose first fragments are requested next.
-    struct Frags { f16x8 ah[TMI], al[TMI], wh[TNI], wl[TNI]; };
-    constexpr int NFR = 2 * (TMI + TNI);                              // ds_read_b128 per fragment set
-    static_assert(NFR <= 15, "counted lgkmcnt wait: 4-bit field");
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_c;
-    auto issue_stage = [&](int st_) {
-        issue_w(st_);
-        const int chunk_ = st_ / n_groups;
-        if (st_ == chunk_ * n_groups) issue_a(chunk_);
-    };
-    // The reads are inline asm and the waits are ours: left to itself hipcc waits lgkmcnt(0) in front of mma(F0) - one path
-    // into the loop header carries the barrier - which would also wait for the F1 requests issued just above it.
-    auto load_frags = [&](Frags& F, int chunk_, int st_, int tap_abs, int tl_, const int s_) {
-        const int arow = arow_base + tap_abs * p.dil;                  // tile row of output row i31 for this tap
-        const int aoff = arow * CK + 8 * ((2 * s_ + g) ^ ((arow >> 2) & 3));
-        const uint32_t wa = lds0 + 2u * (uint32_t)(4 * A_TILE + (st_ & 1) * 2 * W_TILE + tl_ * NP * CK + woff[s_]);
-        const uint32_t aa = lds0 + 2u * (uint32_t)((chunk_ & 1) * 2 * A_TILE + aoff);
-#pragma unroll
-        for (int ni = 0; ni < TNI; ++ni) {
-            F.wh[ni] = lds_read16(wa, ni * 32 * CK * 2);
-            F.wl[ni] = lds_read16(wa, (W_TILE + ni * 32 * CK) * 2);
-        }
-#pragma unroll
-        for (int mi = 0; mi < TMI; ++mi) {
-            F.ah[mi] = lds_read16(aa, mi * 32 * CK * 2);
-            F.al[mi] = lds_read16(aa, (A_TILE + mi * 32 * CK) * 2);
-        }
-    };
-    // every request up to and including F's has landed (the NFR requests issued after them may still be in flight); the
-    // empty asm statements tie F's registers to the wait so that no MFMA on them is scheduled above it
-    auto wait_frags = [&](Frags& F) {
-        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NFR));
-#pragma unroll
-        for (int ni = 0; ni < TNI; ++ni) { asm volatile("" : "+v"(F.wh[ni])); asm volatile("" : "+v"(F.wl[ni])); }
-#pragma unroll
-        for (int mi = 0; mi < TMI; ++mi) { asm volatile("" : "+v"(F.ah[mi])); asm volatile("" : "+v"(F.al[mi])); }
-    };
-    auto mma = [&](const Frags& F) {
-#pragma unroll
-        for (int mi = 0; mi < TMI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TNI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[mi], F.wh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int mi = 0; mi < TMI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TNI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[mi], F.wl[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int mi = 0; mi < TMI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TNI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.ah[mi], F.wh[ni], acc[mi][ni], 0, 0, 0);
-    };
-
-    issue_stage(0);
-    if (steps > 1) issue_stage(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    Frags F0, F1;
-    load_frags(F0, 0, 0, 0, 0, 0);
-    {
-        int chunk = 0, grp = 0;
-        for (int st = 0; st < steps; ++st) {
-            const int t0 = grp * TS, nt = min(TS, ksize - t0);
-            for (int tl = 0; tl < nt; ++tl) {
-                load_frags(F1, chunk, st, t0 + tl, tl, 1);
-                wait_frags(F0);
-                mma(F0);
-                const bool last = tl + 1 == nt;
-                if (last && st + 1 < steps) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (st + 2 < steps) issue_stage(st + 2);
-                }
-                // the next step's s = 0 fragments - requested on ONE control path, so that the wait in front of mma(F1) can
-                // be a counted one (behind the very last step: a dummy read of the other buffers, never used)
-                const bool wrap = last && grp + 1 == n_groups;
-                load_frags(F0, wrap ? chunk + 1 : chunk, last ? st + 1 : st, wrap ? 0 : t0 + tl + 1, last ? 0 : tl + 1, 0);
-                wait_frags(F1);
-                mma(F1);
-            }
-            if (++grp == n_groups) { grp = 0; ++chunk; }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the dummy request behind the last step: its registers are reused below
-#else
     issue_a(0);
     issue_w(0);
     for (int st = 0; st < steps; ++st) {
@@ -299,7 +201,6 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
         }
     }
 
-#endif
 
 #ifdef CVX_CONV_TRACE
     const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
