@@ -96,10 +96,10 @@ class VectorField:
                     self.split[k] = ops.split_f16(v, with_lo=(precision == "f16x3"))
             # the step-invariant columns of to_embed (phoneme embeddings | conditioning mel: one [2BT, 2208] x [2208, 1024] product
             # per solve) - 0.74 ms on the fp32 pipe at the bench shape
-            # (the adaptive-norm table GEMM - [n evaluation times, dim] x the packed [4 depth dim, dim] matrix, pure weight
-            # streaming at 32 rows - stays on the fp32 kernel: 0.66 ms per solve inside the model against 0.77 ms for the
-            # split-precision kernel, although the latter wins 177 vs 312 us with the weights cache-resident; opt-in for A/B)
-            if precision == "f16x3" and self.ada_w.shape[1] % 32 == 0 and os.environ.get("CVX_ADA_F16X3", "0") == "1":
+            # the adaptive-norm table GEMM - [n evaluation times, dim] x the packed [4 depth dim, dim] matrix: pure weight
+            # streaming at 32 rows - 1.35 ms per solve on the fp32 kernel inside the model (cold weights), 0.76 ms here
+            # (rocprofv3; CVX_ADA_F16X3=0 for A/B).  Neither is close to the 134 MB / HBM rate = 30 us: DESIGN 4.4
+            if precision == "f16x3" and self.ada_w.shape[1] % 32 == 0 and os.environ.get("CVX_ADA_F16X3", "1") == "1":
                 self.split["ada"] = ops.split_f16(self.ada_w)
             w_rest = sd["to_embed.weight"][:, d["dim_out"]:]
             if precision == "f16x3" and w_rest.shape[1] % 32 == 0:
