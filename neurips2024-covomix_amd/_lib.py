@@ -240,6 +240,8 @@ SIGNATURES = {
     "cvx_attention_f16x3_varlen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvx_gemm_skinny_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p]),
     "cvx_embed_conv31_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "cvx_dwconv31_gelu_res_varlen_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

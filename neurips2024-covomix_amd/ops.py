@@ -365,6 +365,17 @@ def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out:
     return out
 
 
+def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = ACT_NONE) -> torch.Tensor:
+    """out [M, N] = act(a [M <= 32, K <= 1024] @ w[N, K].T + bias): the weight-streaming kernel (cvx_gemm_skinny_f32)."""
+    _chk_f32(a, w, out, bias)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and tuple(out.shape) == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    _lib.check(_lib.load().cvx_gemm_skinny_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(), out.stride(0),
+                                               M, N, K, act, _stream()), "cvx_gemm_skinny_f32")
+    return out
+
+
 def embed_conv31(x: torch.Tensor, w_embed: torch.Tensor, base: torch.Tensor, dw_w: torch.Tensor, dw_b: torch.Tensor, out: torch.Tensor,
                  Bt: int, T: int, ragged: Optional[Ragged] = None) -> torch.Tensor:
     """out = h0 + gelu(dwconv31(h0) + dw_b) with h0 = x @ w_embed[:, :K].T + base, one launch (cvx_embed_conv31_f32).

@@ -196,6 +196,20 @@ def test_embed_conv31_fused_ragged(ops):
         r += L
 
 
+@pytest.mark.parametrize("M,N,K,act", [(32, 32768, 1024, 0), (7, 1000, 512, 2), (1, 9, 64, 0), (32, 130, 1024, 1), (20, 4096, 264, 0)])
+def test_gemm_skinny(ops, M, N, K, act):
+    """The weight-streaming GEMM for a handful of rows vs fp64 (odd N: the last wave owns one row; K not a multiple of 128)."""
+    a, w, b = randn(M, K, seed=55), randn(N, K, seed=56) / math.sqrt(K), randn(N, seed=57)
+    out = torch.full((M, N), float("nan"), device=dev())
+    ops.gemm_skinny(a, w, out, bias=b, act=act)
+    ref = a.double() @ w.double().t() + b.double()
+    ref = F.gelu(ref) if act == 1 else F.silu(ref) if act == 2 else ref
+    assert rel_l2(out, ref) < TOL
+    tiled = torch.empty(M, N, device=dev())
+    ops.gemm(a, w, tiled, bias=b, act=act)
+    assert rel_l2(out, tiled.double()) < 1e-6
+
+
 def test_cfg_axpy_gather_fourier_int16(ops):
     n = 12345
     fc, fn, y = randn(n, seed=50), randn(n, seed=51), randn(n, seed=52)

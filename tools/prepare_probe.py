@@ -22,7 +22,7 @@ for _ in range(10): ctx = f.prepare(ids, cond, tt, True)
 e.record(); torch.cuda.synchronize()
 print(f"prepare: {s.elapsed_time(e)/10:.3f} ms; table checksum {float(ctx['table'].double().abs().sum()):.6e} base {float(ctx['ws']['base'].double().abs().sum()):.6e}")
 tab_new, base_new = ctx["table"].double().clone(), ctx["ws"]["base"].double().clone()
-f.split.pop("ada"); f.split.pop("to_embed.rest")
+f.split.pop("ada", None); f.split.pop("to_embed.rest"); os.environ["CVX_SKINNY"] = "0"; os.environ["CVX_ADA_F16X3"] = "0"
 for _ in range(3): ctx = f.prepare(ids, cond, tt, True)
 torch.cuda.synchronize()
 s.record()
