@@ -211,7 +211,7 @@ int cvx_dwconv31_gelu_res_f32(const float* x, const float* w, const float* bias,
 /* ragged batch (see RAGGED BATCHES above): x, y [M, C] packed */
 int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, const float* bias, float* y,
                                      const int32_t* cu_seqlens_dev, int32_t n_seq, int32_t max_T, int32_t C, cvx_stream_t s);
-/* C[M][N] = act(A[M][K] . W[N][K]^T + bias) for a HANDFUL of rows (M <= 32, K <= 1024; round 3): weight streaming - every W row
+/* C[M][N] = act(A[M][K] . W[N][K]^T + bias) for a HANDFUL of rows (M <= 32, K % 8 == 0; round 3): weight streaming - every W row
  * is read once (non-temporal) by one wave and multiplied with all rows of A from LDS; exact fp32 FMAs.  The adaptive-norm
  * table of a solve (acoustic.py:360-370 evaluated for all n evaluation times at once: 32 x 32,768 x 1,024) and the time MLP. */
 int cvx_gemm_skinny_f32(const float* A, int32_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,

@@ -100,7 +100,7 @@ class VectorField:
             # streaming at 32 rows - 1.35 ms per solve on the fp32 kernel inside the model (cold weights), 0.76 ms here
             # (rocprofv3; CVX_ADA_F16X3=0 for A/B).  Neither is close to the 134 MB / HBM rate = 30 us: DESIGN 4.4
             if (precision == "f16x3" and self.ada_w.shape[1] % 32 == 0 and os.environ.get("CVX_ADA_F16X3", "1") == "1"
-                    and (self.ada_w.shape[1] > 1024 or os.environ.get("CVX_SKINNY", "1") != "1")):       # (solves of > 32 evaluations build it on demand)
+                    and os.environ.get("CVX_SKINNY", "1") != "1"):       # (solves of > 32 evaluations build it on demand)
                 self.split["ada"] = ops.split_f16(self.ada_w)
             w_rest = sd["to_embed.weight"][:, d["dim_out"]:]
             if precision == "f16x3" and w_rest.shape[1] % 32 == 0:
@@ -281,9 +281,9 @@ class VectorField:
         four = torch.empty(n, d["dim"], dtype=torch.float32, device=self.device)
         ops.time_fourier(times, sd["sinu_pos_emb.0.weights"], four)
         temb = torch.empty(n, d["time_hidden"], dtype=torch.float32, device=self.device)
-        # products with n <= 32 rows are weight streaming: cvx_gemm_skinny_f32 (the table: 1.35 ms on the tiled fp32 kernel,
-        # 0.76 on the split-precision one, 0.07 here)
-        skinny = lambda w: n <= 32 and w.shape[1] <= 1024 and w.shape[1] % 8 == 0 and os.environ.get("CVX_SKINNY", "1") == "1"
+        # products with n <= 32 rows are weight streaming: cvx_gemm_skinny_f32 (the table, 537 MB of weights: 1.35 ms on the tiled fp32
+        # kernel, 0.79 on the split-precision one, 0.25 here)
+        skinny = lambda w: n <= 32 and w.shape[1] % 8 == 0 and os.environ.get("CVX_SKINNY", "1") == "1"
         if skinny(sd["sinu_pos_emb.1.weight"]):
             ops.gemm_skinny(four, sd["sinu_pos_emb.1.weight"], temb, bias=sd["sinu_pos_emb.1.bias"], act=ops.ACT_SILU)
         else:

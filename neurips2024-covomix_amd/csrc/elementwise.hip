@@ -409,60 +409,68 @@ __global__ __launch_bounds__(256, 2) void embed_conv31_kernel(const float* __res
 
 // ---------------------------------------------------------------- skinny GEMM: C[M <= 32][N] = A[M][K] . W[N][K]^T (+ bias)
 // A product with a handful of rows is weight streaming (the adaptive-norm table of a solve - 32 evaluation times x 32,768
-// outputs, K = 1,024 - took 1.35 ms on the tiled fp32 kernel and 0.76 ms on the split-precision one: 134 MB of weights for 2
+// outputs, K = 4,096 - took 1.35 ms on the tiled fp32 kernel and 0.79 ms on the split-precision one: 537 MB of weights for 8.6
 // GFLOP).  Here every wave owns tiles of 32 W rows: lane (r, g) streams 16-byte pieces of ITS row (non-temporal, SK_Q steps
 // requested ahead in registers), all M rows of A sit in LDS ([m][K + 4] fp32: conflict-free b128 reads), and the tile is
 // 32 x 32 outputs of v_mfma_f32_32x32x2_f32 - exact fp32 products; one 16-byte piece of W and of A feeds four MFMAs, the K
 // order being permuted consistently in both operands (lanes g = 0 / 1 take k = 8q + j / 8q + 4 + j in step j).
 constexpr int SK_M = 32;
+constexpr int SK_KC = 1024;                    // columns of A staged in LDS at a time (longer K: chunk by chunk, accumulators stay)
 constexpr int SK_Q = 16;                        // K steps (of 8) requested ahead: 16 x 4 MFMAs = 4096 matrix cycles per round trip
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias, float* __restrict__ Cm, int64_t ldc,
                                                          int M, int N, int K, int act)
 {
-    extern __shared__ __attribute__((aligned(16))) float sk_a[];          // [SK_M][K + 4], rows >= M zero
+    extern __shared__ __attribute__((aligned(16))) float sk_a[];          // [SK_M][KC + 4] (one K chunk of A), rows >= M zero
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int k4 = K >> 2, ldA = K + 4;
-    for (int i = tid; i < SK_M * k4; i += 256) {
-        const int m = i / k4, c = i - m * k4;
-        *reinterpret_cast<f32x4*>(sk_a + (size_t)m * ldA + 4 * c) = m < M ? gload4(A + (size_t)m * lda + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
+    const int KC = min(K, SK_KC), ldA = KC + 4;
     const int i31 = lane & 31, g = lane >> 5;
-    const int nq = K >> 3;                                                // K % 8 == 0
     const float* ar = sk_a + (size_t)i31 * ldA + 4 * g;                   // this lane's A row (m = i31), its half of every 8 k
     const int n_tiles = (N + 31) / 32;
-    for (int tile = blockIdx.x * 4 + wid; tile < n_tiles; tile += gridDim.x * 4) {
+    for (int tile0 = blockIdx.x * 4; tile0 < n_tiles; tile0 += gridDim.x * 4) {       // (block-uniform: the chunk staging has barriers)
+        const int tile = tile0 + wid;
+        const bool active = tile < n_tiles;
         const int n0 = tile * 32;
-        const float* wr = W + (int64_t)min(n0 + i31, N - 1) * ldw + 4 * g;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        f32x4 wb[2][SK_Q];
+        for (int kc = 0; kc < K; kc += KC) {
+            const int kn = min(KC, K - kc), k4 = kn >> 2, nq = kn >> 3;  // K % 8 == 0
+            __syncthreads();                                              // the previous chunk (or tile round) is consumed
+            for (int i = tid; i < SK_M * k4; i += 256) {
+                const int m = i / k4, c = i - m * k4;
+                *reinterpret_cast<f32x4*>(sk_a + (size_t)m * ldA + 4 * c) = m < M ? gload4(A + (size_t)m * lda + kc + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            if (!active) continue;
+            const float* wr = W + (int64_t)min(n0 + i31, N - 1) * ldw + kc + 4 * g;
+            f32x4 wb[2][SK_Q];
 #pragma unroll
-        for (int u = 0; u < SK_Q; ++u) wb[0][u] = u < nq ? gload4_nt(wr + 8 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int q0 = 0; q0 < nq; q0 += 2 * SK_Q) {
+            for (int u = 0; u < SK_Q; ++u) wb[0][u] = u < nq ? gload4_nt(wr + 8 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q0 = 0; q0 < nq; q0 += 2 * SK_Q) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int qb = q0 + half * SK_Q;
-                if (qb < nq) {
+                for (int half = 0; half < 2; ++half) {
+                    const int qb = q0 + half * SK_Q;
+                    if (qb < nq) {
 #pragma unroll
-                    for (int u = 0; u < SK_Q; ++u)                        // the next SK_Q pieces of the row
-                        wb[half ^ 1][u] = qb + SK_Q + u < nq ? gload4_nt(wr + 8 * (qb + SK_Q + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int u = 0; u < SK_Q; ++u)                    // the next SK_Q pieces of the row
+                            wb[half ^ 1][u] = qb + SK_Q + u < nq ? gload4_nt(wr + 8 * (qb + SK_Q + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int u = 0; u < SK_Q; ++u) {
-                        if (qb + u < nq) {
-                            const f32x4 av = *reinterpret_cast<const f32x4*>(ar + 8 * (qb + u));
-                            const f32x4 wv = wb[half][u];
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[0], av[0], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1], av[1], acc1, 0, 0, 0);
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[2], av[2], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[3], av[3], acc1, 0, 0, 0);
+                        for (int u = 0; u < SK_Q; ++u) {
+                            if (qb + u < nq) {
+                                const f32x4 av = *reinterpret_cast<const f32x4*>(ar + 8 * (qb + u));
+                                const f32x4 wv = wb[half][u];
+                                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[0], av[0], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1], av[1], acc1, 0, 0, 0);
+                                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[2], av[2], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[3], av[3], acc1, 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
         }
+        if (!active) continue;
         // acc[r]: W row n0 + (r & 3) + 8 (r >> 2) + 4 g, A row m = i31
         if (i31 < M) {
 #pragma unroll
@@ -720,12 +728,12 @@ extern "C" int cvx_embed_conv31_f32(const float* x, int32_t K, const float* w_em
 extern "C" int cvx_gemm_skinny_f32(const float* A, int32_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                                    int32_t M, int32_t N, int32_t K, int32_t act, cvx_stream_t s)
 {
-    CVX_REQUIRE(A && W && C && M >= 0 && M <= SK_M && N >= 0 && K > 0 && K % 8 == 0 && K <= 1024 && lda >= K && lda % 4 == 0 && ldw >= K &&
+    CVX_REQUIRE(A && W && C && M >= 0 && M <= SK_M && N >= 0 && K > 0 && K % 8 == 0 && lda >= K && lda % 4 == 0 && ldw >= K &&
                 ldw % 4 == 0 && ldc >= N && act >= CVX_ACT_NONE && act <= CVX_ACT_TANH,
-                "gemm_skinny: M <= 32, K <= 1024 and a multiple of 8, lda / ldw multiples of 4 (M=%d N=%d K=%d)", M, N, K);
+                "gemm_skinny: M <= 32, K a multiple of 8, lda / ldw multiples of 4 (M=%d N=%d K=%d)", M, N, K);
     CVX_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm_skinny: 16-byte aligned operands");
     if (M == 0 || N == 0) return CVX_OK;
-    const size_t lds = (size_t)SK_M * (K + 4) * sizeof(float);
+    const size_t lds = (size_t)SK_M * (std::min(K, SK_KC) + 4) * sizeof(float);
     cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_skinny_kernel), (int)lds);
     const int64_t groups = ((int64_t)N + 127) / 128;                       // four 32-row tiles per block and trip
     const unsigned grid = (unsigned)std::min<int64_t>(groups, (int64_t)cvx_device_cus());

@@ -366,7 +366,7 @@ def dwconv31_gelu_res(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out:
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = ACT_NONE) -> torch.Tensor:
-    """out [M, N] = act(a [M <= 32, K <= 1024] @ w[N, K].T + bias): the weight-streaming kernel (cvx_gemm_skinny_f32)."""
+    """out [M, N] = act(a [M <= 32, K] @ w[N, K].T + bias): the weight-streaming kernel (cvx_gemm_skinny_f32)."""
     _chk_f32(a, w, out, bias)
     M, K = a.shape
     N = w.shape[0]

@@ -196,7 +196,7 @@ def test_embed_conv31_fused_ragged(ops):
         r += L
 
 
-@pytest.mark.parametrize("M,N,K,act", [(32, 32768, 1024, 0), (7, 1000, 512, 2), (1, 9, 64, 0), (32, 130, 1024, 1), (20, 4096, 264, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(32, 32768, 1024, 0), (7, 1000, 512, 2), (1, 9, 64, 0), (32, 130, 1024, 1), (20, 4096, 264, 0), (32, 2048, 4096, 0), (5, 333, 1032, 2)])
 def test_gemm_skinny(ops, M, N, K, act):
     """The weight-streaming GEMM for a handful of rows vs fp64 (odd N: the last wave owns one row; K not a multiple of 128)."""
     a, w, b = randn(M, K, seed=55), randn(N, K, seed=56) / math.sqrt(K), randn(N, seed=57)
