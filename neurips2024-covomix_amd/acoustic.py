@@ -211,7 +211,7 @@ class VectorField:
         if ragged_rows:
             q = self.RAGGED_ROW_QUANTUM
             M = (ragged_rows + q - 1) // q * q
-            key = ("ragged", M, ragged_rows >= 2048)             # (the interleaved-pair choice below depends on the real row count)
+            key = ("ragged", M, ragged_rows >= ops.il_min_rows())  # (the interleaved-pair choice below depends on the real row count)
         else:
             M = Bt * T
             key = (Bt, T)
@@ -233,7 +233,7 @@ class VectorField:
             # GEMM A operands: for the large-problem kernel (M >= 2048, interleaved weights available) as INTERLEAVED pairs
             # ([hi 32 | lo 32] per K-step: whole cache lines for the DMA), otherwise as two separate fp16 tensors
             a16 = h16
-            if lo_too and (ragged_rows or M) >= 2048 and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
+            if lo_too and (ragged_rows or M) >= ops.il_min_rows() and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
                 a16 = lambda rows, cols: ops.SplitIL(rows, cols, dev)
             ws["normed16"], ws["att16"], ws["ff16"] = a16(M, d["dim"]), a16(M, d["heads"] * 64), a16(M, 4 * d["dim"])
             ws["pred16"] = h16(M, d["dim"])                      # final norm -> to_pred (N = 80: small-N kernel, plain pair)

@@ -318,6 +318,11 @@ bool launch_gemm_f16x3_p8(const cvx_gemm_args& a, const PreSplitA& A, const _Flo
 bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
                            int map_mode, hipStream_t st);
 
+// gemm_f16x3_p8m.hip: 128 x 128 tiles, two wave groups on alternate K-tiles, for problems of fewer than 2048 rows (interleaved
+// A and W); ksplit > 1: K slices on separate blocks, scaled fp32 partial tiles to `partial` [ksplit][M][N] (the caller reduces)
+bool launch_gemm_f16x3_p8m(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
+                           int ksplit, float* partial, hipStream_t st);
+
 // which specialised epilogue (EPI_*) covers this call; EPI_GENERIC when none does or the vector-path conditions fail
 int classify_epilogue(const cvx_gemm_args& a, const SplitOut& so);
 

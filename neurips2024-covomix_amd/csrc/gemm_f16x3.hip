@@ -669,11 +669,26 @@ static int splitk_factor(int M, int N, int K, int K1, bool has_a2)
     return 1;
 }
 
+// the same for the medium-problem kernel (gemm_f16x3_p8m.hip: interleaved operands, fewer than 2048 rows): slices of at least
+// 8 K-tiles, as many as keep the grid within one block per CU
+static int splitk_factor_p8m(int M, int N, int K, int K1, bool has_a2)
+{
+    const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
+    if (N % 4 != 0) return 1;
+    for (int cand = 4; cand >= 2; cand >>= 1) {
+        const int kp = K / cand;
+        if (tiles * cand <= 256 && K % (32 * cand) == 0 && kp >= 256 && (!has_a2 || K1 % kp == 0)) return cand;
+    }
+    return 1;
+}
+
 extern "C" int64_t cvx_gemm_f16x3_workspace_floats(int32_t M, int32_t N, int32_t K, int32_t K1)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int f = splitk_factor(M, N, K, K1, K1 > 0);
-    return f > 1 ? (int64_t)f * M * N : 0;
+    const int g = M < 2048 ? splitk_factor_p8m(M, N, K, K1, K1 > 0) : 1;
+    const int m = f > g ? f : g;
+    return m > 1 ? (int64_t)m * M * N : 0;
 }
 
 extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
@@ -686,12 +701,11 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
     CVX_REQUIRE((((uintptr_t)W_hi | (uintptr_t)W_lo) & 15) == 0, "gemm_f16x3: split weights must be 16-byte aligned");
     const bool w_il = io && io->w_interleaved != 0;          // [N][K/32][hi 32 | lo 32]: W_lo == W_hi + 32, ldw == 2K
-    if (w_il)
-        CVX_REQUIRE(!single && W_lo == W_hi + 32 && a->ldw >= 2 * (int64_t)a->K && io->A_hi && a->M >= 2048 && a->N >= 512,
-                    "gemm_f16x3: interleaved weights need W_lo == W_hi + 32, ldw >= 2K, a pre-split A and the large-problem kernel");
-    // interleaved activations: A_lo == A_hi + 32 (and A2_lo == A2_hi + 32), lda_h >= 2K - only together with interleaved
-    // weights on the large-problem kernel
+    // interleaved activations: A_lo == A_hi + 32 (and A2_lo == A2_hi + 32), lda_h >= 2K - only together with interleaved weights
     const bool a_il = io && io->A_hi && io->A_lo == io->A_hi + 32;
+    if (w_il)
+        CVX_REQUIRE(!single && W_lo == W_hi + 32 && a->ldw >= 2 * (int64_t)a->K && io->A_hi && ((a->M >= 2048 && a->N >= 512) || a_il),
+                    "gemm_f16x3: interleaved weights need W_lo == W_hi + 32, ldw >= 2K, a pre-split A and - below 2048 rows or 512 columns - an interleaved A");
     if (a_il)
         CVX_REQUIRE(w_il && io->lda_h >= 2 * (int64_t)(a->A2 ? a->K1 : a->K) &&
                     (!a->A2 || (io->A2_lo == io->A2_hi + 32 && io->lda2_h >= 2 * (int64_t)(a->K - a->K1))),
@@ -747,7 +761,27 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
     // Measured on MI355X (tools/bench_kernels.py, M=16000): the 256x256 tile wins on every transformer shape
     // (284-349 vs 263-312 TFLOP/s).  Deeper rings (3-4 stages, K-step 16, 256x128x3) were tried and are slower:
     // the kernel is bound by the per-CU LDS-DMA delivery rate (~35 GB/s/CU), not by DMA latency.
-    if (A.hi && a->M >= 2048 && a->N >= 512) {
+    if (A.hi && w_il && a_il && (a->M < 2048 || a->N < 512)) {
+        // fewer than 2048 rows (one utterance, the last bin of a ragged directory, the HuBERT / text2semantic encoders): 128 x 128
+        // tiles with two wave groups on alternate K-tiles (gemm_f16x3_p8m.hip); K slices on separate blocks when the output has too
+        // few tiles for the chip and the caller provided the scratch
+        int ksplit = 1;
+        if (io->workspace && !a->rope_cos && !so.vt_hi && a->ldc % 4 == 0) {
+            const int f = splitk_factor_p8m(a->M, a->N, a->K, a->K1, a->A2 != nullptr);
+            if (f > 1 && io->workspace_floats >= (int64_t)f * a->M * a->N) ksplit = f;
+        }
+#ifdef CVX_DEV_FLAGS
+        if (io->flags & 0x10000) ksplit = 1;               // (dev A/B: no K slices; 0x20000: two)
+        if ((io->flags & 0x20000) && ksplit > 2) ksplit = 2;
+#endif
+        CVX_REQUIRE(cvxg::launch_gemm_f16x3_p8m(*a, A, wh, acc_scale, so, ksplit, ksplit > 1 ? io->workspace : nullptr, st),
+                    "gemm_f16x3: interleaved operands below 2048 rows need N %% 64 == 0, 16-byte aligned C / residual / bias / RoPE tables "
+                    "and rope_cols %% 128 == 0 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+        if (ksplit > 1) {
+            const int64_t quads = ((int64_t)a->M * a->N + 3) / 4;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, io->workspace, ksplit, *a, so);
+        }
+    } else if (A.hi && a->M >= 2048 && a->N >= 512) {
         const int tn = (a->N + 255) / 256, tm = (a->M + 255) / 256;
         const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
         const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB

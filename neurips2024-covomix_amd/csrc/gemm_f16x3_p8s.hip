@@ -14,237 +14,14 @@
 // counted vmcnt, inline-asm LDS-DMA, chunk ^ ((row >> 1) & 7) swizzle) is as documented in gemm_f16x3_p8.hip.
 // Same contract as cvx_gemm_f16x3 (reference acoustic.py:225-246, :306-310); only full 64-column wave tiles with aligned
 // pointers are accepted (the launcher returns false otherwise and the 32x32 kernel takes the problem).
-#include "gemm_common.h"
+#include "gemm_p8s_epi.h"
 
 namespace {
-
-using namespace cvxg;
-typedef _Float16 f16;
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TILE_B = 256 * 128;                  // bytes per operand tile
 constexpr int BUF_B = 2 * TILE_B;                  // A | W
 constexpr int DUMP_B = 2 * BUF_B;                  // dump area offset (8 KiB)
 constexpr int LDS_B = DUMP_B + 8 * 1024;
-
-__device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0a, uint32_t m0b, const void* sbase)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %5\n\t"
-                 "s_mov_b32 m0, %4\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %5\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff0), "v"(voff1), "s"(m0a), "s"(m0b), "s"(sbase)
-                 : "memory");
-}
-
-#ifndef CVX_P8S_RES_AHEAD
-#define CVX_P8S_RES_AHEAD 2
-#endif
-#ifndef CVX_P8S_AMAX
-#define CVX_P8S_AMAX 0
-#endif
-#define CVX_P8_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define CVX_P8_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#define CVX_P8_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// ---- packed fp32 helpers.  The epilogues are VALU-issue bound (ff1: ~30 VALU instructions per output element, two waves per
-// SIMD in their epilogue at the same time = 19 us of an 83 us tile): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two
-// elements per issue slot, and an MFMA accumulator block of four registers is two aligned register pairs, so the whole
-// element-wise chain is written on pairs.  Per element the same IEEE operations in the same order as the scalar form.
-// a * b with NO licence to be fused into a neighbouring add (the RoPE rotation fixes its rounding points)
-#pragma clang fp contract(off)
-__device__ __forceinline__ f32x2 mul2_rn(const f32x2 a, const f32x2 b) { return a * b; }
-#pragma clang fp contract(fast)
-
-
-// (hi, lo) fp16 halves of two fp32 values, saturating: v_med3 clamp, packed RNE conversion, exact residual x - hi by
-// v_fma_mix_f32 straight from the packed halves, packed conversion of the residuals
-__device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, float& amax)
-{
-#if CVX_P8S_AMAX == 1                          // dev A/B of the saturation bookkeeping: plain C
-    amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
-#elif CVX_P8S_AMAX == 2                        // on the clamped values' bit patterns (integer max of the magnitudes)
-    amax = __builtin_bit_cast(float, max(__builtin_bit_cast(unsigned, amax), max(__builtin_bit_cast(unsigned, v[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[1]) & 0x7fffffffu)));
-#else
-    amax = cvx_amax3(amax, v[0], v[1]);
-#endif
-    const float x0 = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), x1 = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
-    hi = __builtin_convertvector(f32x2{x0, x1}, f16x2);
-    const unsigned int hb = __builtin_bit_cast(unsigned int, hi);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
-    lo = __builtin_convertvector(f32x2{r0, r1}, f16x2);
-}
-__device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, float& amax)
-{
-    f16x2 h01, h23, l01, l23;
-    split2_pk(f32x2{v[0], v[1]}, h01, l01, amax);
-    split2_pk(f32x2{v[2], v[3]}, h23, l23, amax);
-    hi = f16x4{h01[0], h01[1], h23[0], h23[1]};
-    lo = f16x4{l01[0], l01[1], l23[0], l23[1]};
-}
-
-__device__ __forceinline__ f32x2 silu2(const f32x2 v) { return f32x2{silu(v[0]), silu(v[1])}; }
-
-// ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]
-template <int EPI>
-__device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (&acc)[8][4], int row0, int col0, int lane,
-                                              const SplitOut& so_in, float acc_scale)
-{
-    if (col0 >= p_in.N) return;                 // wave tile entirely past the last column (N % 256 != 0; wave-uniform)
-    cvx_gemm_args p = p_in;
-    SplitOut so = so_in;
-    if constexpr (EPI == EPI_QKV) {
-        p.act = CVX_ACT_NONE; p.bias = nullptr; p.residual = nullptr; so.write_f32 = 0;
-    } else if constexpr (EPI == EPI_RES) {
-        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; so.write_f32 = 1;
-    } else if constexpr (EPI == EPI_GELU_SPLIT) {
-        p.act = CVX_ACT_GELU; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 0;
-    } else if constexpr (EPI == EPI_BIAS) {
-        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1; so.hi = nullptr; so.lo = nullptr;
-    }
-    const int lr = lane & 15, lc = 4 * (lane >> 4);
-    const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);          // wave-uniform (64-column wave tile = one head)
-    const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
-    const bool il = so.hi && so.lo == so.hi + 32;
-    float amax = 0.f;
-    const f32x2 sc2 = splat2(acc_scale), cs2 = splat2(cs);
-    f32x2 bias[4][2];                           // [ni][pair]: columns col0 + 16 ni + lc + 2 pair + {0, 1}
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
-        bias[ni][0] = f32x2{b4[0], b4[1]}; bias[ni][1] = f32x2{b4[2], b4[3]};
-    }
-    // residual rows are requested CVX_P8S_RES_AHEAD row groups before they are added (explicitly: where hipcc puts these loads
-    // on its own moves with unrelated changes of the epilogue - the saturation bookkeeping cost 0.65 % of the step that way)
-    constexpr int RA = CVX_P8S_RES_AHEAD;
-    f32x4 rbuf[RA + 1][4];
-    auto load_res = [&](int mi_, f32x4 (&r)[4]) {
-        const int row_ = row0 + 16 * mi_ + lr;
-        const int rr_ = row_ < p.M ? row_ : p.M - 1;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) r[ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr_ * p.ldr + col0 + 16 * ni + lc);
-    };
-    if (RA > 0 && p.residual) {
-#pragma unroll
-        for (int a = 0; a < RA; ++a) load_res(a, rbuf[a]);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int row = row0 + 16 * mi + lr;
-        const bool live = row < p.M;
-        const int rr = live ? row : p.M - 1;
-        if (RA > 0 && p.residual && mi + RA < 8) load_res(mi + RA, rbuf[(mi + RA) % (RA + 1)]);
-        f32x2 v[4][2];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x2 x = fma2(f32x2{acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]}, sc2, bias[ni][h]);
-                if (p.act == CVX_ACT_GELU) x = gelu_fast2(x);
-                else if (p.act == CVX_ACT_SILU) x = silu2(x);
-                v[ni][h] = x;
-            }
-        }
-        if (do_rope) {      // half-split rotation: column j of the head pairs with j + 32 = tile ni + 2, same lane, same register
-            const int pos = rr % p.rope_T;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x2 c2 = f32x2{c[2 * h], c[2 * h + 1]}, s2 = f32x2{s[2 * h], s[2 * h + 1]};
-                    const f32x2 lo = v[ni][h], hi = v[ni + 2][h];
-                    v[ni][h] = fma2(lo, c2, -mul2_rn(hi, s2));          // fixed contraction, as in the 32x32 epilogue
-                    v[ni + 2][h] = fma2(hi, c2, mul2_rn(lo, s2));
-                }
-            }
-        }
-        if (p.residual) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const f32x4 r = RA > 0 ? rbuf[mi % (RA + 1)][ni]
-                                       : *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
-                v[ni][0] += f32x2{r[0], r[1]};
-                v[ni][1] += f32x2{r[2], r[3]};
-            }
-        }
-        if (!live) continue;
-        if (so.write_f32) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + 16 * ni + lc) = f32x4{v[ni][0][0], v[ni][0][1], v[ni][1][0], v[ni][1][1]};
-        }
-        if (so.hi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int c = col0 + 16 * ni + lc;
-                const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
-                f16x2 h01, h23, l01, l23;
-                split2_pk(v[ni][0] * cs2, h01, l01, amax);
-                split2_pk(v[ni][1] * cs2, h23, l23, amax);
-                *reinterpret_cast<f16x4*>(so.hi + o) = f16x4{h01[0], h01[1], h23[0], h23[1]};
-                if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = f16x4{l01[0], l01[1], l23[0], l23[1]};
-            }
-        }
-    }
-    cvx_sat_commit(so.sat, amax);
-}
-
-// ---- epilogue of a V block of a to_qkv projection, UN-swapped layout:
-// acc[mi][ni][r] = C[row0 + 16 mi + 4 (lane >> 4) + r][col0 + 16 ni + (lane & 15)]: 4 consecutive frames per lane ->
-// vt[((b*H + head)*64 + d) * vt_ld + slot(t)], 8 bytes per store when the four frames are one aligned slot group
-__device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)[8][4], int row0, int col0, int lane,
-                                            const SplitOut& so, float acc_scale)
-{
-    if (col0 >= p.N) return;                    // wave tile entirely past the last column (H % 4 != 0; wave-uniform)
-    const int H = p.rope_cols / 128, T = p.rope_T;
-    const int head = (col0 - p.rope_cols) / 64;
-    const float vs = (so.vt_scale ? *so.vt_scale : 1.f) * acc_scale;
-    float amax = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int r0 = row0 + 16 * mi + 4 * (lane >> 4);
-        if (r0 >= p.M) continue;
-        const int b = r0 / T, t0 = r0 - b * T;
-        const bool vec = (t0 & 3) == 0 && t0 + 3 < T && r0 + 3 < p.M;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int d = 16 * ni + (lane & 15);
-            const float bv = p.bias ? p.bias[col0 + d] * (so.vt_scale ? *so.vt_scale : 1.f) : 0.f;
-            f16x4 h, l;
-            split4_pk(f32x4{fmaf(acc[mi][ni][0], vs, bv), fmaf(acc[mi][ni][1], vs, bv), fmaf(acc[mi][ni][2], vs, bv), fmaf(acc[mi][ni][3], vs, bv)}, h, l, amax);
-            if (vec) {
-                const int64_t o = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld + vt_slot(t0);
-                *reinterpret_cast<f16x4*>(so.vt_hi + o) = h;
-                if (so.vt_lo) *reinterpret_cast<f16x4*>(so.vt_lo + o) = l;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = r0 + e;
-                    if (row >= p.M) break;
-                    const int bb = row / T, tt = row - bb * T;
-                    const int64_t o = ((int64_t)(bb * H + head) * 64 + d) * so.vt_ld + vt_slot(tt);
-                    so.vt_hi[o] = h[e];
-                    if (so.vt_lo) so.vt_lo[o] = l[e];
-                }
-            }
-        }
-    }
-    cvx_sat_commit(so.sat, amax);
-}
 
 // the main loop for one output tile; SWAP selects the operand order of every MFMA (see the header)
 // first: this is the block's first tile (issue the six-quarter prologue); (m0n, n0n): the block's NEXT tile, whose first

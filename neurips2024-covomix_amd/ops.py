@@ -74,6 +74,12 @@ _GEMM_FLAGS = {"1": 0, "32": 2, "0": 1, "1t": 4}.get(__import__("os").environ.ge
 _SPLITK_WS: dict = {}
 
 
+def il_min_rows() -> int:
+    """Row count from which GEMM A operands are kept as INTERLEAVED pairs (SplitIL): 128 with the medium-problem kernel
+    (default), 2048 (large-problem kernel only) under CVX_GEMM_P8M=0 (dev A/B: the round-3 small-problem path)."""
+    return 2048 if __import__("os").environ.get("CVX_GEMM_P8M", "1") == "0" else 128
+
+
 def _splitk_workspace(device) -> torch.Tensor:
     """Caller-owned scratch of cvx_gemm_f16x3's split-K path: 4 x 2048 x 4096 floats, allocated once per device and
     never re-allocated (its address is baked into captured HIP graphs)."""
@@ -136,8 +142,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     else:
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
     if isinstance(a_split, SplitIL):
-        assert w_il is not None and M >= 2048 and N >= 512, "an interleaved A operand needs interleaved weights and the large-problem kernel"
-    if w_il is not None and a_split is not None and M >= 2048 and N >= 512 and w_split is not None and w_split[1] is not None:
+        assert w_il is not None, "an interleaved A operand needs interleaved weights"
+    # interleaved weights: the large-problem kernel (M >= 2048, N >= 512; A split either way) or, with an interleaved A, the
+    # medium-problem kernel (gemm_f16x3_p8m.hip)
+    if (w_il is not None and a_split is not None and w_split is not None and w_split[1] is not None
+            and ((M >= 2048 and N >= 512) or isinstance(a_split, SplitIL))):
         il, inv_il = w_il                      # interleaved [N, 2K] copy of the same split weight (split_f16_interleaved)
         assert il.dtype == torch.float16 and il.shape == (N, 2 * K) and il.is_contiguous() and il.is_cuda
         use_il = True
