@@ -139,6 +139,22 @@ int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float s
 int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
                    const cvx_gemm_split_io* io, cvx_stream_t s);
+/* cvx_gemm_f16x3 followed by the AdaptiveRMSNorm / RMSNorm of its fp32 output, as ONE call (reference acoustic.py:306-318: every
+ * to_out, ff2 and skip-combiner product of the transformer is followed by the next norm; :198-204, :175):
+ *     C = epilogue([A | A2] . W^T)  (fp32, written: io->write_f32 must not be 0, ldc == N, act == NONE);
+ *     Y = split( C[r,:] / max(||C[r,:]||_2, eps) * scale * gamma + beta ) * *y_scale_dev     (one gamma / beta row for all rows)
+ * Problems that take the split-K path (fewer than 2048 rows, N <= 1024, N % 256 == 0) run the norm inside the split-K reduction
+ * (the row is in registers there: no extra launch, no re-read of C); every other problem runs cvx_adarmsnorm_scaled_f32 behind
+ * the product.  Both give the same bits. */
+typedef struct {
+    const float* gamma; const float* beta;          /* [N]; beta may be NULL (RMSNorm) */
+    uint16_t* Y_hi; uint16_t* Y_lo; int64_t ldy_h;   /* split pair of the normalised rows, row stride in halves (Y_lo == Y_hi + 32,
+                                                      * ldy_h == 2N: interleaved [hi 32 | lo 32]; otherwise ldy_h == N) */
+    const float* y_scale_dev;                       /* power-of-two pre-scale of Y in DEVICE memory, NULL = 1 */
+    float scale; float eps;                         /* sqrt(N) and 1e-12 in the reference */
+} cvx_gemm_norm;
+int cvx_gemm_f16x3_norm(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
+                        const cvx_gemm_split_io* io, const cvx_gemm_norm* norm, cvx_stream_t s);
 /* Size (in floats) of cvx_gemm_split_io.workspace that lets a problem of this shape split K (0: this shape never does).
  * K1 = the A | A2 boundary of a K-split operand, 0 without A2. */
 int64_t cvx_gemm_f16x3_workspace_floats(int32_t M, int32_t N, int32_t K, int32_t K1);

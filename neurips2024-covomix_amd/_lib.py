@@ -46,6 +46,15 @@ class GemmSplitIO(C.Structure):
     ]
 
 
+class GemmNorm(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("Y_hi", C.c_void_p), ("Y_lo", C.c_void_p), ("ldy_h", C.c_int64),
+        ("y_scale_dev", C.c_void_p),
+        ("scale", C.c_float), ("eps", C.c_float),
+    ]
+
+
 class ItemLengths(C.Structure):
     _fields_ = [("item_len_dev", C.c_void_p), ("mul", C.c_int32), ("add", C.c_int32)]
 
@@ -213,6 +222,8 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p]),
     "cvx_gemm_f16x3": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(GemmSplitIO),
                                  C.c_void_p]),
+    "cvx_gemm_f16x3_norm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(GemmSplitIO),
+                                      C.POINTER(GemmNorm), C.c_void_p]),
     "cvx_adarmsnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                      C.c_int64, C.c_float, C.c_float, C.c_void_p]),
     "cvx_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,

@@ -393,6 +393,12 @@ class VectorField:
             tw = twin[id(h)]
             ops.split_act_f16(h, tw, scale=hp) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw, scale=hp)
 
+        # every to_out / ff2 / skip-combiner product is followed by a norm of its output: one call (ops.gemm(norm=...)), so that
+        # problems on the split-K path (one utterance) normalise inside the reduction.  CVX_FUSE_NORM=0: separate launches (A/B)
+        fuse_norm = split_io and os.environ.get("CVX_FUSE_NORM", "1") == "1"
+        normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
+        def tab_rows(i_, k_):
+            return tab[(4 * i_ + k_) * dim:(4 * i_ + k_ + 1) * dim]
         skips: List[torch.Tensor] = []
         for i in range(d["depth"]):
             p = f"transformer.layers.{i}"
@@ -404,8 +410,11 @@ class VectorField:
                 s = skips.pop()
                 comb = take()
                 if split_io:
+                    nm = dict(gamma=g_attn, beta=b_attn, out_split=ws["normed16"],
+                              scale=sp_step[i][0] if sp_step is not None else None) if fuse_norm else None
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
-                             a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp)
+                             a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp, norm=nm)
+                    normed_ahead = nm is not None
                 else:
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"))
                 free += [h, s]
@@ -417,7 +426,9 @@ class VectorField:
                 n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
                 # device pointers of this (evaluation, layer)'s activation pre-scales: normed, q|k, v, attention out, normed, ff
                 s_na, s_qk, s_v, s_at, s_nf, s_ff = sp_step[i] if sp_step is not None else (None,) * 6
-                ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16, split_scale=s_na)
+                if not normed_ahead:
+                    ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16, split_scale=s_na)
+                normed_ahead = False
                 # q | k split row-major, v split + transposed, straight into the f16x3 attention (any T: sequences whose
                 # length is not a multiple of 4 store their v columns 2 bytes at a time)
                 ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
@@ -427,16 +438,24 @@ class VectorField:
                                     qk_scale=s_qk, v_scale=s_v, out_scale=s_at, ragged=rg)
                 h_att = take() if keep_input else h
                 ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
-                         a_split=a16, a_scale=s_at)
+                         a_split=a16, a_scale=s_at, norm=dict(gamma=g_ff, beta=b_ff, out_split=n16, scale=s_nf) if fuse_norm else None)
                 h = h_att
-                ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
+                if not fuse_norm:
+                    ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
                 ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
                          w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
                          a_scale=s_nf, c_scale=s_ff)
                 last = i + 1 == d["depth"]
+                nm = None
+                if fuse_norm and last:                   # the final RMSNorm in front of to_pred
+                    nm = dict(gamma=sd["transformer.final_norm.gamma"], beta=None, out_split=ws["pred16"], scale=pp)
+                elif fuse_norm and (f"transformer.layers.{i + 1}.0.weight") not in sd:      # next layer starts with its attention norm
+                    nm = dict(gamma=tab_rows(i + 1, 0), beta=tab_rows(i + 1, 1), out_split=n16,
+                              scale=sp_step[i + 1][0] if sp_step is not None else None)
                 ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h,
                          w_split=sp(p + ".4.2.weight"), w_il=il(p + ".4.2.weight"), a_split=f16,
-                         out_split=None if last else twin[id(h)], a_scale=s_ff, c_scale=None if last else hp)
+                         out_split=None if last else twin[id(h)], a_scale=s_ff, c_scale=None if last else hp, norm=nm)
+                normed_ahead = nm is not None
                 continue
             ops.adarmsnorm(h, g_attn, b_attn, ws["normed"])
             ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
@@ -450,7 +469,8 @@ class VectorField:
                      w_split=sp(p + ".4.0.weight"))
             ops.gemm(ws["ff"], sd[p + ".4.2.weight"], h, bias=sd[p + ".4.2.bias"], residual=h, w_split=sp(p + ".4.2.weight"))
         if split_io:
-            ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"], split_scale=pp)
+            if not normed_ahead:
+                ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"], split_scale=pp)
             ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"], a_scale=pp)
         else:
             ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])

@@ -644,6 +644,83 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The same reduction for whole rows (one wave per row, N <= 1024, N % 256 == 0) FOLLOWED by the row's AdaptiveRMSNorm, whose
+// split pair feeds the next GEMM (cvx_gemm_f16x3_norm): the arithmetic of splitk_reduce_kernel (act == NONE) and of
+// adarmsnorm_kernel<NV> (elementwise.hip), operation for operation, on the registers that hold the finished row.
+typedef _Float16 f16x4_r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_split4_r(_Float16* hi, _Float16* lo, int64_t row_off, int col, const f32x4 o, float& amax)
+{
+    amax = cvx_amax4(amax, o);
+    const int64_t off = row_off + ((lo == hi + 32) ? il_col(col) : col);
+    f16x4_r h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(o[e], -65504.f), 65504.f);
+        h[e] = (_Float16)x;
+        l[e] = (_Float16)(x - (float)h[e]);
+    }
+    *reinterpret_cast<f16x4_r*>(hi + off) = h;
+    if (lo) *reinterpret_cast<f16x4_r*>(lo + off) = l;
+}
+// One BLOCK per row, one quad of columns per thread (NW = N / 256 waves): a wave per row (the norm kernel's shape) leaves this
+// latency-bound pass with one wave per SIMD.  The row's sum of squares is put together in the norm kernel's order - per lane
+// the quads lane, lane + 64, ... in sequence, then the wave butterfly - so both paths round identically.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void splitk_reduce_norm_kernel(const float* __restrict__ partial, int ksplit, const cvx_gemm_args p, SplitOut so,
+                                                                    const cvx_gemm_norm nm)
+{
+    __shared__ float qs[NW][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = (int)blockIdx.x;
+    const int64_t total = (int64_t)p.M * p.N;
+    const int col = 4 * (int)threadIdx.x;
+    const float* pr = partial + (int64_t)row * p.N + col;
+    f32x4 v = gload4(pr);
+    const f32x4 gv = gload4(nm.gamma + col);
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, rv = bv, bi = bv;
+    if (nm.beta) bv = gload4(nm.beta + col);
+    if (p.residual) rv = gload4(p.residual + (int64_t)row * p.ldr + col);
+    if (p.bias) bi = gload4(p.bias + col);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 w = gload4(pr + (int64_t)s * total);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+    const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
+    const float ys = nm.y_scale_dev ? *nm.y_scale_dev : 1.f;
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (p.bias ? bi[e] : 0.f);
+        if (p.residual) x += rv[e];
+        v[e] = x;
+    }
+    if (so.write_f32) *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = v;
+    if (so.hi) store_split4_r(so.hi, so.lo, (int64_t)row * so.ldc_h, col, f32x4{v[0] * cs, v[1] * cs, v[2] * cs, v[3] * cs}, amax);
+    float ss = 0.f;
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    if (NW > 1) {
+        qs[wv][lane] = ss;
+        __syncthreads();
+        ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ss += qs[w][lane];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = nm.scale / fmaxf(sqrtf(ss), nm.eps);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] * inv * gv[e];
+    if (nm.beta) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += bv[e];
+    }
+    store_split4_r(reinterpret_cast<_Float16*>(nm.Y_hi), reinterpret_cast<_Float16*>(nm.Y_lo), (int64_t)row * nm.ldy_h, col,
+                   f32x4{o[0] * ys, o[1] * ys, o[2] * ys, o[3] * ys}, amax);
+    cvx_sat_commit(so.sat, amax);
+}
+
 template <int STAGES, int NT>
 static void launch_dma(const cvx_gemm_args& a, const PreSplitA& A, const f16* wh, const f16* wl, float acc_scale,
                        const SplitOut& so, dim3 grid, int tiles_m, int tiles_n, int map_mode, hipStream_t st,
@@ -691,11 +768,32 @@ extern "C" int64_t cvx_gemm_f16x3_workspace_floats(int32_t M, int32_t N, int32_t
     return m > 1 ? (int64_t)m * M * N : 0;
 }
 
+static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
+                           const cvx_gemm_split_io* io, const cvx_gemm_norm* norm, cvx_stream_t s);
+
 extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
                               const cvx_gemm_split_io* io, cvx_stream_t s)
 {
+    return gemm_f16x3_impl(a, W_hi, W_lo, acc_scale, io, nullptr, s);
+}
+
+extern "C" int cvx_gemm_f16x3_norm(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
+                                   const cvx_gemm_split_io* io, const cvx_gemm_norm* norm, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && norm && norm->gamma && norm->Y_hi, "gemm_f16x3_norm: null pointer");
+    CVX_REQUIRE(a->act == CVX_ACT_NONE && a->ldc == a->N && a->N % 4 == 0 && (!io || io->write_f32 != 0 || !io->C_hi) && !a->rope_cos,
+                "gemm_f16x3_norm: needs act == NONE, a contiguous fp32 C (ldc == N, written) and no RoPE");
+    CVX_REQUIRE((norm->Y_lo == norm->Y_hi + 32 && norm->ldy_h == 2 * (int64_t)a->N && a->N % 32 == 0) || norm->ldy_h == a->N,
+                "gemm_f16x3_norm: Y must be an interleaved pair with ldy_h == 2N or a plain pair with ldy_h == N");
+    return gemm_f16x3_impl(a, W_hi, W_lo, acc_scale, io, norm, s);
+}
+
+static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,
+                           const cvx_gemm_split_io* io, const cvx_gemm_norm* norm, cvx_stream_t s)
+{
     const int rc = cvxg::validate_gemm_args(a);
     if (rc != CVX_OK) return rc;
+    bool norm_done = false;
     CVX_REQUIRE(W_hi, "gemm_f16x3: null split weights");
     const bool single = (W_lo == nullptr);      // plain fp16 operands (hi halves only), one MFMA product
     CVX_REQUIRE(a->K % BK == 0 && a->ldw % 8 == 0, "gemm_f16x3: K must be a multiple of 32 and ldw of 8 (K=%d ldw=%ld)", a->K, (long)a->ldw);
@@ -773,11 +871,20 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
 #ifdef CVX_DEV_FLAGS
         if (io->flags & 0x10000) ksplit = 1;               // (dev A/B: no K slices; 0x20000: two)
         if ((io->flags & 0x20000) && ksplit > 2) ksplit = 2;
+        if ((so.dbg & 4) && io->workspace)                 // stamps behind the split-K partials (tools/gemm_small_trace.py)
+            so.trace = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(io->workspace) + ((size_t)100 << 20));
 #endif
         CVX_REQUIRE(cvxg::launch_gemm_f16x3_p8m(*a, A, wh, acc_scale, so, ksplit, ksplit > 1 ? io->workspace : nullptr, st),
                     "gemm_f16x3: interleaved operands below 2048 rows need N %% 64 == 0, 16-byte aligned C / residual / bias / RoPE tables "
                     "and rope_cols %% 128 == 0 (M=%d N=%d K=%d)", a->M, a->N, a->K);
-        if (ksplit > 1) {
+        if (ksplit > 1 && norm && a->N <= 1024 && a->N % 256 == 0 && a->ldc % 4 == 0 && (!a->residual || a->ldr % 4 == 0)) {
+            const dim3 g((unsigned)a->M);                      // the row's norm rides in the reduction: one block per row
+            if (a->N == 1024) hipLaunchKernelGGL(splitk_reduce_norm_kernel<4>, g, dim3(256), 0, st, io->workspace, ksplit, *a, so, *norm);
+            else if (a->N == 768) hipLaunchKernelGGL(splitk_reduce_norm_kernel<3>, g, dim3(192), 0, st, io->workspace, ksplit, *a, so, *norm);
+            else if (a->N == 512) hipLaunchKernelGGL(splitk_reduce_norm_kernel<2>, g, dim3(128), 0, st, io->workspace, ksplit, *a, so, *norm);
+            else hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, g, dim3(64), 0, st, io->workspace, ksplit, *a, so, *norm);
+            norm_done = true;
+        } else if (ksplit > 1) {
             const int64_t quads = ((int64_t)a->M * a->N + 3) / 4;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, io->workspace, ksplit, *a, so);
         }
@@ -839,5 +946,8 @@ extern "C" int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, cons
         hipLaunchKernelGGL(gemm_f16x3_kernel, grid, dim3(256), lds, st, *a, wh, wl, acc_scale, so, tiles_m, tiles_n, map_mode);
     }
     CVX_CHECK_LAUNCH("cvx_gemm_f16x3");
+    if (norm && !norm_done)
+        return cvx_adarmsnorm_scaled_f32(a->C, norm->gamma, norm->beta, nullptr, norm->Y_hi, norm->Y_lo, a->M, a->N, a->M > 0 ? a->M : 1,
+                                         norm->scale, norm->eps, norm->y_scale_dev, s);
     return CVX_OK;
 }

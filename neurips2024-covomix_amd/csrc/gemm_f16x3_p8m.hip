@@ -34,6 +34,11 @@ constexpr int MBUF_B = 2 * MT_B;                   // A | W
 constexpr int NBUF = 5;
 constexpr int MLDS_B = NBUF * MBUF_B;              // 160 KiB
 
+#ifdef CVX_DEV_FLAGS          // per-block s_memtime stamps of waves 0 and 4 (tools/gemm_small_trace.py; never in the shipped library)
+#define CVX_P8M_STAMP(i) do { if (tr) { tr[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define CVX_P8M_STAMP(i) do { } while (0)
+#endif
 #define CVX_P8M_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define CVX_P8M_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define CVX_P8M_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -43,7 +48,7 @@ constexpr int MLDS_B = NBUF * MBUF_B;              // 160 KiB
 template <bool HAS_A2, bool SWAP>
 __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
                                                 int m0, int n0, int kt0, int nk, int lane, int grp, int w4, int wr, int wc,
-                                                f32x4 (&acc)[4][4])
+                                                f32x4 (&acc)[4][4], unsigned long long* tr)
 {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // DMA: wave w4 of a group moves rows [32 w4, 32 w4 + 32) of the A tile and of the W tile, 8 rows x 128 bytes per piece
@@ -98,6 +103,7 @@ __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const Pr
     issue(grp + 2, grp + 2);
     CVX_P8M_WAIT_DMA();
     CVX_P8M_BARRIER();
+    CVX_P8M_STAMP(1);
     if (grp == 1) CVX_P8M_BARRIER();                    // group 1 runs one interval behind group 0
 
 #define CVX_P8M_MM(x, y, c) (SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(y, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0))
@@ -146,6 +152,7 @@ __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const Pr
 #undef CVX_P8M_MM
     if (grp == 0) CVX_P8M_BARRIER();                    // pairs with group 1's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the tail's dummy pieces before LDS is reused
+    CVX_P8M_STAMP(2);
 }
 
 template <bool HAS_A2, int EPI>
@@ -172,6 +179,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
         p.bias = nullptr;
     }
 
+    unsigned long long* tr = nullptr;
+#ifdef CVX_DEV_FLAGS
+    if ((so.dbg & 4) && so.trace && lane == 0 && w4 == 0) {
+        tr = so.trace + ((int64_t)blockIdx.x * 2 + grp) * 8;
+        unsigned long long rt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt));
+        tr[5] = rt; tr[0] = __builtin_readcyclecounter();
+    }
+#endif
     f32x4 acc[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -179,8 +194,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool v_block = false;
     if constexpr (EPI == EPI_QKV) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
-    if (v_block) tile_mainloop_m<HAS_A2, false>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc);
-    else tile_mainloop_m<HAS_A2, true>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc);
+    // everything the epilogue reads besides the accumulators is requested now (older than every DMA piece, so the counted waits
+    // of the K loop cover it)
+    const int row0 = m0 + wr * 64 + grp * 32, col0 = n0 + wc * 64;
+    EpiPre<2> pre;
+    epilogue_prefetch<EPI, 2>(p, so, row0, col0, lane, v_block, pre);
+    if (v_block) tile_mainloop_m<HAS_A2, false>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc, tr);
+    else tile_mainloop_m<HAS_A2, true>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc, tr);
 
     // ---- exchange: group 0 keeps rows 0-31 of every wave tile (blocks mi = 0, 1), group 1 rows 32-63 (mi = 2, 3)
     CVX_P8M_BARRIER();                                  // every wave is past its last fragment read and its last DMA piece
@@ -211,10 +231,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) e[i][j] = X[theirs + (i * 4 + j) * 64] + acc[2 + i][j];
     }
+    CVX_P8M_STAMP(3);
     if (so.dbg & 1) return;                             // (dev: main loop only, timing)
-    const int row0 = m0 + wr * 64 + grp * 32, col0 = n0 + wc * 64;
-    if (v_block) epilogue_vt<2>(p, e, row0, col0, lane, so, acc_scale);
-    else epilogue_rows<EPI, 2>(p, e, row0, col0, lane, so, acc_scale);
+    if (v_block) epilogue_vt<2, true>(p, e, row0, col0, lane, so, acc_scale, &pre);
+    else epilogue_rows<EPI, 2, true>(p, e, row0, col0, lane, so, acc_scale, &pre);
+#ifdef CVX_DEV_FLAGS
+    if (tr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[4] = __builtin_readcyclecounter();
+        unsigned long long rt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt));
+        tr[6] = rt;
+    }
+#endif
 }
 
 }  // namespace

@@ -80,14 +80,14 @@ __device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, f
 
 __device__ __forceinline__ f32x2 silu2(const f32x2 v) { return f32x2{silu(v[0]), silu(v[1])}; }
 
-// ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]
-template <int EPI, int MI = 8>
-__device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (&acc)[MI][4], int row0, int col0, int lane,
-                                              const SplitOut& so_in, float acc_scale)
+// what an epilogue reads besides the accumulators, requested BEFORE the K loop by the medium-problem kernel (a tile there is one
+// short K loop; per-block stamps showed 7-10 k cycles of exposed bias / RoPE-table / residual / scale round trips behind it)
+template <int MI> struct EpiPre { f32x4 bias[4]; f32x4 res[MI][4]; f32x4 rc[MI][2], rs[MI][2]; float cs, vs; };
+
+// pins the switches of a specialised epilogue (see EPI_* in gemm_common.h)
+template <int EPI>
+__device__ __forceinline__ void epi_specialise(cvx_gemm_args& p, SplitOut& so)
 {
-    if (col0 >= p_in.N) return;                 // wave tile entirely past the last column (N % 256 != 0; wave-uniform)
-    cvx_gemm_args p = p_in;
-    SplitOut so = so_in;
     if constexpr (EPI == EPI_QKV) {
         p.act = CVX_ACT_NONE; p.bias = nullptr; p.residual = nullptr; so.write_f32 = 0;
     } else if constexpr (EPI == EPI_RES) {
@@ -97,9 +97,54 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     } else if constexpr (EPI == EPI_BIAS) {
         p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1; so.hi = nullptr; so.lo = nullptr;
     }
+}
+
+template <int EPI, int MI>
+__device__ __forceinline__ void epilogue_prefetch(const cvx_gemm_args& p_in, const SplitOut& so_in, int row0, int col0, int lane,
+                                                  bool v_block, EpiPre<MI>& pre)
+{
+    cvx_gemm_args p = p_in;
+    SplitOut so = so_in;
+    epi_specialise<EPI>(p, so);
+    pre.cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
+    pre.vs = so.vt_scale ? *so.vt_scale : 1.f;
+    if (col0 >= p.N || v_block) return;
+    const int lr = lane & 15, lc = 4 * (lane >> 4);
+    const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+        if (p.bias) pre.bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int rr = min(row0 + 16 * mi + lr, p.M - 1);
+        if (do_rope) {
+            const int pos = rr % p.rope_T;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                pre.rc[mi][ni] = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
+                pre.rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
+            }
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) pre.res[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
+        }
+    }
+}
+
+// ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]
+template <int EPI, int MI = 8, bool PRE = false>
+__device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (&acc)[MI][4], int row0, int col0, int lane,
+                                              const SplitOut& so_in, float acc_scale, const EpiPre<MI>* pre = nullptr)
+{
+    if (col0 >= p_in.N) return;                 // wave tile entirely past the last column (N % 256 != 0; wave-uniform)
+    cvx_gemm_args p = p_in;
+    SplitOut so = so_in;
+    epi_specialise<EPI>(p, so);
     const int lr = lane & 15, lc = 4 * (lane >> 4);
     const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);          // wave-uniform (64-column wave tile = one head)
-    const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
+    float cs;
+    if constexpr (PRE) cs = pre->cs; else cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
     const bool il = so.hi && so.lo == so.hi + 32;
     float amax = 0.f;
     const f32x2 sc2 = splat2(acc_scale), cs2 = splat2(cs);
@@ -107,7 +152,8 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+        if constexpr (PRE) { if (p.bias) b4 = pre->bias[ni]; }
+        else if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
         bias[ni][0] = f32x2{b4[0], b4[1]}; bias[ni][1] = f32x2{b4[2], b4[3]};
     }
     // residual rows are requested CVX_P8S_RES_AHEAD row groups before they are added (explicitly: where hipcc puts these loads
@@ -118,7 +164,10 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
         const int row_ = row0 + 16 * mi_ + lr;
         const int rr_ = row_ < p.M ? row_ : p.M - 1;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) r[ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr_ * p.ldr + col0 + 16 * ni + lc);
+        for (int ni = 0; ni < 4; ++ni) {
+            if constexpr (PRE) r[ni] = pre->res[mi_][ni];
+            else r[ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr_ * p.ldr + col0 + 16 * ni + lc);
+        }
     };
     if (RA > 0 && p.residual) {
 #pragma unroll
@@ -145,8 +194,12 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
             const int pos = rr % p.rope_T;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
+                f32x4 c, s;
+                if constexpr (PRE) { c = pre->rc[mi][ni]; s = pre->rs[mi][ni]; }
+                else {
+                    c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
+                    s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f32x2 c2 = f32x2{c[2 * h], c[2 * h + 1]}, s2 = f32x2{s[2 * h], s[2 * h + 1]};
@@ -190,14 +243,16 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 // ---- epilogue of a V block of a to_qkv projection, UN-swapped layout:
 // acc[mi][ni][r] = C[row0 + 16 mi + 4 (lane >> 4) + r][col0 + 16 ni + (lane & 15)]: 4 consecutive frames per lane ->
 // vt[((b*H + head)*64 + d) * vt_ld + slot(t)], 8 bytes per store when the four frames are one aligned slot group
-template <int MI = 8>
+template <int MI = 8, bool PRE = false>
 __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)[MI][4], int row0, int col0, int lane,
-                                            const SplitOut& so, float acc_scale)
+                                            const SplitOut& so, float acc_scale, const EpiPre<MI>* pre = nullptr)
 {
     if (col0 >= p.N) return;                    // wave tile entirely past the last column (H % 4 != 0; wave-uniform)
     const int H = p.rope_cols / 128, T = p.rope_T;
     const int head = (col0 - p.rope_cols) / 64;
-    const float vs = (so.vt_scale ? *so.vt_scale : 1.f) * acc_scale;
+    float vs0;
+    if constexpr (PRE) vs0 = pre->vs; else vs0 = so.vt_scale ? *so.vt_scale : 1.f;
+    const float vs = vs0 * acc_scale;
     float amax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -208,7 +263,7 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int d = 16 * ni + (lane & 15);
-            const float bv = p.bias ? p.bias[col0 + d] * (so.vt_scale ? *so.vt_scale : 1.f) : 0.f;
+            const float bv = p.bias ? p.bias[col0 + d] * vs0 : 0.f;
             f16x4 h, l;
             split4_pk(f32x4{fmaf(acc[mi][ni][0], vs, bv), fmaf(acc[mi][ni][1], vs, bv), fmaf(acc[mi][ni][2], vs, bv), fmaf(acc[mi][ni][3], vs, bv)}, h, l, amax);
             if (vec) {

@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, GemmArgs, GemmSplitIO
+from ._lib import ConvArgs, GemmArgs, GemmNorm, GemmSplitIO
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
@@ -101,7 +101,7 @@ def _sp(t: Optional[torch.Tensor]) -> Optional[int]:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
          a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None,
-         a_scale=None, c_scale=None, vt_scale=None) -> torch.Tensor:
+         a_scale=None, c_scale=None, vt_scale=None, norm=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -111,7 +111,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     Any `lo` may be None: w_split = (hi, None, 1/scale) selects the single-term fp16 kernel (plain fp16 operands,
     fp32 accumulate; needs a_split and K % 64 == 0), whose inputs / outputs only carry the hi halves.
     a_scale / c_scale / vt_scale: one-element fp32 CUDA tensors (powers of two) - the pre-scale the producer of a_split (and
-    a2_split) applied, and the pre-scales to apply to out_split / vt_split (see cvx_gemm_split_io in the header)."""
+    a2_split) applied, and the pre-scales to apply to out_split / vt_split (see cvx_gemm_split_io in the header).
+    norm = dict(gamma, beta (or None), out_split, scale (device pre-scale or None)[, eps]): the AdaptiveRMSNorm / RMSNorm of the
+    rows of `out` as part of the same call (cvx_gemm_f16x3_norm): its split pair feeds the next GEMM; on the split-K path the
+    norm rides in the reduction (no launch, no re-read)."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -184,9 +187,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
             io.flags = _GEMM_FLAGS
             io.w_interleaved, g.ldw = 1, 2 * K
             w_hi_ptr, w_lo_ptr, inv_scale = il.data_ptr(), il.data_ptr() + 64, inv_il
+        if norm is not None:
+            nm = GemmNorm()
+            _chk_f32(norm["gamma"], norm.get("beta"))
+            assert norm["gamma"].stride(-1) == 1 and norm["gamma"].numel() == N and out.is_contiguous() and write_f32
+            nm.gamma, nm.beta = norm["gamma"].data_ptr(), _p(norm.get("beta"))
+            nm.Y_hi, nm.Y_lo, nm.ldy_h = _pair(norm["out_split"], M, N)
+            nm.y_scale_dev = _sp(norm.get("scale"))
+            nm.scale, nm.eps = float(N) ** 0.5, float(norm.get("eps", 1e-12))
+            _lib.check(_lib.load().cvx_gemm_f16x3_norm(C.byref(g), w_hi_ptr, w_lo_ptr, inv_scale, C.byref(io), C.byref(nm), _stream()),
+                       "cvx_gemm_f16x3_norm")
+            return out
         _lib.check(_lib.load().cvx_gemm_f16x3(C.byref(g), w_hi_ptr, w_lo_ptr, inv_scale, C.byref(io), _stream()),
                    "cvx_gemm_f16x3")
         return out
+    assert norm is None, "a fused norm needs the f16x3 kernel"
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
     assert a_scale is None and c_scale is None and vt_scale is None
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
