@@ -116,7 +116,7 @@ class VectorField:
         self.split_il: Dict[str, tuple] = {}
         if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
             for k, v in self.split.items():
-                if v[0].shape[0] >= 512:
+                if v[0].shape[0] >= 512 or k == "to_pred.weight":
                     self.split_il[k] = ops.split_f16_interleaved(v)
 
     # ------------------------------------------------------------------ activation pre-scales (scale-free split pairs)
@@ -211,7 +211,7 @@ class VectorField:
         if ragged_rows:
             q = self.RAGGED_ROW_QUANTUM
             M = (ragged_rows + q - 1) // q * q
-            key = ("ragged", M, ragged_rows >= ops.il_min_rows())  # (the interleaved-pair choice below depends on the real row count)
+            key = ("ragged", M, ragged_rows >= ops.il_min_rows(), ragged_rows < 2048)  # (the pair layouts below depend on the real row count)
         else:
             M = Bt * T
             key = (Bt, T)
@@ -236,7 +236,9 @@ class VectorField:
             if lo_too and (ragged_rows or M) >= ops.il_min_rows() and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
                 a16 = lambda rows, cols: ops.SplitIL(rows, cols, dev)
             ws["normed16"], ws["att16"], ws["ff16"] = a16(M, d["dim"]), a16(M, d["heads"] * 64), a16(M, 4 * d["dim"])
-            ws["pred16"] = h16(M, d["dim"])                      # final norm -> to_pred (N = 80: small-N kernel, plain pair)
+            # final norm -> to_pred (N = 80): the medium-problem kernel takes it with K slices (interleaved pair); 2048 rows and more: plain
+            # pair on the small-N kernel
+            ws["pred16"] = a16(M, d["dim"]) if (a16 is not h16 and (ragged_rows or M) < 2048 and d["dim_out"] % 16 == 0) else h16(M, d["dim"])
             ws["qk16"] = h16(M, 2 * d["heads"] * 64)
             ws["h16"] = [a16(M, d["dim"]) for _ in ws["h"]]      # split twins of the residual-stream buffers (skip GEMMs)
             # V^T rows, zero (always finite) beyond the last frame: read by the last key tile with weight 0
@@ -471,7 +473,8 @@ class VectorField:
         if split_io:
             if not normed_ahead:
                 ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"], split_scale=pp)
-            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"], a_scale=pp)
+            ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"], a_scale=pp,
+                     w_il=il("to_pred.weight") if isinstance(ws["pred16"], ops.SplitIL) else None)
         else:
             ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, ws["normed"])
             ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"))

@@ -19,6 +19,7 @@
 // 16s+8+4g+{0..3}); the producer stores V^T with exactly those eight keys adjacent (frame-slot order above), so a
 // V^T fragment is one 16-byte read and P never moves between lanes.
 #include "cvx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -75,8 +76,14 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 // T = 1000, H = 16, NW = 4): DMA switched off after the first tile 177 instead of 211 us and 0.233
 // instead of 0.286 J (on zero operands, i.e. at full clock, 130 instead of 159 us); no LDS fragment reads -7 %; no
 // v_exp_f32 -1 %; no P.V MFMAs 140 us; no K.Q MFMAs 134 us.  Halving the DMA BYTES (NW = 8) does not buy the DMA-off time.
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
+// KS = key-split groups per block (1, 2 or 3; NW = 4): a SHORT launch - one utterance: 2 x 16 (sequence, head) pairs x 4 query
+// tiles = 128 blocks of one wave per SIMD, each walking all key tiles in a dependent chain of ~1.45 us per tile (23 us at
+// T = 500, while the same wave-tiles take 0.44 us each at three waves per SIMD) - gets KS x 4 waves per block: group s walks
+// key tiles s, s + KS, ... through its own two-stage ring with its own running (m, l, O), and group 0 merges the groups' states
+// through LDS in the fixed order 0, 1, 2 (the flash-decoding combine: O = sum O_s 2^(m_s - m), l likewise) before it normalises
+// and stores.  The chain shortens KS-fold and every SIMD holds KS waves to overlap.
+template <int NT, int NW, int KS = 1>
+__global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? KS : CVX_ATT_WAVES)) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
                                                                 const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
                                                                 int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
@@ -86,9 +93,11 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
 {
     // activation pre-scales (device scalars, powers of two): scores carry qk_scale^2, O carries v_scale
     if (qk_scale) { const float q = *qk_scale; scale_log2e /= q * q; }
-    __shared__ __attribute__((aligned(16))) f16 smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) f16 smem_all[2 * STAGE * KS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wall = tid >> 6, ks = KS > 1 ? wall / NW : 0, wid = KS > 1 ? wall % NW : wall;     // key group, query wave
+    f16* const smem = smem_all + ks * 2 * STAGE;
     const int g = lane >> 5, l31 = lane & 31;
     const int grp = (blockIdx.x / (8 * n_qt)) * 8 + (blockIdx.x & 7);      // same (batch, head) -> same XCD
     if (grp >= n_groups) return;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
     fetch(tile0 * KT);
     commit(0);
 #else
-    issue(tile0 * KT, 0);
+    if (KS == 1 || ks == 0) issue(tile0 * KT, 0);
 #endif
 #ifdef CVX_ATT_TRACE
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
@@ -207,8 +216,17 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
 #endif
     f16x8 kfh[4], kfl[4];                         // K fragments of the running tile
     f16x8 vfh[2][2], vfl[2][2];                   // V^T fragments [s][dt]
-    for (int it = 0; it < ntiles; ++it) {
-        const int cur = it & 1, key0 = (tile0 + it) * KT;
+    if (KS > 1 && ks > 0 && ks < ntiles) issue((tile0 + ks) * KT, 0);      // (group 0's first tile was requested above)
+    const int n_it = KS > 1 ? (ntiles + KS - 1) / KS : ntiles;
+    for (int jt = 0; jt < n_it; ++jt) {
+        const int it = KS > 1 ? jt * KS + ks : jt;
+        const int cur = jt & 1, key0 = (tile0 + it) * KT;
+        if (KS > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // this group's tile landed (all four waves); its other stage is free
+            if (it + KS < ntiles) issue(key0 + KS * KT, cur ^ 1);
+            if (it >= ntiles) continue;                     // (group-uniform: a group past its last tile only keeps the barriers company)
+        } else {
 #ifdef CVX_ATT_REGSTAGE
         __syncthreads();                                    // every wave's ds_writes of tile `it` are visible; stage cur^1 is free
         if (it + 1 < ntiles) fetch(key0 + KT);
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
         TSTAMP(0)
         if (it + 1 < ntiles && !((CVX_ATT_ABLATE & 1) && it > 0)) issue(key0 + KT, cur ^ 1);
 #endif
+        }
         const f16* S = smem + cur * STAGE;
 
         // ---- S^T = K . Q^T  (3 products per 16-wide d slice), ONE accumulator: the matrix pipe forwards the result of an
@@ -349,6 +368,40 @@ __global__ __launch_bounds__(64 * NW, CVX_ATT_WAVES) void attention_f16x3_kernel
     out = nullptr;
 #endif
 
+    if constexpr (KS > 1) {
+        // merge the key groups' states: groups 1 .. KS-1 park (m, l, O) in LDS (the rings are dead), group 0 folds them in order
+        __syncthreads();
+        f32x4* const X = reinterpret_cast<f32x4*>(smem_all);
+        if (ks > 0) {
+            f32x4* const dst = X + ((size_t)((ks - 1) * NW + wid) * 9) * 64 + lane;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                dst[q4 * 64] = f32x4{o0[4 * q4], o0[4 * q4 + 1], o0[4 * q4 + 2], o0[4 * q4 + 3]};
+                dst[(4 + q4) * 64] = f32x4{o1[4 * q4], o1[4 * q4 + 1], o1[4 * q4 + 2], o1[4 * q4 + 3]};
+            }
+            dst[8 * 64] = f32x4{m_run, l_run, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int s2 = 1; s2 < KS; ++s2) {
+            const f32x4* const src = X + ((size_t)((s2 - 1) * NW + wid) * 9) * 64 + lane;
+            const f32x4 ml = src[8 * 64];
+            const float m_new = fmaxf(m_run, ml[0]);
+            const float fa = __builtin_amdgcn_exp2f(m_run - m_new), fb = __builtin_amdgcn_exp2f(ml[0] - m_new);
+            m_run = m_new;
+            l_run = l_run * fa + ml[1] * fb;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 a = src[q4 * 64], c = src[(4 + q4) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[4 * q4 + e] = o0[4 * q4 + e] * fa + a[e] * fb;
+                    o1[4 * q4 + e] = o1[4 * q4 + e] * fa + c[e] * fb;
+                }
+            }
+        }
+    }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot / (v_scale ? *v_scale : 1.f);        // fp32 output: the true value
     const float osc = out_scale ? *out_scale : 1.f;                        // split output: times the consumer's pre-scale
@@ -406,14 +459,29 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
     const int n_qt = (T + qb - 1) / qb, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     uint32_t* sat = cvx_sat_flag_dev();
+    // key-split groups for short launches (see the kernel): three when the grid leaves CUs with a single block (96 KiB of LDS),
+    // two while two such blocks fit a CU
+    int ksplit = 1;
+    if (nw == 4 && T >= 4 * KT) ksplit = grid.x <= 256 ? 3 : (grid.x <= 512 ? 2 : 1);
+    static const bool no_ks = getenv("CVX_ATT_KS") && atoi(getenv("CVX_ATT_KS")) == 0;      // dev A/B
+    if (no_ks) ksplit = 1;
 #define CVX_ATT_LAUNCH(NT_, NW_)                                                                                                          \
     hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_>), grid, dim3(64 * NW_), 0, reinterpret_cast<hipStream_t>(s),                       \
                        reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
                        reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
                        out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
                        T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
-    if (single) { if (nw == 8) CVX_ATT_LAUNCH(1, 8); else CVX_ATT_LAUNCH(1, 4); }
+#define CVX_ATT_LAUNCH_KS(NT_, KS_)                                                                                                       \
+    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, 4, KS_>), grid, dim3(256 * KS_), 0, reinterpret_cast<hipStream_t>(s),                    \
+                       reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
+                       reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
+                       out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
+                       T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
+    if (ksplit == 3) { if (single) CVX_ATT_LAUNCH_KS(1, 3); else CVX_ATT_LAUNCH_KS(3, 3); }
+    else if (ksplit == 2) { if (single) CVX_ATT_LAUNCH_KS(1, 2); else CVX_ATT_LAUNCH_KS(3, 2); }
+    else if (single) { if (nw == 8) CVX_ATT_LAUNCH(1, 8); else CVX_ATT_LAUNCH(1, 4); }
     else { if (nw == 8) CVX_ATT_LAUNCH(3, 8); else CVX_ATT_LAUNCH(3, 4); }
+#undef CVX_ATT_LAUNCH_KS
 #undef CVX_ATT_LAUNCH
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;

@@ -752,9 +752,9 @@ static int splitk_factor_p8m(int M, int N, int K, int K1, bool has_a2)
 {
     const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
     if (N % 4 != 0) return 1;
-    for (int cand = 4; cand >= 2; cand >>= 1) {
+    for (int cand = 8; cand >= 2; cand >>= 1) {
         const int kp = K / cand;
-        if (tiles * cand <= 256 && K % (32 * cand) == 0 && kp >= 256 && (!has_a2 || K1 % kp == 0)) return cand;
+        if (tiles * cand <= (cand == 8 ? 128 : 256) && K % (32 * cand) == 0 && kp >= (cand == 8 ? 128 : 256) && (!has_a2 || K1 % kp == 0)) return cand;
     }
     return 1;
 }
@@ -875,8 +875,8 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
             so.trace = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(io->workspace) + ((size_t)100 << 20));
 #endif
         CVX_REQUIRE(cvxg::launch_gemm_f16x3_p8m(*a, A, wh, acc_scale, so, ksplit, ksplit > 1 ? io->workspace : nullptr, st),
-                    "gemm_f16x3: interleaved operands below 2048 rows need N %% 64 == 0, 16-byte aligned C / residual / bias / RoPE tables "
-                    "and rope_cols %% 128 == 0 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+                    "gemm_f16x3: interleaved operands below 2048 rows need N %% 16 == 0 (N %% 64 == 0 with RoPE), 16-byte aligned C / residual / "
+                    "bias / RoPE tables and rope_cols %% 128 == 0 (M=%d N=%d K=%d)", a->M, a->N, a->K);
         if (ksplit > 1 && norm && a->N <= 1024 && a->N % 256 == 0 && a->ldc % 4 == 0 && (!a->residual || a->ldr % 4 == 0)) {
             const dim3 g((unsigned)a->M);                      // the row's norm rides in the reduction: one block per row
             if (a->N == 1024) hipLaunchKernelGGL(splitk_reduce_norm_kernel<4>, g, dim3(256), 0, st, io->workspace, ksplit, *a, so, *norm);

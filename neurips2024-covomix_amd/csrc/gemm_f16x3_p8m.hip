@@ -253,7 +253,9 @@ namespace cvxg {
 bool launch_gemm_f16x3_p8m(const cvx_gemm_args& a, const PreSplitA& A, const f16* w_il, float acc_scale, const SplitOut& so,
                            int ksplit, float* partial, hipStream_t st)
 {
-    if (a.K % 32 != 0 || (A.hi2 && a.K1 % 32 != 0) || a.N % 64 != 0) return false;
+    // N % 16 == 0: a trailing partial wave tile is computed on clamped W rows and not stored (to_pred: N = 80); RoPE / V^T epilogues
+    // work on whole heads
+    if (a.K % 32 != 0 || (A.hi2 && a.K1 % 32 != 0) || a.N % 16 != 0 || (a.N % 64 != 0 && (a.rope_cos || so.vt_hi))) return false;
     if ((int64_t)a.M * A.ld * 2 >= (int64_t)1 << 32 || (A.hi2 && (int64_t)a.M * A.ld2 * 2 >= (int64_t)1 << 32) ||
         (int64_t)a.N * a.ldw * 2 >= (int64_t)1 << 32) return false;
     SplitOut s2 = so;

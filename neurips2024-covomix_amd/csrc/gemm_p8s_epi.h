@@ -113,7 +113,7 @@ __device__ __forceinline__ void epilogue_prefetch(const cvx_gemm_args& p_in, con
     const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-        if (p.bias) pre.bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+        if (p.bias && col0 + 16 * ni < p.N) pre.bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int rr = min(row0 + 16 * mi + lr, p.M - 1);
@@ -127,7 +127,8 @@ __device__ __forceinline__ void epilogue_prefetch(const cvx_gemm_args& p_in, con
         }
         if (p.residual) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) pre.res[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
+            for (int ni = 0; ni < 4; ++ni)
+                if (col0 + 16 * ni < p.N) pre.res[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
         }
     }
 }
@@ -221,12 +222,15 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
         if (!live) continue;
         if (so.write_f32) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (PRE) { if (col0 + 16 * ni >= p.N) continue; }      // (N % 16 == 0 on the medium-problem kernel: partial wave tile)
                 *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + 16 * ni + lc) = f32x4{v[ni][0][0], v[ni][0][1], v[ni][1][0], v[ni][1][1]};
+            }
         }
         if (so.hi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (PRE) { if (col0 + 16 * ni >= p.N) continue; }
                 const int c = col0 + 16 * ni + lc;
                 const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
                 f16x2 h01, h23, l01, l23;

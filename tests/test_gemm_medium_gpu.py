@@ -167,3 +167,20 @@ def test_gemm_norm_equals_gemm_then_norm(ops, M, N, K, il_out):
         want = h / h.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(N) * gam.double() + (beta.double() if beta is not None else 0.0)
         got = (dense(y1)[0].double() + dense(y1)[1].double()) / 4.0
         assert rel_l2(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 80, 1024), (300, 16, 256), (700, 208, 512)])
+def test_partial_wave_tile(ops, M, N, K):
+    """N % 16 == 0 only (to_pred: N = 80, eight K slices): the trailing partial wave tile multiplies clamped W rows and stores
+    nothing; fp32 output inside a NaN-filled wider buffer is not required to be contiguous."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev())
+    il, xs = _il(ops, x)
+    w, ws, wil = _weights(ops, g, N, K)
+    b = torch.randn(N, generator=g).to(dev())
+    c = torch.full((M + 1, N), float("nan"), device=dev())
+    ops.gemm(x, w, c[:M], w_split=ws, w_il=wil, a_split=il, bias=b)
+    assert rel_l2(c[:M], xs @ w.double().T + b.double()) < 1e-6 and bool(torch.isnan(c[M]).all())
+    cw = torch.full((M, N + 16), float("nan"), device=dev())
+    ops.gemm(x, w, cw[:, :N], w_split=ws, w_il=wil, a_split=il)
+    assert rel_l2(cw[:, :N], xs @ w.double().T) < 1e-6 and bool(torch.isnan(cw[:, N:]).all())

@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from covomix_amd import ops
 dev = torch.device("cuda:0")
-Bt, T, H = 16, int(os.environ.get("T", "1000")), 16
+Bt, T, H = int(os.environ.get("BT", "16")), int(os.environ.get("T", "1000")), 16
 Tp = (T + 31) // 32 * 32
 def timeit(fn, iters=30, warm=5):
     for _ in range(warm): fn()
