@@ -83,6 +83,160 @@ class GemmTimer:
         return self.flops, secs, self.launches, self.seen
 
 
+class ClassTimer:
+    """HIP-event brackets around every n-th call of one Python-level op (a kernel class of the step: attention, the stand-alone
+    AdaptiveRMSNorm launches, the whole vocoder call) -> ms per step next to the dominant GEMM's, so that a slower box or a
+    slower kernel class can be told apart from the bench line alone."""
+
+    def __init__(self, owner, name, every):
+        self.owner, self.name, self.every = owner, name, max(1, every)
+        self.inner = getattr(owner, name)
+        self.seen, self.pairs = 0, []
+
+        def timed(*a, **kw):
+            self.seen += 1
+            if self.seen % self.every:
+                return self.inner(*a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.inner(*a, **kw)
+            e.record()
+            self.pairs.append((s, e))
+            return r
+        setattr(owner, name, timed)
+
+    def remove(self):
+        setattr(self.owner, self.name, self.inner)
+
+    def result(self, steps):
+        if not self.pairs:
+            return None
+        avg_ms = sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
+        return {"launches_per_step": round(self.seen / steps, 1), "timed": len(self.pairs), "avg_launch_ms": round(avg_ms, 4),
+                "ms_per_step": round(avg_ms * self.seen / steps, 3)}
+
+
+class PowerSampler:
+    """Package power and shader clock of the GPU while the timed region runs (a host thread reading the amdgpu hwmon files, or
+    `rocm-smi --showpower --showclocks` when there are none): the launch times of the MFMA-bound kernels are joules / power cap on
+    this chip, and boxes of the pool differ - without these two numbers a slower bench line cannot be told
+    from a slower box.  The node exposes the hwmon directories of ALL its GPUs, also of those this process cannot see: every card
+    is sampled and the one that drew the most power during the timed region is this process's GPU (the others idle at ~250 W)."""
+
+    def __init__(self, period=0.1, device_index=0):
+        import glob
+        import threading
+        self.period, self.stop_ev = period, threading.Event()
+        self.cards = []
+        self.mine = None                       # PCI address of this process's GPU, when torch tells it
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            self.mine = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pci = os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(h))))
+            if self.mine and pci != self.mine and any(os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(x)))) == self.mine
+                                                      for x in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+                continue
+            for pw in ("power1_average", "power1_input"):
+                if os.path.isfile(os.path.join(h, pw)):
+                    self.cards.append((h, pw))
+                    break
+        self.samples = {h: [] for h, _ in self.cards}
+        self.smi = "/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None
+        self.smi_samples = []
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _num(path, scale):
+        try:
+            return int(open(path).read()) / scale
+        except Exception:
+            return None
+
+    def _read_smi(self):
+        import re
+        import subprocess
+        out = subprocess.run([self.smi, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        p = re.search(r"Power \(W\): ([\d.]+)", out)
+        c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+        return (float(p.group(1)) if p else None), (float(c.group(1)) if c else None)
+
+    def _run(self):
+        while not self.stop_ev.is_set():
+            t = time.perf_counter()
+            try:
+                if self.cards:
+                    for h, pw in self.cards:
+                        p = self._num(os.path.join(h, pw), 1e6)
+                        if p is not None:
+                            self.samples[h].append((t, p, self._num(os.path.join(h, "freq1_input"), 1e6)))
+                elif self.smi:
+                    p, f = self._read_smi()
+                    if p is not None:
+                        self.smi_samples.append((t, p, f))
+                else:
+                    return
+            except Exception:
+                pass
+            self.stop_ev.wait(self.period)
+
+    def start(self):
+        self.thread.start()
+
+    def stop(self, t0, t1):
+        self.stop_ev.set()
+        self.thread.join(timeout=15)
+        src, cap, sel = None, None, []
+        if self.cards:
+            best = None
+            for h, pw in self.cards:
+                w = [x for x in self.samples[h] if t0 <= x[0] <= t1]
+                if w and (best is None or sum(x[1] for x in w) / len(w) > best[0]):
+                    best = (sum(x[1] for x in w) / len(w), h, pw, w)
+            if best:
+                _, h, pw, sel = best
+                src = f"hwmon {pw} of {os.path.basename(os.path.dirname(os.path.dirname(os.path.dirname(h))))} ({'PCI ' + self.mine if self.mine and len(self.cards) == 1 else 'busiest of %d cards' % len(self.cards)})"
+                cap = self._num(os.path.join(h, "power1_cap"), 1e6)
+        elif self.smi_samples:
+            sel = [x for x in self.smi_samples if t0 <= x[0] <= t1] or self.smi_samples[-1:]
+            src = "rocm-smi"
+        if not sel:
+            return {"power_w": None, "sclk_mhz": None, "power_cap_w": None, "power_samples": 0, "power_source": src}
+        pw_ = [x[1] for x in sel]
+        ck = [x[2] for x in sel if x[2]]
+        return {"power_w": round(sum(pw_) / len(pw_), 1), "power_w_max": round(max(pw_), 1),
+                "sclk_mhz": round(sum(ck) / len(ck), 1) if ck else None, "power_cap_w": cap,
+                "power_samples": len(sel), "power_source": src}
+
+
+def config2(dev, calls: int = 5):
+    """BASELINE config 2 next to the headline: VoSingle, 32 NFE, ONE 500-frame utterance (200-frame prompt) per call - the
+    reference's own calling pattern (monologue_generation.py:259-304).  ms per utterance, frames/s and the fraction of the dense
+    fp16 MFMA peak its algorithmic FLOPs (15.18 GFLOP per frame) reach."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    shapes = syn.acoustic_param_shapes(dim_cond=80, streams=1)
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
+    sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
+    model = CoVoMixModel.from_state_dict(sd, nfe=NFE).eval().to(dev)
+    inp = syn.synthetic_inputs("vosingle", 1, 500, 200, seed=1234)
+    ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
+    for _ in range(2):
+        model.synthesis_sample(ids, cond, mask, COND_SCALE)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        model.synthesis_sample(ids, cond, mask, COND_SCALE)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / calls
+    flop_per_frame = 64 * 237_139_968
+    return {"workload": "VoSingle 32-NFE, B=1, T=500 (200-frame prompt), acoustic model only", "calls": calls,
+            "ms_per_utterance": round(dt * 1e3, 3), "frames_per_s": round(500 / dt, 1),
+            "frac": round(500 / dt * flop_per_frame / PEAK_F16_MFMA, 4), "vs_f32_mfma_peak": round(500 / dt * flop_per_frame / PEAK_F32_MFMA, 4)}
+
+
 def make_models(dev, rank, world, precision=None):
     import covomix_amd.synthetic as syn
     from covomix_amd import dp
@@ -190,6 +344,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true")
+    ap.add_argument("--no-c2", action="store_true", help="skip the BASELINE config-2 figure (extra key `c2`, N = 1 only)")
     ap.add_argument("--precision", choices=["f16x3", "f16", "fp32"], default=None,
                     help="default f16x3 (fp32-class); f16 = opt-in single-term fp16 operands (<= 1e-3 rel-L2 budget)")
     args = ap.parse_args()
@@ -217,10 +372,16 @@ def main():
     ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
     noise = torch.Generator(device=dev).manual_seed(1234 + rank)
 
+    voc_events = []
+
     def step():
         y0 = torch.randn(B, T, 80, device=dev, generator=noise)
         mel = model.synthesis_sample(ids, cond, mask, COND_SCALE, y0=y0)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
         wav = gen(mel.permute(0, 2, 1).contiguous())
+        ev[1].record()
+        voc_events.append(ev)
         return ops.wav_to_int16(wav.squeeze(1).contiguous())
 
     def barrier():
@@ -233,13 +394,24 @@ def main():
         step()
     timer = GemmTimer(split=(model.precision in ("f16x3", "f16")), every=int(os.environ.get("CVX_BENCH_TIMER_EVERY", "7")))
     timer.install(ops)
+    every = int(os.environ.get("CVX_BENCH_TIMER_EVERY", "7"))
+    classes = {"attention": ClassTimer(ops, "attention_f16x3" if model.precision != "fp32" else "attention", every),
+               "adarmsnorm": ClassTimer(ops, "adarmsnorm", every)}
+    voc_events.clear()
+    power = PowerSampler(device_index=local) if rank == 0 else None
+    if power:
+        power.start()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pcm = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
     timer.remove()
+    for c in classes.values():
+        c.remove()
+    power_info = power.stop(t0, t1) if power else {}
     my_elapsed = elapsed
     assert pcm.shape == (B, 160 * T + 32) and pcm.dtype == torch.int16
     frames, elapsed = dp.reduce_metric(float(B * T * args.steps), elapsed, dev)
@@ -294,16 +466,26 @@ def main():
                          "vs_f32_mfma_peak": round(achieved / (PEAK_F32_MFMA / 1e12), 4),
                          "launches": all_launches, "timed_launches": launches,
                          "avg_launch_ms": round(gemm_s / launches * 1e3, 4),
-                         "time_share_of_step": round(gemm_s / launches * all_launches / elapsed, 4)},
+                         "time_share_of_step": round(gemm_s / launches * all_launches / elapsed, 4),
+                         "ms_per_step": round(gemm_s / launches * all_launches / args.steps * 1e3, 3)},
         }
+        out["roofline"].update(power_info)          # power_w, sclk_mhz, power_cap_w of the timed region (rank 0's GPU)
+        out["kernel_classes_ms_per_step"] = {k: c.result(args.steps) for k, c in classes.items()}
+        voc_ms = sum(a.elapsed_time(b) for a, b in voc_events) / max(len(voc_events), 1)
+        out["kernel_classes_ms_per_step"]["vocoder"] = {"launches_per_step": 1, "timed": len(voc_events), "avg_launch_ms": round(voc_ms, 4),
+                                                        "ms_per_step": round(voc_ms, 3), "note": "whole Generator call incl. its saturation-flag read"}
         if world > 1:
             out["ranks"] = {"elapsed_s": [round(x, 4) for x in per_rank], "skew_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 4),
                             "load_and_broadcast_s": [round(x, 3) for x in loads]}
+        model_precision = model.precision
         if world == 1 and not args.no_fp32_exact and model.precision == "f16x3":
             del model, gen
             torch.cuda.empty_cache()
             with contextlib.redirect_stdout(sys.stderr):
                 out["fp32_exact"] = fp32_exact(dev, rank, world)
+        if world == 1 and not args.no_c2 and model_precision == "f16x3":
+            with contextlib.redirect_stdout(sys.stderr):
+                out["c2"] = config2(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_sd)
         print(json.dumps(out), flush=True)

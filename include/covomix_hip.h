@@ -36,19 +36,25 @@ int         cvx_version(void);
 const char* cvx_last_error_string(void);
 
 /* ------------------------------------------------------------------------
- * Sticky saturation flag (one uint32 per device, owned by the library).
+ * Sticky saturation flag: CALLER-OWNED, one uint32 of device memory per (device, stream) (round 4; until version 102 the
+ * library allocated one per device on first use - a hidden hipMalloc and a word two host threads could clear under each other).
  * The split-precision path stores activations as (fp16 hi, fp16 lo) pairs times a power-of-two pre-scale chosen so that
  * the tensor's expected RMS sits at 2^4 (transformer: a weights-only gain model) or its measured max at 2^10 (vocoder):
  * 2^12 resp. 2^6 of headroom before `hi` saturates at 65504.  A checkpoint with one outlier row / channel can leave that
  * window; the pair is then CLAMPED and no longer represents the fp32 value.  Every kernel that writes split pairs (GEMM
  * epilogues incl. the transposed V^T store, AdaRMSNorm, attention, cvx_split_f16*, the HiFi-GAN convolutions and layout
- * converter) ORs bit 0 into this flag when a value it stored exceeded 65504 in magnitude (the attention kernel also when
- * a softmax normaliser is not a positive finite number).  The flag is never cleared by a kernel: reset it, run any number
- * of calls, query once.  The host path (CoVoMixModel.synthesis_sample, Generator.__call__) does exactly that and re-runs
- * the call on the exact-fp32 kernels when the flag is set - a saturated result is never returned silently.
- *   cvx_saturation_flag_reset: enqueue a clear on stream s (no host synchronisation).
- *   cvx_saturation_flag_query: copy the flag to *host_out behind everything enqueued on s (SYNCHRONISES s), then
+ * converter) ORs bit 0 into the flag BOUND TO THE STREAM IT IS LAUNCHED ON when a value it stored exceeded 65504 in magnitude
+ * (the attention kernel also when a softmax normaliser is not a positive finite number).  The flag is never cleared by a kernel:
+ * reset it, run any number of calls, query once.  The host path (CoVoMixModel.synthesis_sample, Generator.__call__) does exactly
+ * that and re-runs the call on the exact-fp32 kernels when the flag is set - a saturated result is never returned silently.
+ *   cvx_saturation_flag_bind:  attach dev_flag (4-byte aligned device memory the caller zeroed and keeps alive) to stream s of the
+ *                              current device; NULL detaches.  Several streams may share one flag (the side stream of a
+ *                              two-stream schedule, a graph-capture stream).  A stream with no flag runs without the
+ *                              bookkeeping (nothing is allocated, nothing is reported).  Host-side only: legal during capture.
+ *   cvx_saturation_flag_reset: enqueue a clear of s's flag on s (no host synchronisation); CVX_EINVAL if s has none.
+ *   cvx_saturation_flag_query: copy s's flag to *host_out behind everything enqueued on s (SYNCHRONISES s), then
  *                              optionally enqueue a clear. */
+int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s);
 int cvx_saturation_flag_reset(cvx_stream_t s);
 int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t s);
 

@@ -243,6 +243,7 @@ SIGNATURES = {
     "cvx_hifigan_post_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p]),
     "cvx_wav_to_int16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvx_saturation_flag_bind": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvx_saturation_flag_reset": (C.c_int, [C.c_void_p]),
     "cvx_saturation_flag_query": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.c_void_p]),
     # ragged batches (cu_seqlens)

@@ -112,6 +112,14 @@ class VectorField:
         self.fused_embed = (os.environ.get("CVX_FUSED_EMBED", "0") == "1" and d["dim_out"] % 8 == 0 and d["dim_out"] <= 80
                             and d["dim"] % 64 == 0 and sd["to_embed.weight"].stride(0) % 4 == 0)
         self._init_gain_model()
+        # DEV STUDY (round 4, joules per useful flop): CVX_WLO_BITS = b keeps only the top b significand bits of every weight's lo
+        # half (11 = all, 0 = lo == 0): fewer toggling operand bits in two of the three MFMA products.  Never set by the product.
+        wlo_bits = int(os.environ.get("CVX_WLO_BITS", "11"))
+        if precision == "f16x3" and wlo_bits < 11:
+            keep = torch.tensor(-(1 << (11 - wlo_bits)) if wlo_bits > 0 else 0, dtype=torch.int16, device=device)
+            for k, v in self.split.items():
+                if v[1] is not None:
+                    v[1].view(torch.int16).bitwise_and_(keep)
         # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
         self.split_il: Dict[str, tuple] = {}
         if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
@@ -397,7 +405,8 @@ class VectorField:
 
         # every to_out / ff2 / skip-combiner product is followed by a norm of its output: one call (ops.gemm(norm=...)), so that
         # problems on the split-K path (one utterance) normalise inside the reduction.  CVX_FUSE_NORM=0: separate launches (A/B)
-        fuse_norm = split_io and os.environ.get("CVX_FUSE_NORM", "1") == "1"
+        # (2048 rows and more never split K: the call would run the same two kernels, so it stays two calls there)
+        fuse_norm = split_io and M < 2048 and os.environ.get("CVX_FUSE_NORM", "1") == "1"
         normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
         def tab_rows(i_, k_):
             return tab[(4 * i_ + k_) * dim:(4 * i_ + k_ + 1) * dim]
@@ -538,6 +547,7 @@ class FlowMatchingSampler:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=f.device)
             side = self._side
+            ops.saturation_share(main, side)             # both chains report into this call's flag
             full_eval = f.evaluate
 
             skew = int(float(os.environ.get("CVX_CHAIN_SKEW_US", "0")) * 1000)      # dev: start the second chain late (ns of spin)
@@ -592,7 +602,9 @@ class FlowMatchingSampler:
         if os.environ.get("CVX_GRAPH", "1") == "0" or rows > int(os.environ.get("CVX_GRAPH_MAX_ROWS", "8192")):
             self._integrate(phoneme_ids, cond, y, times.to(dev), dts, s, use_null)
             return y
-        key = (B, T, use_null, s, self.nfe, self.method)
+        main = torch.cuda.current_stream()
+        # (the saturation flag of the launching stream is a kernel argument of the captured launches: one graph per stream)
+        key = (B, T, use_null, s, self.nfe, self.method, main.cuda_stream)
         cache = f.__dict__.setdefault("_graphs", {})
         ent = cache.get(key)
         if ent is None:
@@ -601,7 +613,12 @@ class FlowMatchingSampler:
             st["ws"] = ctx["ws"]             # keep this shape's workspace alive for as long as the graph is
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            if getattr(self, "_cap", None) is None:
+                self._cap = torch.cuda.Stream(device=dev)
+            ops.saturation_share(main, self._cap)        # the captured launches report into the calling stream's flag
+            # (thread-local capture mode: another host thread driving its own model on this device - its allocations and
+            #  synchronisations are "unsafe calls" under the default global mode - must not break this capture, nor be broken by it)
+            with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
                 self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)
             if len(cache) >= self.GRAPH_CACHE:
                 cache.pop(next(iter(cache)))

@@ -458,13 +458,16 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
     const int qb = 32 * nw;
     const int n_qt = (T + qb - 1) / qb, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
-    uint32_t* sat = cvx_sat_flag_dev();
-    // key-split groups for short launches (see the kernel): three when the grid leaves CUs with a single block (96 KiB of LDS),
-    // two while two such blocks fit a CU
+    uint32_t* sat = cvx_sat_flag_for(s);
+    // key-split groups for short launches (see the kernel): three when the grid leaves every CU with at most one block (96 KiB of
+    // LDS).  Fewer than 256 blocks = fewer than 2048 query rows: the halves of the two-chain schedule (>= 2048 rows each) and the
+    // whole batch always agree on the variant, so that schedule stays bit-identical to the single chain.
     int ksplit = 1;
-    if (nw == 4 && T >= 4 * KT) ksplit = grid.x <= 256 ? 3 : (grid.x <= 512 ? 2 : 1);
-    static const bool no_ks = getenv("CVX_ATT_KS") && atoi(getenv("CVX_ATT_KS")) == 0;      // dev A/B
+    if (nw == 4 && T >= 4 * KT && grid.x < 256) ksplit = 3;
+#ifdef CVX_DEV_FLAGS          // (dev builds only: the shipped library reads no environment variable)
+    static const bool no_ks = getenv("CVX_ATT_KS") && atoi(getenv("CVX_ATT_KS")) == 0;
     if (no_ks) ksplit = 1;
+#endif
 #define CVX_ATT_LAUNCH(NT_, NW_)                                                                                                          \
     hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_>), grid, dim3(64 * NW_), 0, reinterpret_cast<hipStream_t>(s),                       \
                        reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
@@ -478,7 +481,6 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
                        out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
                        T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
     if (ksplit == 3) { if (single) CVX_ATT_LAUNCH_KS(1, 3); else CVX_ATT_LAUNCH_KS(3, 3); }
-    else if (ksplit == 2) { if (single) CVX_ATT_LAUNCH_KS(1, 2); else CVX_ATT_LAUNCH_KS(3, 2); }
     else if (single) { if (nw == 8) CVX_ATT_LAUNCH(1, 8); else CVX_ATT_LAUNCH(1, 4); }
     else { if (nw == 8) CVX_ATT_LAUNCH(3, 8); else CVX_ATT_LAUNCH(3, 4); }
 #undef CVX_ATT_LAUNCH_KS

@@ -212,7 +212,7 @@ extern "C" int cvx_attention_varlen_f32(const float* qkv, float* out, uint16_t* 
     hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
                        qkv, out, reinterpret_cast<_Float16*>(out_hi), reinterpret_cast<_Float16*>(out_lo),
                        max_T, H, n_groups, n_qt, scale * 1.44269504088896340736f, cu_seqlens_dev,
-                       out_hi ? cvx_sat_flag_dev() : nullptr);
+                       out_hi ? cvx_sat_flag_for(s) : nullptr);
     CVX_CHECK_LAUNCH("cvx_attention_f32");
     return CVX_OK;
 }

@@ -15,12 +15,11 @@ void cvx_set_error(const char* fmt, ...);
 void cvx_allow_dynamic_lds(const void* kernel, int bytes);
 // compute units of the current device (cached per device)
 int cvx_device_cus();
-// Sticky saturation flag: one uint32 per device, owned by the library (cvx_saturation_flag_* in the header).  Every kernel
-// that writes (fp16 hi, fp16 lo) split pairs clamps to +-65504 and ORs bit 0 into the flag when a value it stored was
-// larger than that - the pair then no longer represents the fp32 value and the caller must not trust the result.
-// Returns the device pointer for the current device (allocated and zeroed on first use; NULL if that failed, e.g. first
-// use inside a stream capture - the kernels then skip the bookkeeping).
-uint32_t* cvx_sat_flag_dev();
+// Sticky saturation flag: one uint32 of CALLER-OWNED device memory per (device, stream), attached with
+// cvx_saturation_flag_bind (covomix_hip.h).  Every kernel that writes (fp16 hi, fp16 lo) split pairs clamps to +-65504 and ORs bit 0
+// into the flag of the stream it runs on when a value it stored was larger than that - the pair then no longer represents the
+// fp32 value and the caller must not trust the result.  NULL (no flag bound to the stream): the kernels skip the bookkeeping.
+uint32_t* cvx_sat_flag_for(cvx_stream_t s);
 
 #define CVX_REQUIRE(cond, ...)                       \
     do {                                             \

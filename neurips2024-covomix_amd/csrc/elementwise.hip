@@ -54,39 +54,61 @@ int cvx_device_cus()
     }
     return n_cu[dev];
 }
-uint32_t* cvx_sat_flag_dev()
+// Saturation flags are CALLER-OWNED (round 4): cvx_saturation_flag_bind attaches one uint32 of device memory to a (device,
+// stream) pair; every entry point looks up the flag of the stream it launches on.  No allocation, no per-device global: two
+// host threads / streams on one device each have their own flag, and a first launch inside a stream capture allocates nothing.
+namespace {
+struct SatBinding { int dev; hipStream_t st; uint32_t* flag; };
+std::mutex g_sat_mu;
+SatBinding g_sat[256];
+int g_sat_n = 0;
+}
+uint32_t* cvx_sat_flag_for(cvx_stream_t s)
 {
-    static std::mutex mu;
-    static uint32_t* flag[64] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!flag[dev]) {
-        uint32_t* p = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(p, 0, sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
-        flag[dev] = p;
-    }
-    return flag[dev];
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    std::lock_guard<std::mutex> lock(g_sat_mu);
+    for (int i = 0; i < g_sat_n; ++i)
+        if (g_sat[i].dev == dev && g_sat[i].st == st) return g_sat[i].flag;
+    return nullptr;                      // no flag bound to this stream: the kernels skip the bookkeeping
+}
+extern "C" int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { cvx_set_error("saturation_flag_bind: no current device"); return CVX_EHIP; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    CVX_REQUIRE((reinterpret_cast<uintptr_t>(dev_flag) & 3) == 0, "saturation_flag_bind: the flag must be 4-byte aligned");
+    std::lock_guard<std::mutex> lock(g_sat_mu);
+    for (int i = 0; i < g_sat_n; ++i)
+        if (g_sat[i].dev == dev && g_sat[i].st == st) {
+            if (dev_flag) g_sat[i].flag = dev_flag;
+            else g_sat[i] = g_sat[--g_sat_n];              // NULL unbinds
+            return CVX_OK;
+        }
+    if (!dev_flag) return CVX_OK;
+    CVX_REQUIRE(g_sat_n < 256, "saturation_flag_bind: more than 256 (device, stream) bindings");
+    g_sat[g_sat_n++] = SatBinding{dev, st, dev_flag};
+    return CVX_OK;
 }
 extern "C" int cvx_saturation_flag_reset(cvx_stream_t s)
 {
-    uint32_t* f = cvx_sat_flag_dev();
-    CVX_REQUIRE(f, "saturation_flag: could not allocate the device flag");
+    uint32_t* f = cvx_sat_flag_for(s);
+    CVX_REQUIRE(f, "saturation_flag_reset: no flag bound to this (device, stream): call cvx_saturation_flag_bind first");
     if (hipMemsetAsync(f, 0, sizeof(uint32_t), reinterpret_cast<hipStream_t>(s)) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
     return CVX_OK;
 }
 extern "C" int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t s)
 {
-    uint32_t* f = cvx_sat_flag_dev();
-    CVX_REQUIRE(f && host_out, "saturation_flag: no device flag / null output");
+    uint32_t* f = cvx_sat_flag_for(s);
+    CVX_REQUIRE(f && host_out, "saturation_flag_query: no flag bound to this (device, stream) / null output");
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     if (hipMemcpyAsync(host_out, f, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { cvx_set_error("saturation_flag: read failed: %s", hipGetErrorString(hipGetLastError())); return CVX_EHIP; }
     if (reset && hipMemsetAsync(f, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
     return CVX_OK;
 }
-extern "C" int cvx_version(void) { return 102; }
+extern "C" int cvx_version(void) { return 103; }
 
 namespace {
 
@@ -612,7 +634,7 @@ extern "C" int cvx_adarmsnorm_scaled_f32(const float* x, const float* gamma, con
     if (rows == 0) return CVX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     dim3 grid((unsigned)((rows + 3) / 4));
-    uint32_t* sat = y_hi ? cvx_sat_flag_dev() : nullptr;
+    uint32_t* sat = y_hi ? cvx_sat_flag_for(s) : nullptr;
     if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
     else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
     else if (D <= 1024) hipLaunchKernelGGL(adarmsnorm_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);

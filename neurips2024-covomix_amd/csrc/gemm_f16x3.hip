@@ -602,7 +602,7 @@ extern "C" int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int
     CVX_REQUIRE(w && hi && n >= 0, "split_f16: bad arguments");      // lo == NULL: plain fp16 cast (saturating)
     if (n == 0) return CVX_OK;
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
-                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale, scale_dev, cvx_sat_flag_dev());
+                       w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale, scale_dev, cvx_sat_flag_for(s));
     CVX_CHECK_LAUNCH("cvx_split_f16");
     return CVX_OK;
 }
@@ -815,7 +815,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
                     "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
     SplitOut so{nullptr, nullptr, 0, 1, nullptr, nullptr, 0};
-    so.sat = cvx_sat_flag_dev();
+    so.sat = cvx_sat_flag_for(s);
     PreSplitA A{nullptr, nullptr, 0, nullptr, nullptr, 0};
     if (io) {
         if (io->C_hi || io->C_lo) {

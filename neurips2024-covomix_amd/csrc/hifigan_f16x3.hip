@@ -831,7 +831,7 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
                  reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
                  a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev,
-                 a->out_zhi ? cvx_sat_flag_dev() : nullptr, a->items, {}, {}, {}, 0, 0, 0, 0, 0, 0, nullptr};
+                 a->out_zhi ? cvx_sat_flag_for(s) : nullptr, a->items, {}, {}, {}, 0, 0, 0, 0, 0, 0, nullptr};
     k.zk[0] = a->ksize; k.zpad[0] = pad; k.zw[0] = 0;                  // one output-column tile, the plain layout
     k.out_bs = (long long)a->Lp * a->Np; k.out_base = (long long)a->halo_l * a->Np;
     k.ldo = a->Np; k.ostride = 1; k.ph_shift = 31; k.L_out = a->L;
@@ -883,7 +883,7 @@ extern "C" int cvx_hifigan_split_channels_last(const float* x_cl, uint16_t* z_hi
     const int64_t n4 = n / 4;
     const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)cvx_device_cus() * 16);
     hipLaunchKernelGGL(cl_split_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(s), x_cl,
-                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), n4, slope, z_scale_dev, cvx_sat_flag_dev());
+                       reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), n4, slope, z_scale_dev, cvx_sat_flag_for(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_split_channels_last");
     return CVX_OK;
 }
@@ -924,7 +924,7 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
     PairArgs k{a->x, reinterpret_cast<const f16*>(a->c1.w_hi), reinterpret_cast<const f16*>(a->c1.w_lo),
                reinterpret_cast<const f16*>(a->c2.w_hi), reinterpret_cast<const f16*>(a->c2.w_lo), a->c1.bias, a->c2.bias,
                a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
-               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_dev(), a->items};
+               a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_for(s), a->items};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const int cus = cvx_device_cus();
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU
@@ -958,7 +958,7 @@ extern "C" int cvx_hifigan_to_channels_last_scaled(const float* x, float* x_cl, 
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
     hipLaunchKernelGGL(cm_to_cl_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, x_cl,
                        reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope, z_scale_dev,
-                       z_hi ? cvx_sat_flag_dev() : nullptr);
+                       z_hi ? cvx_sat_flag_for(s) : nullptr);
     CVX_CHECK_LAUNCH("cvx_hifigan_to_channels_last");
     return CVX_OK;
 }

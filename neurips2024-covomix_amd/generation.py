@@ -328,15 +328,19 @@ def run(dialogue: bool, argv=None) -> int:
         # and one device-to-host copy per batch, sliced per utterance on the host
         n_prompt = [int((~items[i][2]).sum()) for i in batch]
         js = [j for j, i in enumerate(batch) if lengths[i] - n_prompt[j] > 0]
-        if js:
-            tgen = [lengths[batch[j]] - n_prompt[j] for j in js]
-            mel = torch.zeros(len(js), n_out, max(tgen), dtype=torch.float32, device=device)
-            for r, j in enumerate(js):
+        # (items of similar length only: the ragged vocoder call pads to its longest item and skips no work behind a short
+        #  one, dp.group_by_padding keeps that padding below 25 % of the real frames)
+        tg_all = [lengths[batch[j]] - n_prompt[j] for j in js]
+        for grp in dp.group_by_padding(tg_all):
+            gj = [js[k] for k in grp]
+            tgen = [tg_all[k] for k in grp]
+            mel = torch.zeros(len(gj), n_out, max(tgen), dtype=torch.float32, device=device)
+            for r, j in enumerate(gj):
                 mel[r, :, : tgen[r]] = sampled[j][n_prompt[j]:, :].T
             wav = generator(mel, lengths=tgen) if len(set(tgen)) > 1 else generator(mel)
             pcm = ops.wav_to_int16(wav.squeeze(1).contiguous()).cpu().numpy()              # mel_decode_to_wav (:52-59), batched
             frames += sum(tgen)
-            for r, j in enumerate(js):
+            for r, j in enumerate(gj):
                 n, seg = owner[batch[j]]
                 segments[n][seg] = pcm[r, : generator.output_length(tgen[r])].copy()
     torch.cuda.synchronize()

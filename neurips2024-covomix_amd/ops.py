@@ -81,13 +81,21 @@ def il_min_rows() -> int:
 
 
 def _splitk_workspace(device) -> torch.Tensor:
-    """Caller-owned scratch of cvx_gemm_f16x3's split-K path: 4 x 2048 x 4096 floats, allocated once per device and
-    never re-allocated (its address is baked into captured HIP graphs)."""
-    ws = _SPLITK_WS.get(device)
+    """Caller-owned scratch of cvx_gemm_f16x3's split-K path: 4 x 2048 x 4096 floats per (device, stream) - two host threads on
+    one device run their GEMMs on different streams and must not share partial sums - allocated once and never re-allocated
+    (its address is baked into captured HIP graphs; launches inside a capture use the scratch of the stream that captures)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = torch.cuda.current_stream(idx)
+    key = (idx, _CAPTURE_OWNER.get((idx, st.cuda_stream), st.cuda_stream))
+    ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = torch.empty(4 * 2048 * 4096, dtype=torch.float32, device=device)
-        _SPLITK_WS[device] = ws
+        ws = torch.empty(4 * 2048 * 4096, dtype=torch.float32, device=dev)
+        _SPLITK_WS[key] = ws
     return ws
+
+
+_CAPTURE_OWNER: dict = {}        # (device, side / capture stream) -> the stream whose call it serves (saturation_share)
 
 
 def _sp(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -270,15 +278,53 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     return out if out is not None else out_split
 
 
+# Saturation flags are CALLER-OWNED: one int32 of device memory per (device, stream), bound to the stream with
+# cvx_saturation_flag_bind; the kernels a stream runs OR bit 0 into THAT flag (two threads / streams on one device never see or
+# clear each other's).  Allocated once and never freed (their addresses are baked into captured HIP graphs).
+_SAT_FLAGS: dict = {}
+
+
+def _bind_saturation_flag(flag: torch.Tensor, stream_handle: int) -> None:
+    _lib.check(_lib.load().cvx_saturation_flag_bind(flag.data_ptr(), stream_handle), "cvx_saturation_flag_bind")
+
+
+def saturation_flag(stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
+    """The flag of `stream` (default: the current stream), allocated and bound on first use."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    f = _SAT_FLAGS.get(key)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=st.device)
+        torch.cuda.current_stream(st.device).synchronize()        # (the zero fill is on the current stream; `stream` may be another)
+        _SAT_FLAGS[key] = f
+        with torch.cuda.device(st.device):
+            _bind_saturation_flag(f, st.cuda_stream)
+    return f
+
+
+def saturation_share(src: "torch.cuda.Stream", dst: "torch.cuda.Stream") -> None:
+    """Kernels launched on `dst` report into the flag of `src`: the side stream of the two-chain schedule and the capture stream
+    of a HIP graph belong to the call that runs on `src`."""
+    f = saturation_flag(src)
+    key = (dst.device.index, dst.cuda_stream)
+    _CAPTURE_OWNER[key] = src.cuda_stream
+    if _SAT_FLAGS.get(key) is not f:
+        _SAT_FLAGS[key] = f
+        with torch.cuda.device(dst.device):
+            _bind_saturation_flag(f, dst.cuda_stream)
+
+
 def saturation_reset() -> None:
-    """Clear the device's sticky saturation flag (enqueued on the current stream; no host synchronisation)."""
+    """Clear the current stream's sticky saturation flag (enqueued on that stream; no host synchronisation)."""
+    saturation_flag()
     _lib.check(_lib.load().cvx_saturation_flag_reset(_stream()), "cvx_saturation_flag_reset")
 
 
 def saturation_query(reset: bool = True) -> int:
-    """The sticky saturation flag after everything enqueued so far on the current stream (synchronises that stream):
+    """The current stream's sticky saturation flag after everything enqueued so far on it (synchronises that stream):
     non-zero = some split-pair store since the last reset had to clamp (or a softmax normaliser was not finite) - the
     split-precision result must not be trusted."""
+    saturation_flag()
     v = C.c_uint32(0)
     _lib.check(_lib.load().cvx_saturation_flag_query(C.byref(v), 1 if reset else 0, _stream()), "cvx_saturation_flag_query")
     return int(v.value)

@@ -261,6 +261,19 @@ def hubert_kmeans_centers(seed: int = 0, n_clusters: int = 500, dim: int = 768) 
     return rs.standard_normal((n_clusters, dim)).astype(np.float32)
 
 
+def hubert_kmeans_centers_near(features: np.ndarray, seed: int = 0, n_clusters: int = 500, jitter: float = 0.35) -> np.ndarray:
+    """Cluster centres that LIVE WHERE THE FEATURES DO: centre j = frame (j mod T) of `features` [T, dim] plus Gaussian jitter of
+    `jitter` x the features' RMS.  With N(0, 1) centres (hubert_kmeans_centers) a random-weight network's layer-12 frames all
+    fall into one or two cells - the labels hardly test the argmin (round-3 review); with these every frame has its own handful
+    of nearby centres (about n_clusters / T jittered copies of itself and of its neighbours), so a fixture sees dozens of distinct
+    labels with margins from ~0 upwards."""
+    feats = np.asarray(features, dtype=np.float32)
+    rs = np.random.RandomState((zlib.crc32(b"hubert.kmeans.centers_near") ^ seed) & 0xFFFFFFFF)
+    rms = float(np.sqrt((feats.astype(np.float64) ** 2).mean()))
+    idx = np.arange(n_clusters) % feats.shape[0]
+    return (feats[idx] + jitter * rms * rs.standard_normal((n_clusters, feats.shape[1]))).astype(np.float32)
+
+
 def rotary_inv_freq(dim_head: int = 64, theta: float = 10000.0) -> np.ndarray:
     """The `transformer.rotary_emb.inv_freq` buffer (acoustic.py:117-120), computed the
     way torch does it in fp32: 1 / theta ** (arange(0, d, 2) / d)."""

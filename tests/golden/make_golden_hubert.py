@@ -196,6 +196,24 @@ def main():
         out[f"{tag}_margin"] = (top2[:, 1] - top2[:, 0]).numpy()
         print(tag, n, "frames", feats[12].shape, "codes", codes[:12], "min margin", float(out[f"{tag}_margin"].min()),
               "feat12 rms", float(np.sqrt((feats[12] ** 2).mean())), "conv rms", float(np.sqrt((out[f'{tag}_conv'] ** 2).mean())))
+    # second k-means fixture (round-3 review: with N(0, 1) centres nearly every frame gets the same label): centres drawn from
+    # the fixtures' OWN layer-12 frames (all three waveforms pooled, jittered: synthetic.hubert_kmeans_centers_near), labelled by
+    # the reference's ApplyKmeans - dozens of distinct labels, none dominant
+    pool = np.concatenate([out[f"{t_}_feat12"] for t_ in ("a", "b", "c")], 0)
+    km2 = reference_apply_kmeans(syn.hubert_kmeans_centers_near(pool, seed=0))
+    for tag in ("a", "b", "c"):
+        f12 = torch.from_numpy(out[f"{tag}_feat12"])
+        with torch.no_grad():
+            codes2 = km2(f12)
+            dist = f12.pow(2).sum(1, keepdim=True) - 2 * torch.matmul(f12, km2.C) + km2.Cnorm
+            top2 = torch.topk(dist, 2, dim=1, largest=False).values
+        out[f"{tag}_codes_near"] = np.asarray(codes2, dtype=np.int64)
+        out[f"{tag}_margin_near"] = (top2[:, 1] - top2[:, 0]).numpy()
+    allc = np.concatenate([out[f"{t_}_codes_near"] for t_ in ("a", "b", "c")])
+    cnt = np.bincount(allc, minlength=500)
+    print("near-centre labels:", len(np.unique(allc)), "distinct of", allc.size, "frames; most frequent label holds",
+          f"{cnt.max() / allc.size:.1%}; min margin", float(min(out[f"{t_}_margin_near"].min() for t_ in ("a", "b", "c"))))
+    assert len(np.unique(allc)) >= 50 and cnt.max() <= 0.2 * allc.size
     # normalize=True path of get_feats (hubert_feature_reader.py:66-67): F.layer_norm over the whole waveform
     x = torch.from_numpy(out["a_wav"])
     with torch.no_grad():

@@ -183,6 +183,16 @@ def test_sharding_plan():
     assert bins == [[2], [7, 1, 6], [0, 4], [5, 8, 3]] and bins == pack_by_frames(list(range(9))[::-1], ragged, 1000, 32)
     assert pack_by_frames([2, 7], ragged, max_frames=100, max_batch=32) == [[2], [7]]         # longer than a bin: alone
     assert pack_by_frames(list(range(9)), ragged, max_frames=10 ** 9, max_batch=4) == [[2, 7, 0, 4], [5, 1, 8, 6], [3]]
+    # vocoder sub-groups of a bin: padding to the group's longest item stays below 25 % of its real frames (round-3 advisor
+    # finding: an 8000-frame item with 31 short fillers was vocoded as 32 x 8000 frames)
+    from covomix_amd.dp import group_by_padding
+    tg = [8000] + [150 + 3 * i for i in range(31)]
+    groups = group_by_padding(tg)
+    assert sorted(i for g_ in groups for i in g_) == list(range(32)) and groups[0] == [0]
+    for g_ in groups:
+        assert len(g_) * max(tg[i] for i in g_) <= 1.25 * sum(tg[i] for i in g_)
+    assert sum(len(g_) * max(tg[i] for i in g_) for g_ in groups) < 1.25 * sum(tg)
+    assert group_by_padding([600, 600, 600]) == [[0, 1, 2]] and group_by_padding([]) == []
     lens16 = [400, 1200, 451, 1149, 503, 1097, 555, 1044, 607, 993, 659, 941, 711, 889, 763, 837]
     b16 = pack_by_frames(list(range(16)), lens16, 8192, 32)
     assert len(b16) == 2 and sum(lens16[i] for i in b16[0]) >= 8000
@@ -320,7 +330,8 @@ def test_workspace_queries():
     assert lib.cvx_gemm_f16x3_workspace_floats(1000, 1024, 4096, 0) == 4 * 1000 * 1024          # one utterance, long K: 4 slices
     assert lib.cvx_gemm_f16x3_workspace_floats(1000, 1024, 2048, 1024) == 4 * 1000 * 1024       # skip combiner: slices end at A | A2
     assert lib.cvx_gemm_f16x3_workspace_floats(16000, 1024, 4096, 0) == 0                       # large grids never split K
-    assert lib.cvx_gemm_f16x3_workspace_floats(1000, 80, 1024, 0) == 2 * 1000 * 80
+    assert lib.cvx_gemm_f16x3_workspace_floats(1000, 80, 1024, 0) == 8 * 1000 * 80              # to_pred on the medium-problem kernel: 8 slices
+    assert lib.cvx_gemm_f16x3_workspace_floats(1000, 1024, 1024, 0) == 4 * 1000 * 1024          # to_out: 64 tiles x 4 slices fill the chip
     assert lib.cvx_rope_attention_workspace_floats(2, 130, 4) == 2 * 130 * 3 * 4 * 64
     assert lib.cvx_rope_attention_workspace_floats(0, 130, 4) == 0
 

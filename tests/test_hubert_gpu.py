@@ -132,6 +132,14 @@ def test_features_and_codes_match_reference_goldens(gold, enc, tag):
     assert safe.mean() > 0.9
     np.testing.assert_array_equal(codes[safe], gold[f"{tag}_codes"][safe])
     assert (codes != gold[f"{tag}_codes"]).sum() <= 1
+    # centres near the features (round-3 review: the N(0, 1) centres leave one dominant label): every frame has its own label
+    # here, runner-up margins from 0.06 upwards; distance error 2 |dx| |c_a - c_b| ~ 2 * 3e-5 * 28 * 14 < 3e-2
+    pool = np.concatenate([gold[f"{t}_feat12"] for t in ("a", "b", "c")], 0)
+    near = ApplyKmeans(synthetic.hubert_kmeans_centers_near(pool, seed=0))(f)
+    safe = gold[f"{tag}_margin_near"] > 3e-2
+    assert safe.mean() > 0.9 and len(np.unique(gold[f"{tag}_codes_near"])) >= min(len(near), 16)
+    np.testing.assert_array_equal(near[safe], gold[f"{tag}_codes_near"][safe])
+    assert (near != gold[f"{tag}_codes_near"]).sum() <= 1
 
 
 def test_kmeans_argmin_kernel_vs_oracle_with_ties():

@@ -47,6 +47,13 @@ def test_oracle_matches_reference_features_and_codes(gold, sd, tag):
             assert rel(f.numpy(), gold[f"{tag}_feat{layer}"]) < {1: 3e-6, 6: 1.2e-5, 12: 3e-5}[layer], layer
         codes = ho.apply_kmeans(synthetic.hubert_kmeans_centers(seed=0), f)
     np.testing.assert_array_equal(codes, gold[f"{tag}_codes"])
+    # second fixture: centres near the features themselves (91 distinct labels over the three waveforms, none dominant - the
+    # N(0, 1) centres above put almost every frame into cell 452); labelled by the reference's ApplyKmeans
+    pool = np.concatenate([gold[f"{t}_feat12"] for t in ("a", "b", "c")], 0)
+    near = ho.apply_kmeans(synthetic.hubert_kmeans_centers_near(pool, seed=0), f)
+    safe = gold[f"{tag}_margin_near"] > 3e-2
+    assert safe.mean() > 0.9 and len(np.unique(gold[f"{tag}_codes_near"])) >= min(len(near), 16)
+    np.testing.assert_array_equal(near[safe], gold[f"{tag}_codes_near"][safe])
 
 
 def test_fp64_oracle_is_the_common_limit(gold, sd):

@@ -83,6 +83,23 @@ def test_c3_vomix_b8_t1000_eight_nfe_vs_oracle():
     assert e < AT_SIZE_TOL and worst < 2 * AT_SIZE_TOL
 
 
+@pytest.mark.slow
+def test_c3_vomix_t1000_full_32nfe_rollout_vs_oracle():
+    """The WHOLE 32-NFE rollout of BASELINE config 3 against the oracle, on the kernels the metric configuration runs (4000 rows
+    per evaluation: the large-problem GEMM, the full-occupancy attention) - B = 2 utterances x T = 1000 frames keeps the oracle at
+    about a minute of CPU (B = 8: four); round 3 compared 2 and 8 NFE only and left the 32-NFE solve to bench.py."""
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    sd = _state("vomix")
+    inp = syn.synthetic_inputs("vomix", 2, 1000, 400, seed=2468)
+    out = _run(sd, inp, 32)
+    ref = orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=32)
+    e = rel_l2(out, ref)
+    worst = max(rel_l2(out[b], ref[b]) for b in range(2))
+    print("C3 VoMix B=2 T=1000 32-NFE rel-L2 vs oracle:", e, "worst utterance", worst)
+    assert e < AT_SIZE_TOL and worst < 2 * AT_SIZE_TOL
+
+
 @pytest.mark.parametrize("B", [1, 8])
 def test_c1_c4_vocoder_t1000_vs_oracle(B):
     """HiFi-GAN config_covomix at BASELINE size against the CPU oracle (not only against this build's own fp32 path):

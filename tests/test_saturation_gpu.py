@@ -208,3 +208,78 @@ def test_vocoder_resblock_gain_outside_the_window_is_rerun_or_raises(monkeypatch
     monkeypatch.setenv("CVX_ON_SATURATION", "raise")
     with pytest.raises(CovomixHipError, match="saturat"):
         gen(mel.cuda())
+
+
+def test_flags_are_per_stream_and_caller_owned(ops):
+    """Round-3 review: the flag was ONE library-owned word per device, so a reset on one stream could clear what another
+    stream's kernels had raised.  Now the caller owns one word per (device, stream) (cvx_saturation_flag_bind): a saturating
+    launch on stream A flags A only, a reset / clean launch / query on stream B neither sees nor clears it, a stream without a
+    flag runs without bookkeeping, and a shared flag (two-chain side stream, capture stream) collects both streams."""
+    dev_ = dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(300, 256, generator=g).to(dev_)
+    big = x.clone(); big[5, 7] = 1e5
+    sa, sb, sc = torch.cuda.Stream(device=dev_), torch.cuda.Stream(device=dev_), torch.cuda.Stream(device=dev_)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        ops.saturation_reset()
+        ops.split_act_f16(big)                    # raises A's flag
+    with torch.cuda.stream(sb):
+        ops.saturation_reset()                    # must not clear A's
+        ops.split_act_f16(x)
+        assert ops.saturation_query() == 0        # B: clean, and B's query does not consume A's
+    with torch.cuda.stream(sa):
+        assert ops.saturation_query(reset=False) != 0
+        assert ops.saturation_flag().data_ptr() != ops.saturation_flag(sb).data_ptr()
+    # a stream nobody bound a flag to: no bookkeeping, nobody else's flag moves
+    with torch.cuda.stream(sb):
+        ops.saturation_reset()
+    with torch.cuda.stream(sc):
+        ops.split_act_f16(big)
+    sc.synchronize()
+    with torch.cuda.stream(sb):
+        assert ops.saturation_query() == 0
+    # shared flag: kernels on sc report into A's
+    with torch.cuda.stream(sa):
+        ops.saturation_reset()
+    sa.synchronize()
+    ops.saturation_share(sa, sc)
+    with torch.cuda.stream(sc):
+        ops.split_act_f16(big)
+    sc.synchronize()
+    with torch.cuda.stream(sa):
+        assert ops.saturation_query() != 0 and ops.saturation_query() == 0
+
+
+def test_two_threads_two_models_one_device():
+    """Two host threads on one device, each with its own stream and model: only the thread whose input leaves the window is
+    flagged (fp32 re-run, warning); the other thread's result is its undisturbed split-precision result."""
+    import threading
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    dev_ = dev()
+    shapes = syn.acoustic_param_shapes(dim=128, dim_emb=64, depth=4, heads=2, dim_cond=80, streams=1)
+    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(shapes, seed=0).items()}
+    sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
+    inp = syn.synthetic_inputs("vosingle", 1, 200, 80, seed=5)
+    ids, cond, mask = inp["phoneme_ids"].to(dev_), inp["cond"].to(dev_), inp["mask"].to(dev_)
+    y0 = torch.randn(1, 200, 80, device=dev_)
+    ref = CoVoMixModel.from_state_dict(sd, nfe=4).eval().to(dev_).synthesis_sample(ids, cond, mask, 0.7, y0=y0)
+    res, reran = {}, {}
+
+    def run(name, scale):
+        st = torch.cuda.Stream(device=dev_)
+        with torch.cuda.stream(st):
+            m = CoVoMixModel.from_state_dict(sd, nfe=4).eval().to(dev_)
+            for _ in range(6):
+                out = m.synthesis_sample(ids, cond * scale, mask, 0.7, y0=y0)
+            st.synchronize()
+            res[name] = out
+            reran[name] = m._field_fp32 is not None      # (the exact-fp32 twin is built by the first flagged call; the warnings
+                                                         #  module's recorder is process-global, so it cannot tell the threads apart)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ta, tb = threading.Thread(target=run, args=("hot", 4000.0)), threading.Thread(target=run, args=("cool", 1.0))
+        ta.start(); tb.start(); ta.join(); tb.join()
+    assert reran["hot"] and not reran["cool"]
+    assert rel_l2(res["cool"], ref) < 1e-6
