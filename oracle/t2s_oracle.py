@@ -15,9 +15,10 @@ Follows (reference file:line, all under covomix/covomix_model/):
   * TextToSemanticWrapper.sample (target[target_mask]) :1237-1251
 
 Pinned against the imported reference by tests/golden/make_golden_t2s.py (teacher-forced logits and sampled tokens
-with injected uniform noise).  Only the branch the generation scripts reach is restated: cond_scale == 1 (the
-reference asserts on anything else with its default cond_drop_prob = 0), no beam search, no speculative decoding,
-B = 1 or equal-length batches.
+with injected uniform noise).  Restated: the sampling branch (no beam search, no speculative decoding, B = 1 or equal-length
+batches), with classifier-free guidance (cond_scale > 1, text2semantic.py:780-792: a second decode with the context masked out,
+i.e. cross-attention over the learned null key / value only, its own cache) for one-output models - the reference's two-output
+guidance feeds the full-width hidden state to the half-width logit head and cannot run.
 """
 import math
 from typing import Dict, List, Optional
@@ -153,7 +154,7 @@ def gumbel_from_uniform(u):
 
 
 def generate(sd: SD, source_ids: torch.Tensor, uniforms: torch.Tensor, max_length: int = 2048, temperature: float = 1.0,
-             forced: Optional[torch.Tensor] = None, on_step=None):
+             forced: Optional[torch.Tensor] = None, on_step=None, cond_scale: float = 1.0):
     """Sampling branch of TextToSemantic.generate + TextToSemanticWrapper.sample.
     uniforms [max_length, S, B, V]: the U(0,1) draws the reference takes from torch's RNG (S = 2 for two_output, in
     the order stream 1 then stream 2 each step).  forced [B, S, L]: teacher forcing (tokens appended instead of the
@@ -167,6 +168,8 @@ def generate(sd: SD, source_ids: torch.Tensor, uniforms: torch.Tensor, max_lengt
     targets = [torch.empty((B, 0), dtype=torch.long) for _ in range(S)]
     start = sd["start_token.speech"][None, None, :].expand(B, 1, -1)
     cache = None
+    null_cache = None
+    assert cond_scale >= 1.0 and (cond_scale == 1.0 or S == 1), "guidance: one-output models only (see the module docstring)"
     all_logits = []
     steps = max_length if forced is None else forced.shape[-1]
     for t in range(steps):
@@ -174,10 +177,16 @@ def generate(sd: SD, source_ids: torch.Tensor, uniforms: torch.Tensor, max_lengt
         temb = torch.cat((start, temb), dim=1)
         att, cache = transformer(sd, "target_transformer", temb, d, d["target_depth"], context=enc, context_mask=smask,
                                  causal=True, cache=cache)
+        if cond_scale > 1.0:                   # text2semantic.py:780-792: the same decode with every context position masked
+            att_n, null_cache = transformer(sd, "target_transformer", temb, d, d["target_depth"], context=enc,
+                                            context_mask=torch.zeros_like(smask), causal=True, cache=null_cache)
+            null_logits = (att_n @ E.T)[:, -1]
         half = att.shape[-1] // S
         step_logits, done = [], []
         for s in range(S):
             logits = (att[..., s * half:(s + 1) * half] @ E.T)[:, -1]
+            if cond_scale > 1.0:
+                logits = null_logits + (logits - null_logits) * cond_scale
             step_logits.append(logits)
             if forced is not None:
                 sampled = forced[:, s, t]

@@ -47,6 +47,10 @@ CASES = {
     "comix_small": dict(two_output=True, dim=64, dim_target=128, source_depth=2, target_depth=2, heads=1, num_text=200),
 }
 MAX_LEN = 48
+# classifier-free guidance (text2semantic.py:780-792): the same weights in a reference model built with cond_drop_prob > 0 (the
+# flag only gates the assert at :684 at inference), decoded with cond_scale = 1.5 -> t2s_<base>_cfg.npz
+CFG_CASES = {"cosingle_cfg": "cosingle", "cosingle_small_cfg": "cosingle_small"}
+CFG_SCALE = 1.5
 
 
 def main():
@@ -144,6 +148,59 @@ def main():
                     min_margin=np.float32(min(margins)))
         if "small" in name:                                      # reduced-width cases also carry their weights
             save.update({"w::" + k: v.numpy() for k, v in sd.items()})
+        np.savez_compressed(os.path.join(OUT, f"t2s_{name}.npz"), **save)
+        print(name, report[name])
+    for name, base in CFG_CASES.items():
+        kw = CASES[base]
+        shapes = syn.t2s_param_shapes(**kw)
+        ref = TextToSemantic(dim=kw["dim"], source_depth=kw.get("source_depth", 4), target_depth=kw.get("target_depth", 4),
+                             semantic_pad_id=-1, text_pad_id=0, heads=kw.get("heads", 8),
+                             num_text_token_ids=kw.get("num_text", 30530), num_semantic_token_ids=501,
+                             no_source_transformer=False, two_output=False, two_input=False,
+                             target_transformer_dim=kw["dim_target"], cond_drop_prob=0.25)
+        sd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(shapes, seed=0).items()}
+        missing, unexpected = ref.load_state_dict(sd, strict=False)
+        assert not unexpected
+        ref.eval()
+        n_src, V = (12 if "small" in name else 24), 502
+        found = False
+        orig = ref_mod.gumbel_noise
+        for seed in range(4321, 4321 + 400):         # a run that ends with eos AND keeps a top-2 margin the GPU's fp32 noise cannot flip
+            rs = np.random.RandomState(seed)
+            src = torch.from_numpy(rs.randint(1, kw.get("num_text", 30530) - 1, size=(1, n_src)).astype(np.int64))
+            uniforms = torch.from_numpy(rs.uniform(1e-6, 1.0 - 1e-6, size=(MAX_LEN, 1, 1, V)).astype(np.float32))
+            o = orc.generate(sd, src, uniforms, max_length=MAX_LEN, cond_scale=CFG_SCALE)
+            L = o["streams"].shape[-1]
+            if not (10 <= L < MAX_LEN and bool((o["streams"][..., -1] == V - 1).any())):
+                continue
+            feed = [uniforms[t, 0] for t in range(MAX_LEN)]
+            margins = []
+
+            def injected_cfg(t):
+                u = feed.pop(0)
+                g = -ref_mod.log(-ref_mod.log(u))
+                top2 = torch.topk(t + g, 2, dim=-1).values
+                margins.append(float((top2[..., 0] - top2[..., 1]).min()))
+                return g
+            ref_mod.gumbel_noise = injected_cfg
+            with torch.no_grad():
+                target, target_mask = ref.generate(src.clone(), source_type="text", target_type="speech", return_target_mask=True,
+                                                   return_source=False, temperature=1.0, beam_search_decode=False,
+                                                   cond_scale=CFG_SCALE, prompt_mel=None, max_length=MAX_LEN)
+                tokens_ref = target[target_mask]
+            ref_mod.gumbel_noise = orig
+            if min(margins) >= 5e-3:
+                found = True
+                break
+        assert found
+        o = orc.generate(sd, src, uniforms, max_length=MAX_LEN, cond_scale=CFG_SCALE)
+        assert torch.equal(o["tokens"], tokens_ref), (o["tokens"], tokens_ref)
+        o1 = orc.generate(sd, src, uniforms, max_length=MAX_LEN)
+        report[name] = dict(steps=len(margins), tokens=int(tokens_ref.numel()), min_margin=min(margins), ended_with_eos=found,
+                            cond_scale=CFG_SCALE, differs_from_unguided=not torch.equal(o1["tokens"], tokens_ref))
+        save = dict(source_ids=src.numpy(), uniforms=uniforms[:len(margins)].numpy(), tokens=tokens_ref.numpy(),
+                    streams=o["streams"].numpy(), logits=o["logits"].numpy().astype(np.float32), min_margin=np.float32(min(margins)),
+                    cond_scale=np.float32(CFG_SCALE))
         np.savez_compressed(os.path.join(OUT, f"t2s_{name}.npz"), **save)
         print(name, report[name])
     json.dump(report, open(os.path.join(OUT, "REPORT_t2s.json"), "w"), indent=1)
