@@ -520,6 +520,10 @@ typedef struct {
     float *x, *q, *att, *h, *logits;             /* per utterance: [dim], [inner], [inner], [ff_inner_pad], [streams, vocab] */
     int64_t* tokens;
     int32_t* state;
+    float cfg_scale;                             /* <= 1: off.  > 1: classifier-free guidance (text2semantic.py:780-792), streams == 1, batch
+                                                  * even: slot 2u decodes with the text context, slot 2u + 1 with the context masked out
+                                                  * (state[3] = 1: the null key / value row only); every step samples slot 2u's token from
+                                                  * null + (cond - null) * cfg_scale (uniforms of slot 2u) and feeds it to both slots */
 } cvx_t2s_decoder;
 
 int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream_t stream);

@@ -132,7 +132,7 @@ class T2SDecoder(C.Structure):
                                          "dim_emb", "n_ctx", "max_len", "top_k", "batch", "ctx_rows")] + \
                [("temperature", C.c_float), ("layers", C.POINTER(T2SLayer))] + \
                [(n, C.c_void_p) for n in ("final_gamma", "emb", "rope_cos", "rope_sin", "uniforms",
-                                          "x", "q", "att", "h", "logits", "tokens", "state")]
+                                          "x", "q", "att", "h", "logits", "tokens", "state")] + [("cfg_scale", C.c_float)]
 
 
 class ResblockArgs(C.Structure):

@@ -231,15 +231,19 @@ class CoVoMixModel:
         returns a list (the reference decodes utterances one by one; the tokens are the same)."""
         if not self.is_text2semantic:
             raise TypeError("this checkpoint is an acoustic model: use synthesis_sample")
-        assert cond_scale >= 1., "cond_scale >= 1 (text2semantic.py:690)"
-        assert not cond_scale > 1, ("you need to train with conditional drop probability greater than 0 to use classifier "
-                                    "free guidance at inference (text2semantic.py:691; the reference builds the model with 0)")
+        assert cond_scale >= 1., "cond_scale >= 1 (text2semantic.py:683)"
+        # text2semantic.py:684: guidance needs a model trained with condition dropping - the checkpoint's `cond_drop_prob`
+        # hyper-parameter (conditional_model.py:52, :78, :114); checkpoints without the key were built with the default 0
+        assert not (cond_scale > 1 and float(self.hparams.get("cond_drop_prob", 0.0)) == 0.0), \
+            ("you need to train with conditional drop probability greater than 0 to use classifier free guidance at inference "
+             "(text2semantic.py:684): this checkpoint's hyper_parameters['cond_drop_prob'] is 0 or absent")
         if beam_search_decode:
             raise NotImplementedError("beam search decoding is not built (the generation scripts sample)")
         self._get_t2s()
         ids = grapheme_token_ids
         if isinstance(ids, (list, tuple)):          # extension: several utterances decoded together (bit-identical tokens)
-            res = self._t2s.generate_batch(list(ids), uniforms, max_length, float(temprature), generator)
+            res = self._t2s.generate_batch(list(ids), uniforms, max_length, float(temprature), generator, cond_scale=float(cond_scale))
             return [r[0].to(i.device) for r, i in zip(res, ids)]
-        out = self._t2s.generate(ids, uniforms=uniforms, max_length=max_length, temperature=float(temprature), generator=generator)
+        out = self._t2s.generate(ids, uniforms=uniforms, max_length=max_length, temperature=float(temprature), generator=generator,
+                                 cond_scale=float(cond_scale))
         return out.to(ids.device) if ids.device != out.device else out

@@ -344,6 +344,9 @@ struct SampleArgs {
     int batch;
     int V, dim_emb, streams, max_len, top_k, eos_id;
     float inv_temp;
+    float cfg_scale;         // > 1: classifier-free guidance (text2semantic.py:780-792) - slots 2u (text context) and 2u + 1 (context
+                             // masked out: the learned null key / value only) decode the SAME tokens: slot 2u samples from
+                             // null + (cond - null) * cfg_scale and feeds both; one-output models
 };
 
 // NT threads (a multiple of 64, <= 1024); every thread owns the vocabulary entries tid, tid + NT, ...  The selection is an
@@ -353,12 +356,20 @@ template <int NT>
 __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* lg, float* bv, int* bi, int* chosen)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool cfg = a.cfg_scale > 1.0f;
+    if (cfg && (b & 1)) return;                     // the null-context slot follows its partner (block-uniform)
     int* const state = a.state + 4 * b;
     const int pos = state[0];
     if (pos >= a.max_len) return;                   // (block-uniform)
     bool eos = false;
     for (int s = 0; s < a.streams; ++s) {
-        for (int i = tid; i < a.V; i += NT) lg[i] = a.logits[((int64_t)b * a.streams + s) * a.V + i];
+        for (int i = tid; i < a.V; i += NT) {
+            const float c = a.logits[((int64_t)b * a.streams + s) * a.V + i];
+            if (cfg) {          // null_logits + (logits - null_logits) * cond_scale, the reference's operation order (no contraction here)
+                const float n = a.logits[((int64_t)(b + 1) * a.streams + s) * a.V + i];
+                lg[i] = n + (c - n) * a.cfg_scale;
+            } else lg[i] = c;
+        }
         __syncthreads();
         float val = -INFINITY;
         int idx = tid;
@@ -392,13 +403,18 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
         __syncthreads();
         const int tok = *chosen;
         eos = eos || (tok == a.eos_id);
-        for (int d = tid; d < a.dim_emb; d += NT)
-            a.x[((int64_t)b * a.streams + s) * a.dim_emb + d] = a.emb[(int64_t)tok * a.dim_emb + d];
+        for (int d = tid; d < a.dim_emb; d += NT) {
+            const float e = a.emb[(int64_t)tok * a.dim_emb + d];
+            a.x[((int64_t)b * a.streams + s) * a.dim_emb + d] = e;
+            if (cfg) a.x[((int64_t)(b + 1) * a.streams + s) * a.dim_emb + d] = e;
+        }
+        if (cfg && tid == 0) a.tokens[((int64_t)(b + 1) * a.streams + s) * a.max_len + pos] = tok;
         __syncthreads();
     }
     if (tid == 0) {
         if (eos && state[1] == 0) { state[1] = 1; state[2] = pos + 1; }
         state[0] = pos + 1;
+        if (cfg) { int* const sn = state + 4; sn[1] = state[1]; sn[2] = state[2]; sn[0] = pos + 1; }
     }
 }
 
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(256) void t2s_persistent_kernel(const PersistArgs P
         bar.arrive_and_wait();
         if (bid < nb) {
             const SampleArgs sa{d.logits, d.uniforms, d.emb, d.x, d.tokens, d.state, nb, d.vocab, d.dim_emb, d.streams, d.max_len,
-                                d.top_k, d.vocab - 1, 1.0f / fmaxf(d.temperature, 1e-10f)};
+                                d.top_k, d.vocab - 1, 1.0f / fmaxf(d.temperature, 1e-10f), d.cfg_scale};
             sample_body<256>(sa, bid, lg, bv, bi, &chosen);
         }
         if (step + 1 < P.n_steps) { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
@@ -645,6 +661,9 @@ static int t2s_validate(const cvx_t2s_decoder* d, int32_t n_steps)
                 "t2s_decode: bad dimensions (dim=%d inner=%d heads=%d streams=%d dim_emb=%d vocab=%d ff=%d/%d n_ctx=%d/%d max_len=%d batch=%d)",
                 d->dim, d->inner, d->heads, d->streams, d->dim_emb, d->vocab, d->ff_inner, d->ff_inner_pad, d->n_ctx, d->ctx_rows,
                 d->max_len, d->batch);
+    CVX_REQUIRE(!(d->cfg_scale > 1.f) || (d->streams == 1 && d->batch % 2 == 0 && d->n_ctx == 0),
+                "t2s_decode: guidance (cfg_scale > 1) needs a one-output model, an even batch (context / null-context slot pairs) and "
+                "per-slot context rows (n_ctx == 0)");
     CVX_REQUIRE(d->final_gamma && d->emb && d->rope_cos && d->rope_sin && d->uniforms && d->x && d->q && d->att && d->h &&
                 d->logits && d->tokens && d->state, "t2s_decode: null buffer");
     for (int l = 0; l < d->depth; ++l) {
@@ -739,7 +758,7 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
         g.y_stride = d->streams * d->vocab; g.N = d->vocab; g.K = d->dim_emb; g.streams = d->streams;
         launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), nb, st);
         SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, nb, d->vocab, d->dim_emb, d->streams, d->max_len,
-                      d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f)};
+                      d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f), d->cfg_scale};
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)nb), dim3(1024), 0, st, sa);
     }
     CVX_CHECK_LAUNCH("cvx_t2s_decode_steps");

@@ -169,10 +169,11 @@ class TextToSemanticDecoder:
         return enc
 
     # ------------------------------------------------------------------ decoder
-    def _descriptor(self, temperature: float, batch: int = 1) -> "_lib.T2SDecoder":
+    def _descriptor(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0) -> "_lib.T2SDecoder":
         d, b = self.d, self.buf
         dec = _lib.T2SDecoder()
         dec.batch, dec.ctx_rows = batch, self.max_source + 2
+        dec.cfg_scale = float(cfg_scale)
         dec.dim, dec.inner, dec.heads = d["dim_target"], d["inner"], d["heads"]
         dec.ff_inner, dec.ff_inner_pad, dec.depth = d["ff_tgt"], self.Fp, d["target_depth"]
         dec.streams, dec.vocab, dec.dim_emb = d["streams"], d["vocab"], d["dim_emb"]
@@ -184,14 +185,14 @@ class TextToSemanticDecoder:
             setattr(dec, n, b[n].data_ptr())
         return dec
 
-    def _steps(self, temperature: float, batch: int, n: int) -> None:
+    def _steps(self, temperature: float, batch: int, n: int, cfg_scale: float = 1.0) -> None:
         """n token steps on the current stream without a graph."""
         st = torch.cuda.current_stream().cuda_stream
         if self.persistent:
-            _lib.check(_lib.load().cvx_t2s_decode_persistent(C.byref(self._descriptor(temperature, batch)), n,
+            _lib.check(_lib.load().cvx_t2s_decode_persistent(C.byref(self._descriptor(temperature, batch, cfg_scale)), n,
                                                              self._stsync[MAX_BATCH].data_ptr(), st), "cvx_t2s_decode_persistent")
         else:
-            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch)), n, st), "cvx_t2s_decode_steps")
+            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), n, st), "cvx_t2s_decode_steps")
 
     def _read_state(self, nb: int) -> list:
         """state rows of the first nb utterances (the one host sync per chunk); raises if the persistent kernel reported a
@@ -202,19 +203,19 @@ class TextToSemanticDecoder:
                                        "tokens of this chunk are invalid - set CVX_T2S_PERSISTENT=0 to use the per-launch path")
         return rows[:nb]
 
-    def _run_chunk(self, temperature: float, batch: int = 1) -> None:
+    def _run_chunk(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0) -> None:
         """CHUNK token steps on the current stream (one persistent launch, or a graph replay of the per-launch path)."""
         if self.persistent:
-            self._steps(temperature, batch, CHUNK)
+            self._steps(temperature, batch, CHUNK, cfg_scale)
             return
 
         def launch():
-            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch)), CHUNK,
+            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), CHUNK,
                                                         torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
         if os.environ.get("CVX_GRAPH", "1") != "1":
             launch()
             return
-        g = self._graphs.get((temperature, batch))
+        g = self._graphs.get((temperature, batch, cfg_scale))
         if g is None:
             saved = {k: v.clone() for k, v in self.buf.items()}
             caches = [(L["k_cache"].clone(), L["v_cache"].clone()) for L in self.dec]
@@ -233,18 +234,29 @@ class TextToSemanticDecoder:
                 L["k_cache"].copy_(kc); L["v_cache"].copy_(vc)
             if len(self._graphs) >= 4:
                 self._graphs.clear()
-            self._graphs[(temperature, batch)] = g
+            self._graphs[(temperature, batch, cfg_scale)] = g
         g.replay()
 
     @torch.no_grad()          # (not inference_mode: tensors torch creates lazily during the first graph capture,
                               #  e.g. the generator's graph-safe state, would become inference tensors)
     def generate_batch(self, sources, uniforms=None, max_length: Optional[int] = None, temperature: float = 1.0,
-                       generator: Optional[torch.Generator] = None, collect_logits: bool = False):
+                       generator: Optional[torch.Generator] = None, collect_logits: bool = False, cond_scale: float = 1.0):
         """Decode up to MAX_BATCH utterances together.  sources: list of [n] / [1, n] id tensors; uniforms: optional list
         of [steps, streams, vocab] tensors (one per utterance).  Returns a list of (flat tokens, streams[, logits])
-        tuples, each exactly what `generate` returns for that utterance alone."""
+        tuples, each exactly what `generate` returns for that utterance alone.
+        cond_scale > 1: classifier-free guidance (text2semantic.py:780-792; one-output models, up to MAX_BATCH / 2 utterances):
+        every utterance takes two decode slots - the text context and the context masked out (cross-attention then sees the
+        learned null key / value only) - and each step samples from null + (cond - null) * cond_scale; logits returned under
+        collect_logits are the conditional slot's (pre-combination)."""
         d, b = self.d, self.buf
-        S, V, nb = d["streams"], d["vocab"], len(sources)
+        S, V = d["streams"], d["vocab"]
+        cfg = float(cond_scale) > 1.0
+        if cfg:
+            if S != 1:
+                raise NotImplementedError("guidance (cond_scale > 1) on a two-output model: the reference feeds the full-width hidden "
+                                          "state to the half-width logit head there (text2semantic.py:783-785) and cannot run")
+            return self._generate_guided(sources, uniforms, max_length, temperature, generator, collect_logits, float(cond_scale))
+        nb = len(sources)
         if not 1 <= nb <= MAX_BATCH:
             raise ValueError(f"1..{MAX_BATCH} utterances per decode batch, got {nb}")
         max_len = min(int(max_length or self.max_length), self.max_length)
@@ -297,9 +309,68 @@ class TextToSemanticDecoder:
             out.append(item)
         return out
 
+    def _generate_guided(self, sources, uniforms, max_length, temperature, generator, collect_logits, cond_scale):
+        """generate_batch with cond_scale > 1: slots 2u (text context) / 2u + 1 (null context) per utterance u."""
+        d, b = self.d, self.buf
+        V, nu = d["vocab"], len(sources)
+        nb = 2 * nu
+        if not 1 <= nu <= MAX_BATCH // 2:
+            raise ValueError(f"1..{MAX_BATCH // 2} utterances per guided decode batch, got {nu}")
+        max_len = min(int(max_length or self.max_length), self.max_length)
+        us = None
+        if uniforms is not None:
+            us = [u.to(self.device, torch.float32).reshape(u.shape[0], 1, V) for u in uniforms]
+            max_len = min([max_len] + [u.shape[0] for u in us])
+        ctx = []
+        for u_, src in enumerate(sources):
+            if src.ndim == 2 and src.shape[0] != 1:
+                raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
+            enc = self.encode(src)
+            n = enc.shape[0]
+            ctx += [n + 1, 1]                                            # the null slot: row 0 (null k/v) only = every context key masked
+            for L in self.dec:
+                L["kv_c"][2 * u_, 0].copy_(L["null"])
+                ops.gemm(enc, L["wkv_c"], L["kv_c"][2 * u_, 1:n + 1])
+                L["kv_c"][2 * u_ + 1, 0].copy_(L["null"])
+        uview = b["uniforms"][: max_len * nb * V].view(max_len, nb, 1, V)
+        if us is None:
+            uview[:, 0::2].copy_(torch.rand(max_len, nu, 1, V, device=self.device, generator=generator))
+        else:
+            for u_, u in enumerate(us):
+                uview[:, 2 * u_].copy_(u[:max_len])
+        b["x"][:nb].copy_(self.start[None, :].expand(nb, -1))
+        b["state"].copy_(torch.tensor([[0, 0, 0, ctx[i] if i < nb else 1] for i in range(MAX_BATCH)], dtype=torch.int32))
+        steps, logits = 0, []
+        while steps < max_len:
+            if collect_logits:
+                self._steps(float(temperature), nb, 1, cond_scale)
+                lg = b["logits"][:nb].clone()
+                logits.append(lg[1::2] + (lg[0::2] - lg[1::2]) * cond_scale)
+                steps += 1
+            else:
+                self._run_chunk(float(temperature), nb, cond_scale)
+                steps += CHUNK
+            st = self._read_state(nb)
+            if all(st[2 * u_][1] for u_ in range(nu)):
+                break
+        st = self._read_state(nb)
+        eos, out = V - 1, []
+        for u_ in range(nu):
+            i = 2 * u_
+            length = min(st[i][2] if st[i][1] and st[i][2] <= max_len else max_len, max_len)
+            streams = b["tokens"][i, :, :length].clone()
+            after = (streams == eos).cumsum(dim=-1) > 0
+            after = torch.nn.functional.pad(after, (1, -1), value=False)
+            flat = streams.masked_fill(after, PAD_ID).reshape(-1)
+            item = (flat[flat != PAD_ID], streams)
+            if collect_logits:
+                item = item + (torch.stack([lg[u_] for lg in logits])[:length],)
+            out.append(item)
+        return out
+
     def generate(self, source_ids: torch.Tensor, uniforms: Optional[torch.Tensor] = None, max_length: Optional[int] = None,
                  temperature: float = 1.0, generator: Optional[torch.Generator] = None, return_streams: bool = False,
-                 collect_logits: bool = False):
+                 collect_logits: bool = False, cond_scale: float = 1.0):
         """== TextToSemanticWrapper.sample(grapheme_token_ids): flat int64 tensor, stream 1 then stream 2 (two-output
         models), each cut after its eos.  uniforms [steps, streams, vocab] (or [steps, streams, 1, vocab]) replaces
         the random draws of gumbel_noise (text2semantic.py:108-110); default: torch.rand from `generator`.
@@ -308,7 +379,7 @@ class TextToSemanticDecoder:
         if source_ids.ndim == 2 and source_ids.shape[0] != 1:
             raise NotImplementedError("one utterance per call (the generation scripts run batch 1); see generate_batch")
         res = self.generate_batch([source_ids], None if uniforms is None else [uniforms], max_length, temperature, generator,
-                                  collect_logits)[0]
+                                  collect_logits, cond_scale)[0]
         if collect_logits:
             return res
         return res if return_streams else res[0]

@@ -166,3 +166,48 @@ def test_persistent_kernel_is_bit_identical_to_per_launch_path(case):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for a, b in zip(p[3], q[3]):
         assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("name", ["cosingle_small", "cosingle"])
+def test_classifier_free_guidance_vs_reference_golden(name):
+    """cond_scale = 1.5 (text2semantic.py:780-792): tokens sampled from null + (cond - null) * scale, BIT-EXACT against the
+    reference built with cond_drop_prob > 0 (tests/golden/t2s_*_cfg.npz; top-2 margin >= 2e-2), the combined logits against the
+    oracle's, stepwise, graph-replayed and persistent paths alike; two utterances in one guided batch decode like each alone."""
+    from covomix_amd.t2s import TextToSemanticDecoder
+    _, sd = load_case(name)
+    g = np.load(os.path.join(GOLDEN, f"t2s_{name}_cfg.npz"))
+    model = TextToSemanticDecoder(sd, torch.device("cuda:0"), max_length=256)
+    src, uni, scale = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"]), float(g["cond_scale"])
+    flat, streams, logits = model.generate(src, uniforms=uni, collect_logits=True, cond_scale=scale)
+    ref_logits = torch.from_numpy(g["logits"])[:, :, 0, :]
+    e = rel_l2(logits[:, None, :] if logits.ndim == 2 else logits, ref_logits)
+    print(name, "guided logits vs oracle", e, "min margin", float(g["min_margin"]))
+    assert e < TOL
+    assert torch.equal(flat.cpu(), torch.from_numpy(g["tokens"]))
+    flat2 = model.generate(src, uniforms=uni, cond_scale=scale)                    # chunked graph replay
+    assert torch.equal(flat2.cpu(), torch.from_numpy(g["tokens"]))
+    unguided = model.generate(src, uniforms=uni)
+    assert not torch.equal(unguided.cpu(), torch.from_numpy(g["tokens"]))
+    g1 = np.load(os.path.join(GOLDEN, f"t2s_{name}.npz"))                          # a second utterance in the same guided batch
+    src_b, uni_b = torch.from_numpy(g1["source_ids"]), torch.from_numpy(g1["uniforms"])
+    alone_b = model.generate(src_b, uniforms=uni_b, cond_scale=scale)
+    both = model.generate_batch([src, src_b], [uni, uni_b], cond_scale=scale)
+    n = min(uni.shape[0], uni_b.shape[0])          # (a batch runs as many steps as its shortest list of draws provides)
+    assert torch.equal(both[0][0].cpu()[:n], torch.from_numpy(g["tokens"])[:n]) and torch.equal(both[1][0][:n], alone_b[:n])
+
+
+def test_guidance_follows_the_reference_asserts():
+    from covomix_amd.conditional_model import CoVoMixModel
+    _, sd = load_case("cosingle_small")
+    ids = torch.from_numpy(np.load(os.path.join(GOLDEN, "t2s_cosingle_small_cfg.npz"))["source_ids"])
+    plain = CoVoMixModel.from_state_dict(sd).eval().to("cuda:0")
+    with pytest.raises(AssertionError):             # text2semantic.py:684: cond_drop_prob == 0 (the default) forbids guidance
+        plain.synthesis_sample_text2semantic(ids, cond_scale=1.5)
+    g = np.load(os.path.join(GOLDEN, "t2s_cosingle_small_cfg.npz"))
+    guided = CoVoMixModel(sd, hparams={"cond_drop_prob": 0.25, "text2semantic": True}).eval().to("cuda:0")
+    out = guided.synthesis_sample_text2semantic(ids, cond_scale=float(g["cond_scale"]), uniforms=torch.from_numpy(g["uniforms"]))
+    assert torch.equal(out.cpu(), torch.from_numpy(g["tokens"]))
+    _, sd2 = load_case("comix_small")
+    two = CoVoMixModel(sd2, hparams={"cond_drop_prob": 0.25, "text2semantic": True}).eval().to("cuda:0")
+    with pytest.raises(NotImplementedError):
+        two.synthesis_sample_text2semantic(ids, cond_scale=1.5)

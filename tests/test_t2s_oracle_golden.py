@@ -48,6 +48,19 @@ def test_t2s_oracle_vs_reference_golden(name):
     assert rel_l2(orc.encode(sd, src)[0], torch.from_numpy(g["encoder"])) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["cosingle_small", "cosingle"])
+def test_t2s_oracle_guidance_vs_reference_golden(name):
+    """Classifier-free guidance (text2semantic.py:780-792): the tokens the REFERENCE (built with cond_drop_prob > 0) sampled at
+    cond_scale = 1.5 from the recorded draws, reproduced bit-exactly; they differ from the unguided run's."""
+    _, sd = load_case(name)
+    g = np.load(os.path.join(GOLDEN, f"t2s_{name}_cfg.npz"))
+    src, uni = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
+    torch.set_num_threads(8)
+    o = orc.generate(sd, src, uni, max_length=uni.shape[0], cond_scale=float(g["cond_scale"]))
+    assert torch.equal(o["tokens"], torch.from_numpy(g["tokens"])) and int(o["streams"][0, 0, -1]) == 501
+    assert not torch.equal(orc.generate(sd, src, uni, max_length=uni.shape[0])["tokens"], o["tokens"])
+
+
 def test_t2s_helpers():
     t = torch.tensor([[5, 7, 0, 0], [3, 4, 6, 9]])
     out = orc.set_eos_id(t.clone(), 99, 0)
