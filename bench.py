@@ -345,6 +345,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="skip the BASELINE config-2 figure (extra key `c2`, N = 1 only)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): 8 utterances per GPU per step.  strong: BASELINE config 4 literally - 64 utterances per step "
+                         "dealt over the N ranks (N must divide 8), i.e. 64/N per GPU in batches of 8")
     ap.add_argument("--precision", choices=["f16x3", "f16", "fp32"], default=None,
                     help="default f16x3 (fp32-class); f16 = opt-in single-term fp16 operands (<= 1e-3 rel-L2 budget)")
     args = ap.parse_args()
@@ -374,7 +377,7 @@ def main():
 
     voc_events = []
 
-    def step():
+    def one_batch():
         y0 = torch.randn(B, T, 80, device=dev, generator=noise)
         mel = model.synthesis_sample(ids, cond, mask, COND_SCALE, y0=y0)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -383,6 +386,16 @@ def main():
         ev[1].record()
         voc_events.append(ev)
         return ops.wav_to_int16(wav.squeeze(1).contiguous())
+
+    strong = args.scaling == "strong"
+    if strong and (64 // B) % world != 0:
+        raise SystemExit(f"--scaling strong deals {64 // B} batches of {B} utterances over the ranks: --gpus must divide {64 // B}")
+    batches_per_step = (64 // B) // world if strong else 1
+
+    def step():
+        for _ in range(batches_per_step):
+            pcm_ = one_batch()
+        return pcm_
 
     def barrier():
         torch.cuda.synchronize()
@@ -414,7 +427,7 @@ def main():
     power_info = power.stop(t0, t1) if power else {}
     my_elapsed = elapsed
     assert pcm.shape == (B, 160 * T + 32) and pcm.dtype == torch.int16
-    frames, elapsed = dp.reduce_metric(float(B * T * args.steps), elapsed, dev)
+    frames, elapsed = dp.reduce_metric(float(B * T * args.steps * batches_per_step), elapsed, dev)
     per_rank = [my_elapsed]
     loads = [t_load]
     if world > 1:                                        # diagnosis of the first hardware scaling runs: who was slow, and where
@@ -446,14 +459,15 @@ def main():
             "metric": "mel-frames/sec (VoMix 32-step + HiFi-GAN, Bx1000x80)",
             "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f16x3": "f16x3->f32 (fp32 operands split into fp16 hi/lo pairs, 3 MFMA products, fp32 accumulate)",
                       "f16": "f16->f32 (OPT-IN reduced precision: fp16 GEMM/attention operands, fp32 accumulate/softmax/norm/residual)",
                       "fp32": "f32"}[model.precision],
             "data": "synthetic",
             "config": {"workload": f"VoMix 32-NFE (16 midpoint steps, CFG 0.7) + HiFi-GAN config_covomix, "
                                    f"B={B} utterances x T={T} frames per GPU, prompt {PROMPT}",
-                       "per_gpu_batch": B, "frames": T, "nfe": NFE, "parallelism": f"dp{world} (utterance-sharded)"},
+                       "per_gpu_batch": B, "frames": T, "nfe": NFE, "parallelism": f"dp{world} (utterance-sharded)",
+                       "utterances_per_step": B * batches_per_step * world},
             "path_flop_per_frame": FLOP_PER_FRAME,
             "path_frac_of_f32_mfma_peak": round(value / world * FLOP_PER_FRAME / PEAK_F32_MFMA, 4),
             # dominant kernel.  achieved = ALGORITHMIC flops (2*M*N*K per launch) / HIP-event time of the launches;
@@ -477,6 +491,7 @@ def main():
         if world > 1:
             out["ranks"] = {"elapsed_s": [round(x, 4) for x in per_rank], "skew_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 4),
                             "load_and_broadcast_s": [round(x, 3) for x in loads]}
+            out["ranks"].update({k: v for k, v in dp.INFO.items()})       # transports, RCCL version, IPC mode, a fallback's reason
         model_precision = model.precision
         if world == 1 and not args.no_fp32_exact and model.precision == "f16x3":
             del model, gen

@@ -139,6 +139,8 @@ typedef struct {
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
 #define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */
+#define CVX_GEMM_FLAG_MEDIUM 8      /* interleaved operands, 2048 rows and more: take the medium-problem kernel (128 x 128 tiles) whatever the tile count */
+#define CVX_GEMM_FLAG_NO_MEDIUM 16  /* ... never take it there (the large-problem kernel's rounds of 256 x 256 tiles): A/B measurements */
 #define CVX_GEMM_FLAG_ONE_TILE 4    /* eight-phase 16x16x32 kernel: one output tile per block instead of persistent blocks (bit-identical results) */
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 /* the same with an additional DEVICE-resident factor (the pair holds w * scale * *scale_dev; scale_dev may be NULL) */

@@ -543,6 +543,10 @@ class FlowMatchingSampler:
         if (chains == 2 and ctx["ragged"] is None and Bt % 2 == 0 and (Bt // 2) * ctx["T"] >= 2048
                 and not torch.cuda.is_current_stream_capturing()):
             ctx["parts"] = [(0, Bt // 2), (Bt // 2, Bt)]
+            # (the halves must run the kernels the whole batch would: the library's choice between the large- and the medium-problem
+            #  GEMM depends on the row count - pinned to the large one for this schedule, which is bit-identical to one chain then)
+            saved_flags = ops._GEMM_FLAGS
+            ops._GEMM_FLAGS |= 16
             main = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream(device=f.device)
@@ -564,16 +568,21 @@ class FlowMatchingSampler:
             evaluate = evaluate2
         else:
             evaluate = f.evaluate
+            saved_flags = None
         e = 0
-        for dt in dts:
-            if self.method == "midpoint":
-                pred = evaluate(ctx, e); e += 1
-                ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, 0.5 * dt, x_c, x_n)
-                pred = evaluate(ctx, e); e += 1
-                ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
-            else:
-                pred = evaluate(ctx, e); e += 1
-                ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
+        try:
+            for dt in dts:
+                if self.method == "midpoint":
+                    pred = evaluate(ctx, e); e += 1
+                    ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, 0.5 * dt, x_c, x_n)
+                    pred = evaluate(ctx, e); e += 1
+                    ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
+                else:
+                    pred = evaluate(ctx, e); e += 1
+                    ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
+        finally:
+            if saved_flags is not None:
+                ops._GEMM_FLAGS = saved_flags
         return ctx
 
     @torch.no_grad()

@@ -859,7 +859,20 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     // Measured on MI355X (tools/bench_kernels.py, M=16000): the 256x256 tile wins on every transformer shape
     // (284-349 vs 263-312 TFLOP/s).  Deeper rings (3-4 stages, K-step 16, 256x128x3) were tried and are slower:
     // the kernel is bound by the per-CU LDS-DMA delivery rate (~35 GB/s/CU), not by DMA latency.
-    if (A.hi && w_il && a_il && (a->M < 2048 || a->N < 512)) {
+    // 2048 rows and more on 256 x 256 tiles run in ROUNDS of one tile per CU: 4000 rows (two utterances) x N = 1024 are 64 tiles =
+    // one round on a quarter of the chip; 9298 rows (the second bin of a directory) 148 tiles = one round at 58 %.  The
+    // medium-problem kernel works in 128 x 128 tiles at ~80 % of the large kernel's rate per tile area (measured at 16000 rows:
+    // 1.20x the time), so a tile costs 0.31 of a large one: it takes the problem when its rounds come out shorter - out / ff2 /
+    // skip at 4000 rows 2.5x faster, at 9298 rows 5 %; to_qkv / ff1 stay on the large kernel from ~4000 rows on.
+    // (CVX_GEMM_FLAG_MEDIUM forces it, CVX_GEMM_FLAG_NO_MEDIUM and the A/B kernel flags keep the large kernel.)
+    bool medium = a->M < 2048 || a->N < 512;
+    if (!medium && A.hi && w_il && a_il && io && !(io->flags & (CVX_GEMM_FLAG_NO_MEDIUM | CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32 | CVX_GEMM_FLAG_ONE_TILE))) {
+        const long ncu = cvx_device_cus();
+        const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+        const double large = (double)((t256 + ncu - 1) / ncu), med = 0.31 * (double)((t128 + ncu - 1) / ncu);
+        medium = (io->flags & CVX_GEMM_FLAG_MEDIUM) || med < 0.97 * large;
+    }
+    if (A.hi && w_il && a_il && medium) {
         // fewer than 2048 rows (one utterance, the last bin of a ragged directory, the HuBERT / text2semantic encoders): 128 x 128
         // tiles with two wave groups on alternate K-tiles (gemm_f16x3_p8m.hip); K slices on separate blocks when the output has too
         // few tiles for the chip and the caller provided the scratch

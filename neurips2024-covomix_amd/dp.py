@@ -41,6 +41,37 @@ def launch_ranks(script: str, argv: Sequence[str], n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+# what happened at start-up, for the `ranks` block of the bench line / the CLI log: which transport carried the weight broadcast,
+# library versions and the environment RCCL depends on, and - if RCCL could not be used - why
+INFO: Dict[str, object] = {}
+
+
+def pin_host_threads(local: int, local_world: int) -> int:
+    """Give this rank its share of the host: torch intra-op threads = cores / ranks, and (when the affinity mask is wide enough)
+    a disjoint slice of the allowed CPUs - eight ranks each spawning a full-width OpenMP team oversubscribe the cgroup quota."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cpus = list(range(os.cpu_count() or 1))
+    n = len(cpus)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    share = max(1, n // max(1, local_world))
+    torch.set_num_threads(share)
+    if local_world > 1 and len(cpus) >= 2 * local_world:
+        per = len(cpus) // local_world
+        try:
+            os.sched_setaffinity(0, cpus[local * per:(local + 1) * per])
+        except Exception:
+            pass
+    INFO["host_threads_per_rank"] = share
+    return share
+
+
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the process group when world > 1.
     MASTER_ADDR defaults to 127.0.0.1; MASTER_PORT must come from the launcher (torch.distributed.run sets it; launch_ranks
@@ -59,12 +90,62 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL says why when it fails
+        # The DEFAULT group runs on gloo (TCP on 127.0.0.1: rendezvous, the scalar metric reduction, diagnostics) - it works
+        # wherever torch.distributed does.  The one collective that carries data, the start-up weight broadcast, goes over an
+        # RCCL group on top of it (broadcast_state_dict); if RCCL cannot come up on a node (e.g. hipIpcGetMemHandle under the
+        # legacy IPC mode) the broadcast falls back to the gloo group and says so - a rank never dies at start-up for it.
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        INFO.update(default_backend="gloo", requested_backend=backend,
+                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), NCCL_DEBUG=os.environ.get("NCCL_DEBUG"))
+        if backend == "nccl":
+            try:
+                INFO["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:                            # noqa: BLE001
+                INFO["rccl_version"] = f"unavailable ({type(e).__name__})"
+        pin_host_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     return rank, world, local
 
 
+_RCCL = {"group": None, "tried": False, "error": None}
+
+
+def rccl_group():
+    """The RCCL (backend 'nccl') group for device-to-device collectives, created and PROVEN on first use (a tiny all-reduce,
+    synchronised); None when the requested backend is not nccl, in the single-device test mode, or when RCCL failed - the reason
+    is kept in INFO['rccl_error'] and every rank agrees on the outcome (the verdict is all-reduced over the gloo group)."""
+    if _RCCL["tried"]:
+        return _RCCL["group"]
+    _RCCL["tried"] = True
+    if INFO.get("requested_backend") != "nccl" or single_device_test_mode() or not torch.cuda.is_available():
+        INFO["broadcast_backend"] = "gloo (" + ("single-device test mode" if single_device_test_mode() else "no RCCL requested") + \
+                                    ": weights staged through host memory)"
+        return None
+    import datetime
+    ok, err, g = 1.0, None, None
+    try:
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe, group=g)
+        torch.cuda.synchronize()
+        if float(probe.item()) != float(dist.get_world_size()):
+            raise RuntimeError(f"RCCL all-reduce probe returned {float(probe.item())}")
+    except Exception as e:                                    # noqa: BLE001
+        ok, err = 0.0, f"{type(e).__name__}: {str(e)[:300]}"
+    flag = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # (default group = gloo)
+    if float(flag.item()) < 1.0:
+        INFO["rccl_error"] = err or "another rank failed to bring RCCL up"
+        g = None
+    INFO["broadcast_backend"] = "nccl (RCCL)" if g is not None else "gloo (RCCL unavailable: weights staged through host memory)"
+    _RCCL["group"] = g
+    return g
+
+
 def _on_gloo() -> bool:
-    return dist.is_initialized() and dist.get_backend() == "gloo"
+    """True when device tensors must be staged through the host for a collective (no usable RCCL group)."""
+    return dist.is_initialized() and rccl_group() is None
 
 
 def shard_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
@@ -174,9 +255,10 @@ def broadcast_state_dict(sd: Dict[str, torch.Tensor], device: torch.device, src:
         nonlocal bucket, size
         if not bucket:
             return
-        cdev = torch.device("cpu") if _on_gloo() else device       # gloo (tests): collectives on host tensors
+        g = rccl_group()
+        cdev = torch.device("cpu") if g is None else device        # no RCCL (tests, or it failed): through host tensors on gloo
         flat = torch.cat([sd[k].to(device=cdev, dtype=torch.float32).reshape(-1) for k in bucket])
-        dist.broadcast(flat, src=src)
+        dist.broadcast(flat, src=src, group=g)
         flat = flat.to(device)
         off = 0
         for k in bucket:
@@ -199,8 +281,7 @@ def reduce_metric(frames: float, seconds: float, device: torch.device) -> tuple[
     """(sum of frames over ranks, max of elapsed over ranks)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return frames, seconds
-    if _on_gloo():
-        device = torch.device("cpu")
+    device = torch.device("cpu")                               # scalars: the default (gloo) group
     t = torch.tensor([frames], dtype=torch.float64, device=device)
     m = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -212,8 +293,7 @@ def gather_floats(values: Sequence[float], device: torch.device) -> List[List[fl
     """Every rank's list of floats, on every rank (diagnostics of a scaling run)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [list(values)]
-    if _on_gloo():
-        device = torch.device("cpu")
+    device = torch.device("cpu")
     buf = torch.tensor(list(values), dtype=torch.float64, device=device)
     allb = [torch.zeros_like(buf) for _ in range(dist.get_world_size())]
     dist.all_gather(allb, buf)

@@ -70,6 +70,9 @@ def _pair(x, rows=None, cols=None):
 # dev A/B (read here, never inside the library): CVX_GEMM_P8 = 1 (default) eight-phase kernel on the 16x16x32 MFMA,
 # 32 = eight-phase kernel on the 32x32x16 MFMA, 0 = two-stage kernel, 1t = one tile per block.  cvx_gemm_split_io.flags.
 _GEMM_FLAGS = {"1": 0, "32": 2, "0": 1, "1t": 4}.get(__import__("os").environ.get("CVX_GEMM_P8", "1"), 0)
+# CVX_GEMM_MEDIUM_AUTO=0: 2048 rows and more always on the large-problem kernel (flag 16), =force: always on the medium one (8);
+# default: the library picks by how full the large kernel's last round of tiles would be
+_GEMM_FLAGS |= {"0": 16, "force": 8}.get(__import__("os").environ.get("CVX_GEMM_MEDIUM_AUTO", "1"), 0)
 
 _SPLITK_WS: dict = {}
 
@@ -289,27 +292,35 @@ def _bind_saturation_flag(flag: torch.Tensor, stream_handle: int) -> None:
 
 
 def saturation_flag(stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
-    """The flag of `stream` (default: the current stream), allocated and bound on first use."""
+    """The OWN flag of `stream` (default: the current stream), allocated and bound on first use.  A binding that was only lent to
+    the stream (saturation_share: torch hands stream handles out of a small pool, so a stream a caller just created may be the very
+    side / capture stream some earlier call borrowed) is replaced: whoever resets or queries a stream owns its flag."""
     st = stream if stream is not None else torch.cuda.current_stream()
     key = (st.device.index, st.cuda_stream)
-    f = _SAT_FLAGS.get(key)
-    if f is None:
+    ent = _SAT_FLAGS.get(key)
+    if ent is None or ent[1] != key:
         f = torch.zeros(1, dtype=torch.int32, device=st.device)
         torch.cuda.current_stream(st.device).synchronize()        # (the zero fill is on the current stream; `stream` may be another)
-        _SAT_FLAGS[key] = f
+        _SAT_FLAGS[key] = (f, key)
+        _CAPTURE_OWNER.pop(key, None)
         with torch.cuda.device(st.device):
             _bind_saturation_flag(f, st.cuda_stream)
-    return f
+        return f
+    return ent[0]
 
 
 def saturation_share(src: "torch.cuda.Stream", dst: "torch.cuda.Stream") -> None:
-    """Kernels launched on `dst` report into the flag of `src`: the side stream of the two-chain schedule and the capture stream
-    of a HIP graph belong to the call that runs on `src`."""
+    """Kernels launched on `dst` report into the flag of `src` until further notice: the side stream of the two-chain schedule and
+    the capture stream of a HIP graph belong to the call that runs on `src` (call it before every such use)."""
     f = saturation_flag(src)
+    skey = (src.device.index, src.cuda_stream)
     key = (dst.device.index, dst.cuda_stream)
+    if key == skey:
+        return
     _CAPTURE_OWNER[key] = src.cuda_stream
-    if _SAT_FLAGS.get(key) is not f:
-        _SAT_FLAGS[key] = f
+    ent = _SAT_FLAGS.get(key)
+    if ent is None or ent[0] is not f:
+        _SAT_FLAGS[key] = (f, skey)
         with torch.cuda.device(dst.device):
             _bind_saturation_flag(f, dst.cuda_stream)
 

@@ -743,7 +743,7 @@ def test_gemm_large_problem_kernels_every_epilogue(ops, M):
         return w, ws, ops.split_f16_interleaved(ws)
     saved = ops._GEMM_FLAGS
     try:
-        for flags in (0, 2, 1):
+        for flags in (16, 0, 2, 1):              # large-problem 16x16 kernel pinned / the library's choice (medium kernel here) / 32x32 / two-stage
             ops._GEMM_FLAGS = flags
             # plain + bias / residual / twin
             w, ws, wil = weights(1024)
@@ -815,7 +815,7 @@ def test_gemm_large_problem_kernels_n_not_multiple_of_256(ops):
     xs = il.dense()[0].double() + il.dense()[1].double()
     saved = ops._GEMM_FLAGS
     try:
-        for flags in (0, 2, 1):
+        for flags in (16, 0, 2, 1):
             ops._GEMM_FLAGS = flags
             for N in (576, 640):
                 w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev_)
@@ -886,7 +886,7 @@ def test_gemm_persistent_blocks_walk_several_tiles(ops):
     saved = ops._GEMM_FLAGS
     try:
         outs = []
-        for flags in (0, 4):
+        for flags in (16, 16 | 4):               # (16 = CVX_GEMM_FLAG_NO_MEDIUM: 5000 rows would otherwise go to the medium-problem kernel)
             ops._GEMM_FLAGS = flags
             o = ops.SplitIL(M, 4096, dev_)
             ops.gemm(x, w, torch.empty(M, 4096, device=dev_), w_split=ws, w_il=wil, a_split=il, bias=b, act=1, out_split=o, write_f32=False)
@@ -898,7 +898,7 @@ def test_gemm_persistent_blocks_walk_several_tiles(ops):
         # residual + fp32 on a narrower N (4 tile columns x 24 slots = 96 slots: one tile per block) and a wide one
         r = torch.randn(M, 4096, generator=g).to(dev_)
         c = torch.full((M, 4096), float("nan"), device=dev_)
-        ops._GEMM_FLAGS = 0
+        ops._GEMM_FLAGS = 16
         ops.gemm(x, w, c, w_split=ws, w_il=wil, a_split=il, residual=r)
         assert rel_l2(c, xs @ w.double().T + r.double()) < 1e-6
         # QKV form with 16 heads: 12 tile columns x 24 slots = 288 slots, V blocks interleaved with q | k blocks in a block's walk

@@ -37,6 +37,22 @@ def test_bench_self_launches_two_ranks():
     assert "cpu_baseline" not in out and "fp32_exact" not in out        # N = 1 only
     # whole-job rate = frames of BOTH ranks / max elapsed
     assert abs(out["value"] - 2 * 8 * 1000 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
+    # start-up diagnostics of the ranks block: transports and what RCCL depends on (here: the single-device test mode, so the
+    # weight broadcast went through host memory on gloo and says so)
+    rk = out["ranks"]
+    assert rk["default_backend"] == "gloo" and rk["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and rk["host_threads_per_rank"] >= 1
+    assert rk["broadcast_backend"].startswith("gloo") and "rccl_error" not in rk
+
+
+def test_bench_strong_scaling_deals_64_utterances():
+    """--scaling strong = BASELINE config 4 literally: 64 utterances per step dealt over the ranks (32 per rank here, four
+    batches of 8)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scaling", "strong"],
+                       env=_env(), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["utterances_per_step"] == 64
+    assert abs(out["value"] - 64 * 1000 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
 
 
 def test_cli_two_ranks_write_every_utterance_once_like_one_rank(tmp_path):
