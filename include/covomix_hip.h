@@ -537,6 +537,15 @@ int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream
  * out (some block was not resident: another kernel held its CU for > 0.1 s) and the step results are invalid; the kernel
  * always terminates.  Needs heads * batch <= the device's CU count. */
 int cvx_t2s_decode_persistent(const cvx_t2s_decoder* dec, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t stream);
+/* The same token steps with ONE XCD PER UTTERANCE (round 4): 8 groups of 32 blocks, group u = the blocks b with b % 8 == u decodes
+ * utterance u (batch <= 8, no guidance) on the XCD those blocks were dispatched to.  The CUs of an XCD share its L2, so a phase
+ * boundary inside a group is one L2 atomic + a relaxed poll with NO cache maintenance (every activation read of the decode device
+ * code bypasses L1) - against ~15 us for the device-wide hand-off of cvx_t2s_decode_persistent.  Same device code per phase:
+ * logits and tokens bit-identical to cvx_t2s_decode_steps.  Block -> XCD placement is observed behaviour, not a HIP contract:
+ * every block checks HW_REG_XCC_ID against its group's first block.  sync_ws_dev: 160 uint32 of DEVICE memory owned by the caller for
+ * the duration of the launch (zeroed by the call); word [1] != 0 afterwards = the results are INVALID (bit 0: a barrier timed out,
+ * bit 1: a group was not placed on one XCD) - run cvx_t2s_decode_steps instead.  n_steps == 0 runs the placement check alone. */
+int cvx_t2s_decode_xcd(const cvx_t2s_decoder* dec, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t stream);
 
 /* out[r, c] = h[r, c] * gelu(h[r, F + c]) for c < F, 0 for F <= c < ld_out   (GEGLU, text2semantic.py:154-157;
  * the encoder's feed-forward; ld_out >= F pads the K dimension of the following GEMM). */

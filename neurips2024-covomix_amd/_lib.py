@@ -180,6 +180,7 @@ SIGNATURES = {
     "cvx_mel_log_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "cvx_t2s_decode_steps": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p]),
     "cvx_t2s_decode_persistent": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p, C.c_void_p]),
+    "cvx_t2s_decode_xcd": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p, C.c_void_p]),
     "cvx_geglu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "cvx_hubert_conv0_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32]),
     "cvx_hubert_conv0_gn_gelu_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

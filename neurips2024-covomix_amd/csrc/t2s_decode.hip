@@ -71,6 +71,19 @@ constexpr int PF = 4;                                      // 4 x 256 floats per
 #endif
 // weight rows: streamed once per token step by one wave each -> non-temporal loads (A/B: -DCVX_T2S_NT=0)
 __device__ __forceinline__ f32x4 wload4(const float* p) { return CVX_T2S_NT ? gload4_nt(p) : gload4(p); }
+// ACTIVATION reads (x, q, att, h, logits, the state record, cache rows) go through these.  Round 4 measured them as L1-bypassing
+// (nt) loads - what an in-kernel hand-off between CUs without an invalidate needs - and the PER-LAUNCH path lost 36 % to it (CoSingle
+// batch 1: 147.8 -> 201.2 us per step; batch 8: 28.3k -> 21.8k tokens/s, same box): plain loads, and the persistent kernels
+// invalidate their CU's L1 behind every barrier instead.  -DCVX_T2S_NT_ACT restores the nt form for A/B runs.
+#ifdef CVX_T2S_NT_ACT
+__device__ __forceinline__ float aload(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ int aloadi(const int* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ f32x4 aload4(const float* p) { return gload4_nt(p); }
+#else
+__device__ __forceinline__ float aload(const float* p) { return *p; }
+__device__ __forceinline__ int aloadi(const int* p) { return *p; }
+__device__ __forceinline__ f32x4 aload4(const float* p) { return gload4(p); }
+#endif
 
 // the two rows of row-pair `pair` (the pairs are chosen so that the epilogue has both members of a RoPE pair / a GEGLU
 // (value, gate) pair in one wave)
@@ -131,7 +144,7 @@ __device__ __forceinline__ void stage_input(const GemvArgs& a, int Kin, float* x
         const float gk = a.gamma ? a.gamma[k] : 1.f;
         float v[BQ];
 #pragma unroll
-        for (int b = 0; b < BQ; ++b) v[b] = a.x[(int64_t)b * a.x_stride + k];
+        for (int b = 0; b < BQ; ++b) v[b] = aload(a.x + (int64_t)b * a.x_stride + k);
 #pragma unroll
         for (int b = 0; b < BQ; ++b) { ss[b] = fmaf(v[b], v[b], ss[b]); xs[b * Kin + k] = v[b] * gk; }
     }
@@ -210,7 +223,7 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
 #pragma unroll
     for (int b = 0; b < BQ; ++b) { acc0[b] = wave_sum(acc0[b]) * inv[b]; acc1[b] = wave_sum(acc1[b]) * inv[b]; }
     if (lane != 0) return;
-    const int pos = (MODE == MODE_QKV) ? min(a.state[0], a.max_len - 1) : 0;
+    const int pos = (MODE == MODE_QKV) ? min(aloadi(a.state), a.max_len - 1) : 0;
 #pragma unroll
     for (int b = 0; b < BQ; ++b) {
         float s0 = acc0[b], s1 = acc1[b];
@@ -228,8 +241,8 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
             dst[c0] = s0;
             dst[c0 + 32] = s1;
         } else if (MODE == MODE_RES) {
-            yb[r0] += s0;
-            if (has1) yb[r1] += s1;
+            yb[r0] = aload(yb + r0) + s0;
+            if (has1) yb[r1] = aload(yb + r1) + s1;
         } else if (MODE == MODE_GEGLU) {
             yb[r0] = s0 * gelu_erf(s1);                                   // F.gelu(gate) * x, text2semantic.py:154-157
         } else if (MODE == MODE_LOGITS) {
@@ -278,17 +291,17 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int HD64 = heads * 64;
     const int n = a.n_fixed >= 0 ? a.n_fixed
-                                 : (a.n_fixed == -1 ? min(a.state[0] + 1, a.max_len) : min(a.state[4 * b + 3], T2S_MAX_KEYS));
+                                 : (a.n_fixed == -1 ? min(aloadi(a.state) + 1, a.max_len) : min(aloadi(a.state + 4 * b + 3), T2S_MAX_KEYS));
     const float* const kb = a.k + b * a.batch_stride;
     const float* const vb = a.v + b * a.batch_stride;
     const int sub = tid & 15, grp = tid >> 4;              // 16 lanes per key, 16 keys per pass
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + (int64_t)b * HD64 + h * 64 + 4 * sub);
+    const f32x4 q4 = aload4(a.q + (int64_t)b * HD64 + h * 64 + 4 * sub);
     float mx = -3.0e38f;
     for (int j0 = 0; j0 < n; j0 += 16) {
         const int j = j0 + grp;
         float d = 0.f;
         if (j < n) {
-            const f32x4 k4 = gload4(kb + (int64_t)j * a.stride + h * 64 + 4 * sub);
+            const f32x4 k4 = aload4(kb + (int64_t)j * a.stride + h * 64 + 4 * sub);
             d = k4[0] * q4[0] + k4[1] * q4[1] + k4[2] * q4[2] + k4[3] * q4[3];
         }
 #pragma unroll
@@ -310,7 +323,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
     sum = red[0] + red[1] + red[2] + red[3];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int j = grp; j < n; j += 16) {
-        const f32x4 v4 = gload4(vb + (int64_t)j * a.stride + h * 64 + 4 * sub);
+        const f32x4 v4 = aload4(vb + (int64_t)j * a.stride + h * 64 + 4 * sub);
         const float p = sc[j];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, v4[e], acc[e]);
@@ -359,14 +372,14 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
     const bool cfg = a.cfg_scale > 1.0f;
     if (cfg && (b & 1)) return;                     // the null-context slot follows its partner (block-uniform)
     int* const state = a.state + 4 * b;
-    const int pos = state[0];
+    const int pos = aloadi(state);
     if (pos >= a.max_len) return;                   // (block-uniform)
     bool eos = false;
     for (int s = 0; s < a.streams; ++s) {
         for (int i = tid; i < a.V; i += NT) {
-            const float c = a.logits[((int64_t)b * a.streams + s) * a.V + i];
+            const float c = aload(a.logits + ((int64_t)b * a.streams + s) * a.V + i);
             if (cfg) {          // null_logits + (logits - null_logits) * cond_scale, the reference's operation order (no contraction here)
-                const float n = a.logits[((int64_t)(b + 1) * a.streams + s) * a.V + i];
+                const float n = aload(a.logits + ((int64_t)(b + 1) * a.streams + s) * a.V + i);
                 lg[i] = n + (c - n) * a.cfg_scale;
             } else lg[i] = c;
         }
@@ -412,9 +425,10 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
         __syncthreads();
     }
     if (tid == 0) {
-        if (eos && state[1] == 0) { state[1] = 1; state[2] = pos + 1; }
+        int done = aloadi(state + 1), len = aloadi(state + 2);
+        if (eos && done == 0) { done = 1; len = pos + 1; state[1] = 1; state[2] = len; }
         state[0] = pos + 1;
-        if (cfg) { int* const sn = state + 4; sn[1] = state[1]; sn[2] = state[2]; sn[0] = pos + 1; }
+        if (cfg) { int* const sn = state + 4; sn[1] = done; sn[2] = len; sn[0] = pos + 1; }
     }
 }
 
@@ -617,6 +631,185 @@ __global__ __launch_bounds__(256) void t2s_persistent_kernel(const PersistArgs P
     }
 }
 
+// ================================================================ one XCD per utterance (round 4)
+// The whole-chip persistent kernel above loses to the launch chain because its phase boundary is a hand-off ACROSS the eight
+// non-coherent L2s: release (L2 write-back) + device-wide counter + acquire (invalidate) = ~15 us per barrier, 34 per token.
+// Inside ONE XCD the 32 CUs share the L2: a store that has completed (vmcnt) is in it - no L2 write-back, only the reading CU's
+// L1 has to be invalidated behind the barrier.  MEASURED (tools/t2s_ab.sh, same box): 366 us per CoSingle step at every batch size
+// 1..8 (batch 8: 21.1k tokens/s) against 148 us / 28.3k for the launch chain; CoMix 702 vs 196 us.  Per phase ~7 us of fixed cost (the
+// device-scope atomics and polls of the barrier go to the memory side, not to the XCD's L2; workgroup-scope atomics do not order
+// across CUs at all: the barrier then times out) + 0.38 TB/s of weight streaming (128 waves per utterance walk their row pairs
+// one after the other with one pair in flight).  A second measured negative result next to the whole-chip kernel: kept opt-in
+// (CVX_T2S_XCD=1) as an independent implementation the bit-identity test cross-checks.  Layout:
+// block b serves utterance b & 7 on "its" XCD (blocks are dispatched round-robin over the XCDs - an OBSERVATION, not a contract:
+// every block compares HW_REG_XCC_ID with the XCD of the group's first block and raises the error word on a mismatch, the caller
+// then repeats the chunk on the launch chain), with (b >> 3) as its index among the G blocks of the group; up to eight utterances
+// decode side by side, each streaming the weights through its own L2 (the 60 / 186 MB of a token step stay in the 256 MB
+// Infinity Cache between the groups).  Phases run the same device functions as the other paths with BQ = 1 and the utterance's
+// slice of every buffer: the per-utterance arithmetic - and so every logit and token - is bit-identical.
+struct XcdBarrier {
+    unsigned* ctr;           // this group's counter (own 64-byte line)
+    unsigned* err;           // the launch's error word
+    unsigned target, nblocks;
+    bool dead;
+    __device__ __forceinline__ void arrive_and_wait()
+    {
+        __syncthreads();     // every wave's stores have completed (vmcnt(0) inside): they are in the XCD's L2
+        if (threadIdx.x == 0) {
+            target += nblocks;
+#ifndef CVX_XCD_SCOPE
+#define CVX_XCD_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, CVX_XCD_SCOPE);
+            unsigned spins = 0;
+            while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, CVX_XCD_SCOPE) < target) {
+#ifndef CVX_XCD_NOSLEEP
+                __builtin_amdgcn_s_sleep(1);
+#endif
+                if (++spins > (1u << 22) || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 may hold the previous step's x / q / att / h / logits lines
+        }
+        __syncthreads();
+    }
+};
+
+__global__ __launch_bounds__(256) void t2s_xcd_kernel(const PersistArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const xs = lds;
+    float* const sc = lds;
+    float (*const part)[64] = reinterpret_cast<float (*)[64]>(lds + T2S_MAX_KEYS);
+    float* const lg = lds;
+    __shared__ float red[1][4];
+    __shared__ float red4[4];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int chosen;
+
+    const cvx_t2s_decoder& d = P.d;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int u = (int)blockIdx.x & 7, lb = (int)blockIdx.x >> 3, G = (int)gridDim.x >> 3;     // utterance / group, index in the group
+    if (u >= d.batch) return;
+    unsigned* const err = P.sync + 1;
+    // placement check: every block of a group must sit on the XCD of the group's block 0 (published through word 16 u + 8)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    unsigned* const gctr = P.sync + 16 * (u + 1);
+    if (threadIdx.x == 0) {
+        if (lb == 0) __hip_atomic_store(gctr + 8, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    XcdBarrier bar{gctr, err, 0u, (unsigned)G, false};
+    bar.arrive_and_wait();
+    if (threadIdx.x == 0) {
+        const unsigned want = __hip_atomic_load(gctr + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (want != xcc + 1u) __hip_atomic_fetch_or(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int gwave = lb * 4 + wid, n_gwaves = G * 4;
+    const float scale = 0.125f;
+    const int64_t cache_stride = (int64_t)d.max_len * d.inner;
+    // this utterance's slice of every per-utterance buffer
+    float* const X = d.x + (int64_t)u * d.dim;
+    float* const Q = d.q + (int64_t)u * d.inner;
+    float* const ATT = d.att + (int64_t)u * d.inner;
+    float* const Hh = d.h + (int64_t)u * d.ff_inner_pad;
+    float* const LOG = d.logits + (int64_t)u * d.streams * d.vocab;
+    int* const ST = d.state + 4 * u;
+
+    auto qkv_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.wqkv_s; g.ldw = d.dim; g.x = X; g.x_stride = d.dim; g.gamma = L.gamma_s; g.y = Q; g.y_stride = d.inner;
+        g.N = 3 * d.inner; g.K = d.dim;
+        g.inner = d.inner; g.rope_cos = d.rope_cos; g.rope_sin = d.rope_sin; g.k_cache = L.k_cache + u * cache_stride;
+        g.v_cache = L.v_cache + u * cache_stride; g.cache_stride = cache_stride; g.state = ST; g.max_len = d.max_len;
+        return g;
+    };
+    auto out_args = [&](const float* W) {
+        GemvArgs g{};
+        g.W = W; g.ldw = d.inner; g.x = ATT; g.x_stride = d.inner; g.y = X; g.y_stride = d.dim; g.N = d.dim; g.K = d.inner;
+        return g;
+    };
+    auto qc_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.wq_c; g.ldw = d.dim; g.x = X; g.x_stride = d.dim; g.gamma = L.gamma_c; g.y = Q; g.y_stride = d.inner;
+        g.N = d.inner; g.K = d.dim;
+        return g;
+    };
+    auto ff1_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.w1; g.ldw = d.dim; g.x = X; g.x_stride = d.dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = Hh;
+        g.y_stride = d.ff_inner_pad; g.N = 2 * d.ff_inner; g.K = d.dim; g.y_pad = d.ff_inner_pad;
+        return g;
+    };
+    auto ff2_args = [&](const cvx_t2s_layer& L) {
+        GemvArgs g{};
+        g.W = L.w2; g.ldw = d.ff_inner_pad; g.x = Hh; g.x_stride = d.ff_inner_pad; g.bias = L.b2; g.y = X; g.y_stride = d.dim;
+        g.N = d.dim; g.K = d.ff_inner_pad;
+        return g;
+    };
+    auto logit_args = [&]() {
+        GemvArgs g{};
+        g.W = d.emb; g.ldw = d.dim_emb; g.x = X; g.x_stride = d.dim; g.gamma = d.final_gamma; g.y = LOG;
+        g.y_stride = d.streams * d.vocab; g.N = d.vocab; g.K = d.dim_emb; g.streams = d.streams;
+        return g;
+    };
+    const int p_qkv = 3 * d.inner / 2, p_out = (d.dim + 1) / 2, p_qc = d.inner / 2, p_ff1 = d.ff_inner_pad,
+              p_logit = d.streams * ((d.vocab + 1) / 2);
+    // attention: head h on local block h (the caches / context of utterance u are reached through the batch index of attn_body)
+    RowPrefetch pf;
+    { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
+    for (int step = 0; step < P.n_steps; ++step) {
+        for (int l = 0; l < d.depth; ++l) {
+            const cvx_t2s_layer& L = P.layers[l];
+            { const GemvArgs g = qkv_args(L); phase_gemv<MODE_QKV, 1>(g, p_qkv, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = out_args(L.wo_s); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            for (int h = lb; h < d.heads; h += G) {
+                const AttnArgs at{d.q, L.k_cache, L.v_cache, d.inner, cache_stride, d.att, ST, -1, scale, d.max_len};
+                attn_body(at, h, u, d.heads, sc, red4, part);
+                __syncthreads();
+            }
+            bar.arrive_and_wait();
+            { const GemvArgs g = out_args(L.wo_s); phase_gemv<MODE_RES, 1>(g, p_out, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = qc_args(L); if (gwave < p_qc) prefetch_pair<MODE_PLAIN>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            { const GemvArgs g = qc_args(L); phase_gemv<MODE_PLAIN, 1>(g, p_qc, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = out_args(L.wo_c); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            for (int h = lb; h < d.heads; h += G) {
+                const AttnArgs ac{d.q, L.kv_c, L.kv_c + d.inner, 2 * (int64_t)d.inner, (int64_t)d.ctx_rows * 2 * d.inner, d.att, d.state,
+                                  d.n_ctx > 0 ? d.n_ctx : -2, scale, d.max_len};
+                attn_body(ac, h, u, d.heads, sc, red4, part);
+                __syncthreads();
+            }
+            bar.arrive_and_wait();
+            { const GemvArgs g = out_args(L.wo_c); phase_gemv<MODE_RES, 1>(g, p_out, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = ff1_args(L); if (gwave < p_ff1) prefetch_pair<MODE_GEGLU>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            { const GemvArgs g = ff1_args(L); phase_gemv<MODE_GEGLU, 1>(g, p_ff1, xs, red, gwave, n_gwaves, pf); }
+            { const GemvArgs g = ff2_args(L); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+            { const GemvArgs g = ff2_args(L); phase_gemv<MODE_RES, 1>(g, p_out, xs, red, gwave, n_gwaves, pf); }
+            if (l + 1 < d.depth) { const GemvArgs g = qkv_args(P.layers[l + 1]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
+            else { const GemvArgs g = logit_args(); if (gwave < p_logit) prefetch_pair<MODE_LOGITS>(g, gwave, lane, pf); }
+            bar.arrive_and_wait();
+        }
+        { const GemvArgs g = logit_args(); phase_gemv<MODE_LOGITS, 1>(g, p_logit, xs, red, gwave, n_gwaves, pf); }
+        bar.arrive_and_wait();
+        if (lb == 0) {
+            const SampleArgs sa{d.logits, d.uniforms, d.emb, d.x, d.tokens, d.state, d.batch, d.vocab, d.dim_emb, d.streams, d.max_len,
+                                d.top_k, d.vocab - 1, 1.0f / fmaxf(d.temperature, 1e-10f), 1.0f};
+            sample_body<256>(sa, u, lg, bv, bi, &chosen);
+        }
+        if (step + 1 < P.n_steps) { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
+        bar.arrive_and_wait();
+    }
+}
+
 template <int MODE, int BQ>
 void launch_gemv_b(const GemvArgs& g, int pairs, hipStream_t st)
 {
@@ -762,5 +955,38 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)nb), dim3(1024), 0, st, sa);
     }
     CVX_CHECK_LAUNCH("cvx_t2s_decode_steps");
+    return CVX_OK;
+}
+
+extern "C" int cvx_t2s_decode_xcd(const cvx_t2s_decoder* d, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t s)
+{
+    const int rc = t2s_validate(d, n_steps);
+    if (rc != CVX_OK) return rc;
+    CVX_REQUIRE(sync_ws_dev && d->depth <= T2S_MAX_DEPTH && !(d->cfg_scale > 1.f) && d->batch <= 8,
+                "t2s_decode_xcd: needs a 160-word device workspace, depth <= %d, at most 8 utterances and no guidance", T2S_MAX_DEPTH);
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    const int cus = cvx_device_cus();
+#ifndef CVX_XCD_BPC
+#define CVX_XCD_BPC 1
+#endif
+    const int G = (cus / 8 < 32 ? cus / 8 : 32) * CVX_XCD_BPC;      // blocks per group: CVX_XCD_BPC per CU of an XCD (all co-resident)
+    CVX_REQUIRE(G >= 1, "t2s_decode_xcd: %d compute units", cus);
+    PersistArgs P{};
+    P.d = *d;
+    for (int l = 0; l < d->depth; ++l) P.layers[l] = d->layers[l];
+    P.d.layers = nullptr;
+    P.sync = sync_ws_dev;
+    P.n_steps = n_steps;                                // 0: placement check only
+    int kin = d->dim > d->inner ? d->dim : d->inner;
+    if (d->ff_inner_pad > kin) kin = d->ff_inner_pad;
+    size_t floats = (size_t)kin;
+    if (floats < (size_t)T2S_MAX_KEYS + 16 * 64) floats = (size_t)T2S_MAX_KEYS + 16 * 64;
+    P.lds_x_floats = (int)floats;
+    const size_t lds = floats * sizeof(float);
+    CVX_REQUIRE(lds <= 150 * 1024, "t2s_decode_xcd: %zu bytes of LDS per block", lds);
+    if (hipMemsetAsync(sync_ws_dev, 0, 160 * sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("t2s_decode_xcd: memset failed"); return CVX_EHIP; }
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&t2s_xcd_kernel), (int)lds);
+    hipLaunchKernelGGL(t2s_xcd_kernel, dim3((unsigned)(8 * G)), dim3(256), lds, st, P);
+    CVX_CHECK_LAUNCH("cvx_t2s_decode_xcd");
     return CVX_OK;
 }

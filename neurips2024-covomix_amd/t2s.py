@@ -129,6 +129,10 @@ class TextToSemanticDecoder:
         self._stsync = torch.zeros(MAX_BATCH + 1, 4, dtype=torch.int32, device=device)
         self.buf["state"] = self._stsync[:MAX_BATCH]
         self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "0") == "1"
+        # one XCD per utterance (cvx_t2s_decode_xcd): CVX_T2S_XCD = 1 on / 0 off; placement is probed once (n_steps = 0)
+        self.xcd = os.environ.get("CVX_T2S_XCD", "0") == "1" and not self.persistent        # measured 2.5x slower: opt-in
+        self._xsync = torch.zeros(160, dtype=torch.int32, device=device)
+        self._xcd_ok = None
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
             for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
@@ -185,9 +189,29 @@ class TextToSemanticDecoder:
             setattr(dec, n, b[n].data_ptr())
         return dec
 
+    def _use_xcd(self, cfg_scale: float) -> bool:
+        """One XCD per utterance?  Needs the blocks of a group to land on one XCD: checked once with an empty launch."""
+        if not self.xcd or cfg_scale > 1.0:
+            return False
+        if self._xcd_ok is None:
+            _lib.check(_lib.load().cvx_t2s_decode_xcd(C.byref(self._descriptor(1.0, 1)), 0, self._xsync.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_xcd")
+            self._xcd_ok = int(self._xsync[1].item()) == 0
+        return self._xcd_ok
+
+    def _check_xcd(self) -> None:
+        if int(self._xsync[1].item()) != 0:
+            self._xcd_ok = False
+            raise _lib.CovomixHipError("cvx_t2s_decode_xcd: a group barrier timed out or a group was not placed on one XCD; the tokens "
+                                       "of this chunk are invalid - set CVX_T2S_XCD=0 to use the per-launch path")
+
     def _steps(self, temperature: float, batch: int, n: int, cfg_scale: float = 1.0) -> None:
         """n token steps on the current stream without a graph."""
         st = torch.cuda.current_stream().cuda_stream
+        if self._use_xcd(cfg_scale):
+            _lib.check(_lib.load().cvx_t2s_decode_xcd(C.byref(self._descriptor(temperature, batch)), n, self._xsync.data_ptr(), st),
+                       "cvx_t2s_decode_xcd")
+            return
         if self.persistent:
             _lib.check(_lib.load().cvx_t2s_decode_persistent(C.byref(self._descriptor(temperature, batch, cfg_scale)), n,
                                                              self._stsync[MAX_BATCH].data_ptr(), st), "cvx_t2s_decode_persistent")
@@ -198,6 +222,8 @@ class TextToSemanticDecoder:
         """state rows of the first nb utterances (the one host sync per chunk); raises if the persistent kernel reported a
         barrier timeout."""
         rows = self._stsync.tolist()
+        if self._xcd_ok:
+            self._check_xcd()
         if self.persistent and rows[MAX_BATCH][1] != 0:
             raise _lib.CovomixHipError("cvx_t2s_decode_persistent: a grid barrier timed out (a block was not resident); the decoded "
                                        "tokens of this chunk are invalid - set CVX_T2S_PERSISTENT=0 to use the per-launch path")
@@ -205,7 +231,7 @@ class TextToSemanticDecoder:
 
     def _run_chunk(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0) -> None:
         """CHUNK token steps on the current stream (one persistent launch, or a graph replay of the per-launch path)."""
-        if self.persistent:
+        if self.persistent or self._use_xcd(cfg_scale):
             self._steps(temperature, batch, CHUNK, cfg_scale)
             return
 

@@ -149,6 +149,7 @@ def test_persistent_kernel_is_bit_identical_to_per_launch_path(case):
     unis = [uni] + [torch.rand(uni.shape[0], S, V, generator=gen) for _ in texts[1:]]
     assert not model.persistent
     out = {}
+    saved_xcd, model.xcd = model.xcd, False          # (the reference point of this test is the per-launch path)
     try:
         for mode in (True, False):
             model.persistent = mode
@@ -158,8 +159,43 @@ def test_persistent_kernel_is_bit_identical_to_per_launch_path(case):
                          model.generate_batch(texts[:3], unis[:3], collect_logits=True))
     finally:
         model.persistent = False
+        model.xcd = saved_xcd
     p, q = out[True], out[False]
     assert torch.equal(p[0][2], q[0][2]) and torch.equal(p[0][0], q[0][0])             # logits and tokens, step by step
+    assert torch.equal(p[0][0].cpu(), torch.from_numpy(g["tokens"]))
+    assert torch.equal(p[1][0], q[1][0]) and torch.equal(p[1][1], q[1][1])
+    for a, b in zip(p[2], q[2]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for a, b in zip(p[3], q[3]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+def test_one_xcd_per_utterance_is_bit_identical_to_per_launch_path(case):
+    """cvx_t2s_decode_xcd (round 4: 8 groups of 32 blocks, an utterance per XCD, L2-local phase barriers without cache maintenance,
+    every activation read bypassing L1) against cvx_t2s_decode_steps: step logits and tokens BITWISE, batch 1 (stepwise and
+    chunked) and a full batch of 8 different texts; the placement probe must have accepted the XCD mode on this box."""
+    name, g, model = case
+    model._xcd_ok = None                                 # (probe again: the mode is opt-in)
+    src, uni = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
+    S, V = uni.shape[1], uni.shape[-1]
+    gen = torch.Generator().manual_seed(29)
+    texts = [src, src[:, :5], torch.cat((src, src[:, :7]), dim=1), src[:, 2:9], src[:, 1:], src[:, :3], src, src[:, 4:]]
+    unis = [uni] + [torch.rand(uni.shape[0], S, V, generator=gen) for _ in texts[1:]]
+    out = {}
+    saved = model.xcd
+    try:
+        for mode in (True, False):
+            model.xcd = mode
+            out[mode] = (model.generate(src, uniforms=uni, collect_logits=True),
+                         model.generate(src, uniforms=uni, return_streams=True),
+                         model.generate_batch(texts, unis),
+                         model.generate_batch(texts[:3], unis[:3], collect_logits=True))
+            if mode:
+                assert model._xcd_ok is True, "the placement probe refused the one-XCD-per-utterance mode on this box"
+    finally:
+        model.xcd = saved
+    p, q = out[True], out[False]
+    assert torch.equal(p[0][2], q[0][2]) and torch.equal(p[0][0], q[0][0])
     assert torch.equal(p[0][0].cpu(), torch.from_numpy(g["tokens"]))
     assert torch.equal(p[1][0], q[1][0]) and torch.equal(p[1][1], q[1][1])
     for a, b in zip(p[2], q[2]):
