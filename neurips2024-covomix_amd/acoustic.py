@@ -219,7 +219,7 @@ class VectorField:
         if ragged_rows:
             q = self.RAGGED_ROW_QUANTUM
             M = (ragged_rows + q - 1) // q * q
-            key = ("ragged", M, ragged_rows >= ops.il_min_rows(), ragged_rows < 2048)  # (the pair layouts below depend on the real row count)
+            key = ("ragged", M, ragged_rows >= ops.il_min_rows())  # (the interleaved-pair choice below depends on the real row count)
         else:
             M = Bt * T
             key = (Bt, T)
@@ -244,9 +244,8 @@ class VectorField:
             if lo_too and (ragged_rows or M) >= ops.il_min_rows() and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
                 a16 = lambda rows, cols: ops.SplitIL(rows, cols, dev)
             ws["normed16"], ws["att16"], ws["ff16"] = a16(M, d["dim"]), a16(M, d["heads"] * 64), a16(M, 4 * d["dim"])
-            # final norm -> to_pred (N = 80): the medium-problem kernel takes it with K slices (interleaved pair); 2048 rows and more: plain
-            # pair on the small-N kernel
-            ws["pred16"] = a16(M, d["dim"]) if (a16 is not h16 and (ragged_rows or M) < 2048 and d["dim_out"] % 16 == 0) else h16(M, d["dim"])
+            # final norm -> to_pred (N = 80): the medium-problem kernel takes it (interleaved pair; K slices below 2048 rows)
+            ws["pred16"] = a16(M, d["dim"]) if (a16 is not h16 and d["dim_out"] % 16 == 0) else h16(M, d["dim"])
             ws["qk16"] = h16(M, 2 * d["heads"] * 64)
             ws["h16"] = [a16(M, d["dim"]) for _ in ws["h"]]      # split twins of the residual-stream buffers (skip GEMMs)
             # V^T rows, zero (always finite) beyond the last frame: read by the last key tile with weight 0

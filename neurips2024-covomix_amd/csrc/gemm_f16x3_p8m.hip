@@ -165,9 +165,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wid >> 2, w4 = wid & 3, wr = w4 >> 1, wc = w4 & 1;
     // unit = (column tile, K slice); XCD x owns units x, x + 8, ...: all row tiles of a unit back to back on one XCD
-    const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
-    const int unit = (q / tiles_m) * 8 + xcd, tm = q % tiles_m;
-    if (unit >= tiles_n * ksplit) return;
+    int unit, tm;
+    if (tiles_n * ksplit >= 8) {
+        const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+        unit = (q / tiles_m) * 8 + xcd; tm = q % tiles_m;
+    } else {                     // fewer W panels than XCDs (to_pred: N = 80): row tiles round-robin over the XCDs, every XCD reads the small W
+        unit = (int)blockIdx.x % (tiles_n * ksplit); tm = (int)blockIdx.x / (tiles_n * ksplit);
+    }
+    if (unit >= tiles_n * ksplit || tm >= tiles_m) return;
     const int tn = unit % tiles_n, ks = unit / tiles_n;
     const int m0 = tm * 128, n0 = tn * 128;
     cvx_gemm_args p = p_in;
@@ -278,7 +283,7 @@ bool launch_gemm_f16x3_p8m(const cvx_gemm_args& a, const PreSplitA& A, const f16
     if (s2.vt_hi && !(a2.rope_cos && s2.hi && !s2.write_f32 && !a2.residual && a2.act == CVX_ACT_NONE)) return false;   // V^T only in QKV form
     const int tn = (a.N + 127) / 128, tm = (a.M + 127) / 128;
     const int units = tn * (ksplit > 1 ? ksplit : 1);
-    const dim3 grid((unsigned)(((units + 7) / 8) * 8 * tm));
+    const dim3 grid((unsigned)(units >= 8 ? ((units + 7) / 8) * 8 * tm : units * tm));
     int epi = ksplit > 1 ? (int)EPI_BIAS : classify_epilogue(a2, s2);
     if (epi == EPI_QKV && a2.bias) epi = EPI_GENERIC;
     if (epi == EPI_GENERIC && s2.vt_hi) return false;
