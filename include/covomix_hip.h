@@ -32,6 +32,11 @@ extern "C" {
 
 typedef void* cvx_stream_t;   /* hipStream_t */
 
+/* ABI version of the library: CVX_ABI_VERSION of the header it was built from.  The argument structs carry no size field, so a
+ * caller built against another header version must not call in: compare once after loading (the ctypes binding does,
+ * covomix_amd/_lib.py).  104: round 4 (cvx_gemm_f16x3_norm, caller-owned saturation flags, cvx_t2s_decoder.cfg_scale,
+ * cvx_t2s_decode_xcd, CVX_GEMM_FLAG_MEDIUM / _NO_MEDIUM). */
+#define CVX_ABI_VERSION 104
 int         cvx_version(void);
 const char* cvx_last_error_string(void);
 

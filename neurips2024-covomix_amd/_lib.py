@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB_PATH") or os.path.join(_HERE, "libcovomix_hip.so")      # CVX_LIB_PATH: dev A/B builds
 
 _f32p = C.POINTER(C.c_float)
+ABI_VERSION = 104          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
 
 
 class GemmArgs(C.Structure):
@@ -279,6 +280,10 @@ def load() -> C.CDLL:
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "covomix_amd has no CPU / PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
+    lib.cvx_version.restype = C.c_int
+    if lib.cvx_version() != ABI_VERSION:          # struct layouts below are this version's (the C structs carry no size field)
+        raise CovomixHipError(f"{LIB_PATH} reports ABI version {lib.cvx_version()}, this binding is written for {ABI_VERSION}: "
+                              "rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI drift; let it propagate
         fn.restype = res

@@ -108,7 +108,7 @@ extern "C" int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_
     if (reset && hipMemsetAsync(f, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
     return CVX_OK;
 }
-extern "C" int cvx_version(void) { return 103; }
+extern "C" int cvx_version(void) { return CVX_ABI_VERSION; }
 
 namespace {
 
