@@ -81,6 +81,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if single_device_test_mode():
         backend, local = "gloo", 0
+    elif os.environ.get("CVX_DP_RCCL_ON_ONE_DEVICE", "0") == "1":
+        local = 0           # TEST ONLY: every rank on cuda:0 but RCCL still requested - it must refuse (duplicate GPU) and the start-up
+                            # path must fall back to gloo with the reason in INFO (tests/test_multirank_gpu.py)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
@@ -125,7 +128,7 @@ def rccl_group():
     import datetime
     ok, err, g = 1.0, None, None
     try:
-        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("CVX_DP_RCCL_TIMEOUT_S", "180"))))
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe, group=g)
         torch.cuda.synchronize()

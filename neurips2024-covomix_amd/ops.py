@@ -73,6 +73,7 @@ _GEMM_FLAGS = {"1": 0, "32": 2, "0": 1, "1t": 4}.get(__import__("os").environ.ge
 # CVX_GEMM_MEDIUM_AUTO=0: 2048 rows and more always on the large-problem kernel (flag 16), =force: always on the medium one (8);
 # default: the library picks by how full the large kernel's last round of tiles would be
 _GEMM_FLAGS |= {"0": 16, "force": 8}.get(__import__("os").environ.get("CVX_GEMM_MEDIUM_AUTO", "1"), 0)
+_GEMM_FLAGS |= int(__import__("os").environ.get("CVX_GEMM_FLAGS_EXTRA", "0"), 0)      # dev builds (-DCVX_DEV_FLAGS): 0x10000 no K slices, 0x20000 at most two
 
 _SPLITK_WS: dict = {}
 
