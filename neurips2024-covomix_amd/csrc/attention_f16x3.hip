@@ -71,6 +71,9 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 #ifndef CVX_ATT_ABLATE
 #define CVX_ATT_ABLATE 0
 #endif
+#ifndef CVX_ATT_SHORT_NW2
+#define CVX_ATT_SHORT_NW2 1
+#endif
 // NW = waves per block (4 or 8), 32 queries each.  The K / V^T tiles a block streams through LDS are shared by its waves:
 // with 8 waves (256 queries) the L2 -> LDS DMA bytes per score halve.  Round-3 ablations (tools/attn_ablate.py, Bt = 16,
 // T = 1000, H = 16, NW = 4): DMA switched off after the first tile 177 instead of 211 us and 0.233
@@ -83,7 +86,7 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 // through LDS in the fixed order 0, 1, 2 (the flash-decoding combine: O = sum O_s 2^(m_s - m), l likewise) before it normalises
 // and stores.  The chain shortens KS-fold and every SIMD holds KS waves to overlap.
 template <int NT, int NW, int KS = 1>
-__global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? KS : CVX_ATT_WAVES)) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
+__global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? (NW * KS + 3) / 4 : CVX_ATT_WAVES)) void attention_f16x3_kernel(const f16* __restrict__ qk_hi, const f16* __restrict__ qk_lo,
                                                                 const f16* __restrict__ vt_hi, const f16* __restrict__ vt_lo,
                                                                 float* __restrict__ out, f16* __restrict__ out_hi, f16* __restrict__ out_lo,
                                                                 int T, int Tp, int H, int n_groups, int n_qt, float scale_log2e,
@@ -136,26 +139,36 @@ __global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? KS : CVX_ATT_WAVES)) void a
 
     // ---- DMA sources.  NW = 4: wave w fetches K rows [8w, 8w+8) (hi, lo) and V^T rows [16w, 16w+16) (hi, lo): 4 pieces per
     // tile and wave.  NW = 8: waves 0-3 fetch the K pieces, waves 4-7 the V^T pieces (2 per tile and wave).
-    const int wq = wid & 3;
-    const bool dma_k = NW == 4 || wid < 4, dma_v = NW == 4 || wid >= 4;
-    const int k_r = 8 * wq + (lane >> 3);                                   // key row inside the tile
-    const int k_c = (lane & 7) ^ ((k_r >> 1) & 7);                          // source chunk for LDS chunk (lane & 7)
-    const int64_t k_col = (int64_t)H * HD + head * HD + 8 * k_c;
-    const int v_r = 16 * wq + (lane >> 2);                                  // head-dim row inside the tile
-    const int v_c = (lane & 3) ^ ((v_r >> 2) & 3);
-    const int64_t v_row = ((int64_t)vt_grp * HD + v_r) * Tp + 8 * v_c;
+    // NW = 2 (64-query blocks of the key-split form): every wave fetches two of the four row groups of K and of V^T.
+    constexpr int PW = NW == 2 ? 2 : 1;                                     // row groups per wave
+    const int wq = NW == 2 ? 2 * wid : (wid & 3);
+    const bool dma_k = NW <= 4 || wid < 4, dma_v = NW <= 4 || wid >= 4;
+    int k_r[PW], k_c[PW], v_r[PW], v_c[PW];
+    int64_t k_col[PW], v_row[PW];
+#pragma unroll
+    for (int pp = 0; pp < PW; ++pp) {
+        k_r[pp] = 8 * (wq + pp) + (lane >> 3);                              // key row inside the tile
+        k_c[pp] = (lane & 7) ^ ((k_r[pp] >> 1) & 7);                        // source chunk for LDS chunk (lane & 7)
+        k_col[pp] = (int64_t)H * HD + head * HD + 8 * k_c[pp];
+        v_r[pp] = 16 * (wq + pp) + (lane >> 2);                             // head-dim row inside the tile
+        v_c[pp] = (lane & 3) ^ ((v_r[pp] >> 2) & 3);
+        v_row[pp] = ((int64_t)vt_grp * HD + v_r[pp]) * Tp + 8 * v_c[pp];
+    }
     auto issue = [&](int key0, int stage) {
         f16* S = smem + stage * STAGE;
-        if (dma_k) {                                                        // (wave-uniform)
-            const int key = min(max(key0 + k_r, kc0), kc1 - 1);
-            const int64_t ko = (roff + key) * ldqk + k_col;
-            glds16(qk_hi + ko, S + 8 * wq * HD);
-            if constexpr (NT == 3) glds16(qk_lo + ko, S + TILE + 8 * wq * HD);
-        }
-        if (dma_v) {
-            const int64_t vo = v_row + key0;
-            glds16(vt_hi + vo, S + 2 * TILE + 16 * wq * KT);
-            if constexpr (NT == 3) glds16(vt_lo + vo, S + 3 * TILE + 16 * wq * KT);
+#pragma unroll
+        for (int pp = 0; pp < PW; ++pp) {
+            if (dma_k) {                                                    // (wave-uniform)
+                const int key = min(max(key0 + k_r[pp], kc0), kc1 - 1);
+                const int64_t ko = (roff + key) * ldqk + k_col[pp];
+                glds16(qk_hi + ko, S + 8 * (wq + pp) * HD);
+                if constexpr (NT == 3) glds16(qk_lo + ko, S + TILE + 8 * (wq + pp) * HD);
+            }
+            if (dma_v) {
+                const int64_t vo = v_row[pp] + key0;
+                glds16(vt_hi + vo, S + 2 * TILE + 16 * (wq + pp) * KT);
+                if constexpr (NT == 3) glds16(vt_lo + vo, S + 3 * TILE + 16 * (wq + pp) * KT);
+            }
         }
     };
 
@@ -164,11 +177,11 @@ __global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? KS : CVX_ATT_WAVES)) void a
     // computed and VGPR -> LDS (same swizzled layout) behind its last MFMA, instead of by LDS-DMA.  NW = 4 only.
     f16x8 st_kh, st_kl, st_vh, st_vl;
     auto fetch = [&](int key0) {
-        const int key = min(max(key0 + k_r, kc0), kc1 - 1);
-        const int64_t ko = (roff + key) * ldqk + k_col;
+        const int key = min(max(key0 + k_r[0], kc0), kc1 - 1);
+        const int64_t ko = (roff + key) * ldqk + k_col[0];
         st_kh = gload8h(qk_hi + ko);
         if constexpr (NT == 3) st_kl = gload8h(qk_lo + ko);
-        const int64_t vo = v_row + key0;
+        const int64_t vo = v_row[0] + key0;
         st_vh = gload8h(vt_hi + vo);
         if constexpr (NT == 3) st_vl = gload8h(vt_lo + vo);
     };
@@ -455,15 +468,27 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
 #else
     const int nw = 4;
 #endif
-    const int qb = 32 * nw;
-    const int n_qt = (T + qb - 1) / qb, n_groups = Bt * H;
+    int qb = 32 * nw;
+    int n_qt = (T + qb - 1) / qb;
+    const int n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     uint32_t* sat = cvx_sat_flag_for(s);
-    // key-split groups for short launches (see the kernel): three when the grid leaves every CU with at most one block (96 KiB of
-    // LDS).  Fewer than 256 blocks = fewer than 2048 query rows: the halves of the two-chain schedule (>= 2048 rows each) and the
-    // whole batch always agree on the variant, so that schedule stays bit-identical to the single chain.
-    int ksplit = 1;
-    if (nw == 4 && T >= 4 * KT && grid.x < 256) ksplit = 3;
+    // key-split groups for short launches (see the kernel): fewer than 2048 query rows = at most one 128-query block per CU (96 KiB of
+    // LDS with three groups).  The halves of the two-chain schedule (>= 2048 rows each) and the whole batch always agree on the
+    // variant, so that schedule stays bit-identical to the single chain.
+    int ksplit = 1, nwk = 4;
+    const int64_t q_rows = cu_seqlens_dev ? cols : (int64_t)Bt * T;             // query rows of the launch
+    if (nw == 4 && T >= 4 * KT && q_rows < 2048) {
+        ksplit = 3;
+#if CVX_ATT_SHORT_NW2
+        // half of the chip's SIMDs hold no wave at all when the 128-query blocks number fewer than 128: 64-query blocks (two query waves,
+        // four key groups: 8 waves per block) put a wave on every SIMD
+        if (grid.x <= 128) {
+            nwk = 2; ksplit = 4; qb = 64; n_qt = (T + qb - 1) / qb;
+            grid = dim3((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
+        }
+#endif
+    }
 #ifdef CVX_DEV_FLAGS          // (dev builds only: the shipped library reads no environment variable)
     static const bool no_ks = getenv("CVX_ATT_KS") && atoi(getenv("CVX_ATT_KS")) == 0;
     if (no_ks) ksplit = 1;
@@ -474,16 +499,19 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
                        reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
                        out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
                        T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
-#define CVX_ATT_LAUNCH_KS(NT_, KS_)                                                                                                       \
-    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, 4, KS_>), grid, dim3(256 * KS_), 0, reinterpret_cast<hipStream_t>(s),                    \
+#define CVX_ATT_LAUNCH_KS(NT_, KS_) CVX_ATT_LAUNCH_KW(NT_, 4, KS_)
+#define CVX_ATT_LAUNCH_KW(NT_, NW_, KS_)                                                                                                  \
+    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_, KS_>), grid, dim3(64 * NW_ * KS_), 0, reinterpret_cast<hipStream_t>(s),              \
                        reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
                        reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
                        out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
                        T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
-    if (ksplit == 3) { if (single) CVX_ATT_LAUNCH_KS(1, 3); else CVX_ATT_LAUNCH_KS(3, 3); }
+    if (nwk == 2) { if (single) CVX_ATT_LAUNCH_KW(1, 2, 4); else CVX_ATT_LAUNCH_KW(3, 2, 4); }
+    else if (ksplit == 3) { if (single) CVX_ATT_LAUNCH_KS(1, 3); else CVX_ATT_LAUNCH_KS(3, 3); }
     else if (single) { if (nw == 8) CVX_ATT_LAUNCH(1, 8); else CVX_ATT_LAUNCH(1, 4); }
     else { if (nw == 8) CVX_ATT_LAUNCH(3, 8); else CVX_ATT_LAUNCH(3, 4); }
 #undef CVX_ATT_LAUNCH_KS
+#undef CVX_ATT_LAUNCH_KW
 #undef CVX_ATT_LAUNCH
     CVX_CHECK_LAUNCH("cvx_attention_f16x3");
     return CVX_OK;

@@ -39,6 +39,9 @@ constexpr int MLDS_B = NBUF * MBUF_B;              // 160 KiB
 #else
 #define CVX_P8M_STAMP(i) do { } while (0)
 #endif
+#ifndef CVX_P8M_DMA_FIRST
+#define CVX_P8M_DMA_FIRST 0         // dev A/B: the load segment requests K-tile t + 4 before (1) or after (0) its 16 fragment reads
+#endif
 #define CVX_P8M_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define CVX_P8M_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define CVX_P8M_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -112,6 +115,10 @@ __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const Pr
     for (int it = 0; it < nit; ++it, t += 2) {
         // ---- load segment (the other group multiplies): fragments of K-tile t, request K-tile t + 4
         const char* sb = smem + bi * MBUF_B;
+        const int bn = bi + 4 >= NBUF ? bi + 4 - NBUF : bi + 4;
+#if CVX_P8M_DMA_FIRST
+        issue(t + 4, bn);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fbh[i] = *reinterpret_cast<const f16x8*>(sb + i * 16 * 128 + boh);
@@ -122,8 +129,9 @@ __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const Pr
             fah[i] = *reinterpret_cast<const f16x8*>(sb + i * 16 * 128 + aoh);
             fal[i] = *reinterpret_cast<const f16x8*>(sb + i * 16 * 128 + aol);
         }
-        const int bn = bi + 4 >= NBUF ? bi + 4 - NBUF : bi + 4;
+#if !CVX_P8M_DMA_FIRST
         issue(t + 4, bn);
+#endif
         CVX_P8M_WAIT_LDS();
         CVX_P8M_BARRIER();
         // ---- compute segment: 4 x 4 tiles x three terms = 48 MFMAs, term-major (consecutive MFMAs hit different accumulators)
