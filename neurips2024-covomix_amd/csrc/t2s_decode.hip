@@ -255,21 +255,30 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
     }
 }
 
-template <int MODE, int BQ>
+// PPW = row pairs per wave (1; 2 is a measured A/B, see CVX_T2S_PPW below).  Every block stages all BQ input vectors (BQ x Kin floats
+// from the L2) for its 4 x PPW row pairs.  Per-pair arithmetic does not depend on PPW: same bits.
+template <int MODE, int BQ, int PPW>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];         // [BQ][Kin] (Kin a multiple of 4)
     __shared__ float red[BQ][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per utterance
-    const int pair = blockIdx.x * 4 + wid;                              // every wave owns TWO output rows
+    const int pair = (blockIdx.x * 4 + wid) * PPW;                      // every wave owns TWO output rows per pair
     // weights first: their HBM / MALL round trip overlaps the staging of x below (the step is a chain of 34 dependent
     // launches; every microsecond of latency counts)
     RowPrefetch pf;
     prefetch_pair<MODE>(a, pair, lane, pf);
     float inv[BQ];
     stage_input<BQ>(a, Kin, xs, red, inv);
-    gemv_pair<MODE, BQ, true>(a, pair, xs, Kin, inv, pf);
+    if constexpr (PPW == 1) {
+        gemv_pair<MODE, BQ, true>(a, pair, xs, Kin, inv, pf);
+    } else {
+        RowPrefetch pf2;
+        prefetch_pair<MODE>(a, pair + 1, lane, pf2);
+        gemv_pair<MODE, BQ, true>(a, pair, xs, Kin, inv, pf);
+        gemv_pair<MODE, BQ, true>(a, pair + 1, xs, Kin, inv, pf2);
+    }
 }
 
 // ---------------------------------------------------------------- attention of ONE query over n cached keys
@@ -810,14 +819,18 @@ __global__ __launch_bounds__(256) void t2s_xcd_kernel(const PersistArgs P)
     }
 }
 
+#ifndef CVX_T2S_PPW
+#define CVX_T2S_PPW 1          // measured (round 4): 2 pairs per wave at batch 8 is SLOWER (394 vs 285 us per CoSingle step): half the blocks, half the
+#endif                         // rows in flight - the step is bound by how many weight rows are outstanding, not by the staging of x
 template <int MODE, int BQ>
 void launch_gemv_b(const GemvArgs& g, int pairs, hipStream_t st)
 {
     const int Kin = (MODE == MODE_LOGITS) ? g.K * g.streams : g.K;
     const size_t lds = sizeof(float) * (size_t)BQ * Kin;
+    constexpr int PPW = BQ >= 4 ? CVX_T2S_PPW : 1;
     if (lds > 48 * 1024)          // per-(device, kernel) bookkeeping, mutex-protected (cvx_common.h)
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ>), (int)lds);
-    hipLaunchKernelGGL((gemv_kernel<MODE, BQ>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), lds, st, g);
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ, PPW>), (int)lds);
+    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3((unsigned)((pairs + 4 * PPW - 1) / (4 * PPW))), dim3(256), lds, st, g);
 }
 
 template <int MODE>
