@@ -584,6 +584,7 @@ class FlowMatchingSampler:
                 ops._GEMM_FLAGS = saved_flags
         return ctx
 
+    @ops.gated
     @torch.no_grad()
     def sample(self, *, phoneme_ids: torch.Tensor, cond: torch.Tensor, mask: Optional[torch.Tensor] = None,
                cond_scale: float = 1.0, y0: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -619,15 +620,17 @@ class FlowMatchingSampler:
             st = dict(ids=phoneme_ids.clone(), cond=cond.clone(), y=y.clone(), times=times.to(dev))
             ctx = self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)   # eager warm-up
             st["ws"] = ctx["ws"]             # keep this shape's workspace alive for as long as the graph is
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            if getattr(self, "_cap", None) is None:
-                self._cap = torch.cuda.Stream(device=dev)
-            ops.saturation_share(main, self._cap)        # the captured launches report into the calling stream's flag
-            # (thread-local capture mode: another host thread driving its own model on this device - its allocations and
-            #  synchronisations are "unsafe calls" under the default global mode - must not break this capture, nor be broken by it)
-            with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
-                self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)
+            # (thread-local capture mode + the package's capture gate: another host thread driving its own model on this device
+            #  must not break this capture, nor be broken by it - HIP rejects its synchronisations while a capture is open even
+            #  in thread-local mode, so the capture waits until the package's other entry points have left; ops._CaptureGate)
+            with ops.CAPTURE_GATE.exclusive():
+                main.synchronize()
+                g = torch.cuda.CUDAGraph()
+                if getattr(self, "_cap", None) is None:
+                    self._cap = torch.cuda.Stream(device=dev)
+                ops.saturation_share(main, self._cap)    # the captured launches report into the calling stream's flag
+                with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
+                    self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)
             if len(cache) >= self.GRAPH_CACHE:
                 cache.pop(next(iter(cache)))
             ent = cache[key] = (g, st)
@@ -638,6 +641,7 @@ class FlowMatchingSampler:
         g.replay()
         return st["y"].clone()
 
+    @ops.gated
     @torch.no_grad()
     def sample_ragged(self, *, phoneme_ids: List[torch.Tensor], cond: List[torch.Tensor], cond_scale: float = 1.0,
                       y0: Optional[List[torch.Tensor]] = None) -> List[torch.Tensor]:

@@ -30,6 +30,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import ops
 from .acoustic import FlowMatchingSampler, VectorField
 
 _PREFIX = "cfm_wrapper.CoVoMix."
@@ -159,6 +160,7 @@ class CoVoMixModel:
         return self._field
 
     # ---- sampling -----------------------------------------------------------------------------
+    @ops.gated
     @torch.no_grad()
     def synthesis_sample(self, phoneme_ids, cond, mask, cond_scale, y0=None):
         """reference conditional_model.py:295-302 -> ConditionalFlowMatcherWrapper.sample.
@@ -221,6 +223,7 @@ class CoVoMixModel:
             self._t2s = TextToSemanticDecoder(self.active_state_dict(), self.device)
         return self._t2s
 
+    @ops.gated
     @torch.no_grad()
     def synthesis_sample_text2semantic(self, grapheme_token_ids, temprature=1.0, cond_scale=1.0, beam_search_decode=False,
                                        prompt_mel=None, uniforms=None, generator=None, max_length=None):

@@ -43,9 +43,9 @@ __device__ __forceinline__ f16x8 gload8h(const f16* p)
     return *reinterpret_cast<gp>(reinterpret_cast<uintptr_t>(p));
 }
 
-__device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, const f32x4 o, float& amax)
+__device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, const f32x4 o, CvxSat& amax)
 {
-    amax = cvx_amax4(amax, o);
+    cvx_amax4(amax, o);
     // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
     // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
     if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? (NW * KS + 3) / 4 : CVX_ATT
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot / (v_scale ? *v_scale : 1.f);        // fp32 output: the true value
     const float osc = out_scale ? *out_scale : 1.f;                        // split output: times the consumer's pre-scale
-    float amax = 0.f;
+    CvxSat amax;
     if (q_valid) {
         const int64_t o_off = q_grow * (H * HD) + head * HD + 4 * g;
 #pragma unroll
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * NW * KS, (KS > 1 ? (NW * KS + 3) / 4 : CVX_ATT
         }
     }
     // a non-finite normaliser (overflowed scores, all-masked row) also means the result cannot be trusted: flag it
-    if (!(l_tot > 0.f && l_tot < __builtin_inff())) amax = __builtin_inff();
+    if (!(l_tot > 0.f && l_tot < __builtin_inff())) amax.bad = true;
     cvx_sat_commit(sat, amax);
 }
 

@@ -28,9 +28,9 @@ constexpr int K_LD = HD + 4;    // padded K row in LDS (floats): conflict-free d
 constexpr int V_LD = HD;
 
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, float& amax)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, CvxSat& amax)
 {
-    amax = cvx_amax4(amax, o);
+    cvx_amax4(amax, o);
     // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
     // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
     if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
     // ---- normalise and store: lane holds O[q][d] for d = dt*32 + (r&3) + 8*(r>>2) + 4*half
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    float amax = 0.f;
+    CvxSat amax;
     if (q_valid) {
         const int64_t o_off = (row0 + qrow) * (H * HD) + head * HD + 4 * half;
 #pragma unroll

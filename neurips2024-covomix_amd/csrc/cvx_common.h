@@ -54,31 +54,49 @@ __device__ __forceinline__ int cvx_item_len(const cvx_item_lengths& it, int b, i
     return it.item_len_dev ? min(L, max(0, it.item_len_dev[b] * it.mul + it.add)) : L;
 }
 
+// Saturation bookkeeping of the values a lane stores as split pairs: the running max |v| and a NaN bit.  The clamps
+// (v_med3 / fmin(fmax)) turn a NaN into -65504 and v_max3 skips NaN operands, so NaN needs its own predicate: one v_cmp_u_f32
+// per two values into a scalar mask (no vector register).  -DCVX_NO_NAN_TRACK: dev A/B of what that costs.
+struct CvxSat {
+    float m; bool bad;
+    __device__ __forceinline__ CvxSat() : m(0.f), bad(false) {}
+};
 // max(m, |a|, |b|) in ONE instruction (fmaxf would add a canonicalising v_max per operand in IEEE mode and, in the big unrolled
 // GEMM epilogues, enough live values to spill)
-__device__ __forceinline__ float cvx_amax3(float m, const float a, const float b)
+__device__ __forceinline__ void cvx_amax3(CvxSat& s, const float a, const float b)
 {
 #ifndef CVX_NO_SAT_TRACK                      // (dev A/B: what the bookkeeping costs)
-    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(s.m) : "v"(a), "v"(b));
+#ifndef CVX_NO_NAN_TRACK
+    s.bad |= __builtin_isunordered(a, b);
 #endif
-    return m;
+#endif
 }
-// max |.| bookkeeping of the values a lane stores as split pairs, and the commit (one atomic, only when saturated)
-__device__ __forceinline__ float cvx_amax4(float m, const f32x4 v)
+__device__ __forceinline__ void cvx_amax4(CvxSat& s, const f32x4 v)
 {
-    return cvx_amax3(cvx_amax3(m, v[0], v[1]), v[2], v[3]);
+    cvx_amax3(s, v[0], v[1]);
+    cvx_amax3(s, v[2], v[3]);
 }
-// the same in plain C for the 32 x 32 GEMM epilogues of gemm_common.h: there the inline asm (opaque to the optimiser) made the
-// compiler keep a 576-byte copy of the accumulator block in scratch in every kernel that carries the generic epilogue
-// (round 3: the opt-in f16 mode lost 22 % to it before this was found)
+// the same in plain C on one float for the 32 x 32 GEMM epilogues of gemm_common.h: there the inline asm (opaque to the
+// optimiser) made the compiler keep a 576-byte copy of the accumulator block in scratch in every kernel that carries the generic
+// epilogue (round 3: the opt-in f16 mode lost 22 % to it before this was found).  A value that is not <= 65504 in magnitude
+// (too large, infinite or NaN) makes the running maximum infinite.
 #ifndef CVX_NO_SAT_TRACK
-__device__ __forceinline__ float cvx_amax3_c(float m, const float a, const float b) { return fmaxf(m, fmaxf(fabsf(a), fabsf(b))); }
+__device__ __forceinline__ float cvx_amax3_c(float m, const float a, const float b)
+{
+    return (fabsf(a) <= 65504.f && fabsf(b) <= 65504.f) ? m : __builtin_inff();
+}
 #else
 __device__ __forceinline__ float cvx_amax3_c(float m, const float, const float) { return m; }
 #endif
+// the commit: one atomic, only when saturated (a NaN maximum counts: "not <=", so a direct cvx_sat_commit(flag, |v|) is covered too)
 __device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, float amax)
 {
-    if (flag && amax > 65504.f) atomicOr(flag, 1u);
+    if (flag && !(amax <= 65504.f)) atomicOr(flag, 1u);
+}
+__device__ __forceinline__ void cvx_sat_commit(uint32_t* flag, const CvxSat& s)
+{
+    if (flag && (s.m > 65504.f || s.bad)) atomicOr(flag, 1u);
 }
 
 // the same, NON-TEMPORAL (global_load_dwordx4 ... nt): for weight rows that ONE CU reads once per pass (batch-1 decode GEMVs) -

@@ -124,9 +124,9 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 #define CVX_NORM_NT 0          // dev A/B: bit 0 = non-temporal loads of x, bit 1 = non-temporal stores of the split pair (AdaRMSNorm)
 #endif
 // split 4 floats into fp16 (hi, lo) and store 8 bytes each (for GEMMs that take their A operand pre-split)
-__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, float& amax)
+__device__ __forceinline__ void store_split4(_Float16* hi, _Float16* lo, int64_t off, const f32x4 o, CvxSat& amax)
 {
-    amax = cvx_amax4(amax, o);
+    cvx_amax4(amax, o);
     // lo == hi + 32: INTERLEAVED pair, [hi 32 | lo 32] per block of 32 values (one 128-byte line per K-step and row for
     // the consumer GEMM's DMA); the mapping is a function of the flat offset because every row is a multiple of 32 wide
     if (lo == hi + 32) off = ((off >> 5) << 6) | (off & 31);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float amax = 0.f;
+    CvxSat amax;
     const float ssc = split_scale ? *split_scale : 1.f;      // power-of-two pre-scale of the split copy (device scalar)
     const float* xr = x + row * D;
     const int64_t g = row / rows_per_group;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void adarmsnorm_generic_kernel(const float* __
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float amax = 0.f;
+    CvxSat amax;
     const float ssc = split_scale ? *split_scale : 1.f;
     const float* xr = x + row * D;
     const int64_t g = row / rows_per_group;

@@ -28,7 +28,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo, floa
 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        amax = fmaxf(amax, fabsf(v[e] * pre));
+        amax = cvx_amax3_c(amax, v[e] * pre, v[e] * pre);
         const float x = fminf(fmaxf(v[e] * pre, -F16_MAX), F16_MAX);     // saturate instead of inf - inf
         const f16 h = (f16)x;
         hi[e] = h;
@@ -648,9 +648,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // split pair feeds the next GEMM (cvx_gemm_f16x3_norm): the arithmetic of splitk_reduce_kernel (act == NONE) and of
 // adarmsnorm_kernel<NV> (elementwise.hip), operation for operation, on the registers that hold the finished row.
 typedef _Float16 f16x4_r __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_split4_r(_Float16* hi, _Float16* lo, int64_t row_off, int col, const f32x4 o, float& amax)
+__device__ __forceinline__ void store_split4_r(_Float16* hi, _Float16* lo, int64_t row_off, int col, const f32x4 o, CvxSat& amax)
 {
-    amax = cvx_amax4(amax, o);
+    cvx_amax4(amax, o);
     const int64_t off = row_off + ((lo == hi + 32) ? il_col(col) : col);
     f16x4_r h, l;
 #pragma unroll
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64 * NW) void splitk_reduce_norm_kernel(const float
     }
     const float cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
     const float ys = nm.y_scale_dev ? *nm.y_scale_dev : 1.f;
-    float amax = 0.f;
+    CvxSat amax;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float x = v[e] + (p.bias ? bi[e] : 0.f);

@@ -52,14 +52,14 @@ __device__ __forceinline__ f32x2 mul2_rn(const f32x2 a, const f32x2 b) { return 
 
 // (hi, lo) fp16 halves of two fp32 values, saturating: v_med3 clamp, packed RNE conversion, exact residual x - hi by
 // v_fma_mix_f32 straight from the packed halves, packed conversion of the residuals
-__device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, float& amax)
+__device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, CvxSat& amax)
 {
 #if CVX_P8S_AMAX == 1                          // dev A/B of the saturation bookkeeping: plain C
-    amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    amax.m = fmaxf(amax.m, fmaxf(fabsf(v[0]), fabsf(v[1])));
 #elif CVX_P8S_AMAX == 2                        // on the clamped values' bit patterns (integer max of the magnitudes)
-    amax = __builtin_bit_cast(float, max(__builtin_bit_cast(unsigned, amax), max(__builtin_bit_cast(unsigned, v[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[1]) & 0x7fffffffu)));
+    amax.m = __builtin_bit_cast(float, max(__builtin_bit_cast(unsigned, amax.m), max(__builtin_bit_cast(unsigned, v[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, v[1]) & 0x7fffffffu)));
 #else
-    amax = cvx_amax3(amax, v[0], v[1]);
+    cvx_amax3(amax, v[0], v[1]);
 #endif
     const float x0 = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), x1 = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
     hi = __builtin_convertvector(f32x2{x0, x1}, f16x2);
@@ -69,7 +69,7 @@ __device__ __forceinline__ void split2_pk(const f32x2 v, f16x2& hi, f16x2& lo, f
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
     lo = __builtin_convertvector(f32x2{r0, r1}, f16x2);
 }
-__device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, float& amax)
+__device__ __forceinline__ void split4_pk(const f32x4 v, f16x4& hi, f16x4& lo, CvxSat& amax)
 {
     f16x2 h01, h23, l01, l23;
     split2_pk(f32x2{v[0], v[1]}, h01, l01, amax);
@@ -147,7 +147,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     float cs;
     if constexpr (PRE) cs = pre->cs; else cs = (so.hi && so.c_scale) ? *so.c_scale : 1.f;
     const bool il = so.hi && so.lo == so.hi + 32;
-    float amax = 0.f;
+    CvxSat amax;
     const f32x2 sc2 = splat2(acc_scale), cs2 = splat2(cs);
     f32x2 bias[4][2];                           // [ni][pair]: columns col0 + 16 ni + lc + 2 pair + {0, 1}
 #pragma unroll
@@ -257,7 +257,7 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
     float vs0;
     if constexpr (PRE) vs0 = pre->vs; else vs0 = so.vt_scale ? *so.vt_scale : 1.f;
     const float vs = vs0 * acc_scale;
-    float amax = 0.f;
+    CvxSat amax;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int r0 = row0 + 16 * mi + 4 * (lane >> 4);

@@ -263,14 +263,14 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] *= p.out_scale;
                     *reinterpret_cast<f32x4*>(p.out_x + o) = w;
-                    omax = cvx_amax3_c(cvx_amax3_c(omax, w[0], w[1]), w[2], w[3]);
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
                 }
                 if (p.out_zhi) {
                     cvx_f16x4 zh, zl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float z = (v[e] > 0.f ? v[e] : v[e] * p.z_slope) * zs;
-                        amax = fmaxf(amax, fabsf(z));
+                        amax = cvx_amax3_c(amax, z, z);
                         z = fminf(fmaxf(z, -65504.f), 65504.f);
                         zh[e] = (_Float16)z;
                         zl[e] = (_Float16)(z - (float)zh[e]);
@@ -335,9 +335,9 @@ struct PairArgs {
 };
 
 // (hi, lo) fp16 halves of four fp32 values, saturating: v_med3 clamp, packed RNE conversions
-__device__ __forceinline__ void pair_split4(const f32x4 v, cvx_f16x4& hi, cvx_f16x4& lo, float& amax)
+__device__ __forceinline__ void pair_split4(const f32x4 v, cvx_f16x4& hi, cvx_f16x4& lo, CvxSat& amax)
 {
-    amax = cvx_amax4(amax, v);
+    cvx_amax4(amax, v);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     float x[4];
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, (TNI == 2 && NW == 8) ? 2 : NW / 2) void r
     const int wm = wid;                                   // 8 x 1 waves: 32 rows x all NP channels each
     const float zs = p.z_scale ? *p.z_scale : 1.f;
     const float a1 = p.acc1 / zs, a2 = p.acc2 / zs;       // (exact: powers of two)
-    float amax = 0.f;
+    CvxSat amax;
     const int k = p.ksize, h2 = (k - 1) / 2, pad1 = (k - 1) * p.dil / 2;
     const int tm_out = ROWS - 2 * h2;
     const int n_groups = (k + TS - 1) / TS;
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void cl_split_kernel(const float* __restrict__
                                                        int64_t n4, float slope, const float* __restrict__ z_scale, uint32_t* __restrict__ sat)
 {
     const float zs = z_scale ? *z_scale : 1.f;
-    float amax = 0.f;
+    CvxSat amax;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const f32x4 v = gload4(x + 4 * i);
         f32x4 z;

@@ -249,6 +249,7 @@ class HubertEncoder:
             x = ops.layernorm(y, *lyr["ln2"], out=x)
         return x
 
+    @ops.gated
     def extract_features(self, source: torch.Tensor, output_layer: Optional[int] = None) -> torch.Tensor:
         """HubertModel.extract_features(source [1, n] or [n], mask=False, output_layer) -> [T, D]."""
         wav = source.reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
@@ -356,6 +357,7 @@ class HubertFeatureReader:
             print(f"ref {ref_len} != read {len(wav)} ({path})")
         return np.ascontiguousarray(wav)
 
+    @ops.gated
     def get_feats(self, file_path, ref_len=None, channel_id=None):
         """-> [T, D] fp32 features of layer `self.layer` on the GPU.  `file_path` may also be a waveform array."""
         x = self.read_audio(file_path, ref_len, channel_id) if isinstance(file_path, str) else np.asarray(file_path, dtype=np.float32)
@@ -393,6 +395,7 @@ class ApplyKmeans(object):
         self.centers = torch.from_numpy(np.ascontiguousarray(np.asarray(centers), dtype=np.float32)).cuda()   # [K, D] = W of x.C
         self.Cnorm = torch.from_numpy(np.ascontiguousarray(self.Cnorm_np.reshape(-1), dtype=np.float32)).cuda()
 
+    @ops.gated
     def labels(self, x: torch.Tensor, with_margin: bool = False):
         x = x.to(device=self.centers.device, dtype=torch.float32).contiguous()
         dots = torch.empty(x.shape[0], self.centers.shape[0], dtype=torch.float32, device=x.device)
@@ -400,6 +403,7 @@ class ApplyKmeans(object):
             ops.gemm(x, self.centers, dots)
         return ops.kmeans_argmin(x, dots, self.Cnorm, with_margin=with_margin)
 
+    @ops.gated
     def __call__(self, x):
         if not isinstance(x, torch.Tensor):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))

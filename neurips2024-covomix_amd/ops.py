@@ -3,6 +3,9 @@ a stream here; every FLOP of the hot path happens in libcovomix_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import threading
+from contextlib import contextmanager
 from typing import Optional
 
 import torch
@@ -97,6 +100,84 @@ def _splitk_workspace(device) -> torch.Tensor:
         ws = torch.empty(4 * 2048 * 4096, dtype=torch.float32, device=dev)
         _SPLITK_WS[key] = ws
     return ws
+
+
+class _CaptureGate:
+    """Host threads vs stream capture.  HIP (ROCm 7.2) refuses device-wide synchronisation and synchronous copies from ANY host
+    thread while one thread captures a stream: thread-local capture mode does not shield the other threads the way CUDA's does
+    (measured: torch.cuda.synchronize() / .item() in thread B fail with hipErrorStreamCaptureUnsupported, thread A's capture
+    ends with hipErrorStreamCaptureInvalidated, sometimes the process aborts).  So the package serialises its captures against
+    its own entry points: an entry point (model upload, a solve, a vocoder call, a text2semantic decode) holds the gate SHARED
+    for its whole host side, a capture (once per shape and stream) holds it EXCLUSIVE.  Steady state - graph replays from many
+    threads - is unaffected (shared holders do not exclude each other).  A thread that holds the gate shared and reaches a
+    capture gives its share back while it waits, so two such threads cannot deadlock; new shared entries queue behind a
+    waiting capture so that it cannot starve.  Torch calls a caller makes from its OWN other threads are outside this gate."""
+
+    def __init__(self):
+        self._c = threading.Condition()
+        self._readers = 0
+        self._writer = False
+        self._waiting = 0
+        self._tl = threading.local()
+
+    @contextmanager
+    def shared(self):
+        tl = self._tl
+        d = getattr(tl, "depth", 0)
+        outer = d == 0 and not getattr(tl, "excl", False)
+        if outer:
+            with self._c:
+                while self._writer or self._waiting:
+                    self._c.wait()
+                self._readers += 1
+        tl.depth = d + 1
+        try:
+            yield
+        finally:
+            tl.depth = d
+            if outer:
+                with self._c:
+                    self._readers -= 1
+                    self._c.notify_all()
+
+    @contextmanager
+    def exclusive(self):
+        tl = self._tl
+        if getattr(tl, "excl", False):
+            yield
+            return
+        held = getattr(tl, "depth", 0) > 0
+        with self._c:
+            if held:
+                self._readers -= 1
+            self._waiting += 1
+            self._c.notify_all()
+            while self._writer or self._readers > 0:
+                self._c.wait()
+            self._waiting -= 1
+            self._writer = True
+        tl.excl = True
+        try:
+            yield
+        finally:
+            tl.excl = False
+            with self._c:
+                self._writer = False
+                if held:
+                    self._readers += 1
+                self._c.notify_all()
+
+
+CAPTURE_GATE = _CaptureGate()
+
+
+def gated(fn):
+    """Decorator: run the entry point with the capture gate held shared (see _CaptureGate)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with CAPTURE_GATE.shared():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 _CAPTURE_OWNER: dict = {}        # (device, side / capture stream) -> the stream whose call it serves (saturation_share)

@@ -250,10 +250,11 @@ class TextToSemanticDecoder:
             with torch.cuda.stream(side):
                 launch()                                   # warm-up outside capture (module load, attributes)
             torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                launch()
+            with ops.CAPTURE_GATE.exclusive():             # (no other entry point of the package syncs / copies meanwhile)
+                torch.cuda.current_stream().synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    launch()
             for k, v in saved.items():                     # capture does not execute, the warm-up did: restore
                 self.buf[k].copy_(v)
             for L, (kc, vc) in zip(self.dec, caches):
@@ -263,6 +264,7 @@ class TextToSemanticDecoder:
             self._graphs[(temperature, batch, cfg_scale)] = g
         g.replay()
 
+    @ops.gated
     @torch.no_grad()          # (not inference_mode: tensors torch creates lazily during the first graph capture,
                               #  e.g. the generator's graph-safe state, would become inference tensors)
     def generate_batch(self, sources, uniforms=None, max_length: Optional[int] = None, temperature: float = 1.0,
@@ -394,6 +396,7 @@ class TextToSemanticDecoder:
             out.append(item)
         return out
 
+    @ops.gated
     def generate(self, source_ids: torch.Tensor, uniforms: Optional[torch.Tensor] = None, max_length: Optional[int] = None,
                  temperature: float = 1.0, generator: Optional[torch.Generator] = None, return_streams: bool = False,
                  collect_logits: bool = False, cond_scale: float = 1.0):

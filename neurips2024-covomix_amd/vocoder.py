@@ -192,6 +192,7 @@ class Generator:
             mul, add = self._affine(c, mul, add)
         return mul * frames + add
 
+    @ops.gated
     @torch.no_grad()
     def __call__(self, mel: torch.Tensor, lengths=None) -> torch.Tensor:
         """mel [B, 80, T] -> [B, 1, L]  ([80, T] -> [1, L]), models.py:100-116.

@@ -369,3 +369,49 @@ def test_every_python_source_compiles():
     for f in ("bench.py", "__graft_entry__.py", "monologue_generation.py", "dialogue_generation.py", "covomix_amd.py"):
         assert compileall.compile_file(os.path.join(ROOT, f), quiet=1), f
     import covomix_amd.t2s, covomix_amd.generation, covomix_amd.hubert, covomix_amd.mel, covomix_amd.vocoder  # noqa: F401,E401
+
+
+def test_capture_gate_shared_entries_overlap_and_a_capture_is_alone():
+    """ops._CaptureGate (host threads vs stream capture on HIP): shared holders run together, an exclusive holder runs alone,
+    a thread that holds the gate shared can take it exclusive (two such threads at once: no deadlock), nested entries are free,
+    and a waiting capture is not starved by a stream of new shared entries."""
+    import threading
+    import time
+    import covomix_amd.ops as ops
+    gate = ops._CaptureGate()
+    state = dict(shared=0, excl=0, max_shared=0, bad=0, captures=0)
+    lock = threading.Lock()
+
+    def entry(i):
+        for k in range(40):
+            with gate.shared():
+                with lock:
+                    state["shared"] += 1
+                    state["max_shared"] = max(state["max_shared"], state["shared"])
+                    state["bad"] += state["excl"] != 0
+                with gate.shared():                      # nested (sample inside synthesis_sample)
+                    time.sleep(0.0005)
+                if k % 10 == i:                          # "first call of a shape": capture from inside the entry point
+                    with lock:
+                        state["shared"] -= 1
+                    with gate.exclusive():
+                        with lock:
+                            state["excl"] += 1
+                            state["bad"] += (state["excl"] != 1) + (state["shared"] != 0)
+                        with gate.shared(), gate.exclusive():
+                            time.sleep(0.001)
+                        with lock:
+                            state["excl"] -= 1
+                            state["captures"] += 1
+                    with lock:
+                        state["shared"] += 1
+                with lock:
+                    state["shared"] -= 1
+    ts = [threading.Thread(target=entry, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not any(t.is_alive() for t in ts), "deadlock"
+    assert state["bad"] == 0 and state["captures"] == 16 and state["max_shared"] >= 2, state
+    assert gate._readers == 0 and not gate._writer and gate._waiting == 0

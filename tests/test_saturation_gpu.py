@@ -82,6 +82,55 @@ def test_flag_is_raised_by_every_family_of_split_stores(ops):
     assert flagged(lambda: ops.attention_f16x3(qk, vt, None, Bt, T, H, 0.125, out_split=op, out_scale=one(2.0 ** 26))) != 0
 
 
+def test_nan_in_an_fp32_operand_raises_the_flag(ops):
+    """The clamps turn NaN into -65504 and v_max3 / fmaxf skip NaN operands (round-3 advice, cvx_common.h): without its own
+    predicate a NaN residual / bias / input would be stored as a finite pair with the flag down.  Every family of split stores
+    that takes an fp32 operand: one NaN in it -> flag up (and a clean repeat -> flag down)."""
+    dev_ = dev()
+    g = torch.Generator().manual_seed(1)
+    nan = float("nan")
+
+    def flagged(fn):
+        ops.saturation_reset()
+        fn()
+        return ops.saturation_query()
+    x = torch.randn(300, 256, generator=g).to(dev_)
+    bad = x.clone(); bad[11, 5] = nan
+    assert flagged(lambda: ops.split_act_f16(x)) == 0 and flagged(lambda: ops.split_act_f16(bad)) != 0
+    il = ops.SplitIL(300, 256, dev_)
+    assert flagged(lambda: ops.split_act_f16(x, il)) == 0 and flagged(lambda: ops.split_act_f16(bad, il)) != 0
+    gam, bet = torch.ones(256, device=dev_), torch.zeros(256, device=dev_)
+    pair = (torch.empty(300, 256, dtype=torch.float16, device=dev_), torch.empty(300, 256, dtype=torch.float16, device=dev_))
+    assert flagged(lambda: ops.adarmsnorm(x, gam, bet, None, out_split=pair)) == 0
+    assert flagged(lambda: ops.adarmsnorm(bad, gam, bet, None, out_split=pair)) != 0
+    badg = gam.clone(); badg[200] = nan
+    assert flagged(lambda: ops.adarmsnorm(x, badg, bet, None, out_split=pair)) != 0
+    # GEMM epilogues: generic (300 rows, flag 16), medium (300 rows interleaved) and large (2304 rows): NaN bias / NaN residual
+    for M, flags in ((300, 16), (300, 0), (2304, 16)):
+        a = torch.randn(M, 256, generator=g).to(dev_)
+        w = (torch.randn(512, 256, generator=g) / 16).to(dev_)
+        ws = ops.split_f16(w)
+        kw = dict(w_split=ws, a_split=ops.split_act_f16(a))
+        if M >= 2048 or flags == 0:
+            ail = ops.SplitIL(M, 256, dev_); ops.split_act_f16(a, ail)
+            kw = dict(w_split=ws, w_il=ops.split_f16_interleaved(ws), a_split=ail)
+        o = ops.SplitIL(M, 512, dev_) if "w_il" in kw else (torch.empty(M, 512, dtype=torch.float16, device=dev_), torch.empty(M, 512, dtype=torch.float16, device=dev_))
+        c = torch.empty(M, 512, device=dev_)
+        bias = torch.randn(512, generator=g).to(dev_)
+        res = torch.randn(M, 512, generator=g).to(dev_)
+        bbad = bias.clone(); bbad[300] = nan
+        rbad = res.clone(); rbad[M - 1, 17] = nan
+        old = ops._GEMM_FLAGS
+        ops._GEMM_FLAGS = old | flags
+        try:
+            assert flagged(lambda: ops.gemm(a, w, c, bias=bias, residual=res, out_split=o, **kw)) == 0, (M, flags)
+            assert flagged(lambda: ops.gemm(a, w, c, bias=bbad, residual=res, out_split=o, **kw)) != 0, (M, flags)
+            assert flagged(lambda: ops.gemm(a, w, c, bias=bias, residual=rbad, out_split=o, **kw)) != 0, (M, flags)
+            assert flagged(lambda: ops.gemm(a, w, c, bias=bbad, act=ops.ACT_GELU, out_split=o, write_f32=False, **kw)) != 0, (M, flags)
+        finally:
+            ops._GEMM_FLAGS = old
+
+
 def _full_width_state(kind="vomix"):
     import covomix_amd.synthetic as syn
     two = kind == "vomix"
@@ -156,6 +205,31 @@ def test_input_outside_the_window_is_rerun_in_fp32_or_raises(monkeypatch):
         warnings.simplefilter("error")
         ok = model.synthesis_sample(inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda(), 0.7, y0=inp["y0"])
     assert rel_l2(ok, orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2)) < 1e-5
+
+
+def test_nan_input_is_not_returned_as_a_finite_result(monkeypatch):
+    """One NaN in the prompt mel / in the vocoder's mel: the fp32 reference returns NaN; the split path used to return finite
+    numbers with the flag down (the clamps swallow NaN).  Now: flag -> fp32 re-run (NaN, like the reference) or a loud error."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd._lib import CovomixHipError
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _full_width_state()
+    inp = syn.synthetic_inputs("vomix", 1, 80, 40, seed=6)
+    cond = inp["cond"].clone(); cond[0, 33, 7] = float("nan")
+    model = CoVoMixModel.from_state_dict(sd, nfe=2).eval().to("cuda:0")
+    args = (inp["phoneme_ids"].cuda(), cond.cuda(), inp["mask"].cuda(), 0.7)
+    with pytest.warns(UserWarning, match="saturat"):
+        out = model.synthesis_sample(*args, y0=inp["y0"])
+    assert not torch.isfinite(out).all()
+    monkeypatch.setenv("CVX_ON_SATURATION", "raise")
+    with pytest.raises(CovomixHipError, match="saturat"):
+        model.synthesis_sample(*args, y0=inp["y0"])
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    mel = (torch.randn(1, 80, 50, generator=torch.Generator().manual_seed(4)) * 2 - 6).clamp(-11.52, 2.0)
+    mel[0, 40, 25] = float("nan")
+    with pytest.raises(CovomixHipError, match="saturat"):
+        _vocoder(h, vsd)(mel.cuda())
 
 
 def _vocoder(h, vsd, precision=None):
