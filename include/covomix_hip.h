@@ -465,7 +465,8 @@ int cvx_hifigan_post_channels_last_f32(const float* x_cl, const float* w, float 
                                        int32_t L, int32_t Lp, int32_t halo_l, float slope, cvx_stream_t s);
 /* *scale_dev = 2^round(log2(target / max|x|)) (1 when x is all zero; exponent clamped to +-40): the power-of-two factor that
  * brings the largest magnitude of x to about `target`.  Everything stays on the device (scratch_dev: one uint32 of
- * caller-owned scratch), so a consumer kernel can use the scale without a host round trip. */
+ * caller-owned scratch, any value before the call, ZERO after it - so the same word can serve as a producer's amax_bits_dev
+ * next), so a consumer kernel can use the scale without a host round trip. */
 int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, float* scale_dev, uint32_t* scratch_dev, cvx_stream_t s);
 
 /* ------------------------------------------------------------------------

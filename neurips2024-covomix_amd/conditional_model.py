@@ -184,7 +184,7 @@ class CoVoMixModel:
         # device's sticky saturation flag (include/covomix_hip.h).  One flag read per call (the only host synchronisation of
         # the solve); a flagged call is re-run on the exact-fp32 kernels (or raises: CVX_ON_SATURATION=raise) - never
         # returned as is.
-        checked = field.precision != "fp32" and os.environ.get("CVX_SAT_CHECK", "1") == "1" and (not ragged or len(cond) > 0)
+        checked = field.precision != "fp32" and ops.saturation_checked() and (not ragged or len(cond) > 0)
         if ragged and y0 is None and checked:       # a re-run must see the same noise
             y0 = [torch.randn(c.shape[0], field.d["dim_out"], device=self.device) for c in cond]
         elif not ragged and y0 is None and checked:

@@ -702,6 +702,10 @@ extern "C" int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, 
         hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, n, scratch_dev);
     }
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, scratch_dev, target, scale_dev);
+    // leave the scratch word ZERO, as cvx_pow2_scale_from_amax_f32 does: a producer kernel that max-accumulates into the same word
+    // afterwards (the vocoder's upsampler of the NEXT call) must not see this call's maximum (round 4: it did - the first call of
+    // a shape and the later ones differed by an fp32 rounding, and a call's scale depended on the previous call's input)
+    if (hipMemsetAsync(scratch_dev, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("amax_pow2_scale: memset failed"); return CVX_EHIP; }
     CVX_CHECK_LAUNCH("cvx_amax_pow2_scale_f32");
     return CVX_OK;
 }

@@ -312,9 +312,8 @@ def run(dialogue: bool, argv=None) -> int:
     # of ANY lengths share a launch sequence: packed back to back (no padding), every utterance attending to itself only
     # (sample_ragged), so each gets the result of its own B = 1 run.  Batches are FILLED to --max_frames (first-fit decreasing,
     # dp.pack_by_frames): the frames of a launch decide how many whole rounds of GEMM tiles it runs.
-    for batch in dp.pack_by_frames(list(range(len(items))), lengths, args.max_frames, args.max_batch):
-        y0 = [torch.randn(lengths[i], n_out, device=device, generator=torch.Generator(device=device).manual_seed(
-            _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch]        # acoustic.py:647-650, per utterance
+    def one_batch(batch, y0):
+        """acoustic solve + vocoder of one packed batch -> [(name, segment, int16 samples)], generated frames"""
         if len(set(lengths[i] for i in batch)) == 1:                                     # equal lengths: the plain [B, T, .] call
             sampled = list(model.synthesis_sample(phoneme_ids=torch.stack([items[i][0] for i in batch]).to(device),
                                                   cond=torch.stack([items[i][1] for i in batch]).to(device),
@@ -331,6 +330,7 @@ def run(dialogue: bool, argv=None) -> int:
         # (items of similar length only: the ragged vocoder call pads to its longest item and skips no work behind a short
         #  one, dp.group_by_padding keeps that padding below 25 % of the real frames)
         tg_all = [lengths[batch[j]] - n_prompt[j] for j in js]
+        out, nfr = [], 0
         for grp in dp.group_by_padding(tg_all):
             gj = [js[k] for k in grp]
             tgen = [tg_all[k] for k in grp]
@@ -339,10 +339,25 @@ def run(dialogue: bool, argv=None) -> int:
                 mel[r, :, : tgen[r]] = sampled[j][n_prompt[j]:, :].T
             wav = generator(mel, lengths=tgen) if len(set(tgen)) > 1 else generator(mel)
             pcm = ops.wav_to_int16(wav.squeeze(1).contiguous()).cpu().numpy()              # mel_decode_to_wav (:52-59), batched
-            frames += sum(tgen)
+            nfr += sum(tgen)
             for r, j in enumerate(gj):
                 n, seg = owner[batch[j]]
-                segments[n][seg] = pcm[r, : generator.output_length(tgen[r])].copy()
+                out.append((n, seg, pcm[r, : generator.output_length(tgen[r])].copy()))
+        return out, nfr
+
+    for batch in dp.pack_by_frames(list(range(len(items))), lengths, args.max_frames, args.max_batch):
+        y0 = [torch.randn(lengths[i], n_out, device=device, generator=torch.Generator(device=device).manual_seed(
+            _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch]        # acoustic.py:647-650, per utterance
+        # one saturation-flag read per batch (after the device-to-host copy that waits for the batch anyway) instead of one
+        # blocking read per call; a flagged batch is repeated with the per-call checks (the stage that saturated warns and
+        # re-runs in fp32, or raises under CVX_ON_SATURATION=raise)
+        with ops.saturation_deferred() as guard:
+            res, nfr = one_batch(batch, y0)
+        if guard.flagged:
+            res, nfr = one_batch(batch, y0)
+        frames += nfr
+        for n, seg, samples in res:
+            segments[n][seg] = samples
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     for n in mine:

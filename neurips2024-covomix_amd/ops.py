@@ -3,6 +3,7 @@ a stream here; every FLOP of the hot path happens in libcovomix_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 import functools
 import threading
 from contextlib import contextmanager
@@ -421,6 +422,41 @@ def saturation_query(reset: bool = True) -> int:
     v = C.c_uint32(0)
     _lib.check(_lib.load().cvx_saturation_flag_query(C.byref(v), 1 if reset else 0, _stream()), "cvx_saturation_flag_query")
     return int(v.value)
+
+
+_SAT_DEFER = threading.local()
+
+
+def saturation_checked() -> bool:
+    """Do the entry points check the saturation flag themselves (reset before, blocking read after)?  False under
+    CVX_SAT_CHECK=0 and inside `saturation_deferred()`."""
+    return _os.environ.get("CVX_SAT_CHECK", "1") == "1" and getattr(_SAT_DEFER, "depth", 0) == 0
+
+
+class saturation_deferred:
+    """with ops.saturation_deferred() as guard: ...several entry-point calls on the current stream...
+    ONE reset before and ONE flag read after the whole block instead of a blocking read per call (round-3 advice: the per-call
+    reads are host synchronisations between acoustic model and vocoder, and they keep the entry points out of a caller's own
+    stream capture).  Inside the block the entry points return their split-precision results unchecked; afterwards
+    `guard.flagged` says whether ANY of them saturated - the caller must then discard the block's results and repeat the calls
+    outside the block (where each call checks itself and a flagged one re-runs in fp32 or raises).  `read=False`: no read at
+    exit either (a caller that captures the block into its own graph reads the flag with ops.saturation_query() after the
+    replay)."""
+
+    def __init__(self, read: bool = True):
+        self.read, self.flagged = read, None
+
+    def __enter__(self):
+        if getattr(_SAT_DEFER, "depth", 0) == 0 and _os.environ.get("CVX_SAT_CHECK", "1") == "1":
+            saturation_reset()
+        _SAT_DEFER.depth = getattr(_SAT_DEFER, "depth", 0) + 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _SAT_DEFER.depth -= 1
+        if et is None and self.read and _SAT_DEFER.depth == 0 and _os.environ.get("CVX_SAT_CHECK", "1") == "1":
+            self.flagged = bool(saturation_query())
+        return False
 
 
 class Ragged:

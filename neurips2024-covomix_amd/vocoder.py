@@ -204,7 +204,7 @@ class Generator:
         ResBlock intermediate outgrows that, the kernels clamp and raise the device's sticky saturation flag
         (include/covomix_hip.h).  One flag read per call; a flagged call is re-run on the all-fp32 kernels (or raises:
         CVX_ON_SATURATION=raise) - never returned as is."""
-        checked = self.precision != "fp32" and os.environ.get("CVX_SAT_CHECK", "1") == "1" and self.device.type == "cuda"
+        checked = self.precision != "fp32" and ops.saturation_checked() and self.device.type == "cuda"
         if not checked:
             return self._forward(mel, lengths)
         with torch.cuda.device(self.device):

@@ -232,6 +232,50 @@ def test_nan_input_is_not_returned_as_a_finite_result(monkeypatch):
         _vocoder(h, vsd)(mel.cuda())
 
 
+def test_deferred_check_reads_the_flag_once_for_a_block_of_calls():
+    """ops.saturation_deferred (round-3 advice: the per-call flag reads are host synchronisations between acoustic model and
+    vocoder): inside the block the entry points neither reset nor read; one read at exit covers every call of the block."""
+    import covomix_amd.ops as ops
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _full_width_state()
+    inp = syn.synthetic_inputs("vomix", 1, 80, 40, seed=5)
+    model = CoVoMixModel.from_state_dict(sd, nfe=2).eval().to("cuda:0")
+    h = dict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    gen = _vocoder(h, vsd)
+    ids, mask = inp["phoneme_ids"].cuda(), inp["mask"].cuda()
+    good = model.synthesis_sample(ids, inp["cond"].cuda(), mask, 0.7, y0=inp["y0"])
+    wav_good = gen(good.transpose(1, 2).contiguous())
+    calls = dict(reset=0, query=0)
+    r0, q0 = ops.saturation_reset, ops.saturation_query
+
+    def counting(fn, key):
+        def f(*a, **k):
+            calls[key] += 1
+            return fn(*a, **k)
+        return f
+    ops.saturation_reset, ops.saturation_query = counting(r0, "reset"), counting(q0, "query")
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")               # no re-run inside a deferred block
+            with ops.saturation_deferred() as guard:
+                mel = model.synthesis_sample(ids, inp["cond"].cuda(), mask, 0.7, y0=inp["y0"])
+                wav = gen(mel.transpose(1, 2).contiguous())
+            assert guard.flagged is False and calls == dict(reset=1, query=1), (guard.flagged, calls)
+            print("deferred block vs checked calls: mel rel-L2", rel_l2(mel, good), "wav rel-L2", rel_l2(wav, wav_good))
+            assert torch.equal(mel, good), "mel differs"
+            assert torch.equal(wav, wav_good), "wav differs"
+            with ops.saturation_deferred() as guard:     # the acoustic model saturates, the vocoder call afterwards is clean:
+                mel = model.synthesis_sample(ids, (inp["cond"] * 4000.0).cuda(), mask, 0.7, y0=inp["y0"])
+                gen(good.transpose(1, 2).contiguous())   # ... the flag is sticky across the block
+            assert guard.flagged is True and calls == dict(reset=2, query=2), (guard.flagged, calls)
+    finally:
+        ops.saturation_reset, ops.saturation_query = r0, q0
+    with pytest.warns(UserWarning, match="saturat"):     # outside the block the calls check themselves again
+        model.synthesis_sample(ids, (inp["cond"] * 4000.0).cuda(), mask, 0.7, y0=inp["y0"])
+
+
 def _vocoder(h, vsd, precision=None):
     from covomix_amd.vocoder import AttrDict, Generator
     gen = Generator(AttrDict(h), precision=precision).to("cuda:0")
