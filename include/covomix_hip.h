@@ -36,7 +36,7 @@ typedef void* cvx_stream_t;   /* hipStream_t */
  * caller built against another header version must not call in: compare once after loading (the ctypes binding does,
  * covomix_amd/_lib.py).  104: round 4 (cvx_gemm_f16x3_norm, caller-owned saturation flags, cvx_t2s_decoder.cfg_scale,
  * cvx_t2s_decode_xcd, CVX_GEMM_FLAG_MEDIUM / _NO_MEDIUM). */
-#define CVX_ABI_VERSION 104
+#define CVX_ABI_VERSION 105
 int         cvx_version(void);
 const char* cvx_last_error_string(void);
 
@@ -141,6 +141,18 @@ typedef struct {
      * full-precision window (|x| in [2^-3, 2^16)) whatever the magnitude of the tensor; living in device memory they can
      * be computed by an earlier kernel without a host round trip (and replayed from a captured graph). */
     const float* a_scale_dev; const float* c_scale_dev; const float* vt_scale_dev;
+    /* Deferred AdaptiveRMSNorm (version 105; all NULL = off).  The norm between a to_out / ff2 / skip-combiner product and the
+     * to_qkv / ff1 product that follows it (acoustic.py:306-318, :198-204) is one gamma / beta row for every frame of an
+     * evaluation, so  norm(x) . W^T = (sqrt(D) / ||x_row||) * ((x * gamma) . W^T) + beta . W^T :
+     *   the PRODUCER call passes c_gamma_dev ([N] floats: C_hi/C_lo then hold C[m,n] * gamma[n] * *c_scale_dev - the fp32 store of C
+     *   is unchanged) and c_rowsq ([M][c_rowsq_ld >= N/64] floats: every 64-column slice of a row leaves its sum of squares there, in
+     *   a fixed order); cvx_rownorm_scale_f32 turns those into one factor per row; the CONSUMER call passes them as a_row_scale_dev
+     *   ([M] floats, multiplied into row m of the accumulators before bias / activation / RoPE) and beta . W^T as (part of) its bias.
+     * No normalised tensor exists in HBM and the norm kernel does not run.  Only the large-problem kernel takes these (pre-split
+     * interleaved A and W, M >= 2048, N >= 512, N % 64 == 0, 16-byte aligned epilogue operands) in four forms - producer:
+     * residual + fp32 store (to_out, ff2) or A2 + bias + fp32 store (skip combiner); consumer: bias + GELU + split store (ff1) or
+     * the QKV mode with an optional bias - and every other combination is refused (CVX_ERR_INVALID). */
+    const float* c_gamma_dev; float* c_rowsq; int64_t c_rowsq_ld; const float* a_row_scale_dev;
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
 #define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */
@@ -182,6 +194,9 @@ int cvx_adarmsnorm_f32(const float* x, const float* gamma, const float* beta, fl
                        cvx_stream_t s);
 /* the same; the split copy (y_hi, y_lo) holds y * *split_scale_dev (a power of two in DEVICE memory, NULL = 1: the
  * activation pre-scale of cvx_gemm_split_io.a_scale_dev).  The fp32 output y is never scaled. */
+/* out[r] = scale / max(sqrt(sum_{j < parts} rowsq[r * ld + j]), eps): the per-row factor of a deferred norm from the partial sums a
+ * producer GEMM left (cvx_gemm_split_io.c_rowsq; F.normalize's eps clamp, acoustic.py:198-204).  parts <= 64, summed in index order. */
+int cvx_rownorm_scale_f32(const float* rowsq, int64_t rows, int32_t parts, int64_t ld, float scale, float eps, float* out, cvx_stream_t s);
 int cvx_adarmsnorm_scaled_f32(const float* x, const float* gamma, const float* beta, float* y,
                               uint16_t* y_hi, uint16_t* y_lo,
                               int64_t rows, int32_t D, int64_t rows_per_group, float scale, float eps,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB_PATH") or os.path.join(_HERE, "libcovomix_hip.so")      # CVX_LIB_PATH: dev A/B builds
 
 _f32p = C.POINTER(C.c_float)
-ABI_VERSION = 104          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
+ABI_VERSION = 105          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
 
 
 class GemmArgs(C.Structure):
@@ -44,6 +44,7 @@ class GemmSplitIO(C.Structure):
         ("w_interleaved", C.c_int32),
         ("flags", C.c_int32),
         ("a_scale_dev", C.c_void_p), ("c_scale_dev", C.c_void_p), ("vt_scale_dev", C.c_void_p),
+        ("c_gamma_dev", C.c_void_p), ("c_rowsq", C.c_void_p), ("c_rowsq_ld", C.c_int64), ("a_row_scale_dev", C.c_void_p),
     ]
 
 
@@ -217,6 +218,7 @@ SIGNATURES = {
                                                       C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_amax_pow2_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvx_split_f16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_rownorm_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_adarmsnorm_scaled_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_attention_f16x3_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

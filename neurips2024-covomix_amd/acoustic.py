@@ -205,6 +205,9 @@ class VectorField:
             h2 = h2 + att_o[i] + ff_o[i]
             hmax = torch.maximum(hmax, h2)
         H = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / hmax.sqrt().clamp_min(tiny))).clamp(-40, 40)).reshape(1).contiguous()
+        # deferred norm: the pairs that feed to_qkv / ff1 hold x * gamma (not normalised): residual-stream magnitude times rms(gamma)
+        g_rms = torch.stack([ms[..., 0], ms[..., 2]], dim=-1).sqrt() * hmax.sqrt()                       # [n, L, 2]
+        self._g_scales = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / g_rms.clamp_min(tiny))).clamp(-40, 40)).contiguous()
         return S, H
 
     # ------------------------------------------------------------------ workspace
@@ -233,6 +236,7 @@ class VectorField:
             normed=f(M, d["dim"]), qkv=f(M, 3 * d["heads"] * 64), att=f(M, d["heads"] * 64),
             ff=f(M, 4 * d["dim"]), base=f(M, d["dim"]), xin=f(M, d["dim_out"]), pred=f(M, d["dim_out"]),
             gathered=f(M, d["streams"] * d["dim_emb"] + d["dim_cond"]),
+            rowsq=f(M, max(d["dim"] // 64, 1)), rs=f(M),           # deferred norm: row sums of squares per 64 columns, factor per row
         )
         if self.precision in ("f16x3", "f16"):      # activations that only feed GEMMs live as (fp16 hi, fp16 lo) pairs
             lo_too = self.precision == "f16x3"          # 'f16': (hi, None)
@@ -326,7 +330,46 @@ class VectorField:
             K = self.N_KINDS
             ctx["sp"] = [[[p0 + 4 * ((e * d["depth"] + i) * K + k) for k in range(K)] for i in range(d["depth"])] for e in range(n)]
             ctx["hp"] = H.data_ptr()
+            if self._defers(ctx["M"], ws):
+                self._deferred_norm_tables(ctx, table)
         return ctx
+
+    # ------------------------------------------------------------------ deferred AdaptiveRMSNorm (large batches)
+    DEFER_MIN_ROWS = int(os.environ.get("CVX_DEFER_NORM_ROWS", "8192"))
+
+    def _defers(self, M: int, ws: dict) -> bool:
+        """The norm in front of ff1 (every layer) and in front of to_qkv behind a skip combiner is ONE gamma / beta row per
+        evaluation, so  norm(x) W^T = (sqrt(D) / ||x_row||) ((x * gamma) W^T) + beta W^T  (acoustic.py:198-204, :306-318): the
+        producing GEMM writes the pair of x * gamma and the rows' sums of squares, the consuming GEMM applies the factor per row and
+        carries beta W^T in its bias - the norm kernel (131 MB per launch at the bench shape) does not run.  Large-problem kernel
+        only: batches of DEFER_MIN_ROWS rows and more.  OPT-IN (CVX_DEFER_NORM=1) while it is being measured."""
+        return (self.precision == "f16x3" and M >= self.DEFER_MIN_ROWS and isinstance(ws.get("normed16"), ops.SplitIL)
+                and self.d["dim"] % 64 == 0 and self.d["dim"] >= 512 and os.environ.get("CVX_DEFER_NORM", "0") == "1")
+
+    def _deferred_norm_tables(self, ctx: dict, table: torch.Tensor) -> None:
+        """beta W^T for every (evaluation time, layer): ff1's bias becomes b1 + beta_ff W1^T; layers behind a skip combiner get
+        beta_attn Wqkv^T as the to_qkv bias (in front of the rotation).  Weight streaming: 32 rows at a time on the skinny kernel."""
+        d, sd = self.d, self.sd
+        n, L, dim = table.shape[0], d["depth"], d["dim"]
+        tab = table.view(n, L, 4, dim)
+
+        def beta_w(beta_rows: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
+            out = torch.empty(n, w.shape[0], dtype=torch.float32, device=self.device)
+            for r0 in range(0, n, 32):
+                r1 = min(n, r0 + 32)
+                if w.shape[1] % 8 == 0:
+                    ops.gemm_skinny(beta_rows[r0:r1], w, out[r0:r1], bias=bias)
+                else:
+                    ops.gemm(beta_rows[r0:r1].contiguous(), w, out[r0:r1], bias=bias)
+            return out
+        b1p, bq = [], []
+        for i in range(L):
+            p = f"transformer.layers.{i}"
+            b1p.append(beta_w(tab[:, i, 3, :], sd[p + ".4.0.weight"], sd[p + ".4.0.bias"]))
+            bq.append(beta_w(tab[:, i, 1, :], sd[p + ".2.to_qkv.weight"], None) if self.has_comb[i] else None)
+        G = self._g_scales
+        g0 = G.data_ptr()
+        ctx["dn"] = dict(b1p=b1p, bq=bq, G=G, gp=[[(g0 + 4 * ((e * L + i) * 2), g0 + 4 * ((e * L + i) * 2 + 1)) for i in range(L)] for e in range(n)])
 
     # ------------------------------------------------------------------ one evaluation (both CFG branches)
     @staticmethod
@@ -407,6 +450,8 @@ class VectorField:
         # (2048 rows and more never split K: the call would run the same two kernels, so it stays two calls there)
         fuse_norm = split_io and M < 2048 and os.environ.get("CVX_FUSE_NORM", "1") == "1"
         normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
+        dn = ctx.get("dn") if (split_io and not fuse_norm and M >= 2048) else None      # (decided per call in prepare(): the halves of a two-chain schedule follow the whole batch)
+        parts64, rt_dim = dim // 64, float(dim) ** 0.5
         def tab_rows(i_, k_):
             return tab[(4 * i_ + k_) * dim:(4 * i_ + k_ + 1) * dim]
         skips: List[torch.Tensor] = []
@@ -419,7 +464,13 @@ class VectorField:
             if (p + ".0.weight") in sd:
                 s = skips.pop()
                 comb = take()
-                if split_io:
+                if split_io and dn is not None:        # deferred attention norm: the pair of comb * gamma + the rows' sums of squares
+                    ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
+                             a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp,
+                             out_split=ws["normed16"], c_scale=dn["gp"][step][i][0], c_gamma=g_attn, c_rowsq=ws["rowsq"])
+                    ops.rownorm_scale(ws["rowsq"], M, parts64, ws["rs"], rt_dim)
+                    normed_ahead = "deferred"
+                elif split_io:
                     nm = dict(gamma=g_attn, beta=b_attn, out_split=ws["normed16"],
                               scale=sp_step[i][0] if sp_step is not None else None) if fuse_norm else None
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
@@ -438,23 +489,37 @@ class VectorField:
                 s_na, s_qk, s_v, s_at, s_nf, s_ff = sp_step[i] if sp_step is not None else (None,) * 6
                 if not normed_ahead:
                     ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16, split_scale=s_na)
-                normed_ahead = False
                 # q | k split row-major, v split + transposed, straight into the f16x3 attention (any T: sequences whose
                 # length is not a multiple of 4 store their v columns 2 bytes at a time)
-                ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                         w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
-                         write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
+                if normed_ahead == "deferred":       # n16 = comb * gamma: the factor per row and beta Wqkv^T ride in the epilogue
+                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
+                             write_f32=False, a_scale=dn["gp"][step][i][0], c_scale=s_qk, vt_scale=s_v, bias=dn["bq"][i][step], a_row_scale=ws["rs"])
+                else:
+                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
+                             write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
+                normed_ahead = False
                 ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16,
                                     qk_scale=s_qk, v_scale=s_v, out_scale=s_at, ragged=rg)
                 h_att = take() if keep_input else h
-                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
-                         a_split=a16, a_scale=s_at, norm=dict(gamma=g_ff, beta=b_ff, out_split=n16, scale=s_nf) if fuse_norm else None)
-                h = h_att
-                if not fuse_norm:
-                    ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
-                ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
-                         w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
-                         a_scale=s_nf, c_scale=s_ff)
+                if dn is not None:                   # deferred FF norm: to_out leaves h_att * gamma_ff as the pair + the rows' sums of squares
+                    ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
+                             a_split=a16, a_scale=s_at, out_split=n16, c_scale=dn["gp"][step][i][1], c_gamma=g_ff, c_rowsq=ws["rowsq"])
+                    ops.rownorm_scale(ws["rowsq"], M, parts64, ws["rs"], rt_dim)
+                    h = h_att
+                    ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=dn["b1p"][i][step], act=ops.ACT_GELU,
+                             w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
+                             a_scale=dn["gp"][step][i][1], c_scale=s_ff, a_row_scale=ws["rs"])
+                else:
+                    ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
+                             a_split=a16, a_scale=s_at, norm=dict(gamma=g_ff, beta=b_ff, out_split=n16, scale=s_nf) if fuse_norm else None)
+                    h = h_att
+                    if not fuse_norm:
+                        ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
+                    ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
+                             w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
+                             a_scale=s_nf, c_scale=s_ff)
                 last = i + 1 == d["depth"]
                 nm = None
                 if fuse_norm and last:                   # the final RMSNorm in front of to_pred

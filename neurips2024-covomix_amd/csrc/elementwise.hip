@@ -651,6 +651,36 @@ extern "C" int cvx_adarmsnorm_f32(const float* x, const float* gamma, const floa
     return cvx_adarmsnorm_scaled_f32(x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, nullptr, s);
 }
 
+// ---------------------------------------------------------------- deferred norm: per-row factor from a producer GEMM's partial sums
+// (cvx_gemm_split_io.c_rowsq: one sum of squares per 64-column slice of a row; reference acoustic.py:198-204, F.normalize's eps)
+namespace {
+__global__ __launch_bounds__(256) void rownorm_scale_kernel(const float* __restrict__ rowsq, int64_t rows, int parts, int64_t ld,
+                                                            float scale, float eps, float* __restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = rowsq + r * ld;
+    float q = 0.f;
+    if ((parts & 3) == 0 && (ld & 3) == 0) {
+        for (int j = 0; j < parts; j += 4) { const f32x4 v = gload4(p + j); q += v[0]; q += v[1]; q += v[2]; q += v[3]; }
+    } else {
+        for (int j = 0; j < parts; ++j) q += p[j];
+    }
+    out[r] = scale / fmaxf(sqrtf(q), eps);
+}
+}  // namespace
+
+extern "C" int cvx_rownorm_scale_f32(const float* rowsq, int64_t rows, int32_t parts, int64_t ld, float scale, float eps, float* out, cvx_stream_t s)
+{
+    CVX_REQUIRE(rowsq && out && rows >= 0 && parts > 0 && parts <= 64 && ld >= parts && (((uintptr_t)rowsq & 15) == 0 || (parts & 3) || (ld & 3)),
+                "rownorm_scale: bad arguments (rows=%ld parts=%d ld=%ld)", (long)rows, parts, (long)ld);
+    if (rows == 0) return CVX_OK;
+    hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       rowsq, rows, parts, ld, scale, eps, out);
+    CVX_CHECK_LAUNCH("cvx_rownorm_scale_f32");
+    return CVX_OK;
+}
+
 // ---------------------------------------------------------------- measured power-of-two pre-scale of a tensor
 namespace {
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ amax_bits)

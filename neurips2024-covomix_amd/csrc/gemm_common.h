@@ -41,7 +41,12 @@ struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
                   _Float16* vt_hi; _Float16* vt_lo; int64_t vt_ld;
                   const float* c_scale; const float* vt_scale; const float* a_scale;
                   int dbg; unsigned long long* trace;
-                  uint32_t* sat; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
+                  uint32_t* sat;
+                  // deferred AdaptiveRMSNorm (round 4; the 16x16x32 epilogues of gemm_p8s_epi.h only - the launchers refuse it elsewhere):
+                  //   producer: the split twin holds C[m,n] * tw_gamma[n] (* c_scale) instead of C, and every 64-column wave tile leaves
+                  //             sum_n C[m,n]^2 over its columns in rowsq[m * rowsq_ld + n0 / 64] (fixed order: deterministic);
+                  //   consumer: row m of the accumulators is multiplied by row_scale[m] (= sqrt(D) / ||x_m||) before bias / RoPE.
+                  const float* tw_gamma; float* rowsq; int rowsq_ld; const float* row_scale; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
 
 // accumulator factor: 1 / (weight pre-scale) / (activation pre-scale); both powers of two, so the division is exact
 __device__ __forceinline__ float total_acc_scale(float acc_scale, const SplitOut& so)
@@ -87,7 +92,12 @@ __device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, 
 enum : int { EPI_GENERIC = 0, EPI_QKV = 1,      // RoPE on q|k, split q|k + transposed split v, no fp32 store, no bias
              EPI_RES = 2,                       // (+ bias) + residual, fp32 store (+ optional split twin): to_out, ff2
              EPI_GELU_SPLIT = 3,                // bias + GELU, split store only: ff1
-             EPI_BIAS = 4 };                    // bias, fp32 store: skip combiners
+             EPI_BIAS = 4,                      // bias, fp32 store: skip combiners
+             // deferred AdaptiveRMSNorm (SplitOut::tw_gamma / rowsq / row_scale; 16x16x32 epilogues of gemm_p8s_epi.h only):
+             EPI_RES_TW = 5,                    // EPI_RES + the split twin times gamma[n] + row sums of squares: to_out, ff2
+             EPI_BIAS_TW = 6,                   // EPI_BIAS + the same twin / sums: skip combiners in front of an attention norm
+             EPI_GELU_RS = 7,                   // EPI_GELU_SPLIT with a factor per row on the accumulators: ff1 behind a deferred norm
+             EPI_QKV_RS = 8 };                  // EPI_QKV with that factor and a bias (beta . W^T) in front of the rotation
 
 template <int TM, int EPI = EPI_GENERIC>
 __device__ __forceinline__ void gemm_epilogue(const cvx_gemm_args& p_in, f32x16 (&acc)[TM][2], int m0, int n0,

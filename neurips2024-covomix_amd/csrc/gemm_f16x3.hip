@@ -823,7 +823,8 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
             so.hi = reinterpret_cast<f16*>(io->C_hi); so.lo = reinterpret_cast<f16*>(io->C_lo); so.ldc_h = io->ldc_h;
         }
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
-        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev; 
+        so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev;
+        so.tw_gamma = io->c_gamma_dev; so.rowsq = io->c_rowsq; so.rowsq_ld = (int)io->c_rowsq_ld; so.row_scale = io->a_row_scale_dev;
 #ifdef CVX_DEV_FLAGS          // timing experiments (tools/): epilogue skipping, per-block stamps, one tile per block - never in the shipped library
         so.dbg = io->flags >> 8; so.trace = (so.dbg & 4) ? reinterpret_cast<unsigned long long*>(io->workspace) : nullptr;
 #else
@@ -848,6 +849,13 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
             }
         }
     }
+    // deferred norm (producer: gamma on the twin + row sums of squares; consumer: a factor per row): the 16x16x32 epilogues only
+    const bool dn = so.tw_gamma || so.rowsq || so.row_scale;
+    if (dn) {
+        CVX_REQUIRE(!single && !norm && a->N % 64 == 0 && (!so.tw_gamma || (so.hi && ((uintptr_t)so.tw_gamma & 15) == 0)) &&
+                    (!so.rowsq || (io->c_rowsq_ld >= a->N / 64 && io->c_rowsq_ld < (1ll << 20))),
+                    "gemm_f16x3: deferred norm needs N %% 64 == 0, a split output for c_gamma_dev (16-byte aligned) and c_rowsq_ld >= N / 64");
+    }
     if (a->M == 0) return CVX_OK;
     const int tiles_n = (a->N + BN - 1) / BN, tiles_m = (a->M + 127) / 128;
     const int map_mode = 1;             // XCD-aware block -> tile map (gemm_common.h)
@@ -871,6 +879,12 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
         const double large = (double)((t256 + ncu - 1) / ncu), med = 0.31 * (double)((t128 + ncu - 1) / ncu);
         medium = (io->flags & CVX_GEMM_FLAG_MEDIUM) || med < 0.97 * large;
+    }
+    if (dn) {
+        CVX_REQUIRE(A.hi && w_il && a_il && a->M >= 2048 && a->N >= 512 && !(io->flags & (CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32)),
+                    "gemm_f16x3: deferred norm (c_gamma_dev / c_rowsq / a_row_scale_dev) runs on the large-problem 16x16x32 kernel only: "
+                    "interleaved pre-split operands, M >= 2048, N >= 512 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+        medium = false;
     }
     if (A.hi && w_il && a_il && medium) {
         // fewer than 2048 rows (one utterance, the last bin of a ragged directory, the HuBERT / text2semantic encoders): 128 x 128
@@ -916,6 +930,9 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         else if (w_il && a_il && !(io->flags & (CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32)) &&
                  cvxg::launch_gemm_f16x3_p8s(*a, A, wh, acc_scale, so, map_mode, st)) {
             /* eight-phase ping-pong kernel on the 16x16x32 MFMA (gemm_f16x3_p8s.hip) */
+        } else if (dn) {
+            CVX_REQUIRE(false, "gemm_f16x3: deferred norm (c_gamma_dev / c_rowsq / a_row_scale_dev) needs interleaved operands and the "
+                               "16-byte vector epilogue of the 16x16x32 kernels (M=%d N=%d K=%d)", a->M, a->N, a->K);
         } else if (w_il && a_il && !(io->flags & CVX_GEMM_FLAG_TWO_STAGE) &&
                  cvxg::launch_gemm_f16x3_p8(*a, A, wh, acc_scale, so, map_mode, st)) {
             /* eight-phase ping-pong kernel on the 32x32x16 MFMA (gemm_f16x3_p8.hip): ragged N, unaligned epilogues */

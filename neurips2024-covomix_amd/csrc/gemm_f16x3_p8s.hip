@@ -213,10 +213,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
         bool v_block = false;
-        if constexpr (EPI == EPI_QKV) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
+        if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_RS) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
         if (v_block) {
             tile_mainloop<HAS_A2, false>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
-            if (!(so.dbg & 1)) epilogue_vt(p, acc, row0, col0, lane, so, acc_scale);
+            if (!(so.dbg & 1)) epilogue_vt<8, false, EPI == EPI_QKV_RS>(p, acc, row0, col0, lane, so, acc_scale);
         } else {
             tile_mainloop<HAS_A2, true>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
             if (!(so.dbg & 1)) epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);      // (dbg bit 0: main loop only, timing)
@@ -259,6 +259,15 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     const dim3 grid((unsigned)g);
     int epi = classify_epilogue(a, so);
     if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;
+    if (so.tw_gamma || so.rowsq || so.row_scale) {         // deferred norm: its own instances, nothing else carries it
+        const bool prod = so.tw_gamma && so.rowsq && so.hi && so.write_f32 && a.act == CVX_ACT_NONE && !a.rope_cos && !so.vt_hi && !so.row_scale;
+        const bool cons = so.row_scale && !so.tw_gamma && !so.rowsq && so.hi && !so.write_f32 && !a.residual;
+        if (prod && a.residual && !A.hi2) epi = EPI_RES_TW;
+        else if (prod && !a.residual && A.hi2) epi = EPI_BIAS_TW;
+        else if (cons && a.bias && a.act == CVX_ACT_GELU && !a.rope_cos && !so.vt_hi && !A.hi2) epi = EPI_GELU_RS;
+        else if (cons && a.act == CVX_ACT_NONE && a.rope_cos && so.vt_hi && !A.hi2) epi = EPI_QKV_RS;
+        else return false;
+    }
     if (epi == EPI_GENERIC && so.vt_hi) return false;
 #define CVX_P8S_LAUNCH(A2, E)                                                                                           \
     do {                                                                                                                \
@@ -266,9 +275,12 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
         hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, n_slots); \
     } while (0)
     if (A.hi2) {
-        if (epi == EPI_BIAS) CVX_P8S_LAUNCH(true, EPI_BIAS); else CVX_P8S_LAUNCH(true, EPI_GENERIC);
+        if (epi == EPI_BIAS) CVX_P8S_LAUNCH(true, EPI_BIAS); else if (epi == EPI_BIAS_TW) CVX_P8S_LAUNCH(true, EPI_BIAS_TW); else CVX_P8S_LAUNCH(true, EPI_GENERIC);
     } else {
         switch (epi) {
+            case EPI_RES_TW: CVX_P8S_LAUNCH(false, EPI_RES_TW); break;
+            case EPI_GELU_RS: CVX_P8S_LAUNCH(false, EPI_GELU_RS); break;
+            case EPI_QKV_RS: CVX_P8S_LAUNCH(false, EPI_QKV_RS); break;
             case EPI_QKV: CVX_P8S_LAUNCH(false, EPI_QKV); break;
             case EPI_RES: CVX_P8S_LAUNCH(false, EPI_RES); break;
             case EPI_GELU_SPLIT: CVX_P8S_LAUNCH(false, EPI_GELU_SPLIT); break;

@@ -90,13 +90,19 @@ __device__ __forceinline__ void epi_specialise(cvx_gemm_args& p, SplitOut& so)
 {
     if constexpr (EPI == EPI_QKV) {
         p.act = CVX_ACT_NONE; p.bias = nullptr; p.residual = nullptr; so.write_f32 = 0;
-    } else if constexpr (EPI == EPI_RES) {
+    } else if constexpr (EPI == EPI_QKV_RS) {
+        p.act = CVX_ACT_NONE; p.residual = nullptr; so.write_f32 = 0;
+    } else if constexpr (EPI == EPI_RES || EPI == EPI_RES_TW) {
         p.act = CVX_ACT_NONE; p.rope_cos = nullptr; so.write_f32 = 1;
-    } else if constexpr (EPI == EPI_GELU_SPLIT) {
+    } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_RS) {
         p.act = CVX_ACT_GELU; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 0;
     } else if constexpr (EPI == EPI_BIAS) {
         p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1; so.hi = nullptr; so.lo = nullptr;
+    } else if constexpr (EPI == EPI_BIAS_TW) {
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1;
     }
+    if constexpr (EPI != EPI_RES_TW && EPI != EPI_BIAS_TW) { so.tw_gamma = nullptr; so.rowsq = nullptr; }
+    if constexpr (EPI != EPI_GELU_RS && EPI != EPI_QKV_RS) so.row_scale = nullptr;
 }
 
 template <int EPI, int MI>
@@ -174,6 +180,13 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 #pragma unroll
         for (int a = 0; a < RA; ++a) load_res(a, rbuf[a]);
     }
+    constexpr bool RS = (EPI == EPI_GELU_RS || EPI == EPI_QKV_RS);          // consumer of a deferred norm: one factor per row
+    constexpr bool TW = (EPI == EPI_RES_TW || EPI == EPI_BIAS_TW);          // producer: gamma on the twin, row sums of squares
+    float rscale[RS ? MI : 1];
+    if constexpr (RS) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) rscale[mi] = so.row_scale[min(row0 + 16 * mi + lr, p.M - 1)];
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int row = row0 + 16 * mi + lr;
@@ -181,11 +194,13 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
         const int rr = live ? row : p.M - 1;
         if (RA > 0 && p.residual && mi + RA < MI) load_res(mi + RA, rbuf[(mi + RA) % (RA + 1)]);
         f32x2 v[4][2];
+        f32x2 scr = sc2;
+        if constexpr (RS) scr = splat2(acc_scale * rscale[mi]);      // deferred norm: sqrt(D) / ||x_row|| rides on the accumulator scale
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                f32x2 x = fma2(f32x2{acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]}, sc2, bias[ni][h]);
+                f32x2 x = fma2(f32x2{acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]}, scr, bias[ni][h]);
                 if (p.act == CVX_ACT_GELU) x = gelu_fast2(x);
                 else if (p.act == CVX_ACT_SILU) x = silu2(x);
                 v[ni][h] = x;
@@ -219,6 +234,16 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 v[ni][1] += f32x2{r[2], r[3]};
             }
         }
+        if constexpr (TW) {      // sum of squares of the row's 64 columns of this wave tile: 16 in-lane, then the 4 lanes that share the row
+            f32x2 q2 = v[0][0] * v[0][0];
+            q2 = fma2(v[0][1], v[0][1], q2);
+#pragma unroll
+            for (int ni = 1; ni < 4; ++ni) { q2 = fma2(v[ni][0], v[ni][0], q2); q2 = fma2(v[ni][1], v[ni][1], q2); }
+            float q = q2[0] + q2[1];
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (live && lc == 0) so.rowsq[(int64_t)row * so.rowsq_ld + (col0 >> 6)] = q;
+        }
         if (!live) continue;
         if (so.write_f32) {
 #pragma unroll
@@ -234,8 +259,15 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 const int c = col0 + 16 * ni + lc;
                 const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
                 f16x2 h01, h23, l01, l23;
-                split2_pk(v[ni][0] * cs2, h01, l01, amax);
-                split2_pk(v[ni][1] * cs2, h23, l23, amax);
+                f32x2 g01 = cs2, g23 = cs2;
+                if constexpr (TW) {          // (re-read per row group - an L1 hit - rather than 16 registers held across the epilogue)
+                    const float* gp = so.tw_gamma + c;
+                    asm volatile("" : "+v"(gp));
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp);
+                    g01 = f32x2{g4[0], g4[1]} * cs2; g23 = f32x2{g4[2], g4[3]} * cs2;
+                }
+                split2_pk(v[ni][0] * g01, h01, l01, amax);
+                split2_pk(v[ni][1] * g23, h23, l23, amax);
                 *reinterpret_cast<f16x4*>(so.hi + o) = f16x4{h01[0], h01[1], h23[0], h23[1]};
                 if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = f16x4{l01[0], l01[1], l23[0], l23[1]};
             }
@@ -247,7 +279,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 // ---- epilogue of a V block of a to_qkv projection, UN-swapped layout:
 // acc[mi][ni][r] = C[row0 + 16 mi + 4 (lane >> 4) + r][col0 + 16 ni + (lane & 15)]: 4 consecutive frames per lane ->
 // vt[((b*H + head)*64 + d) * vt_ld + slot(t)], 8 bytes per store when the four frames are one aligned slot group
-template <int MI = 8, bool PRE = false>
+template <int MI = 8, bool PRE = false, bool RS = false>
 __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)[MI][4], int row0, int col0, int lane,
                                             const SplitOut& so, float acc_scale, const EpiPre<MI>* pre = nullptr)
 {
@@ -264,12 +296,17 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
         if (r0 >= p.M) continue;
         const int b = r0 / T, t0 = r0 - b * T;
         const bool vec = (t0 & 3) == 0 && t0 + 3 < T && r0 + 3 < p.M;
+        f32x4 rs4 = f32x4{vs, vs, vs, vs};          // deferred norm: the four frames' sqrt(D) / ||x|| on the accumulator scale
+        if constexpr (RS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rs4[e] = vs * so.row_scale[min(r0 + e, p.M - 1)];
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int d = 16 * ni + (lane & 15);
             const float bv = p.bias ? p.bias[col0 + d] * vs0 : 0.f;
             f16x4 h, l;
-            split4_pk(f32x4{fmaf(acc[mi][ni][0], vs, bv), fmaf(acc[mi][ni][1], vs, bv), fmaf(acc[mi][ni][2], vs, bv), fmaf(acc[mi][ni][3], vs, bv)}, h, l, amax);
+            split4_pk(f32x4{fmaf(acc[mi][ni][0], rs4[0], bv), fmaf(acc[mi][ni][1], rs4[1], bv), fmaf(acc[mi][ni][2], rs4[2], bv), fmaf(acc[mi][ni][3], rs4[3], bv)}, h, l, amax);
             if (vec) {
                 const int64_t o = ((int64_t)(b * H + head) * 64 + d) * so.vt_ld + vt_slot(t0);
                 *reinterpret_cast<f16x4*>(so.vt_hi + o) = h;

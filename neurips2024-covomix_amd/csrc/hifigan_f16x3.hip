@@ -303,6 +303,220 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 #endif
 }
 
+// ---------------------------------------------------------------- the same convolution on v_mfma_f32_16x16x32_f16 (round 4)
+// Same staging, same stage ring, same arguments as conv_f16x3_kernel; what changes is the matrix instruction and everything that
+// follows from its fragment layout:
+//   * a 16 x 16 x 32 product takes the whole 32-channel chunk of a tap in ONE instruction (a lane's fragment = the 16-byte piece
+//     lane >> 4 of row lane & 15: the four lane groups read the four pieces of a 64-byte row), so an accumulator register is read
+//     and written once per 32 k instead of once per 16 k - the lever that gave the GEMM +13 % under the power cap;
+//   * SWAPPED operands (D = W_frag . Z_frag^T): a lane holds 4 CONSECUTIVE CHANNELS of one position (position = lane & 15,
+//     channels 4 * (lane >> 4) + 0..3 of a 16 x 16 tile), so every epilogue access is a 16-byte (8-byte fp16) vector with no
+//     quad transposes (5 VALU instructions per value in the 32 x 32 epilogue);
+//   * tiles are multiples of 16 positions per wave: 160-position blocks exist (TM16 = 5 on two wave rows), which put the first
+//     ResBlock stage of the bench shape (8 x 5,000 positions) on exactly 256 blocks.
+// MEASURED (round 4, rocprofv3 per launch, B = 8 x T = 1000, same box): the instruction shape itself buys nothing here - with the
+// SAME tiles the Np = 128 stage takes 155.6 us against 146.1 us on the 32x32x16 kernel (+6.5 %; the un-swapped product with quad
+// transposes 158.1), the Np = 64 upsampler 138 vs 127 - as in the attention kernel (DESIGN 4.3 iv) and unlike the GEMM.  What
+// pays is the tile height: 256 blocks of 160 positions 114.0 us against 120.6 us for 216 blocks of 192 (-5.5 %, 19 launches per
+// generator call).  So only the <5, 4, 4> instance is dispatched (dispatch_conv16), and only where it fills the chip better.
+// TM16 / TN16 = 16-position / 16-channel tiles per wave; WN waves side by side over the channels (8 / WN over the positions).
+template <int TM16, int TN16, int WN>
+__global__ __launch_bounds__(512) void conv_f16x3_m16_kernel(const Conv16Args p)
+{
+#define CVX_C16_MM(w, z, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(w, z, c, 0, 0, 0)
+    constexpr int WM = 8 / WN;
+    constexpr int NP = WN * TN16 * 16;
+    constexpr int TS = 256 / NP;                         // taps per weight stage
+    constexpr int TMB = WM * TM16 * 16;                  // positions per block
+    constexpr int A_ROWS = TMB + 64;                     // + halo (<= 50) rounded up to the 16-row DMA piece
+    constexpr int A_TILE = A_ROWS * CK;
+    static_assert(TMB <= ::TMB && TMB % 16 == 0, "block tile: at most 256 positions");
+    extern __shared__ __attribute__((aligned(16))) f16 smem_c[];
+    f16* const As = smem_c;                              // [2 buffers][hi | lo][A_ROWS][32]
+    f16* const Ws = smem_c + 4 * A_TILE;                 // [2 stages][hi | lo][256][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const float zs = p.z_scale ? *p.z_scale : 1.f;          // activation pre-scale of this stage's split pairs
+    const float a_sc = p.acc_scale / zs;                    // (exact: both are powers of two)
+    float amax = 0.f;
+    const int l0 = blockIdx.x * TMB;
+    const int b = blockIdx.y;
+    const int zt = blockIdx.z;
+    const int ksize = p.zk[zt], pad = p.zpad[zt];
+    const f16* const w_hi = p.w_hi + p.zw[zt];
+    const f16* const w_lo = p.w_lo + p.zw[zt];
+    const int Lb = cvx_item_len(p.items, b, p.L_out);
+    const int n_chunks = p.Cp_in / CK;
+    const int n_groups = (ksize + TS - 1) / TS;
+    const int steps = n_chunks * n_groups;
+
+    const int prow = lane >> 2;
+    const int64_t a_row0 = (int64_t)b * p.Lp + p.halo_l + l0 - pad;            // global row of tile row 0 (>= 0)
+    const int64_t last_row = (int64_t)gridDim.y * p.Lp - 1;
+    auto issue_a = [&](int chunk) {
+        f16* dst = As + (chunk & 1) * 2 * A_TILE;
+        for (int pc = wid; pc < A_ROWS / 16; pc += 8) {
+            const int r = 16 * pc + prow;
+            const int c4 = (lane & 3) ^ ((r >> 2) & 3);
+            const int64_t src = min(a_row0 + r, last_row) * p.Cp_in + chunk * CK + 8 * c4;      // (short tiles may reach past roundup(L, 256) + 64)
+            glds16(p.z_hi + src, dst + 16 * pc * CK);
+            glds16(p.z_lo + src, dst + A_TILE + 16 * pc * CK);
+        }
+    };
+    auto issue_w = [&](int st) {
+        const int chunk = st / n_groups, grp = st - chunk * n_groups;
+        const int t0 = grp * TS, nt = min(TS, ksize - t0);
+        f16* dst = Ws + (st & 1) * 2 * W_TILE;
+        const int64_t base = ((int64_t)chunk * ksize + t0) * NP * CK;
+        for (int pc = wid; pc < nt * NP / 16; pc += 8) {
+            const int r = 16 * pc + prow;
+            const int c4 = (lane & 3) ^ ((r >> 2) & 3);
+            const int64_t src = base + (int64_t)r * CK + 8 * c4;
+            glds16(w_hi + src, dst + 16 * pc * CK);
+            glds16(w_lo + src, dst + W_TILE + 16 * pc * CK);
+        }
+    };
+
+    f32x4 acc[TM16][TN16];
+#pragma unroll
+    for (int mi = 0; mi < TM16; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN16; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int i15 = lane & 15, g4 = lane >> 4;
+    const int woff = (wn * TN16 * 16 + i15) * CK + 8 * (g4 ^ ((i15 >> 2) & 3));
+    const int arow_base = wm * TM16 * 16 + i15;
+
+    issue_a(0);
+    issue_w(0);
+    for (int st = 0; st < steps; ++st) {
+        const int chunk = st / n_groups, grp = st - chunk * n_groups;
+        const int t0 = grp * TS, nt = min(TS, ksize - t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // stage st (and its activation tile) landed; the other buffers are free
+        if (st + 1 < steps) {
+            issue_w(st + 1);
+            if (grp == 0 && chunk + 1 < n_chunks) issue_a(chunk + 1);
+        }
+        const f16* Ah = As + (chunk & 1) * 2 * A_TILE;
+        const f16* Al = Ah + A_TILE;
+        const f16* Wh = Ws + (st & 1) * 2 * W_TILE;
+        const f16* Wl = Wh + W_TILE;
+        for (int tl = 0; tl < nt; ++tl) {
+            const int arow = arow_base + (t0 + tl) * p.dil;            // tile row of output position i15 for this tap
+            const int aoff = arow * CK + 8 * (g4 ^ ((arow >> 2) & 3));
+            const f16* wth = Wh + tl * NP * CK + woff;
+            const f16* wtl = Wl + tl * NP * CK + woff;
+            f16x8 fah[TM16], fal[TM16], fwh[TN16], fwl[TN16];
+#pragma unroll
+            for (int ni = 0; ni < TN16; ++ni) {
+                fwh[ni] = *reinterpret_cast<const f16x8*>(wth + ni * 16 * CK);
+                fwl[ni] = *reinterpret_cast<const f16x8*>(wtl + ni * 16 * CK);
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM16; ++mi) {
+                fah[mi] = *reinterpret_cast<const f16x8*>(Ah + mi * 16 * CK + aoff);
+                fal[mi] = *reinterpret_cast<const f16x8*>(Al + mi * 16 * CK + aoff);
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM16; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN16; ++ni)
+                    acc[mi][ni] = CVX_C16_MM(fwh[ni], fal[mi], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < TM16; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN16; ++ni)
+                    acc[mi][ni] = CVX_C16_MM(fwl[ni], fah[mi], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < TM16; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN16; ++ni)
+                    acc[mi][ni] = CVX_C16_MM(fwh[ni], fah[mi], acc[mi][ni]);
+        }
+    }
+
+    // ---- epilogue.  acc[mi][ni][e] of lane (i15, g4): position 16 * mi + i15 of the wave's rows, channel 16 * ni + 4 * g4 + e of
+    // its columns.  The residual / accumulate vectors of TWO 16-position slices are requested together, ahead of their
+    // arithmetic (as many loads in flight as the 32 x 32 epilogue's 32-position slice); rows behind L are inside the
+    // allocation (clamped to its last row), so the loads need no predicate; the stores keep theirs.
+    float omax = 0.f;
+    const int rsel = i15;                                                     // the lane's position inside a 16 x 16 tile
+    const int cw = wn * TN16 * 16 + 4 * g4;                                     // its first channel (+ 16 * ni)
+#pragma unroll
+    for (int mi0 = 0; mi0 < TM16; mi0 += 2) {
+        constexpr int MS = 2;
+        f32x4 rres[MS][TN16], racc[MS][TN16];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            if (mi0 + ms >= TM16) continue;
+            const int lrow = l0 + wm * TM16 * 16 + (mi0 + ms) * 16 + rsel;
+            const int64_t grow = min((int64_t)b * p.Lp + p.halo_l + lrow, last_row);
+            if (p.res) {
+#pragma unroll
+                for (int ni = 0; ni < TN16; ++ni) rres[ms][ni] = gload4(p.res + grow * NP + cw + ni * 16);
+            }
+            if (p.accum) {
+#pragma unroll
+                for (int ni = 0; ni < TN16; ++ni) racc[ms][ni] = gload4(p.accum + grow * NP + cw + ni * 16);
+            }
+        }
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            if (mi0 + ms >= TM16) continue;
+            const int mi = mi0 + ms;
+            const int l = l0 + wm * TM16 * 16 + mi * 16 + rsel;
+            const int64_t orow = (int64_t)b * p.out_bs + p.out_base + (int64_t)l * p.ldo + zt * NP + cw;
+#pragma unroll
+            for (int ni = 0; ni < TN16; ++ni) {
+                const int lpos = l * p.ostride + ((zt * NP + cw + ni * 16) >> p.ph_shift);       // position of the signal (= l for a plain convolution)
+                const float t0 = acc[mi][ni][0], t1 = acc[mi][ni][1], t2 = acc[mi][ni][2], t3 = acc[mi][ni][3];
+                if (l >= p.L || lpos >= p.L_out) continue;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cw + ni * 16);
+                const int64_t o = orow + ni * 16;
+                f32x4 v = {t0 * a_sc + bv[0], t1 * a_sc + bv[1], t2 * a_sc + bv[2], t3 * a_sc + bv[3]};
+                if (p.res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rres[ms][ni][e];
+                }
+                if (lpos >= Lb) v = f32x4{0.f, 0.f, 0.f, 0.f};   // behind a shorter item's end: the zero padding a B = 1 run sees
+                if (p.out_x) {
+                    f32x4 w = v;
+                    if (p.accum) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] += racc[ms][ni][e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] *= p.out_scale;
+                    *reinterpret_cast<f32x4*>(p.out_x + o) = w;
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
+                }
+                if (p.out_zhi) {
+                    cvx_f16x4 zh, zl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float z = (v[e] > 0.f ? v[e] : v[e] * p.z_slope) * zs;
+                        amax = cvx_amax3_c(amax, z, z);
+                        z = fminf(fmaxf(z, -65504.f), 65504.f);
+                        zh[e] = (_Float16)z;
+                        zl[e] = (_Float16)(z - (float)zh[e]);
+                    }
+                    *reinterpret_cast<cvx_f16x4*>(p.out_zhi + o) = zh;
+                    *reinterpret_cast<cvx_f16x4*>(p.out_zlo + o) = zl;
+                }
+            }
+        }
+    }
+    cvx_sat_commit(p.sat, amax);
+    if (p.amax_out) {                       // max |out_x| of the launch (non-negative floats order like their bits)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
+        if (lane == 0 && omax > 0.f && omax < __builtin_inff() && __float_as_uint(omax) > __atomic_load_n(p.amax_out, __ATOMIC_RELAXED))
+            atomicMax(p.amax_out, __float_as_uint(omax));        // (most waves cannot raise the maximum: no atomic)
+    }
+}
+
 // ---------------------------------------------------------------- fused ResBlock pair (narrow stages: Np = 32 / 64)
 // x' = c2(leaky_relu(c1(leaky_relu(x)))) + x   (models.py:36-40) in ONE kernel: the intermediate t never leaves the CU
 // and neither split pair (z = split(lrelu(x)), t) exists in HBM - a pair moves read x + write x' (+ the xs accumulate)
@@ -742,17 +956,28 @@ void launch_conv16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
     dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
     hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN>), grid, dim3(512), lds, st, a);
 }
+template <int TM16, int TN16, int WN>
+void launch_conv16_m16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
+{
+    constexpr int tmb = (8 / WN) * TM16 * 16;
+    const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_m16_kernel<TM16, TN16, WN>), (int)lds);
+    dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
+    hipLaunchKernelGGL((conv_f16x3_m16_kernel<TM16, TN16, WN>), grid, dim3(512), lds, st, a);
+}
 
-// kernel instance by output tile width; Np = 256: one block per CU - when the 256-position tiles leave more than a quarter of
-// the chip idle in their last (or only) round and 192-position tiles fit in fewer block-rows of work, take those (stage 0 of
-// the bench shape: 160 -> 216 blocks of 3/4 the work each on 256 CUs)
+// kernel instance by output tile width; Np = 256: one block per CU, and the block height is the one whose rounds x height comes
+// out smallest on this chip - 256 or 192 positions on the 32x32x16 kernel, or 160 on the 16x16x32 one (measured 13 % slower per
+// position, rocprofv3: 114 us for 256 blocks of 160 against 120.6 for 216 blocks of 192 on stage 0 of the bench shape, 8 x 5,000
+// positions - it wins where it fills the chip: 160 -> 216 -> 256 blocks there)
 void dispatch_conv16(const Conv16Args& k, int B, int n_ztiles, hipStream_t st)
 {
     if (k.Np == 256) {
         const int cus = cvx_device_cus();
-        const int64_t n256 = (int64_t)((k.L + 255) / 256) * B * n_ztiles, n192 = (int64_t)((k.L + 191) / 192) * B * n_ztiles;
-        const int64_t t256 = (n256 + cus - 1) / cus * 4, t192 = (n192 + cus - 1) / cus * 3;      // rounds x tile size
-        if (t192 < t256) launch_conv16<3, 2, 4>(k, B, n_ztiles, st);
+        auto cost = [&](int rows) { const int64_t n = (int64_t)((k.L + rows - 1) / rows) * B * n_ztiles; return (double)((n + cus - 1) / cus * rows); };
+        const double t256 = cost(256), t192 = cost(192), t160 = 1.13 * cost(160);
+        if (t160 < t256 && t160 < t192) launch_conv16_m16<5, 4, 4>(k, B, n_ztiles, st);
+        else if (t192 < t256) launch_conv16<3, 2, 4>(k, B, n_ztiles, st);
         else launch_conv16<4, 2, 4>(k, B, n_ztiles, st);
     }
     else if (k.Np == 128) launch_conv16<2, 2, 2>(k, B, n_ztiles, st);

@@ -195,7 +195,7 @@ def _sp(t: Optional[torch.Tensor]) -> Optional[int]:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
          a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None,
-         a_scale=None, c_scale=None, vt_scale=None, norm=None) -> torch.Tensor:
+         a_scale=None, c_scale=None, vt_scale=None, norm=None, c_gamma=None, c_rowsq=None, a_row_scale=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -208,7 +208,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     a2_split) applied, and the pre-scales to apply to out_split / vt_split (see cvx_gemm_split_io in the header).
     norm = dict(gamma, beta (or None), out_split, scale (device pre-scale or None)[, eps]): the AdaptiveRMSNorm / RMSNorm of the
     rows of `out` as part of the same call (cvx_gemm_f16x3_norm): its split pair feeds the next GEMM; on the split-K path the
-    norm rides in the reduction (no launch, no re-read)."""
+    norm rides in the reduction (no launch, no re-read).
+    Deferred norm (cvx_gemm_split_io, version 105; interleaved operands only): c_gamma [N] multiplies the columns of out_split,
+    c_rowsq [M, >= N/64] receives the rows' sums of squares per 64-column slice (rownorm_scale turns them into one factor per
+    row); a_row_scale [M] multiplies the rows of the accumulators of the GEMM that consumes that pair."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -268,6 +271,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                 io.A2_hi, io.A2_lo, io.lda2_h = _pair(a2_split, M, K - k1)
         if out_split is not None:
             io.C_hi, io.C_lo, io.ldc_h = _pair(out_split, M, rope_cols if vt_split is not None else N)
+        if c_gamma is not None or c_rowsq is not None or a_row_scale is not None:
+            _chk_f32(c_gamma, c_rowsq, a_row_scale)
+            if c_gamma is not None:
+                assert c_gamma.numel() == N and c_gamma.stride(-1) == 1 and out_split is not None
+                io.c_gamma_dev = c_gamma.data_ptr()
+            if c_rowsq is not None:
+                assert c_rowsq.ndim == 2 and c_rowsq.shape[0] >= M and c_rowsq.stride(1) == 1 and c_rowsq.shape[1] * 64 >= N
+                io.c_rowsq, io.c_rowsq_ld = c_rowsq.data_ptr(), c_rowsq.stride(0)
+            if a_row_scale is not None:
+                assert a_row_scale.numel() >= M and a_row_scale.stride(-1) == 1
+                io.a_row_scale_dev = a_row_scale.data_ptr()
         if vt_split is not None:          # QKV mode: v columns transposed per (sequence, head) for the f16x3 attention
             vh, vl = vt_split
             assert vh.dtype == torch.float16 and vh.is_contiguous() and (vl is None or (vl.is_contiguous() and vh.shape == vl.shape))
@@ -298,6 +312,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     assert norm is None, "a fused norm needs the f16x3 kernel"
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
     assert a_scale is None and c_scale is None and vt_scale is None
+    assert c_gamma is None and c_rowsq is None and a_row_scale is None, "a deferred norm needs the f16x3 kernel"
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
     return out
 
@@ -362,6 +377,15 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     _lib.check(_lib.load().cvx_adarmsnorm_scaled_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), oh, ol, rows, D, rpg,
                                                      float(D) ** 0.5, eps, _sp(split_scale), _stream()), "cvx_adarmsnorm_f32")
     return out if out is not None else out_split
+
+
+def rownorm_scale(rowsq: torch.Tensor, rows: int, parts: int, out: torch.Tensor, scale: float, eps: float = 1e-12) -> torch.Tensor:
+    """out[r] = scale / max(sqrt(sum(rowsq[r, :parts])), eps) (cvx_rownorm_scale_f32): the per-row factor of a deferred norm."""
+    _chk_f32(rowsq, out)
+    assert rowsq.ndim == 2 and rowsq.stride(1) == 1 and rowsq.shape[0] >= rows and rowsq.shape[1] >= parts and out.numel() >= rows and out.stride(-1) == 1
+    _lib.check(_lib.load().cvx_rownorm_scale_f32(rowsq.data_ptr(), rows, parts, rowsq.stride(0), scale, eps, out.data_ptr(), _stream()),
+               "cvx_rownorm_scale_f32")
+    return out
 
 
 # Saturation flags are CALLER-OWNED: one int32 of device memory per (device, stream), bound to the stream with

@@ -923,3 +923,94 @@ def test_gemm_persistent_blocks_walk_several_tiles(ops):
         assert rel_l2((vt[0].double() + vt[1].double())[:, ops.vt_frame_slots(T, dev_)], v) < 1e-6
     finally:
         ops._GEMM_FLAGS = saved
+
+
+@pytest.mark.parametrize("M", [2100, 4096])
+def test_gemm_deferred_norm_producer_and_consumers(ops, M):
+    """Deferred AdaptiveRMSNorm (cvx_gemm_split_io version 105; reference acoustic.py:198-204 between :306-318's products):
+    producer forms (residual + fp32 + twin * gamma + row sums of squares; A | A2 + bias + the same), cvx_rownorm_scale_f32, and the
+    consumer forms (bias + GELU + split with a factor per row; QKV with a bias and that factor on q | k | v) - each against fp64, and
+    the chain producer -> factor -> consumer against  norm(x) @ W.T  computed the reference's way."""
+    dev_ = dev()
+    g = torch.Generator().manual_seed(77 + M)
+    K, D, H = 1024, 1024, 4
+    x = torch.randn(M, K, generator=g).to(dev_)
+    il = ops.SplitIL(M, K, dev_); ops.split_act_f16(x, il)
+    xs = il.dense()[0].double() + il.dense()[1].double()
+
+    def weights(N, Kw=K):
+        w = (torch.randn(N, Kw, generator=g) / math.sqrt(Kw)).to(dev_)
+        ws = ops.split_f16(w)
+        return w, ws, ops.split_f16_interleaved(ws)
+    pair = lambda t: t.dense()[0].double() + t.dense()[1].double()
+    gamma = (1.0 + 0.3 * torch.randn(D, generator=g)).to(dev_)
+    beta = (0.2 * torch.randn(D, generator=g)).to(dev_)
+    cs = torch.tensor([4.0], device=dev_)
+    # ---- producer 1: to_out / ff2 form
+    w, ws, wil = weights(D)
+    b, r = torch.randn(D, generator=g).to(dev_), torch.randn(M, D, generator=g).to(dev_)
+    c = torch.full((M, D), float("nan"), device=dev_)
+    tw = ops.SplitIL(M, D, dev_)
+    rowsq = torch.full((M, D // 64), float("nan"), device=dev_)
+    ops.gemm(x, w, c, w_split=ws, w_il=wil, a_split=il, bias=b, residual=r, out_split=tw, c_scale=cs, c_gamma=gamma, c_rowsq=rowsq)
+    want = xs @ w.double().T + b.double() + r.double()
+    assert rel_l2(c, want) < 1e-6
+    assert rel_l2(pair(tw), want * gamma.double() * 4.0) < 1e-6
+    assert rel_l2(rowsq.double(), c.double().square().reshape(M, D // 64, 64).sum(-1)) < 1e-6
+    rs = torch.empty(M, device=dev_)
+    ops.rownorm_scale(rowsq, M, D // 64, rs, float(D) ** 0.5)
+    assert rel_l2(rs.double(), math.sqrt(D) / c.double().norm(dim=-1)) < 1e-6
+    # ---- producer 2: skip-combiner form (A | A2, bias)
+    w2, ws2, wil2 = weights(D, 2 * K)
+    c2 = torch.full((M, D), float("nan"), device=dev_)
+    tw2 = ops.SplitIL(M, D, dev_)
+    rowsq2 = torch.full((M, D // 64), float("nan"), device=dev_)
+    ops.gemm(x, w2, c2, w_split=ws2, w_il=wil2, a_split=il, a2=x, a2_split=il, bias=b, out_split=tw2, c_gamma=gamma, c_rowsq=rowsq2)
+    want2 = torch.cat((xs, xs), 1) @ w2.double().T + b.double()
+    assert rel_l2(c2, want2) < 1e-6 and rel_l2(pair(tw2), want2 * gamma.double()) < 1e-6
+    assert rel_l2(rowsq2.double(), c2.double().square().reshape(M, D // 64, 64).sum(-1)) < 1e-6
+    # ---- the reference's norm of the producer's fp32 output, in fp64
+    cd = c.double()
+    normed = cd / cd.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(D) * gamma.double() + beta.double()
+    a_tw = pair(tw) / 4.0                                   # what the consumer's A operand holds (x * gamma, pre-scale divided out)
+    # ---- consumer 1: ff1 form  (bias' = b1 + beta @ W1.T)
+    w1, ws1, wil1 = weights(2048, D)
+    b1 = torch.randn(2048, generator=g).to(dev_)
+    b1p = (b1.double() + beta.double() @ w1.double().T).float()
+    o = ops.SplitIL(M, 2048, dev_)
+    guard = torch.full((M, 2048), 7.0, device=dev_)
+    ops.gemm(c, w1, guard, w_split=ws1, w_il=wil1, a_split=tw, a_scale=cs, bias=b1p, act=1, out_split=o, write_f32=False, a_row_scale=rs)
+    assert bool((guard == 7.0).all())
+    got = pair(o)
+    assert rel_l2(got, F.gelu(a_tw * rs.double()[:, None] @ w1.double().T + b1p.double())) < 1e-6       # the kernel's own arithmetic
+    assert rel_l2(got, F.gelu(normed @ w1.double().T + b1.double())) < 2e-6                            # = the reference's norm -> ff1
+    # ---- consumer 2: to_qkv form (bias = beta @ Wqkv.T in front of the rotation; q | k split, v transposed)
+    T = M // 4
+    Bt, Mq = 4, 4 * T
+    wq, wsq, wilq = weights(3 * H * 64, D)
+    bq = (beta.double() @ wq.double().T).float()
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(T).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(dev_).contiguous(), ang.sin().to(dev_).contiguous()
+    twq = tw.rows_view(0, Mq)
+    qk = (torch.empty(Mq, 2 * H * 64, dtype=torch.float16, device=dev_), torch.empty(Mq, 2 * H * 64, dtype=torch.float16, device=dev_))
+    Tp = (T + 31) // 32 * 32
+    vt = (torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev_), torch.zeros(Bt * H * 64, Tp, dtype=torch.float16, device=dev_))
+    dummy = torch.empty(Mq, 3 * H * 64, device=dev_)
+    ops.gemm(c[:Mq], wq, dummy, w_split=wsq, w_il=wilq, a_split=twq, a_scale=cs, bias=bq, rope=(cos, sin), rope_cols=2 * H * 64, out_split=qk,
+             vt_split=vt, write_f32=False, a_row_scale=rs)
+    z = normed[:Mq] @ wq.double().T
+    zq = z[:, : 2 * H * 64].reshape(Bt, T, 2 * H, 64)
+    c_, s_ = torch.cat((ang.cos(), ang.cos()), -1).double().to(dev_), torch.cat((ang.sin(), ang.sin()), -1).double().to(dev_)
+    rot = torch.cat((-zq[..., 32:], zq[..., :32]), -1)
+    want_qk = (zq * c_[None, :, None, :] + rot * s_[None, :, None, :]).reshape(Mq, -1)
+    assert rel_l2(qk[0].double() + qk[1].double(), want_qk) < 2e-6
+    v = z[:, 2 * H * 64:].reshape(Bt, T, H, 64).permute(0, 2, 3, 1).reshape(Bt * H * 64, T)
+    slots = ops.vt_frame_slots(T, dev_)
+    assert rel_l2((vt[0].double() + vt[1].double())[:, slots], v) < 2e-6
+    # ---- refused outside the large-problem kernel's four forms
+    with pytest.raises(ops._lib.CovomixHipError):
+        ops.gemm(x[:1000], w, c[:1000], w_split=ws, w_il=wil, a_split=il.rows_view(0, 1000), residual=r[:1000], out_split=tw.rows_view(0, 1000),
+                 c_gamma=gamma, c_rowsq=rowsq)
+    with pytest.raises(ops._lib.CovomixHipError):
+        ops.gemm(x, w, c, w_split=ws, w_il=wil, a_split=il, a_row_scale=rs)            # fp32 store with a row factor: not a consumer form
