@@ -153,6 +153,12 @@ typedef struct {
      * residual + fp32 store (to_out, ff2) or A2 + bias + fp32 store (skip combiner); consumer: bias + GELU + split store (ff1) or
      * the QKV mode with an optional bias - and every other combination is refused (CVX_ERR_INVALID). */
     const float* c_gamma_dev; float* c_rowsq; int64_t c_rowsq_ld; const float* a_row_scale_dev;
+    /* The residual as a split pair (producer forms with a residual only; a->residual must be NULL): residual[m,n] =
+     * (R_hi + R_lo)[m,n] / *r_scale_dev (R_lo == R_hi + 32: interleaved, ldr_h >= 2N).  With write_f32 == 0 the residual stream
+     * of the transformer lives in HBM as pairs only - the to_out / ff2 epilogue then moves the bytes the fp32 form moved (read
+     * 4 B, write 4 B per element) and the norm kernel's 8 B per element are gone.  c_gamma_dev may be NULL (gamma folded into the
+     * consumer's weights instead: cvx_split_f16_colscale_il).  R may alias C_hi / C_lo (same element, same lane). */
+    const uint16_t* R_hi; const uint16_t* R_lo; int64_t ldr_h; const float* r_scale_dev;
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
 #define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */
@@ -160,6 +166,12 @@ typedef struct {
 #define CVX_GEMM_FLAG_NO_MEDIUM 16  /* ... never take it there (the large-problem kernel's rounds of 256 x 256 tiles): A/B measurements */
 #define CVX_GEMM_FLAG_ONE_TILE 4    /* eight-phase 16x16x32 kernel: one output tile per block instead of persistent blocks (bit-identical results) */
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
+/* n_sets interleaved split copies of ONE weight matrix with its COLUMNS scaled: out[s][n][il(k)] = split( W[n,k] * colscale[s*cs_ld + k] *
+ * set_scale_dev[s*ss_ld] * scale ), each [N][K/32][hi 32 | lo 32] (the w_interleaved layout, row length 2K halves), K % 32 == 0.
+ * Deferred AdaptiveRMSNorm with gamma on the weight side: set s = evaluation time s of a solve, colscale = that time's gamma row,
+ * set_scale_dev = a power of two that keeps |gamma| <= 1 (the consumer divides it out through a_scale_dev).  W is read once. */
+int cvx_split_f16_colscale_il(const float* W, int64_t ldw, int32_t N, int32_t K, const float* colscale, int64_t cs_ld,
+                              const float* set_scale_dev, int64_t ss_ld, int32_t n_sets, float scale, uint16_t* out, cvx_stream_t s);
 /* the same with an additional DEVICE-resident factor (the pair holds w * scale * *scale_dev; scale_dev may be NULL) */
 int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev, cvx_stream_t s);
 int cvx_gemm_f16x3(const cvx_gemm_args* a, const uint16_t* W_hi, const uint16_t* W_lo, float acc_scale,

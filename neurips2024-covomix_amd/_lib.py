@@ -45,6 +45,7 @@ class GemmSplitIO(C.Structure):
         ("flags", C.c_int32),
         ("a_scale_dev", C.c_void_p), ("c_scale_dev", C.c_void_p), ("vt_scale_dev", C.c_void_p),
         ("c_gamma_dev", C.c_void_p), ("c_rowsq", C.c_void_p), ("c_rowsq_ld", C.c_int64), ("a_row_scale_dev", C.c_void_p),
+        ("R_hi", C.c_void_p), ("R_lo", C.c_void_p), ("ldr_h", C.c_int64), ("r_scale_dev", C.c_void_p),
     ]
 
 
@@ -218,6 +219,8 @@ SIGNATURES = {
                                                       C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_amax_pow2_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvx_split_f16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "cvx_split_f16_colscale_il": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
+                                            C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_rownorm_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "cvx_adarmsnorm_scaled_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -122,6 +122,7 @@ class VectorField:
                     v[1].view(torch.int16).bitwise_and_(keep)
         # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
         self.split_il: Dict[str, tuple] = {}
+        self._dn_bufs: Dict[tuple, dict] = {}          # deferred norm: W diag(gamma(t)) pairs of one solve (contents rebuilt per call)
         if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
             for k, v in self.split.items():
                 if v[0].shape[0] >= 512 or k == "to_pred.weight":
@@ -205,9 +206,6 @@ class VectorField:
             h2 = h2 + att_o[i] + ff_o[i]
             hmax = torch.maximum(hmax, h2)
         H = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / hmax.sqrt().clamp_min(tiny))).clamp(-40, 40)).reshape(1).contiguous()
-        # deferred norm: the pairs that feed to_qkv / ff1 hold x * gamma (not normalised): residual-stream magnitude times rms(gamma)
-        g_rms = torch.stack([ms[..., 0], ms[..., 2]], dim=-1).sqrt() * hmax.sqrt()                       # [n, L, 2]
-        self._g_scales = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / g_rms.clamp_min(tiny))).clamp(-40, 40)).contiguous()
         return S, H
 
     # ------------------------------------------------------------------ workspace
@@ -338,38 +336,127 @@ class VectorField:
     DEFER_MIN_ROWS = int(os.environ.get("CVX_DEFER_NORM_ROWS", "8192"))
 
     def _defers(self, M: int, ws: dict) -> bool:
-        """The norm in front of ff1 (every layer) and in front of to_qkv behind a skip combiner is ONE gamma / beta row per
-        evaluation, so  norm(x) W^T = (sqrt(D) / ||x_row||) ((x * gamma) W^T) + beta W^T  (acoustic.py:198-204, :306-318): the
-        producing GEMM writes the pair of x * gamma and the rows' sums of squares, the consuming GEMM applies the factor per row and
-        carries beta W^T in its bias - the norm kernel (131 MB per launch at the bench shape) does not run.  Large-problem kernel
-        only: batches of DEFER_MIN_ROWS rows and more.  OPT-IN (CVX_DEFER_NORM=1) while it is being measured."""
+        """Large batches run WITHOUT the norm kernel and with the residual stream as split pairs only.  An AdaptiveRMSNorm is one
+        gamma / beta row per evaluation for every frame (acoustic.py:198-204), so for the product that follows it (:306-318)
+            norm(x) W^T = (sqrt(D) / ||x_row||) * (x (W diag(gamma))^T) + beta W^T :
+        * the producing GEMM (to_out, ff2, skip combiner) writes its output ONLY as the split pair the skip combiners already
+          needed (no fp32 store: it moves the bytes the fp32 form moved), reads its residual from that pair, and leaves the rows'
+          sums of squares per 64 columns (cvx_gemm_split_io.R_hi / c_rowsq); cvx_rownorm_scale_f32 makes one factor per row;
+        * the consuming GEMM (to_qkv, ff1) multiplies its accumulator rows by that factor, carries beta W^T in its bias and runs on
+          W diag(gamma(t)) - split copies of the weights for every evaluation time of the solve, rebuilt by prepare() for every call
+          (cvx_split_f16_colscale_il: 7 GB for 32 evaluation times - capacity HBM3E has - written in ~2 ms per solve).
+        The norm kernel (131 MB of traffic per launch at the bench shape, 16 of 17 launches per evaluation) does not run and ff2 no
+        longer writes its output twice.  Only the first layer's attention norm (input from the embedding, fp32) and the final norm
+        stay.  Large-problem kernel only: batches of DEFER_MIN_ROWS rows and more (CVX_DEFER_NORM=0: off)."""
         return (self.precision == "f16x3" and M >= self.DEFER_MIN_ROWS and isinstance(ws.get("normed16"), ops.SplitIL)
-                and self.d["dim"] % 64 == 0 and self.d["dim"] >= 512 and os.environ.get("CVX_DEFER_NORM", "0") == "1")
+                and self.d["dim"] % 64 == 0 and self.d["dim"] >= 512 and os.environ.get("CVX_DEFER_NORM", "1") == "1")
 
     def _deferred_norm_tables(self, ctx: dict, table: torch.Tensor) -> None:
-        """beta W^T for every (evaluation time, layer): ff1's bias becomes b1 + beta_ff W1^T; layers behind a skip combiner get
-        beta_attn Wqkv^T as the to_qkv bias (in front of the rotation).  Weight streaming: 32 rows at a time on the skinny kernel."""
+        """Per (evaluation time, layer): W diag(gamma) for to_qkv (layers 1..) and ff1 as interleaved split pairs, beta W^T as their
+        bias (ff1: b1 + beta_ff W1^T), and the power of two that keeps |gamma| <= 1 inside the weight pair (divided out on the
+        accumulators through the consumer's a_scale).  Rebuilt for every call: no state survives a call."""
         d, sd = self.d, self.sd
         n, L, dim = table.shape[0], d["depth"], d["dim"]
         tab = table.view(n, L, 4, dim)
+        tiny = torch.finfo(torch.float32).tiny
+        gmax = tab[:, :, 0::2, :].abs().amax(dim=-1)                                     # [n, L, 2]: max |gamma_attn|, max |gamma_ff|
+        gs = torch.exp2(-torch.ceil(torch.log2(gmax.clamp_min(tiny))).clamp(-40, 40)).contiguous()
+        AS = (gs * ctx["h_scale"]).contiguous()                                          # pre-scale of the A pairs (x * H) times the weights' gs
 
         def beta_w(beta_rows: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
             out = torch.empty(n, w.shape[0], dtype=torch.float32, device=self.device)
-            for r0 in range(0, n, 32):
+            for r0 in range(0, n, 32):                                                   # weight streaming: 32 rows at a time on the skinny kernel
                 r1 = min(n, r0 + 32)
-                if w.shape[1] % 8 == 0:
-                    ops.gemm_skinny(beta_rows[r0:r1], w, out[r0:r1], bias=bias)
-                else:
-                    ops.gemm(beta_rows[r0:r1].contiguous(), w, out[r0:r1], bias=bias)
+                ops.gemm_skinny(beta_rows[r0:r1], w, out[r0:r1], bias=bias)
             return out
-        b1p, bq = [], []
+        key = (n, L)
+        bufs = self._dn_bufs.get(key)
+        if bufs is None:
+            self._dn_bufs.clear()
+            mk = lambda N: torch.empty(n, N, 2 * dim, dtype=torch.float16, device=self.device)
+            bufs = dict(wq=[None if i == 0 else mk(3 * d["heads"] * 64) for i in range(L)], w1=[mk(4 * dim) for _ in range(L)])
+            self._dn_bufs[key] = bufs
+        b1p, bq, wq, w1 = [], [], [], []
         for i in range(L):
             p = f"transformer.layers.{i}"
-            b1p.append(beta_w(tab[:, i, 3, :], sd[p + ".4.0.weight"], sd[p + ".4.0.bias"]))
-            bq.append(beta_w(tab[:, i, 1, :], sd[p + ".2.to_qkv.weight"], None) if self.has_comb[i] else None)
-        G = self._g_scales
-        g0 = G.data_ptr()
-        ctx["dn"] = dict(b1p=b1p, bq=bq, G=G, gp=[[(g0 + 4 * ((e * L + i) * 2), g0 + 4 * ((e * L + i) * 2 + 1)) for i in range(L)] for e in range(n)])
+            nq, n1 = p + ".2.to_qkv.weight", p + ".4.0.weight"
+            b1p.append(beta_w(tab[:, i, 3, :], sd[n1], sd[p + ".4.0.bias"]))
+            inv1 = self.split_il[n1][1]
+            ops.split_f16_colscale_il(sd[n1], tab[:, i, 2, :], gs[:, i, 1], 1.0 / inv1, bufs["w1"][i])
+            w1.append([(bufs["w1"][i][e], inv1) for e in range(n)])
+            if i == 0:
+                bq.append(None); wq.append(None)
+                continue
+            bq.append(beta_w(tab[:, i, 1, :], sd[nq], None))
+            invq = self.split_il[nq][1]
+            ops.split_f16_colscale_il(sd[nq], tab[:, i, 0, :], gs[:, i, 0], 1.0 / invq, bufs["wq"][i])
+            wq.append([(bufs["wq"][i][e], invq) for e in range(n)])
+        a0 = AS.data_ptr()
+        ctx["dn"] = dict(b1p=b1p, bq=bq, wq=wq, w1=w1, gs=gs, AS=AS,
+                         asp=[[(a0 + 4 * ((e * L + i) * 2), a0 + 4 * ((e * L + i) * 2 + 1)) for i in range(L)] for e in range(n)])
+
+    def _layers_pair_stream(self, ctx: dict, step: int, ws: dict, h: torch.Tensor, twin: dict, free: list, Bt: int, T: int, M: int, rg):
+        """The transformer layers of one evaluation with the residual stream as split pairs and every AdaptiveRMSNorm deferred into
+        the GEMMs on either side of it (see _defers).  h: the embedding output (fp32, its pair already in twin[id(h)])."""
+        d, sd, dn = self.d, self.sd, ctx["dn"]
+        dim, L = d["dim"], d["depth"]
+        tab = ctx["table"][step]
+        sp, il = self.split.get, self.split_il.get
+        sp_step, hp, pp = ctx["sp"][step], ctx["hp"], self.pred_scale.data_ptr()
+        take = free.pop
+        parts64, rt_dim = dim // 64, float(dim) ** 0.5
+        n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
+        rowsq, rs = ws["rowsq"], ws["rs"]
+        skips: List[torch.Tensor] = []
+        have_rs = False                      # rs = sqrt(D) / ||row|| of the current h
+        for i in range(L):
+            p = f"transformer.layers.{i}"
+            s_na, s_qk, s_v, s_at, s_nf, s_ff = sp_step[i]
+            as_a, as_f = dn["asp"][step][i]
+            last = i + 1 == L
+            if self.has_comb[i]:
+                s = skips.pop()
+                comb = take()
+                ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
+                         a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp, out_split=twin[id(comb)], c_scale=hp, c_rowsq=rowsq, write_f32=False)
+                ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)
+                have_rs = True
+                free += [h, s]
+                h, keep_input = comb, False
+            else:
+                skips.append(h)
+                keep_input = True
+            nq = p + ".2.to_qkv.weight"
+            if have_rs:
+                ops.gemm(ws["normed"], sd[nq], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64, w_split=sp(nq), w_il=dn["wq"][i][step],
+                         a_split=twin[id(h)], out_split=ws["qk16"], vt_split=ws["vt16"], write_f32=False, a_scale=as_a, c_scale=s_qk, vt_scale=s_v,
+                         bias=dn["bq"][i][step], a_row_scale=rs)
+            else:                            # first layer: the embedding output exists in fp32
+                ops.adarmsnorm(h, tab[(4 * i) * dim:(4 * i + 1) * dim], tab[(4 * i + 1) * dim:(4 * i + 2) * dim], None, out_split=n16, split_scale=s_na)
+                ops.gemm(ws["normed"], sd[nq], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64, w_split=sp(nq), w_il=il(nq),
+                         a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"], write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
+            ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16,
+                                qk_scale=s_qk, v_scale=s_v, out_scale=s_at, ragged=rg)
+            h_att = take() if keep_input else h
+            no = p + ".2.to_out.weight"
+            ops.gemm(ws["att"], sd[no], h_att, w_split=sp(no), w_il=il(no), a_split=a16, a_scale=s_at, res_split=twin[id(h)], res_scale=hp,
+                     out_split=twin[id(h_att)], c_scale=hp, c_rowsq=rowsq, write_f32=False)
+            ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)
+            h = h_att
+            n1, n2 = p + ".4.0.weight", p + ".4.2.weight"
+            ops.gemm(ws["normed"], sd[n1], ws["ff"], bias=dn["b1p"][i][step], act=ops.ACT_GELU, w_split=sp(n1), w_il=dn["w1"][i][step],
+                     a_split=twin[id(h)], out_split=f16, write_f32=False, a_scale=as_f, c_scale=s_ff, a_row_scale=rs)
+            next_defers = (not last) and not self.has_comb[i + 1]          # the next layer's attention norm reads THIS output's rows
+            ops.gemm(ws["ff"], sd[n2], h, bias=sd[p + ".4.2.bias"], w_split=sp(n2), w_il=il(n2), a_split=f16, a_scale=s_ff,
+                     res_split=twin[id(h)], res_scale=hp, out_split=twin[id(h)], c_scale=hp, c_rowsq=rowsq if next_defers else None,
+                     write_f32=last)                                      # (the final norm reads fp32)
+            if next_defers:
+                ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)
+            have_rs = next_defers
+        ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"], split_scale=pp)
+        ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"], a_scale=pp,
+                 w_il=il("to_pred.weight") if isinstance(ws["pred16"], ops.SplitIL) else None)
+        return ws["pred"]
 
     # ------------------------------------------------------------------ one evaluation (both CFG branches)
     @staticmethod
@@ -450,8 +537,8 @@ class VectorField:
         # (2048 rows and more never split K: the call would run the same two kernels, so it stays two calls there)
         fuse_norm = split_io and M < 2048 and os.environ.get("CVX_FUSE_NORM", "1") == "1"
         normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
-        dn = ctx.get("dn") if (split_io and not fuse_norm and M >= 2048) else None      # (decided per call in prepare(): the halves of a two-chain schedule follow the whole batch)
-        parts64, rt_dim = dim // 64, float(dim) ** 0.5
+        if split_io and not fuse_norm and M >= 2048 and ctx.get("dn") is not None:       # (decided per call in prepare(): the halves of a two-chain schedule follow the whole batch)
+            return self._layers_pair_stream(ctx, step, ws, h, twin, free, Bt, T, M, rg)
         def tab_rows(i_, k_):
             return tab[(4 * i_ + k_) * dim:(4 * i_ + k_ + 1) * dim]
         skips: List[torch.Tensor] = []
@@ -464,13 +551,7 @@ class VectorField:
             if (p + ".0.weight") in sd:
                 s = skips.pop()
                 comb = take()
-                if split_io and dn is not None:        # deferred attention norm: the pair of comb * gamma + the rows' sums of squares
-                    ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
-                             a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp,
-                             out_split=ws["normed16"], c_scale=dn["gp"][step][i][0], c_gamma=g_attn, c_rowsq=ws["rowsq"])
-                    ops.rownorm_scale(ws["rowsq"], M, parts64, ws["rs"], rt_dim)
-                    normed_ahead = "deferred"
-                elif split_io:
+                if split_io:
                     nm = dict(gamma=g_attn, beta=b_attn, out_split=ws["normed16"],
                               scale=sp_step[i][0] if sp_step is not None else None) if fuse_norm else None
                     ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
@@ -491,35 +572,21 @@ class VectorField:
                     ops.adarmsnorm(h, g_attn, b_attn, None, out_split=n16, split_scale=s_na)
                 # q | k split row-major, v split + transposed, straight into the f16x3 attention (any T: sequences whose
                 # length is not a multiple of 4 store their v columns 2 bytes at a time)
-                if normed_ahead == "deferred":       # n16 = comb * gamma: the factor per row and beta Wqkv^T ride in the epilogue
-                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
-                             write_f32=False, a_scale=dn["gp"][step][i][0], c_scale=s_qk, vt_scale=s_v, bias=dn["bq"][i][step], a_row_scale=ws["rs"])
-                else:
-                    ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
-                             w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
-                             write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
+                ops.gemm(ws["normed"], sd[p + ".2.to_qkv.weight"], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64,
+                         w_split=sp(p + ".2.to_qkv.weight"), w_il=il(p + ".2.to_qkv.weight"), a_split=n16, out_split=ws["qk16"], vt_split=ws["vt16"],
+                         write_f32=False, a_scale=s_na, c_scale=s_qk, vt_scale=s_v)
                 normed_ahead = False
                 ops.attention_f16x3(ws["qk16"], ws["vt16"], None, Bt, T, d["heads"], 64 ** -0.5, out_split=a16,
                                     qk_scale=s_qk, v_scale=s_v, out_scale=s_at, ragged=rg)
                 h_att = take() if keep_input else h
-                if dn is not None:                   # deferred FF norm: to_out leaves h_att * gamma_ff as the pair + the rows' sums of squares
-                    ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
-                             a_split=a16, a_scale=s_at, out_split=n16, c_scale=dn["gp"][step][i][1], c_gamma=g_ff, c_rowsq=ws["rowsq"])
-                    ops.rownorm_scale(ws["rowsq"], M, parts64, ws["rs"], rt_dim)
-                    h = h_att
-                    ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=dn["b1p"][i][step], act=ops.ACT_GELU,
-                             w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
-                             a_scale=dn["gp"][step][i][1], c_scale=s_ff, a_row_scale=ws["rs"])
-                else:
-                    ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
-                             a_split=a16, a_scale=s_at, norm=dict(gamma=g_ff, beta=b_ff, out_split=n16, scale=s_nf) if fuse_norm else None)
-                    h = h_att
-                    if not fuse_norm:
-                        ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
-                    ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
-                             w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
-                             a_scale=s_nf, c_scale=s_ff)
+                ops.gemm(ws["att"], sd[p + ".2.to_out.weight"], h_att, residual=h, w_split=sp(p + ".2.to_out.weight"), w_il=il(p + ".2.to_out.weight"),
+                         a_split=a16, a_scale=s_at, norm=dict(gamma=g_ff, beta=b_ff, out_split=n16, scale=s_nf) if fuse_norm else None)
+                h = h_att
+                if not fuse_norm:
+                    ops.adarmsnorm(h, g_ff, b_ff, None, out_split=n16, split_scale=s_nf)
+                ops.gemm(ws["normed"], sd[p + ".4.0.weight"], ws["ff"], bias=sd[p + ".4.0.bias"], act=ops.ACT_GELU,
+                         w_split=sp(p + ".4.0.weight"), w_il=il(p + ".4.0.weight"), a_split=n16, out_split=f16, write_f32=False,
+                         a_scale=s_nf, c_scale=s_ff)
                 last = i + 1 == d["depth"]
                 nm = None
                 if fuse_norm and last:                   # the final RMSNorm in front of to_pred

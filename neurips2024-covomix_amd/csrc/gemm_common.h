@@ -46,7 +46,10 @@ struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
                   //   producer: the split twin holds C[m,n] * tw_gamma[n] (* c_scale) instead of C, and every 64-column wave tile leaves
                   //             sum_n C[m,n]^2 over its columns in rowsq[m * rowsq_ld + n0 / 64] (fixed order: deterministic);
                   //   consumer: row m of the accumulators is multiplied by row_scale[m] (= sqrt(D) / ||x_m||) before bias / RoPE.
-                  const float* tw_gamma; float* rowsq; int rowsq_ld; const float* row_scale; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
+                  const float* tw_gamma; float* rowsq; int rowsq_ld; const float* row_scale;
+                  // residual given as a split pair (EPI_RES_TW only): residual[m,n] = (res_hi + res_lo)[m,n] / *res_scale; the residual
+                  // stream then lives in HBM as pairs only (write_f32 = 0 on the producer: as many bytes as the fp32 form moved)
+                  const _Float16* res_hi; const _Float16* res_lo; int64_t res_ld; const float* res_scale; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
 
 // accumulator factor: 1 / (weight pre-scale) / (activation pre-scale); both powers of two, so the division is exact
 __device__ __forceinline__ float total_acc_scale(float acc_scale, const SplitOut& so)
@@ -94,7 +97,7 @@ enum : int { EPI_GENERIC = 0, EPI_QKV = 1,      // RoPE on q|k, split q|k + tran
              EPI_GELU_SPLIT = 3,                // bias + GELU, split store only: ff1
              EPI_BIAS = 4,                      // bias, fp32 store: skip combiners
              // deferred AdaptiveRMSNorm (SplitOut::tw_gamma / rowsq / row_scale; 16x16x32 epilogues of gemm_p8s_epi.h only):
-             EPI_RES_TW = 5,                    // EPI_RES + the split twin times gamma[n] + row sums of squares: to_out, ff2
+             EPI_RES_TW = 5,                    // residual (fp32 or a split pair) + optional fp32 store + the split twin (times gamma[n], if given) + row sums of squares: to_out, ff2
              EPI_BIAS_TW = 6,                   // EPI_BIAS + the same twin / sums: skip combiners in front of an attention norm
              EPI_GELU_RS = 7,                   // EPI_GELU_SPLIT with a factor per row on the accumulators: ff1 behind a deferred norm
              EPI_QKV_RS = 8 };                  // EPI_QKV with that factor and a bias (beta . W^T) in front of the rotation

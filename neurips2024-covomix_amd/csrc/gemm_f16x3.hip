@@ -594,7 +594,54 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     if (lo) lo[o] = (f16)(x - (float)h);
 }
 
+// n_sets interleaved split copies of W with scaled columns (deferred norm, gamma on the weight side): thread = 4 consecutive k of
+// one row, W read once, one (hi, lo) store pair per set
+__global__ __launch_bounds__(256) void split_colscale_il_kernel(const float* __restrict__ W, int64_t ldw, int N, int K,
+                                                               const float* __restrict__ colscale, int64_t cs_ld,
+                                                               const float* __restrict__ set_scale, int64_t ss_ld, int n_sets, float scale,
+                                                               f16* __restrict__ out, uint32_t* __restrict__ sat)
+{
+    const int k4 = K / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * k4) return;
+    const int n = (int)(i / k4), k = 4 * (int)(i - (int64_t)n * k4);
+    const f32x4 w = gload4(W + (int64_t)n * ldw + k);
+    const int64_t o = (int64_t)n * 2 * K + (((k >> 5) << 6) | (k & 31));
+    float amax = 0.f;
+    for (int s = 0; s < n_sets; ++s) {
+        const f32x4 g = gload4(colscale + (int64_t)s * cs_ld + k);
+        const float sc = scale * (set_scale ? set_scale[(int64_t)s * ss_ld] : 1.f);
+        cvx_f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = w[e] * g[e] * sc;
+            amax = cvx_amax3_c(amax, x, x);
+            x = fminf(fmaxf(x, -F16_MAX), F16_MAX);
+            h[e] = (f16)x;
+            l[e] = (f16)(x - (float)h[e]);
+        }
+        f16* dst = out + (int64_t)s * N * 2 * K + o;
+        *reinterpret_cast<cvx_f16x4*>(dst) = h;
+        *reinterpret_cast<cvx_f16x4*>(dst + 32) = l;
+    }
+    cvx_sat_commit(sat, amax);
+}
+
 }  // namespace
+
+extern "C" int cvx_split_f16_colscale_il(const float* W, int64_t ldw, int32_t N, int32_t K, const float* colscale, int64_t cs_ld,
+                                         const float* set_scale_dev, int64_t ss_ld, int32_t n_sets, float scale, uint16_t* out, cvx_stream_t s)
+{
+    CVX_REQUIRE(W && colscale && out && N > 0 && K > 0 && K % 32 == 0 && ldw >= K && ldw % 4 == 0 && cs_ld % 4 == 0 && n_sets >= 0 &&
+                (((uintptr_t)W | (uintptr_t)colscale | (uintptr_t)out) & 15) == 0,
+                "split_f16_colscale_il: bad arguments (N=%d K=%d ldw=%ld cs_ld=%ld; K %% 32 == 0, 16-byte aligned rows)", N, K, (long)ldw, (long)cs_ld);
+    if (n_sets == 0) return CVX_OK;
+    const int64_t n = (int64_t)N * (K / 4);
+    hipLaunchKernelGGL(split_colscale_il_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+                       W, ldw, N, K, colscale, cs_ld, set_scale_dev, ss_ld, n_sets, scale, reinterpret_cast<f16*>(out), cvx_sat_flag_for(s));
+    CVX_CHECK_LAUNCH("cvx_split_f16_colscale_il");
+    return CVX_OK;
+}
 
 extern "C" int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, const float* scale_dev,
                                  cvx_stream_t s)
@@ -825,6 +872,8 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         so.write_f32 = (io->write_f32 != 0 || so.hi == nullptr) ? 1 : 0;
         so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev;
         so.tw_gamma = io->c_gamma_dev; so.rowsq = io->c_rowsq; so.rowsq_ld = (int)io->c_rowsq_ld; so.row_scale = io->a_row_scale_dev;
+        so.res_hi = reinterpret_cast<const f16*>(io->R_hi); so.res_lo = reinterpret_cast<const f16*>(io->R_lo); so.res_ld = io->ldr_h;
+        so.res_scale = io->r_scale_dev;
 #ifdef CVX_DEV_FLAGS          // timing experiments (tools/): epilogue skipping, per-block stamps, one tile per block - never in the shipped library
         so.dbg = io->flags >> 8; so.trace = (so.dbg & 4) ? reinterpret_cast<unsigned long long*>(io->workspace) : nullptr;
 #else
@@ -850,11 +899,13 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         }
     }
     // deferred norm (producer: gamma on the twin + row sums of squares; consumer: a factor per row): the 16x16x32 epilogues only
-    const bool dn = so.tw_gamma || so.rowsq || so.row_scale;
+    const bool dn = so.tw_gamma || so.rowsq || so.row_scale || so.res_hi || so.res_lo;
     if (dn) {
         CVX_REQUIRE(!single && !norm && a->N % 64 == 0 && (!so.tw_gamma || (so.hi && ((uintptr_t)so.tw_gamma & 15) == 0)) &&
                     (!so.rowsq || (io->c_rowsq_ld >= a->N / 64 && io->c_rowsq_ld < (1ll << 20))),
                     "gemm_f16x3: deferred norm needs N %% 64 == 0, a split output for c_gamma_dev (16-byte aligned) and c_rowsq_ld >= N / 64");
+        CVX_REQUIRE((so.res_hi == nullptr) == (so.res_lo == nullptr) && (!so.res_hi || (!a->residual && io->ldr_h >= (so.res_lo == so.res_hi + 32 ? 2 : 1) * (int64_t)a->N)),
+                    "gemm_f16x3: a pair residual needs R_hi and R_lo, ldr_h >= N (2N interleaved) and residual == NULL");
     }
     if (a->M == 0) return CVX_OK;
     const int tiles_n = (a->N + BN - 1) / BN, tiles_m = (a->M + 127) / 128;

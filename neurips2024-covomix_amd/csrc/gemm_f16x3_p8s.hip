@@ -26,7 +26,10 @@ constexpr int LDS_B = DUMP_B + 8 * 1024;
 // the main loop for one output tile; SWAP selects the operand order of every MFMA (see the header)
 // first: this is the block's first tile (issue the six-quarter prologue); (m0n, n0n): the block's NEXT tile, whose first
 // six quarters take the place of the tail's dummy pieces (m0n < 0: no next tile), so that it starts without a prologue.
-template <bool HAS_A2, bool SWAP>
+// PERM (the deferred-norm instances): LDS row rho of the W tile holds weight row perm32(rho) (a permutation inside every 32 rows, free:
+// the DMA's source address is per lane) so that a lane's accumulators of a tile PAIR are 8 consecutive output columns - 16-byte
+// split-pair loads / stores in the epilogue instead of 8-byte ones (gemm_p8s_epi.h)
+template <bool HAS_A2, bool SWAP, bool PERM = false>
 __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
                                               int m0, int n0, int m0n, int n0n, bool first, int lane, int wid, int wr, int wc,
                                               f32x4 (&acc)[8][4])
@@ -45,7 +48,7 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
             const int ra = ra0 + (lane >> 3), rb = rb0 + (lane >> 3);
             const uint32_t ca = (uint32_t)(((lane & 7) ^ ((ra >> 1) & 7)) * 16);
             const uint32_t cb = (uint32_t)(((lane & 7) ^ ((rb >> 1) & 7)) * 16);
-            const uint32_t ga = (uint32_t)min(mm + ra, p.M - 1), gb = (uint32_t)min(nn + rb, p.N - 1);
+            const uint32_t ga = (uint32_t)min(mm + ra, p.M - 1), gb = (uint32_t)min(nn + (PERM ? perm32(rb) : rb), p.N - 1);
             offA[h][j] = ga * (uint32_t)ldaB + ca;                 // (every operand spans < 4 GiB: checked by the launcher)
             offA2[h][j] = HAS_A2 ? ga * (uint32_t)lda2B + ca : 0u;
             offW[h][j] = gb * (uint32_t)ldwB + cb;
@@ -214,11 +217,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
         const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
         bool v_block = false;
         if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_RS) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
+        constexpr bool PERM = epi_perm(EPI);
         if (v_block) {
-            tile_mainloop<HAS_A2, false>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
-            if (!(so.dbg & 1)) epilogue_vt<8, false, EPI == EPI_QKV_RS>(p, acc, row0, col0, lane, so, acc_scale);
+            tile_mainloop<HAS_A2, false, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
+            if (!(so.dbg & 1)) epilogue_vt<8, false, EPI == EPI_QKV_RS, PERM>(p, acc, row0, col0, lane, so, acc_scale);
         } else {
-            tile_mainloop<HAS_A2, true>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
+            tile_mainloop<HAS_A2, true, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
             if (!(so.dbg & 1)) epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);      // (dbg bit 0: main loop only, timing)
         }
         if (nslot < 0) break;
@@ -259,14 +263,18 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     const dim3 grid((unsigned)g);
     int epi = classify_epilogue(a, so);
     if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;
-    if (so.tw_gamma || so.rowsq || so.row_scale) {         // deferred norm: its own instances, nothing else carries it
-        const bool prod = so.tw_gamma && so.rowsq && so.hi && so.write_f32 && a.act == CVX_ACT_NONE && !a.rope_cos && !so.vt_hi && !so.row_scale;
-        const bool cons = so.row_scale && !so.tw_gamma && !so.rowsq && so.hi && !so.write_f32 && !a.residual;
-        if (prod && a.residual && !A.hi2) epi = EPI_RES_TW;
-        else if (prod && !a.residual && A.hi2) epi = EPI_BIAS_TW;
+    if (so.tw_gamma || so.rowsq || so.row_scale || so.res_hi) {         // deferred norm: its own instances, nothing else carries it
+        const bool prod = so.hi && a.act == CVX_ACT_NONE && !a.rope_cos && !so.vt_hi && !so.row_scale && !(a.residual && so.res_hi) &&
+                          (!so.res_hi || (so.res_lo && (((uintptr_t)so.res_hi | (uintptr_t)so.res_lo) & 7) == 0 && (so.res_ld & 3) == 0));
+        const bool cons = so.row_scale && !so.tw_gamma && !so.rowsq && !so.res_hi && so.hi && !so.write_f32 && !a.residual;
+        if (prod && (a.residual || so.res_hi) && !A.hi2) epi = EPI_RES_TW;
+        else if (prod && !a.residual && !so.res_hi && A.hi2) epi = EPI_BIAS_TW;
         else if (cons && a.bias && a.act == CVX_ACT_GELU && !a.rope_cos && !so.vt_hi && !A.hi2) epi = EPI_GELU_RS;
         else if (cons && a.act == CVX_ACT_NONE && a.rope_cos && so.vt_hi && !A.hi2) epi = EPI_QKV_RS;
         else return false;
+        // (these instances move split pairs 16 bytes at a time: 8 consecutive columns per lane, see perm32)
+        if (epi_perm(epi) && (((((uintptr_t)so.hi | (uintptr_t)so.lo | (uintptr_t)so.res_hi | (uintptr_t)so.res_lo) & 15) != 0) || (so.ldc_h & 7) != 0 ||
+                              (so.res_hi && (so.res_ld & 7) != 0))) return false;
     }
     if (epi == EPI_GENERIC && so.vt_hi) return false;
 #define CVX_P8S_LAUNCH(A2, E)                                                                                           \

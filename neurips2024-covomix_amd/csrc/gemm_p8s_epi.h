@@ -30,6 +30,17 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
                  : "memory");
 }
 
+// Column permutation of the deferred-norm instances (large-problem kernel only).  LDS row rho = 16 h + 4 g + e of a 32-row group of
+// the W tile holds weight row 8 g + 4 h + e, so accumulator tile ni = 2 t + h of lane group g (lane >> 4) holds the output columns
+// 32 t + 8 g + 4 h + (0..3): the tile pair (2 t, 2 t + 1) is 8 CONSECUTIVE columns per lane.
+#ifndef CVX_P8S_PERM
+#define CVX_P8S_PERM 1                         // dev A/B: 0 = the deferred-norm instances without the permutation (8-byte pair accesses)
+#endif
+__host__ __device__ constexpr bool epi_perm(int epi) { return CVX_P8S_PERM && epi >= EPI_RES_TW; }
+__device__ __forceinline__ int perm32(int r) { return (r & ~31) | ((r & 12) << 1) | ((r & 16) >> 2) | (r & 3); }
+// first of the 4 columns tile ni of lane group lc / 4 holds, relative to the wave tile's first column
+template <bool PERM> __device__ __forceinline__ int tile_col(int ni, int lc) { return PERM ? 32 * (ni >> 1) + 2 * lc + 4 * (ni & 1) : 16 * ni + lc; }
+
 #ifndef CVX_P8S_RES_AHEAD
 #define CVX_P8S_RES_AHEAD 2
 #endif
@@ -92,15 +103,18 @@ __device__ __forceinline__ void epi_specialise(cvx_gemm_args& p, SplitOut& so)
         p.act = CVX_ACT_NONE; p.bias = nullptr; p.residual = nullptr; so.write_f32 = 0;
     } else if constexpr (EPI == EPI_QKV_RS) {
         p.act = CVX_ACT_NONE; p.residual = nullptr; so.write_f32 = 0;
-    } else if constexpr (EPI == EPI_RES || EPI == EPI_RES_TW) {
+    } else if constexpr (EPI == EPI_RES) {
         p.act = CVX_ACT_NONE; p.rope_cos = nullptr; so.write_f32 = 1;
+    } else if constexpr (EPI == EPI_RES_TW) {
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr;
     } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELU_RS) {
         p.act = CVX_ACT_GELU; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 0;
     } else if constexpr (EPI == EPI_BIAS) {
         p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1; so.hi = nullptr; so.lo = nullptr;
     } else if constexpr (EPI == EPI_BIAS_TW) {
-        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr; so.write_f32 = 1;
+        p.act = CVX_ACT_NONE; p.rope_cos = nullptr; p.residual = nullptr;
     }
+    if constexpr (EPI != EPI_RES_TW) so.res_hi = nullptr;
     if constexpr (EPI != EPI_RES_TW && EPI != EPI_BIAS_TW) { so.tw_gamma = nullptr; so.rowsq = nullptr; }
     if constexpr (EPI != EPI_GELU_RS && EPI != EPI_QKV_RS) so.row_scale = nullptr;
 }
@@ -148,6 +162,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     cvx_gemm_args p = p_in;
     SplitOut so = so_in;
     epi_specialise<EPI>(p, so);
+    constexpr bool PERM = !PRE && epi_perm(EPI);                              // a lane's tile pair = 8 consecutive columns
     const int lr = lane & 15, lc = 4 * (lane >> 4);
     const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);          // wave-uniform (64-column wave tile = one head)
     float cs;
@@ -160,23 +175,40 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     for (int ni = 0; ni < 4; ++ni) {
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (PRE) { if (p.bias) b4 = pre->bias[ni]; }
-        else if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+        else if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + tile_col<PERM>(ni, lc));
         bias[ni][0] = f32x2{b4[0], b4[1]}; bias[ni][1] = f32x2{b4[2], b4[3]};
     }
     // residual rows are requested CVX_P8S_RES_AHEAD row groups before they are added (explicitly: where hipcc puts these loads
     // on its own moves with unrelated changes of the epilogue - the saturation bookkeeping cost 0.65 % of the step that way)
     constexpr int RA = CVX_P8S_RES_AHEAD;
     f32x4 rbuf[RA + 1][4];
+    // (EPI_RES_TW: the residual may be a split pair - a lane's 4 hi halves travel in r[ni][0..1], its 4 lo halves in r[ni][2..3])
+    const bool res_pair = (EPI == EPI_RES_TW) && so.res_hi != nullptr;
+    const bool res_il = res_pair && so.res_lo == so.res_hi + 32;
+    const bool has_res = p.residual != nullptr || res_pair;
+    float res_inv = 1.f;
+    if (res_pair && so.res_scale) res_inv = 1.f / *so.res_scale;           // (a power of two: exact)
     auto load_res = [&](int mi_, f32x4 (&r)[4]) {
         const int row_ = row0 + 16 * mi_ + lr;
         const int rr_ = row_ < p.M ? row_ : p.M - 1;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             if constexpr (PRE) r[ni] = pre->res[mi_][ni];
-            else r[ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr_ * p.ldr + col0 + 16 * ni + lc);
+            else if (res_pair) {
+                const int c_ = col0 + tile_col<PERM>(ni, lc);
+                const int64_t o_ = (int64_t)rr_ * so.res_ld + (res_il ? il_col(c_) : c_);
+                if constexpr (PERM) {        // the tile pair's 8 columns: one 16-byte load of hi halves (r[even]), one of lo halves (r[odd])
+                    if (ni & 1) r[ni] = *reinterpret_cast<const f32x4*>(so.res_lo + o_ - 4);
+                    else r[ni] = *reinterpret_cast<const f32x4*>(so.res_hi + o_);
+                } else {
+                    const f32x2 h_ = *reinterpret_cast<const f32x2*>(so.res_hi + o_), l_ = *reinterpret_cast<const f32x2*>(so.res_lo + o_);
+                    r[ni] = f32x4{h_[0], h_[1], l_[0], l_[1]};
+                }
+            }
+            else r[ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr_ * p.ldr + col0 + tile_col<PERM>(ni, lc));
         }
     };
-    if (RA > 0 && p.residual) {
+    if (RA > 0 && has_res) {
 #pragma unroll
         for (int a = 0; a < RA; ++a) load_res(a, rbuf[a]);
     }
@@ -192,7 +224,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
         const int row = row0 + 16 * mi + lr;
         const bool live = row < p.M;
         const int rr = live ? row : p.M - 1;
-        if (RA > 0 && p.residual && mi + RA < MI) load_res(mi + RA, rbuf[(mi + RA) % (RA + 1)]);
+        if (RA > 0 && has_res && mi + RA < MI) load_res(mi + RA, rbuf[(mi + RA) % (RA + 1)]);
         f32x2 v[4][2];
         f32x2 scr = sc2;
         if constexpr (RS) scr = splat2(acc_scale * rscale[mi]);      // deferred norm: sqrt(D) / ||x_row|| rides on the accumulator scale
@@ -213,8 +245,8 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 f32x4 c, s;
                 if constexpr (PRE) { c = pre->rc[mi][ni]; s = pre->rs[mi][ni]; }
                 else {
-                    c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
-                    s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
+                    c = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + tile_col<PERM>(ni, lc));
+                    s = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + tile_col<PERM>(ni, lc));
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -225,16 +257,31 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 }
             }
         }
-        if (p.residual) {
+        if (res_pair) {
+            static_assert(RA > 0 || EPI != EPI_RES_TW, "the pair residual is read through the look-ahead buffers");
+            const f32x2 ri2 = splat2(res_inv);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 r = rbuf[mi % (RA + 1)][ni];
+                if constexpr (PERM) {        // r[even] = 8 hi halves, r[odd] = 8 lo halves of the pair's columns: tile ni takes 4 of each
+                    const f32x4 rh = rbuf[mi % (RA + 1)][ni & ~1], rl = rbuf[mi % (RA + 1)][ni | 1];
+                    r = (ni & 1) ? f32x4{rh[2], rh[3], rl[2], rl[3]} : f32x4{rh[0], rh[1], rl[0], rl[1]};
+                }
+                const f16x4 h4 = __builtin_bit_cast(f16x4, f32x2{r[0], r[1]}), l4 = __builtin_bit_cast(f16x4, f32x2{r[2], r[3]});
+                // hi + lo is exact in fp32 (two 11-bit significands at most 2^11 apart), the un-scaling a power of two
+                v[ni][0] = fma2(f32x2{(float)h4[0] + (float)l4[0], (float)h4[1] + (float)l4[1]}, ri2, v[ni][0]);
+                v[ni][1] = fma2(f32x2{(float)h4[2] + (float)l4[2], (float)h4[3] + (float)l4[3]}, ri2, v[ni][1]);
+            }
+        } else if (p.residual) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const f32x4 r = RA > 0 ? rbuf[mi % (RA + 1)][ni]
-                                       : *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
+                                       : *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + tile_col<PERM>(ni, lc));
                 v[ni][0] += f32x2{r[0], r[1]};
                 v[ni][1] += f32x2{r[2], r[3]};
             }
         }
-        if constexpr (TW) {      // sum of squares of the row's 64 columns of this wave tile: 16 in-lane, then the 4 lanes that share the row
+        if (TW && so.rowsq) {    // sum of squares of the row's 64 columns of this wave tile: 16 in-lane, then the 4 lanes that share the row
             f32x2 q2 = v[0][0] * v[0][0];
             q2 = fma2(v[0][1], v[0][1], q2);
 #pragma unroll
@@ -249,18 +296,19 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 if constexpr (PRE) { if (col0 + 16 * ni >= p.N) continue; }      // (N % 16 == 0 on the medium-problem kernel: partial wave tile)
-                *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + 16 * ni + lc) = f32x4{v[ni][0][0], v[ni][0][1], v[ni][1][0], v[ni][1][1]};
+                *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col0 + tile_col<PERM>(ni, lc)) = f32x4{v[ni][0][0], v[ni][0][1], v[ni][1][0], v[ni][1][1]};
             }
         }
         if (so.hi) {
+            f16x4 ph = f16x4{0, 0, 0, 0}, pl = f16x4{0, 0, 0, 0};
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 if constexpr (PRE) { if (col0 + 16 * ni >= p.N) continue; }
-                const int c = col0 + 16 * ni + lc;
+                const int c = col0 + tile_col<PERM>(ni, lc);
                 const int64_t o = (int64_t)row * so.ldc_h + (il ? il_col(c) : c);
                 f16x2 h01, h23, l01, l23;
                 f32x2 g01 = cs2, g23 = cs2;
-                if constexpr (TW) {          // (re-read per row group - an L1 hit - rather than 16 registers held across the epilogue)
+                if (TW && so.tw_gamma) {     // (re-read per row group - an L1 hit - rather than 16 registers held across the epilogue)
                     const float* gp = so.tw_gamma + c;
                     asm volatile("" : "+v"(gp));
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp);
@@ -268,8 +316,17 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
                 }
                 split2_pk(v[ni][0] * g01, h01, l01, amax);
                 split2_pk(v[ni][1] * g23, h23, l23, amax);
-                *reinterpret_cast<f16x4*>(so.hi + o) = f16x4{h01[0], h01[1], h23[0], h23[1]};
-                if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = f16x4{l01[0], l01[1], l23[0], l23[1]};
+                if constexpr (PERM) {        // tile 2t parks its halves, tile 2t + 1 stores the pair's 8 consecutive columns: 16 bytes of hi, 16 of lo
+                    if (ni & 1) {
+                        *reinterpret_cast<f16x8*>(so.hi + o - 4) = f16x8{ph[0], ph[1], ph[2], ph[3], h01[0], h01[1], h23[0], h23[1]};
+                        if (so.lo) *reinterpret_cast<f16x8*>(so.lo + o - 4) = f16x8{pl[0], pl[1], pl[2], pl[3], l01[0], l01[1], l23[0], l23[1]};
+                    } else {
+                        ph = f16x4{h01[0], h01[1], h23[0], h23[1]}; pl = f16x4{l01[0], l01[1], l23[0], l23[1]};
+                    }
+                } else {
+                    *reinterpret_cast<f16x4*>(so.hi + o) = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                    if (so.lo) *reinterpret_cast<f16x4*>(so.lo + o) = f16x4{l01[0], l01[1], l23[0], l23[1]};
+                }
             }
         }
     }
@@ -279,7 +336,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
 // ---- epilogue of a V block of a to_qkv projection, UN-swapped layout:
 // acc[mi][ni][r] = C[row0 + 16 mi + 4 (lane >> 4) + r][col0 + 16 ni + (lane & 15)]: 4 consecutive frames per lane ->
 // vt[((b*H + head)*64 + d) * vt_ld + slot(t)], 8 bytes per store when the four frames are one aligned slot group
-template <int MI = 8, bool PRE = false, bool RS = false>
+template <int MI = 8, bool PRE = false, bool RS = false, bool PERM = false>
 __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)[MI][4], int row0, int col0, int lane,
                                             const SplitOut& so, float acc_scale, const EpiPre<MI>* pre = nullptr)
 {
@@ -303,7 +360,7 @@ __device__ __forceinline__ void epilogue_vt(const cvx_gemm_args& p, f32x4 (&acc)
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int d = 16 * ni + (lane & 15);
+            const int d = PERM ? perm32(16 * ni + (lane & 15)) : 16 * ni + (lane & 15);      // (the W tile's rows may be permuted inside 32)
             const float bv = p.bias ? p.bias[col0 + d] * vs0 : 0.f;
             f16x4 h, l;
             split4_pk(f32x4{fmaf(acc[mi][ni][0], rs4[0], bv), fmaf(acc[mi][ni][1], rs4[1], bv), fmaf(acc[mi][ni][2], rs4[2], bv), fmaf(acc[mi][ni][3], rs4[3], bv)}, h, l, amax);

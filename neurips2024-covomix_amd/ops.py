@@ -195,7 +195,8 @@ def _sp(t: Optional[torch.Tensor]) -> Optional[int]:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None,
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
          a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None,
-         a_scale=None, c_scale=None, vt_scale=None, norm=None, c_gamma=None, c_rowsq=None, a_row_scale=None) -> torch.Tensor:
+         a_scale=None, c_scale=None, vt_scale=None, norm=None, c_gamma=None, c_rowsq=None, a_row_scale=None,
+         res_split=None, res_scale=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -211,7 +212,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     norm rides in the reduction (no launch, no re-read).
     Deferred norm (cvx_gemm_split_io, version 105; interleaved operands only): c_gamma [N] multiplies the columns of out_split,
     c_rowsq [M, >= N/64] receives the rows' sums of squares per 64-column slice (rownorm_scale turns them into one factor per
-    row); a_row_scale [M] multiplies the rows of the accumulators of the GEMM that consumes that pair."""
+    row); a_row_scale [M] multiplies the rows of the accumulators of the GEMM that consumes that pair; res_split (+ res_scale) gives
+    the residual as a split pair (then residual must be None; may be the very pair out_split names)."""
     _chk_f32(a, w, out, bias, residual, a2)
     M = a.shape[0]
     N = w.shape[0]
@@ -271,6 +273,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                 io.A2_hi, io.A2_lo, io.lda2_h = _pair(a2_split, M, K - k1)
         if out_split is not None:
             io.C_hi, io.C_lo, io.ldc_h = _pair(out_split, M, rope_cols if vt_split is not None else N)
+        if res_split is not None:
+            assert residual is None
+            io.R_hi, io.R_lo, io.ldr_h = _pair(res_split, M, N)
+            io.r_scale_dev = _sp(res_scale)
         if c_gamma is not None or c_rowsq is not None or a_row_scale is not None:
             _chk_f32(c_gamma, c_rowsq, a_row_scale)
             if c_gamma is not None:
@@ -312,7 +318,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     assert norm is None, "a fused norm needs the f16x3 kernel"
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
     assert a_scale is None and c_scale is None and vt_scale is None
-    assert c_gamma is None and c_rowsq is None and a_row_scale is None, "a deferred norm needs the f16x3 kernel"
+    assert c_gamma is None and c_rowsq is None and a_row_scale is None and res_split is None, "a deferred norm needs the f16x3 kernel"
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
     return out
 
@@ -377,6 +383,20 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     _lib.check(_lib.load().cvx_adarmsnorm_scaled_f32(x.data_ptr(), gamma.data_ptr(), _p(beta), _p(out), oh, ol, rows, D, rpg,
                                                      float(D) ** 0.5, eps, _sp(split_scale), _stream()), "cvx_adarmsnorm_f32")
     return out if out is not None else out_split
+
+
+def split_f16_colscale_il(w: torch.Tensor, colscale: torch.Tensor, set_scale: Optional[torch.Tensor], scale: float, out: torch.Tensor) -> torch.Tensor:
+    """out[s] = interleaved split pair of w * colscale[s][None, :] * set_scale[s] * scale for every set s (cvx_split_f16_colscale_il):
+    w [N, K] fp32, colscale [n_sets, K] (row stride free), set_scale [n_sets] (stride free) or None, out [n_sets, N, 2K] fp16."""
+    _chk_f32(w, colscale, set_scale)
+    N, K = w.shape
+    n_sets = colscale.shape[0]
+    assert w.stride(1) == 1 and colscale.shape[1] == K and colscale.stride(1) == 1 and out.dtype == torch.float16 and out.is_contiguous()
+    assert tuple(out.shape) == (n_sets, N, 2 * K) and (set_scale is None or set_scale.shape[0] == n_sets)
+    _lib.check(_lib.load().cvx_split_f16_colscale_il(w.data_ptr(), w.stride(0), N, K, colscale.data_ptr(), colscale.stride(0), _p(set_scale),
+                                                     set_scale.stride(0) if set_scale is not None else 0, n_sets, scale, out.data_ptr(), _stream()),
+               "cvx_split_f16_colscale_il")
+    return out
 
 
 def rownorm_scale(rowsq: torch.Tensor, rows: int, parts: int, out: torch.Tensor, scale: float, eps: float = 1e-12) -> torch.Tensor:

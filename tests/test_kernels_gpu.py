@@ -1008,6 +1008,37 @@ def test_gemm_deferred_norm_producer_and_consumers(ops, M):
     v = z[:, 2 * H * 64:].reshape(Bt, T, H, 64).permute(0, 2, 3, 1).reshape(Bt * H * 64, T)
     slots = ops.vt_frame_slots(T, dev_)
     assert rel_l2((vt[0].double() + vt[1].double())[:, slots], v) < 2e-6
+    # ---- the residual stream as pairs only: residual read from a pair, no fp32 store, raw twin (gamma on the weight side), in place
+    hs = torch.tensor([8.0], device=dev_)
+    rp = ops.SplitIL(M, D, dev_); ops.split_act_f16(r, rp, scale=hs)
+    r_held = pair(rp) / 8.0
+    c3 = torch.full((M, D), 7.0, device=dev_)
+    rowsq3 = torch.full((M, D // 64), float("nan"), device=dev_)
+    ops.gemm(x, w, c3, w_split=ws, w_il=wil, a_split=il, bias=b, res_split=rp, res_scale=hs, out_split=rp, c_scale=hs, c_rowsq=rowsq3, write_f32=False)
+    want3 = xs @ w.double().T + b.double() + r_held
+    assert bool((c3 == 7.0).all()) and rel_l2(pair(rp) / 8.0, want3) < 1e-6
+    assert rel_l2(rowsq3.double(), want3.square().reshape(M, D // 64, 64).sum(-1)) < 1e-6
+    ops.rownorm_scale(rowsq3, M, D // 64, rs, float(D) ** 0.5)
+    # the same with the fp32 store as well (last layer: the final norm reads fp32), no row sums
+    rp2 = ops.SplitIL(M, D, dev_); ops.split_act_f16(r, rp2, scale=hs)
+    tw3 = ops.SplitIL(M, D, dev_)
+    ops.gemm(x, w, c3, w_split=ws, w_il=wil, a_split=il, bias=b, res_split=rp2, res_scale=hs, out_split=tw3, c_scale=hs, write_f32=True)
+    assert rel_l2(c3, want3) < 1e-6 and rel_l2(pair(tw3) / 8.0, want3) < 1e-6
+    # ---- W diag(gamma(t)) pairs for several evaluation times at once, and the consumer on them
+    n_sets = 3
+    gam = (1.0 + 0.5 * torch.randn(n_sets, D, generator=g)).to(dev_)
+    gsc = torch.exp2(-torch.ceil(torch.log2(gam.abs().amax(-1)))).contiguous()
+    wg = torch.empty(n_sets, 2048, 2 * D, dtype=torch.float16, device=dev_)
+    ops.split_f16_colscale_il(w1, gam, gsc, 1.0 / ws1[2], wg)
+    for s_ in range(n_sets):
+        dense = wg[s_].view(2048, D // 32, 2, 32)
+        got_w = (dense[:, :, 0, :].double() + dense[:, :, 1, :].double()).reshape(2048, D)
+        assert rel_l2(got_w, w1.double() * gam[s_].double() * float(gsc[s_]) / ws1[2]) < 1e-6
+    h3 = pair(rp) / 8.0                                     # the pair-only stream from above is the consumer's A operand
+    normed3 = h3 / h3.norm(dim=-1, keepdim=True) * math.sqrt(D) * gam[1].double() + beta.double()
+    a_sc = (hs * gsc[1]).reshape(1).contiguous()
+    ops.gemm(c, w1, guard, w_split=ws1, w_il=(wg[1], ws1[2]), a_split=rp, a_scale=a_sc, bias=b1p, act=1, out_split=o, write_f32=False, a_row_scale=rs)
+    assert rel_l2(pair(o), F.gelu(normed3 @ w1.double().T + b1.double())) < 2e-6
     # ---- refused outside the large-problem kernel's four forms
     with pytest.raises(ops._lib.CovomixHipError):
         ops.gemm(x[:1000], w, c[:1000], w_split=ws, w_il=wil, a_split=il.rows_view(0, 1000), residual=r[:1000], out_split=tw.rows_view(0, 1000),
