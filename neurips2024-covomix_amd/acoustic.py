@@ -349,7 +349,7 @@ class VectorField:
         longer writes its output twice.  Only the first layer's attention norm (input from the embedding, fp32) and the final norm
         stay.  Large-problem kernel only: batches of DEFER_MIN_ROWS rows and more (CVX_DEFER_NORM=0: off)."""
         return (self.precision == "f16x3" and M >= self.DEFER_MIN_ROWS and isinstance(ws.get("normed16"), ops.SplitIL)
-                and self.d["dim"] % 64 == 0 and self.d["dim"] >= 512 and os.environ.get("CVX_DEFER_NORM", "1") == "1")
+                and self.d["dim"] % 64 == 0 and 512 <= self.d["dim"] <= 4096 and os.environ.get("CVX_DEFER_NORM", "1") == "1")
 
     def _deferred_norm_tables(self, ctx: dict, table: torch.Tensor) -> None:
         """Per (evaluation time, layer): W diag(gamma) for to_qkv (layers 1..) and ff1 as interleaved split pairs, beta W^T as their
@@ -406,9 +406,13 @@ class VectorField:
         take = free.pop
         parts64, rt_dim = dim // 64, float(dim) ** 0.5
         n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
-        rowsq, rs = ws["rowsq"], ws["rs"]
+        rowsq = ws["rowsq"]
+        rs = ws["rs"]
+        def factor():                        # sqrt(D) / ||row|| from the producer's partial sums (computing it in the consumer's epilogue instead
+            ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)       # was built and measured: + 5 ms per step against these 480 launches of 5 us)
+        fkw = dict(a_row_scale=rs)
         skips: List[torch.Tensor] = []
-        have_rs = False                      # rs = sqrt(D) / ||row|| of the current h
+        have_rs = False                      # rowsq holds the sums of squares of the current h's rows (per 64 columns)
         for i in range(L):
             p = f"transformer.layers.{i}"
             s_na, s_qk, s_v, s_at, s_nf, s_ff = sp_step[i]
@@ -419,7 +423,7 @@ class VectorField:
                 comb = take()
                 ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
                          a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp, out_split=twin[id(comb)], c_scale=hp, c_rowsq=rowsq, write_f32=False)
-                ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)
+                factor()
                 have_rs = True
                 free += [h, s]
                 h, keep_input = comb, False
@@ -430,7 +434,7 @@ class VectorField:
             if have_rs:
                 ops.gemm(ws["normed"], sd[nq], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64, w_split=sp(nq), w_il=dn["wq"][i][step],
                          a_split=twin[id(h)], out_split=ws["qk16"], vt_split=ws["vt16"], write_f32=False, a_scale=as_a, c_scale=s_qk, vt_scale=s_v,
-                         bias=dn["bq"][i][step], a_row_scale=rs)
+                         bias=dn["bq"][i][step], **fkw)
             else:                            # first layer: the embedding output exists in fp32
                 ops.adarmsnorm(h, tab[(4 * i) * dim:(4 * i + 1) * dim], tab[(4 * i + 1) * dim:(4 * i + 2) * dim], None, out_split=n16, split_scale=s_na)
                 ops.gemm(ws["normed"], sd[nq], ws["qkv"], rope=ws["rope"], rope_cols=2 * d["heads"] * 64, w_split=sp(nq), w_il=il(nq),
@@ -441,17 +445,17 @@ class VectorField:
             no = p + ".2.to_out.weight"
             ops.gemm(ws["att"], sd[no], h_att, w_split=sp(no), w_il=il(no), a_split=a16, a_scale=s_at, res_split=twin[id(h)], res_scale=hp,
                      out_split=twin[id(h_att)], c_scale=hp, c_rowsq=rowsq, write_f32=False)
-            ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)
+            factor()
             h = h_att
             n1, n2 = p + ".4.0.weight", p + ".4.2.weight"
             ops.gemm(ws["normed"], sd[n1], ws["ff"], bias=dn["b1p"][i][step], act=ops.ACT_GELU, w_split=sp(n1), w_il=dn["w1"][i][step],
-                     a_split=twin[id(h)], out_split=f16, write_f32=False, a_scale=as_f, c_scale=s_ff, a_row_scale=rs)
+                     a_split=twin[id(h)], out_split=f16, write_f32=False, a_scale=as_f, c_scale=s_ff, **fkw)
             next_defers = (not last) and not self.has_comb[i + 1]          # the next layer's attention norm reads THIS output's rows
             ops.gemm(ws["ff"], sd[n2], h, bias=sd[p + ".4.2.bias"], w_split=sp(n2), w_il=il(n2), a_split=f16, a_scale=s_ff,
                      res_split=twin[id(h)], res_scale=hp, out_split=twin[id(h)], c_scale=hp, c_rowsq=rowsq if next_defers else None,
                      write_f32=last)                                      # (the final norm reads fp32)
             if next_defers:
-                ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)
+                factor()
             have_rs = next_defers
         ops.adarmsnorm(h, sd["transformer.final_norm.gamma"], None, None, out_split=ws["pred16"], split_scale=pp)
         ops.gemm(ws["normed"], sd["to_pred.weight"], ws["pred"], w_split=sp("to_pred.weight"), a_split=ws["pred16"], a_scale=pp,
