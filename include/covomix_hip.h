@@ -159,6 +159,10 @@ typedef struct {
      * 4 B, write 4 B per element) and the norm kernel's 8 B per element are gone.  c_gamma_dev may be NULL (gamma folded into the
      * consumer's weights instead: cvx_split_f16_colscale_il).  R may alias C_hi / C_lo (same element, same lane). */
     const uint16_t* R_hi; const uint16_t* R_lo; int64_t ldr_h; const float* r_scale_dev;
+    /* A | A2 pairs with DIFFERENT pre-scales (skip-combiner producer form only): A2_hi/A2_lo hold a2 * *a2_scale_dev while A holds
+     * a * *a_scale_dev (NULL: both operands share a_scale_dev).  Every stage of the pair-only residual stream carries its own
+     * power-of-two pre-scale, so a skip saved at the input of layer i and the stream at layer depth-1-i need not share one. */
+    const float* a2_scale_dev;
 } cvx_gemm_split_io;
 #define CVX_GEMM_FLAG_TWO_STAGE 1
 #define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */

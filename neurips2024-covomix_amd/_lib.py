@@ -46,6 +46,7 @@ class GemmSplitIO(C.Structure):
         ("a_scale_dev", C.c_void_p), ("c_scale_dev", C.c_void_p), ("vt_scale_dev", C.c_void_p),
         ("c_gamma_dev", C.c_void_p), ("c_rowsq", C.c_void_p), ("c_rowsq_ld", C.c_int64), ("a_row_scale_dev", C.c_void_p),
         ("R_hi", C.c_void_p), ("R_lo", C.c_void_p), ("ldr_h", C.c_int64), ("r_scale_dev", C.c_void_p),
+        ("a2_scale_dev", C.c_void_p),
     ]
 
 

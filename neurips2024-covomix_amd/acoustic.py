@@ -198,14 +198,22 @@ class VectorField:
         att_o = (att * gn["o"]).square().amax(dim=0)                    # [L]: largest over the evaluation times
         ff_o = (ff * gn["f2"]).square().amax(dim=0)
         skips = []
+        stages = []                          # mean squares of the stream per layer: at its input, behind its skip combiner, behind to_out, behind ff2
         for i in range(L):
+            h_in = h2
             if self.has_comb[i]:
                 h2 = (h2 + skips.pop()) * gn["comb"][i].square()
             else:
                 skips.append(h2)
-            h2 = h2 + att_o[i] + ff_o[i]
+            h_c = h2
+            h_a = h2 + att_o[i]
+            h2 = h_a + ff_o[i]
+            stages.append(torch.stack([h_in, h_c, h_a, h2]))
             hmax = torch.maximum(hmax, h2)
         H = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / hmax.sqrt().clamp_min(tiny))).clamp(-40, 40)).reshape(1).contiguous()
+        # the pair-only residual stream of the deferred-norm path (section 4.1d) carries ONE pre-scale PER STAGE: the stream IS those
+        # pairs there, and a stage far below the largest one would sit under the full-precision window of a shared scale
+        self._stage_scales = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / torch.stack(stages).sqrt().clamp_min(tiny))).clamp(-40, 40)).contiguous()
         return S, H
 
     # ------------------------------------------------------------------ workspace
@@ -361,7 +369,8 @@ class VectorField:
         tiny = torch.finfo(torch.float32).tiny
         gmax = tab[:, :, 0::2, :].abs().amax(dim=-1)                                     # [n, L, 2]: max |gamma_attn|, max |gamma_ff|
         gs = torch.exp2(-torch.ceil(torch.log2(gmax.clamp_min(tiny))).clamp(-40, 40)).contiguous()
-        AS = (gs * ctx["h_scale"]).contiguous()                                          # pre-scale of the A pairs (x * H) times the weights' gs
+        HS = self._stage_scales                                                          # [L, 4]: stream pre-scale at a layer's input / behind its combiner / to_out / ff2
+        AS = (gs * HS[None, :, 1:3]).contiguous()                                        # pre-scale of the consumers' A pairs (stage scale) times the weights' gs
 
         def beta_w(beta_rows: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
             out = torch.empty(n, w.shape[0], dtype=torch.float32, device=self.device)
@@ -391,8 +400,8 @@ class VectorField:
             invq = self.split_il[nq][1]
             ops.split_f16_colscale_il(sd[nq], tab[:, i, 0, :], gs[:, i, 0], 1.0 / invq, bufs["wq"][i])
             wq.append([(bufs["wq"][i][e], invq) for e in range(n)])
-        a0 = AS.data_ptr()
-        ctx["dn"] = dict(b1p=b1p, bq=bq, wq=wq, w1=w1, gs=gs, AS=AS,
+        a0, h0 = AS.data_ptr(), HS.data_ptr()
+        ctx["dn"] = dict(b1p=b1p, bq=bq, wq=wq, w1=w1, gs=gs, AS=AS, HS=HS, hsp=[[h0 + 4 * (4 * i + k) for k in range(4)] for i in range(L)],
                          asp=[[(a0 + 4 * ((e * L + i) * 2), a0 + 4 * ((e * L + i) * 2 + 1)) for i in range(L)] for e in range(n)])
 
     def _layers_pair_stream(self, ctx: dict, step: int, ws: dict, h: torch.Tensor, twin: dict, free: list, Bt: int, T: int, M: int, rg):
@@ -402,7 +411,8 @@ class VectorField:
         dim, L = d["dim"], d["depth"]
         tab = ctx["table"][step]
         sp, il = self.split.get, self.split_il.get
-        sp_step, hp, pp = ctx["sp"][step], ctx["hp"], self.pred_scale.data_ptr()
+        sp_step, pp, hsp = ctx["sp"][step], self.pred_scale.data_ptr(), dn["hsp"]
+        cur = hsp[0][0]                      # device pointer of the pre-scale the current h's pair carries (one per stage, _activation_scales)
         take = free.pop
         parts64, rt_dim = dim // 64, float(dim) ** 0.5
         n16, a16, f16 = ws["normed16"], ws["att16"], ws["ff16"]
@@ -411,7 +421,7 @@ class VectorField:
         def factor():                        # sqrt(D) / ||row|| from the producer's partial sums (computing it in the consumer's epilogue instead
             ops.rownorm_scale(rowsq, M, parts64, rs, rt_dim)       # was built and measured: + 5 ms per step against these 480 launches of 5 us)
         fkw = dict(a_row_scale=rs)
-        skips: List[torch.Tensor] = []
+        skips: List[tuple] = []
         have_rs = False                      # rowsq holds the sums of squares of the current h's rows (per 64 columns)
         for i in range(L):
             p = f"transformer.layers.{i}"
@@ -419,16 +429,18 @@ class VectorField:
             as_a, as_f = dn["asp"][step][i]
             last = i + 1 == L
             if self.has_comb[i]:
-                s = skips.pop()
+                s, s_scale = skips.pop()
                 comb = take()
                 ops.gemm(h, sd[p + ".0.weight"], comb, bias=sd[p + ".0.bias"], a2=s, w_split=sp(p + ".0.weight"), w_il=il(p + ".0.weight"),
-                         a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=hp, out_split=twin[id(comb)], c_scale=hp, c_rowsq=rowsq, write_f32=False)
+                         a_split=twin[id(h)], a2_split=twin[id(s)], a_scale=cur, a2_scale=s_scale, out_split=twin[id(comb)], c_scale=hsp[i][1],
+                         c_rowsq=rowsq, write_f32=False)
+                cur = hsp[i][1]
                 factor()
                 have_rs = True
                 free += [h, s]
                 h, keep_input = comb, False
             else:
-                skips.append(h)
+                skips.append((h, cur))
                 keep_input = True
             nq = p + ".2.to_qkv.weight"
             if have_rs:
@@ -443,8 +455,9 @@ class VectorField:
                                 qk_scale=s_qk, v_scale=s_v, out_scale=s_at, ragged=rg)
             h_att = take() if keep_input else h
             no = p + ".2.to_out.weight"
-            ops.gemm(ws["att"], sd[no], h_att, w_split=sp(no), w_il=il(no), a_split=a16, a_scale=s_at, res_split=twin[id(h)], res_scale=hp,
-                     out_split=twin[id(h_att)], c_scale=hp, c_rowsq=rowsq, write_f32=False)
+            ops.gemm(ws["att"], sd[no], h_att, w_split=sp(no), w_il=il(no), a_split=a16, a_scale=s_at, res_split=twin[id(h)], res_scale=cur,
+                     out_split=twin[id(h_att)], c_scale=hsp[i][2], c_rowsq=rowsq, write_f32=False)
+            cur = hsp[i][2]
             factor()
             h = h_att
             n1, n2 = p + ".4.0.weight", p + ".4.2.weight"
@@ -452,8 +465,9 @@ class VectorField:
                      a_split=twin[id(h)], out_split=f16, write_f32=False, a_scale=as_f, c_scale=s_ff, **fkw)
             next_defers = (not last) and not self.has_comb[i + 1]          # the next layer's attention norm reads THIS output's rows
             ops.gemm(ws["ff"], sd[n2], h, bias=sd[p + ".4.2.bias"], w_split=sp(n2), w_il=il(n2), a_split=f16, a_scale=s_ff,
-                     res_split=twin[id(h)], res_scale=hp, out_split=twin[id(h)], c_scale=hp, c_rowsq=rowsq if next_defers else None,
+                     res_split=twin[id(h)], res_scale=cur, out_split=twin[id(h)], c_scale=hsp[i][3], c_rowsq=rowsq if next_defers else None,
                      write_f32=last)                                      # (the final norm reads fp32)
+            cur = hsp[i][3]
             if next_defers:
                 factor()
             have_rs = next_defers
@@ -532,16 +546,18 @@ class VectorField:
         sp_step = ctx["sp"][step] if (split_io and "sp" in ctx) else None
         hp = ctx["hp"] if sp_step is not None else None
         pp = self.pred_scale.data_ptr() if sp_step is not None else None
+        use_dn = split_io and M >= 2048 and ctx.get("dn") is not None
         if split_io:
             tw = twin[id(h)]
-            ops.split_act_f16(h, tw, scale=hp) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw, scale=hp)
+            h0s = ctx["dn"]["hsp"][0][0] if use_dn else hp      # (deferred-norm path: one pre-scale per stage of the stream)
+            ops.split_act_f16(h, tw, scale=h0s) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw, scale=h0s)
 
         # every to_out / ff2 / skip-combiner product is followed by a norm of its output: one call (ops.gemm(norm=...)), so that
         # problems on the split-K path (one utterance) normalise inside the reduction.  CVX_FUSE_NORM=0: separate launches (A/B)
         # (2048 rows and more never split K: the call would run the same two kernels, so it stays two calls there)
         fuse_norm = split_io and M < 2048 and os.environ.get("CVX_FUSE_NORM", "1") == "1"
         normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
-        if split_io and not fuse_norm and M >= 2048 and ctx.get("dn") is not None:       # (decided per call in prepare(): the halves of a two-chain schedule follow the whole batch)
+        if use_dn:                           # (decided per call in prepare(): the halves of a two-chain schedule follow the whole batch)
             return self._layers_pair_stream(ctx, step, ws, h, twin, free, Bt, T, M, rg)
         def tab_rows(i_, k_):
             return tab[(4 * i_ + k_) * dim:(4 * i_ + k_ + 1) * dim]

@@ -49,12 +49,17 @@ struct SplitOut { _Float16* hi; _Float16* lo; int64_t ldc_h; int write_f32;
                   const float* tw_gamma; float* rowsq; int rowsq_ld; const float* row_scale;
                   // residual given as a split pair (EPI_RES_TW only): residual[m,n] = (res_hi + res_lo)[m,n] / *res_scale; the residual
                   // stream then lives in HBM as pairs only (write_f32 = 0 on the producer: as many bytes as the fp32 form moved)
-                  const _Float16* res_hi; const _Float16* res_lo; int64_t res_ld; const float* res_scale; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
+                  const _Float16* res_hi; const _Float16* res_lo; int64_t res_ld; const float* res_scale;
+                  // K-split operand pairs with DIFFERENT pre-scales (EPI_BIAS_TW on the large-problem kernel only): A holds x * *a_scale,
+                  // A2 holds x2 * *a2_scale; the accumulators are multiplied by *a2_scale / *a_scale (a power of two) where the K loop
+                  // switches operands, and divided by *a2_scale at the end
+                  const float* a2_scale; };      // sticky saturation flag of the device (cvx_common.h), NULL = no bookkeeping   // trace (dbg bit 2): per-block s_memtime stamps (dev only)          // dbg: timing experiments only (bit 0: skip the epilogue) - cvx_gemm_split_io.flags >> 8
 
 // accumulator factor: 1 / (weight pre-scale) / (activation pre-scale); both powers of two, so the division is exact
 __device__ __forceinline__ float total_acc_scale(float acc_scale, const SplitOut& so)
 {
-    return so.a_scale ? acc_scale / *so.a_scale : acc_scale;
+    const float* s = so.a2_scale ? so.a2_scale : so.a_scale;
+    return s ? acc_scale / *s : acc_scale;
 }
 typedef _Float16 cvx_f16x4 __attribute__((ext_vector_type(4)));
 

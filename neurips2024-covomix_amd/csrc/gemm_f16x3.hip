@@ -873,7 +873,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         so.c_scale = io->c_scale_dev; so.vt_scale = io->vt_scale_dev; so.a_scale = io->a_scale_dev;
         so.tw_gamma = io->c_gamma_dev; so.rowsq = io->c_rowsq; so.rowsq_ld = (int)io->c_rowsq_ld; so.row_scale = io->a_row_scale_dev;
         so.res_hi = reinterpret_cast<const f16*>(io->R_hi); so.res_lo = reinterpret_cast<const f16*>(io->R_lo); so.res_ld = io->ldr_h;
-        so.res_scale = io->r_scale_dev;
+        so.res_scale = io->r_scale_dev; so.a2_scale = io->a2_scale_dev;
 #ifdef CVX_DEV_FLAGS          // timing experiments (tools/): epilogue skipping, per-block stamps, one tile per block - never in the shipped library
         so.dbg = io->flags >> 8; so.trace = (so.dbg & 4) ? reinterpret_cast<unsigned long long*>(io->workspace) : nullptr;
 #else
@@ -899,7 +899,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         }
     }
     // deferred norm (producer: gamma on the twin + row sums of squares; consumer: a factor per row): the 16x16x32 epilogues only
-    const bool dn = so.tw_gamma || so.rowsq || so.row_scale || so.res_hi || so.res_lo;
+    const bool dn = so.tw_gamma || so.rowsq || so.row_scale || so.res_hi || so.res_lo || so.a2_scale;
     if (dn) {
         CVX_REQUIRE(!single && !norm && a->N % 64 == 0 && (!so.tw_gamma || (so.hi && ((uintptr_t)so.tw_gamma & 15) == 0)) &&
                     (!so.rowsq || (io->c_rowsq_ld >= a->N / 64 && io->c_rowsq_ld < (1ll << 20))),

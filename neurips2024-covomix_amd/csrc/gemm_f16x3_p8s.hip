@@ -32,7 +32,7 @@ constexpr int LDS_B = DUMP_B + 8 * 1024;
 template <bool HAS_A2, bool SWAP, bool PERM = false>
 __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
                                               int m0, int n0, int m0n, int n0n, bool first, int lane, int wid, int wr, int wc,
-                                              f32x4 (&acc)[8][4])
+                                              f32x4 (&acc)[8][4], const float a2_ratio = 1.f)
 {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     uint32_t offA[2][2], offA2[2][2], offW[2][2];                // per-lane source byte offsets of the tile being FETCHED
@@ -142,6 +142,9 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
 #define CVX_P8S_KTILE(buf, t)                                                                                    \
     {                                                                                                            \
         if (has_next && (t) == nk - 2 + (buf)) set_offsets((buf), m0n, n0n);                                     \
+        if (HAS_A2 && a2_ratio != 1.f && (t) == t_sw) {          /* the A2 pairs carry another pre-scale: bring the sums so far to it */ \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] *= a2_ratio;    \
+        }                                                                                                        \
         CVX_P8S_READ_B(buf, 0) CVX_P8S_READ_A(buf, 0)                                                            \
         issue_W(1, (t) + 1);                                                                                     \
         CVX_P8S_SYNC() CVX_P8S_MFMA(0, 0)                                                                        \
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     acc_scale = total_acc_scale(acc_scale, so);
+    const float a2_ratio = (HAS_A2 && so.a2_scale && so.a_scale) ? *so.a2_scale / *so.a_scale : 1.f;
 
     auto tile_of_slot = [&](int s, int& m0, int& n0) {          // -> false for the padding slots of the XCD map
         const int xcd = s & 7, q = s >> 3;
@@ -219,10 +223,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
         if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_RS) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
         constexpr bool PERM = epi_perm(EPI);
         if (v_block) {
-            tile_mainloop<HAS_A2, false, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
+            tile_mainloop<HAS_A2, false, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc, a2_ratio);
             if (!(so.dbg & 1)) epilogue_vt<8, false, EPI == EPI_QKV_RS, PERM>(p, acc, row0, col0, lane, so, acc_scale);
         } else {
-            tile_mainloop<HAS_A2, true, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc);
+            tile_mainloop<HAS_A2, true, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc, a2_ratio);
             if (!(so.dbg & 1)) epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);      // (dbg bit 0: main loop only, timing)
         }
         if (nslot < 0) break;
@@ -277,6 +281,7 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
                               (so.res_hi && (so.res_ld & 7) != 0))) return false;
     }
     if (epi == EPI_GENERIC && so.vt_hi) return false;
+    if (so.a2_scale && !(epi == EPI_BIAS_TW && so.a_scale)) return false;
 #define CVX_P8S_LAUNCH(A2, E)                                                                                           \
     do {                                                                                                                \
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8s_kernel<A2, E>), LDS_B);                     \

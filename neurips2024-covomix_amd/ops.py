@@ -196,7 +196,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
          a2: Optional[torch.Tensor] = None, rope=None, rope_cols: int = 0, w_split=None,
          a_split=None, a2_split=None, out_split=None, write_f32: bool = True, vt_split=None, w_il=None,
          a_scale=None, c_scale=None, vt_scale=None, norm=None, c_gamma=None, c_rowsq=None, a_row_scale=None,
-         res_split=None, res_scale=None) -> torch.Tensor:
+         res_split=None, res_scale=None, a2_scale=None) -> torch.Tensor:
     """out[M,N] = epilogue([a | a2] @ w[:, :K].T).  `a`, `a2`, `out`, `residual` are 2-D with unit
     inner stride (row stride may exceed the width); `w` may be a column-slice view of a wider matrix.
     w_split = (hi, lo) fp16 halves from split_f16(w): run the split-precision f16x3 MFMA kernel instead
@@ -273,6 +273,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                 io.A2_hi, io.A2_lo, io.lda2_h = _pair(a2_split, M, K - k1)
         if out_split is not None:
             io.C_hi, io.C_lo, io.ldc_h = _pair(out_split, M, rope_cols if vt_split is not None else N)
+        if a2_scale is not None:
+            assert a2 is not None and a_scale is not None
+            io.a2_scale_dev = _sp(a2_scale)
         if res_split is not None:
             assert residual is None
             io.R_hi, io.R_lo, io.ldr_h = _pair(res_split, M, N)
@@ -318,7 +321,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
     assert norm is None, "a fused norm needs the f16x3 kernel"
     assert a_split is None and out_split is None and write_f32, "split I/O needs the f16x3 kernel (w_split, K % 32 == 0, M > 64)"
     assert a_scale is None and c_scale is None and vt_scale is None
-    assert c_gamma is None and c_rowsq is None and a_row_scale is None and res_split is None, "a deferred norm needs the f16x3 kernel"
+    assert c_gamma is None and c_rowsq is None and a_row_scale is None and res_split is None and a2_scale is None, "a deferred norm needs the f16x3 kernel"
     _lib.check(_lib.load().cvx_gemm_bias_act_f32(C.byref(g), _stream()), "cvx_gemm_bias_act_f32")
     return out
 

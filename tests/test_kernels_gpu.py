@@ -969,6 +969,16 @@ def test_gemm_deferred_norm_producer_and_consumers(ops, M):
     want2 = torch.cat((xs, xs), 1) @ w2.double().T + b.double()
     assert rel_l2(c2, want2) < 1e-6 and rel_l2(pair(tw2), want2 * gamma.double()) < 1e-6
     assert rel_l2(rowsq2.double(), c2.double().square().reshape(M, D // 64, 64).sum(-1)) < 1e-6
+    # the two K halves with DIFFERENT pre-scales (every stage of the pair-only residual stream carries its own)
+    sa, sb = torch.tensor([2.0], device=dev_), torch.tensor([32.0], device=dev_)
+    ila, ilb = ops.SplitIL(M, K, dev_), ops.SplitIL(M, K, dev_)
+    ops.split_act_f16(x, ila, scale=sa); ops.split_act_f16(x, ilb, scale=sb)
+    xa, xb = pair(ila) / 2.0, pair(ilb) / 32.0
+    c2b = torch.full((M, D), float("nan"), device=dev_)
+    tw2b = ops.SplitIL(M, D, dev_)
+    ops.gemm(x, w2, c2b, w_split=ws2, w_il=wil2, a_split=ila, a2=x, a2_split=ilb, a_scale=sa, a2_scale=sb, bias=b, out_split=tw2b, c_rowsq=rowsq2)
+    want2b = torch.cat((xa, xb), 1) @ w2.double().T + b.double()
+    assert rel_l2(c2b, want2b) < 1e-6 and rel_l2(pair(tw2b), want2b) < 1e-6
     # ---- the reference's norm of the producer's fp32 output, in fp64
     cd = c.double()
     normed = cd / cd.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(D) * gamma.double() + beta.double()

@@ -202,6 +202,66 @@ def test_split_precision_is_scale_free(group, exp):
     assert torch.isfinite(out).all() and e < 5e-6
 
 
+def _count_deferred(monkeypatch, min_rows=2048):
+    """Run batches of `min_rows` rows and more on the deferred-norm path (default: 8192) and count its factor-per-row launches."""
+    import covomix_amd.acoustic as ac
+    import covomix_amd.ops as ops_
+    calls = []
+    real = ops_.rownorm_scale
+    monkeypatch.setattr(ac.VectorField, "DEFER_MIN_ROWS", min_rows)
+    monkeypatch.setattr(ops_, "rownorm_scale", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    return calls
+
+
+@pytest.mark.parametrize("group,exp", [("adaln_ff", -7), ("adaln_ff", 7), ("adaln_attn", -7), ("embed", -7), ("embed", 7), ("ff", -7), ("ff", 7),
+                                       ("vo", 7)])
+def test_deferred_norm_is_scale_free(group, exp, monkeypatch):
+    """The same weight rescalings on the DEFERRED-norm path (residual stream as split pairs only, gamma on
+    per-evaluation weight copies, a factor per row on the consumer's accumulators) - it runs from 8192 rows by default; here from
+    2048 so that the 2 x 1100-row problem takes it.  gamma x 2^+-7 moves the weight copies' power-of-two normaliser; to_embed /
+    FeedForward x 2^+-7 the magnitude of the pair-only stream FROM STAGE TO STAGE (FeedForward x 2^7: 2^14 between the embedding
+    output and the first ff2 output - with ONE pre-scale for the whole stream this case was 4.6e-3; every stage carries its own):
+    fp32-class against the fp64 oracle (<= 5e-6; the fp32 residual stream gives 0.8e-6 ... 3.3e-6 on the same cases)."""
+    import covomix_amd.synthetic as syn
+    calls = _count_deferred(monkeypatch)
+    sd = _scaled(_state("vomix"), group, 2.0 ** exp)
+    inp = syn.synthetic_inputs("vomix", 1, 1100, 300, seed=31)
+    out = _run(sd, inp, 2)
+    ref64 = _fp64_reference(sd, inp, 2)
+    e = rel_l2(out, ref64)
+    print(f"deferred norm, scale-free: {group} x 2^{exp}: rel-L2 vs the fp64 oracle {e:.3e} ({len(calls)} factor launches)")
+    assert len(calls) == 2 * 2 * 15                        # 15 deferred norms per evaluation x 2 evaluations, issued twice (warm-up pass + graph capture)
+    assert torch.isfinite(out).all() and e < 5e-6
+
+
+@pytest.mark.parametrize("key,row", [("transformer.layers.2.2.to_out.weight", 500), ("transformer.layers.3.4.2.weight", 17),
+                                     ("transformer.layers.5.0.weight", 300)])
+def test_deferred_norm_outlier_channel_is_never_silently_wrong(key, row, monkeypatch):
+    """One output channel of a producer of the pair-only residual stream (to_out, ff2, skip combiner) times 2^14: the stage
+    pre-scales come from the gain model's Frobenius norms and barely move.  The result must be fp32-class - inside the window or
+    through the flagged fp32 re-run - never a silently clamped stream.  One channel 2^14 above the rest makes the problem itself
+    ill-conditioned for fp32 (the norms downstream divide everything else by that channel), so fp32-class is measured against fp64:
+    within 4x of what the fp32 CPU oracle itself loses there (and <= 1e-5 where that is smaller)."""
+    import warnings
+    import covomix_oracle as orc
+    import covomix_amd.synthetic as syn
+    calls = _count_deferred(monkeypatch)
+    sd = _state("vomix")
+    sd[key] = sd[key].clone()
+    sd[key][row] *= 2.0 ** 14
+    inp = syn.synthetic_inputs("vomix", 1, 1100, 300, seed=33)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = _run(sd, inp, 2)
+    rerun = any("saturat" in str(w.message) for w in rec)
+    ref64 = _fp64_reference(sd, inp, 2)
+    e32 = rel_l2(orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2), ref64)
+    e = rel_l2(out, ref64)
+    print(f"deferred norm, outlier {key}[{row}] x 2^14: rel-L2 vs fp64 {e:.3e} (fp32 oracle vs fp64: {e32:.3e}; "
+          f"{'flagged -> fp32 re-run' if rerun else 'inside the window'})")
+    assert len(calls) > 0 and torch.isfinite(out).all() and e < max(1e-5, 4 * e32)
+
+
 @pytest.mark.parametrize("exp", [-7, 7])
 def test_split_precision_is_scale_free_small_problem(exp):
     """The same on the small-problem kernels (one short utterance: split-K, graph replay)."""
