@@ -42,13 +42,17 @@ constexpr int MLDS_B = NBUF * MBUF_B;              // 160 KiB
 #ifndef CVX_P8M_DMA_FIRST
 #define CVX_P8M_DMA_FIRST 0         // dev A/B: the load segment requests K-tile t + 4 before (1) or after (0) its 16 fragment reads
 #endif
+#ifndef CVX_P8M_PERM
+#define CVX_P8M_PERM 1              // dev A/B: 0 = 8-byte pair stores in the to_qkv / ff1 epilogues (rounds 1-4 before the permutation)
+#endif
 #define CVX_P8M_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define CVX_P8M_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define CVX_P8M_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // K loop of one 128 x 128 tile over K-tiles [kt0, kt0 + nk) (32 k each) of [A | A2] . W^T; this wave's group takes the K-tiles
 // of its parity.  acc[mi][ni]: 16 x 16 blocks of the wave's 64 x 64 sub-tile (layout: gemm_p8s_epi.h).
-template <bool HAS_A2, bool SWAP>
+// PERM: LDS row rho of the W tile is filled from weight row perm32(rho) (gemm_p8s_epi.h): a lane's tile pair = 8 consecutive columns
+template <bool HAS_A2, bool SWAP, bool PERM = false>
 __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
                                                 int m0, int n0, int kt0, int nk, int lane, int grp, int w4, int wr, int wc,
                                                 f32x4 (&acc)[4][4], unsigned long long* tr)
@@ -61,7 +65,7 @@ __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const Pr
     for (int j = 0; j < 4; ++j) {
         const int r = 32 * w4 + 8 * j + (lane >> 3);
         const uint32_t c = (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-        const uint32_t ga = (uint32_t)min(m0 + r, p.M - 1), gb = (uint32_t)min(n0 + r, p.N - 1);
+        const uint32_t ga = (uint32_t)min(m0 + r, p.M - 1), gb = (uint32_t)min(n0 + (PERM ? perm32(r) : r), p.N - 1);
         offA[j] = ga * (uint32_t)ldaB + c;             // (every operand spans < 4 GiB: checked by the launcher)
         offA2[j] = HAS_A2 ? ga * (uint32_t)lda2B + c : 0u;
         offW[j] = gb * (uint32_t)ldwB + c;
@@ -163,7 +167,8 @@ __device__ __forceinline__ void tile_mainloop_m(const cvx_gemm_args& p, const Pr
     CVX_P8M_STAMP(2);
 }
 
-template <bool HAS_A2, int EPI>
+// PERM (round 4, the pair-writing epilogues EPI_QKV / EPI_GELU_SPLIT on whole 64-column wave tiles): 16-byte pair stores, see perm32
+template <bool HAS_A2, int EPI, bool PERM = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
     const cvx_gemm_args p_in, const PreSplitA A, const f16* __restrict__ W, float acc_scale, SplitOut so,
     int tiles_m, int tiles_n, int ksplit, int k_per, float* __restrict__ partial)
@@ -211,9 +216,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
     // of the K loop cover it)
     const int row0 = m0 + wr * 64 + grp * 32, col0 = n0 + wc * 64;
     EpiPre<2> pre;
-    epilogue_prefetch<EPI, 2>(p, so, row0, col0, lane, v_block, pre);
-    if (v_block) tile_mainloop_m<HAS_A2, false>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc, tr);
-    else tile_mainloop_m<HAS_A2, true>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc, tr);
+    epilogue_prefetch<EPI, 2, PERM>(p, so, row0, col0, lane, v_block, pre);
+    if (v_block) tile_mainloop_m<HAS_A2, false, PERM>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc, tr);
+    else tile_mainloop_m<HAS_A2, true, PERM>(p, A, W, smem_p8m, m0, n0, kt0, nk, lane, grp, w4, wr, wc, acc, tr);
 
     // ---- exchange: group 0 keeps rows 0-31 of every wave tile (blocks mi = 0, 1), group 1 rows 32-63 (mi = 2, 3)
     CVX_P8M_BARRIER();                                  // every wave is past its last fragment read and its last DMA piece
@@ -246,8 +251,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8m_kernel(
     }
     CVX_P8M_STAMP(3);
     if (so.dbg & 1) return;                             // (dev: main loop only, timing)
-    if (v_block) epilogue_vt<2, true>(p, e, row0, col0, lane, so, acc_scale, &pre);
-    else epilogue_rows<EPI, 2, true>(p, e, row0, col0, lane, so, acc_scale, &pre);
+    if (v_block) epilogue_vt<2, true, false, PERM>(p, e, row0, col0, lane, so, acc_scale, &pre);
+    else epilogue_rows<EPI, 2, true, PERM ? 1 : 0>(p, e, row0, col0, lane, so, acc_scale, &pre);
 #ifdef CVX_DEV_FLAGS
     if (tr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -296,6 +301,19 @@ bool launch_gemm_f16x3_p8m(const cvx_gemm_args& a, const PreSplitA& A, const f16
     if (epi == EPI_QKV && a2.bias) epi = EPI_GENERIC;
     if (epi == EPI_GENERIC && s2.vt_hi) return false;
     const int ks = ksplit > 1 ? ksplit : 1;
+    // the pair-writing epilogues on whole wave tiles: permuted W tile rows, 16-byte pair stores (CVX_P8M_PERM=0 in a dev build: off)
+    const bool perm = CVX_P8M_PERM && ksplit <= 1 && !A.hi2 && (epi == EPI_QKV || epi == EPI_GELU_SPLIT) && a.N % 64 == 0 && s2.hi &&
+                      (((uintptr_t)s2.hi | (uintptr_t)s2.lo) & 15) == 0 && (s2.ldc_h & 7) == 0;
+#define CVX_P8M_LAUNCH_P(E)                                                                                              \
+    do {                                                                                                                \
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8m_kernel<false, E, true>), MLDS_B);            \
+        hipLaunchKernelGGL((gemm_f16x3_p8m_kernel<false, E, true>), grid, dim3(512), MLDS_B, st, a2, A, w_il, acc_scale, s2, tm, tn, ks, k_per, partial); \
+    } while (0)
+    if (perm) {
+        if (epi == EPI_QKV) CVX_P8M_LAUNCH_P(EPI_QKV); else CVX_P8M_LAUNCH_P(EPI_GELU_SPLIT);
+        return true;
+    }
+#undef CVX_P8M_LAUNCH_P
 #define CVX_P8M_LAUNCH(A2, E)                                                                                           \
     do {                                                                                                                \
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8m_kernel<A2, E>), MLDS_B);                    \

@@ -119,7 +119,7 @@ __device__ __forceinline__ void epi_specialise(cvx_gemm_args& p, SplitOut& so)
     if constexpr (EPI != EPI_GELU_RS && EPI != EPI_QKV_RS) so.row_scale = nullptr;
 }
 
-template <int EPI, int MI>
+template <int EPI, int MI, bool PERM = false>
 __device__ __forceinline__ void epilogue_prefetch(const cvx_gemm_args& p_in, const SplitOut& so_in, int row0, int col0, int lane,
                                                   bool v_block, EpiPre<MI>& pre)
 {
@@ -133,7 +133,7 @@ __device__ __forceinline__ void epilogue_prefetch(const cvx_gemm_args& p_in, con
     const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-        if (p.bias && col0 + 16 * ni < p.N) pre.bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + 16 * ni + lc);
+        if (p.bias && col0 + 16 * ni < p.N) pre.bias[ni] = *reinterpret_cast<const f32x4*>(p.bias + col0 + tile_col<PERM>(ni, lc));
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int rr = min(row0 + 16 * mi + lr, p.M - 1);
@@ -141,20 +141,21 @@ __device__ __forceinline__ void epilogue_prefetch(const cvx_gemm_args& p_in, con
             const int pos = rr % p.rope_T;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                pre.rc[mi][ni] = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + 16 * ni + lc);
-                pre.rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + 16 * ni + lc);
+                pre.rc[mi][ni] = *reinterpret_cast<const f32x4*>(p.rope_cos + (int64_t)pos * 32 + tile_col<PERM>(ni, lc));
+                pre.rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.rope_sin + (int64_t)pos * 32 + tile_col<PERM>(ni, lc));
             }
         }
         if (p.residual) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                if (col0 + 16 * ni < p.N) pre.res[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + 16 * ni + lc);
+                if (col0 + 16 * ni < p.N) pre.res[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rr * p.ldr + col0 + tile_col<PERM>(ni, lc));
         }
     }
 }
 
 // ---- epilogue, swapped layout: acc[mi][ni][r] = C[row0 + 16 mi + (lane & 15)][col0 + 16 ni + 4 (lane >> 4) + r]
-template <int EPI, int MI = 8, bool PRE = false>
+// PERMSEL: -1 = the large-problem kernel's rule (the deferred-norm instances are permuted), 0 / 1 = the caller's W tile is not / is
+template <int EPI, int MI = 8, bool PRE = false, int PERMSEL = -1>
 __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (&acc)[MI][4], int row0, int col0, int lane,
                                               const SplitOut& so_in, float acc_scale, const EpiPre<MI>* pre = nullptr)
 {
@@ -162,7 +163,7 @@ __device__ __forceinline__ void epilogue_rows(const cvx_gemm_args& p_in, f32x4 (
     cvx_gemm_args p = p_in;
     SplitOut so = so_in;
     epi_specialise<EPI>(p, so);
-    constexpr bool PERM = !PRE && epi_perm(EPI);                              // a lane's tile pair = 8 consecutive columns
+    constexpr bool PERM = PERMSEL < 0 ? (!PRE && epi_perm(EPI)) : (PERMSEL != 0);        // a lane's tile pair = 8 consecutive columns
     const int lr = lane & 15, lc = 4 * (lane >> 4);
     const bool do_rope = (p.rope_cos != nullptr) && (col0 < p.rope_cols);          // wave-uniform (64-column wave tile = one head)
     float cs;
