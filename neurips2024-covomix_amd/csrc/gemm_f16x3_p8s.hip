@@ -276,10 +276,11 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
         else if (cons && a.bias && a.act == CVX_ACT_GELU && !a.rope_cos && !so.vt_hi && !A.hi2) epi = EPI_GELU_RS;
         else if (cons && a.act == CVX_ACT_NONE && a.rope_cos && so.vt_hi && !A.hi2) epi = EPI_QKV_RS;
         else return false;
-        // (these instances move split pairs 16 bytes at a time: 8 consecutive columns per lane, see perm32)
-        if (epi_perm(epi) && (((((uintptr_t)so.hi | (uintptr_t)so.lo | (uintptr_t)so.res_hi | (uintptr_t)so.res_lo) & 15) != 0) || (so.ldc_h & 7) != 0 ||
-                              (so.res_hi && (so.res_ld & 7) != 0))) return false;
     }
+    // (the permuted instances move split pairs 16 bytes at a time: 8 consecutive columns per lane, see perm32; anything less aligned
+    //  goes to the 32x32x16 kernel)
+    if (epi_perm(epi) && (((((uintptr_t)so.hi | (uintptr_t)so.lo | (uintptr_t)so.res_hi | (uintptr_t)so.res_lo) & 15) != 0) || (so.ldc_h & 7) != 0 ||
+                          (so.res_hi && (so.res_ld & 7) != 0))) return false;
     if (epi == EPI_GENERIC && so.vt_hi) return false;
     if (so.a2_scale && !(epi == EPI_BIAS_TW && so.a_scale)) return false;
 #define CVX_P8S_LAUNCH(A2, E)                                                                                           \

@@ -30,13 +30,18 @@ __device__ __forceinline__ void dma2(uint32_t voff0, uint32_t voff1, uint32_t m0
                  : "memory");
 }
 
-// Column permutation of the deferred-norm instances (large-problem kernel only).  LDS row rho = 16 h + 4 g + e of a 32-row group of
+// Column permutation of the pair-moving instances (the deferred-norm forms and to_qkv / ff1 of the large-problem kernel; the medium
+// kernel passes its own switch).  LDS row rho = 16 h + 4 g + e of a 32-row group of
 // the W tile holds weight row 8 g + 4 h + e, so accumulator tile ni = 2 t + h of lane group g (lane >> 4) holds the output columns
 // 32 t + 8 g + 4 h + (0..3): the tile pair (2 t, 2 t + 1) is 8 CONSECUTIVE columns per lane.
 #ifndef CVX_P8S_PERM
 #define CVX_P8S_PERM 1                         // dev A/B: 0 = the deferred-norm instances without the permutation (8-byte pair accesses)
 #endif
-__host__ __device__ constexpr bool epi_perm(int epi) { return CVX_P8S_PERM && epi >= EPI_RES_TW; }
+// (and the large-problem kernel's plain to_qkv / ff1 instances: the same 16-byte pair stores)
+#ifndef CVX_P8S_PERM_PLAIN
+#define CVX_P8S_PERM_PLAIN 1                   // dev A/B: 0 = only the deferred-norm instances
+#endif
+__host__ __device__ constexpr bool epi_perm(int epi) { return CVX_P8S_PERM && (epi >= EPI_RES_TW || (CVX_P8S_PERM_PLAIN && (epi == EPI_QKV || epi == EPI_GELU_SPLIT))); }
 __device__ __forceinline__ int perm32(int r) { return (r & ~31) | ((r & 12) << 1) | ((r & 16) >> 2) | (r & 3); }
 // first of the 4 columns tile ni of lane group lc / 4 holds, relative to the wave tile's first column
 template <bool PERM> __device__ __forceinline__ int tile_col(int ni, int lc) { return PERM ? 32 * (ni >> 1) + 2 * lc + 4 * (ni & 1) : 16 * ni + lc; }
