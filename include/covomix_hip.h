@@ -35,7 +35,8 @@ typedef void* cvx_stream_t;   /* hipStream_t */
 /* ABI version of the library: CVX_ABI_VERSION of the header it was built from.  The argument structs carry no size field, so a
  * caller built against another header version must not call in: compare once after loading (the ctypes binding does,
  * covomix_amd/_lib.py).  104: round 4 (cvx_gemm_f16x3_norm, caller-owned saturation flags, cvx_t2s_decoder.cfg_scale,
- * cvx_t2s_decode_xcd, CVX_GEMM_FLAG_MEDIUM / _NO_MEDIUM). */
+ * cvx_t2s_decode_xcd, CVX_GEMM_FLAG_MEDIUM / _NO_MEDIUM).  105: round 4, the deferred AdaptiveRMSNorm - cvx_gemm_split_io grew
+ * c_gamma_dev ... a2_scale_dev at its end; cvx_rownorm_scale_f32, cvx_split_f16_colscale_il. */
 #define CVX_ABI_VERSION 105
 int         cvx_version(void);
 const char* cvx_last_error_string(void);
