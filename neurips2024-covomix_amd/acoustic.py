@@ -342,6 +342,7 @@ class VectorField:
 
     # ------------------------------------------------------------------ deferred AdaptiveRMSNorm (large batches)
     DEFER_MIN_ROWS = int(os.environ.get("CVX_DEFER_NORM_ROWS", "8192"))
+    DEFER_RULE = os.environ.get("CVX_DEFER_NORM_RULE", "1") == "1"       # 0: every batch of DEFER_MIN_ROWS rows and more (tests, A/B)
 
     def _defers(self, M: int, ws: dict) -> bool:
         """Large batches run WITHOUT the norm kernel and with the residual stream as split pairs only.  An AdaptiveRMSNorm is one
@@ -356,8 +357,22 @@ class VectorField:
         The norm kernel (131 MB of traffic per launch at the bench shape, 16 of 17 launches per evaluation) does not run and ff2 no
         longer writes its output twice.  Only the first layer's attention norm (input from the embedding, fp32) and the final norm
         stay.  Large-problem kernel only: batches of DEFER_MIN_ROWS rows and more (CVX_DEFER_NORM=0: off)."""
-        return (self.precision == "f16x3" and M >= self.DEFER_MIN_ROWS and isinstance(ws.get("normed16"), ops.SplitIL)
-                and self.d["dim"] % 64 == 0 and 512 <= self.d["dim"] <= 4096 and os.environ.get("CVX_DEFER_NORM", "1") == "1")
+        if not (self.precision == "f16x3" and M >= self.DEFER_MIN_ROWS and isinstance(ws.get("normed16"), ops.SplitIL)
+                and self.d["dim"] % 64 == 0 and 512 <= self.d["dim"] <= 4096 and os.environ.get("CVX_DEFER_NORM", "1") == "1"):
+            return False
+        if not self.DEFER_RULE:
+            return True
+        # The deferred forms exist on the large-problem kernel only, whose N = dim products run in rounds of 256 x 256 tiles: where
+        # the library would hand those products to the medium-problem kernel (cvx_gemm_f16x3's rule: 128 x 128 tiles at 0.31 of a
+        # large tile's time) because the rounds come out part-empty, forcing the large kernel costs more than the norm saves.
+        # Measured (tools/defer_rows_bench.py, 32-NFE solve, ms with / without): 10,000 rows 260.2 / 265.8, 12,000 294.8 / 302.7,
+        # 16,000 352.6 / 361.1, 24,000 555.4 / 583.7 - and 20,480 rows (a full bin of the CLI: two rounds at 62 %) 497.7 / 491.5.
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        dim = self.d["dim"]
+        up = lambda a, b: -(-a // b)
+        large = up(up(M, 256) * up(dim, 256), ncu)
+        medium = 0.31 * up(up(M, 128) * up(dim, 128), ncu)
+        return medium >= 0.85 * large
 
     def _deferred_norm_tables(self, ctx: dict, table: torch.Tensor) -> None:
         """Per (evaluation time, layer): W diag(gamma) for to_qkv (layers 1..) and ff1 as interleaved split pairs, beta W^T as their

@@ -94,6 +94,7 @@ def test_c3_vomix_t1000_full_32nfe_rollout_vs_oracle(monkeypatch):
     import covomix_amd.acoustic as ac
     import covomix_amd.synthetic as syn
     monkeypatch.setattr(ac.VectorField, "DEFER_MIN_ROWS", 2048)
+    monkeypatch.setattr(ac.VectorField, "DEFER_RULE", False)
     sd = _state("vomix")
     inp = syn.synthetic_inputs("vomix", 2, 1000, 400, seed=2468)
     out = _run(sd, inp, 32)
@@ -213,6 +214,7 @@ def _count_deferred(monkeypatch, min_rows=2048):
     calls = []
     real = ops_.rownorm_scale
     monkeypatch.setattr(ac.VectorField, "DEFER_MIN_ROWS", min_rows)
+    monkeypatch.setattr(ac.VectorField, "DEFER_RULE", False)           # (the row-count rule would keep 2,200 rows on the medium-problem kernel)
     monkeypatch.setattr(ops_, "rownorm_scale", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     return calls
 
