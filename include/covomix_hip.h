@@ -36,8 +36,12 @@ typedef void* cvx_stream_t;   /* hipStream_t */
  * caller built against another header version must not call in: compare once after loading (the ctypes binding does,
  * covomix_amd/_lib.py).  104: round 4 (cvx_gemm_f16x3_norm, caller-owned saturation flags, cvx_t2s_decoder.cfg_scale,
  * cvx_t2s_decode_xcd, CVX_GEMM_FLAG_MEDIUM / _NO_MEDIUM).  105: round 4, the deferred AdaptiveRMSNorm - cvx_gemm_split_io grew
- * c_gamma_dev ... a2_scale_dev at its end; cvx_rownorm_scale_f32, cvx_split_f16_colscale_il. */
-#define CVX_ABI_VERSION 105
+ * c_gamma_dev ... a2_scale_dev at its end; cvx_rownorm_scale_f32, cvx_split_f16_colscale_il.  106: round 5 - CU-partitioned
+ * streams (cvx_stream_create_cu_mask / _destroy / cvx_stream_set_cus / cvx_stream_cus); the library reads no environment
+ * variable in any build; REMOVED (measured slower, numbers in
+ * HISTORY.md): cvx_t2s_decode_persistent, cvx_t2s_decode_xcd, cvx_embed_conv31_f32, CVX_GEMM_FLAG_TWO_STAGE / _MFMA32 (the superseded
+ * large-problem GEMM forms: shapes the eight-phase kernel cannot take run on the 128 x 128 kernel). */
+#define CVX_ABI_VERSION 106
 int         cvx_version(void);
 const char* cvx_last_error_string(void);
 
@@ -63,6 +67,26 @@ const char* cvx_last_error_string(void);
 int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s);
 int cvx_saturation_flag_reset(cvx_stream_t s);
 int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * CU-partitioned streams (round 5): the text2semantic decode of the NEXT batch of dialogues (a latency chain of 34 dependent
+ * launches per token that needs a handful of CUs; reference loop dialogue_generation.py:272-329, decode
+ * covomix/covomix_model/text2semantic.py:749-848) runs UNDER the acoustic solve of the current one.  The large-problem GEMM is a
+ * persistent kernel that owns every CU it gets for a whole launch, so a plain side stream would only be served at launch
+ * boundaries: the two stages run on streams restricted to DISJOINT CU sets instead.
+ *   cvx_stream_create_cu_mask: hipExtStreamCreateWithCUMask.  Bit k of the mask names CU (k / 8) of XCD (k % 8); inside an XCD
+ *                              consecutive indices go round the four shader engines (measured on MI355X, tools/cu_mask_probe.hip).
+ *                              One-block-per-CU kernels are only co-resident when every shader engine keeps the same number of
+ *                              CUs, i.e. when the CUs per XCD are a multiple of 4 (tools/cu_mask_probe2.hip: 30 CUs per XCD ->
+ *                              12 of 240 blocks wait for a second round; 28 -> none).  The stream belongs to the caller.
+ *   cvx_stream_set_cus:        tell the library how many CUs stream s of the current device owns (0: forget): the persistent grids
+ *                              (large-problem GEMM, vocoder pair kernel, skinny GEMM) and the large / medium GEMM choice are sized from
+ *                              it instead of from the device's CU count.  Host-side bookkeeping only (legal during capture).
+ *   cvx_stream_cus:            that number, or the device's CU count for a stream nobody described. */
+int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, cvx_stream_t* out);
+int cvx_stream_destroy(cvx_stream_t s);
+int cvx_stream_set_cus(cvx_stream_t s, int32_t n_cus);
+int cvx_stream_cus(cvx_stream_t s);
 
 /* ------------------------------------------------------------------------
  * C[M,N] = epilogue( [A | A2][M,K] * W[N,K]^T )      fp32 MFMA (v_mfma_f32_32x32x2_f32)
@@ -165,8 +189,7 @@ typedef struct {
      * power-of-two pre-scale, so a skip saved at the input of layer i and the stream at layer depth-1-i need not share one. */
     const float* a2_scale_dev;
 } cvx_gemm_split_io;
-#define CVX_GEMM_FLAG_TWO_STAGE 1
-#define CVX_GEMM_FLAG_MFMA32 2      /* eight-phase kernel on the 32x32x16 MFMA instead of the 16x16x32 one (A/B measurements) */
+/* (bits 1 and 2 selected the two superseded large-problem kernels until version 105: ignored now) */
 #define CVX_GEMM_FLAG_MEDIUM 8      /* interleaved operands, 2048 rows and more: take the medium-problem kernel (128 x 128 tiles) whatever the tile count */
 #define CVX_GEMM_FLAG_NO_MEDIUM 16  /* ... never take it there (the large-problem kernel's rounds of 256 x 256 tiles): A/B measurements */
 #define CVX_GEMM_FLAG_ONE_TILE 4    /* eight-phase 16x16x32 kernel: one output tile per block instead of persistent blocks (bit-identical results) */
@@ -277,17 +300,6 @@ int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, const float
  * table of a solve (acoustic.py:360-370 evaluated for all n evaluation times at once: 32 x 32,768 x 1,024) and the time MLP. */
 int cvx_gemm_skinny_f32(const float* A, int32_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                         int32_t M, int32_t N, int32_t K, int32_t act, cvx_stream_t s);
-/* to_embed's state columns + ConvPositionEmbed in one launch (acoustic.py:174-176, :60-68; round 3):
- *     h0 = x . W[:, :K]^T + base;      y = h0 + gelu(dwconv31(h0) + dw_b)
- * x [rows, K] (K % 8 == 0, K <= 80: the ODE state), w_embed [C, ldw] (its first K columns are used), base [rows, C] (the
- * step-invariant part of to_embed, bias included), dw_w [C, 31], y [rows, C], C % 64 == 0.  Sequences as in
- * cvx_dwconv31_gelu_res_varlen_f32 (cu_seqlens_dev NULL: Bt sequences of max_T rows).  Exact fp32 products on the fp32 matrix
- * pipe; the depthwise taps in the order of cvx_dwconv31_gelu_res_f32.  Replaces a GEMM that writes h0 and a convolution
- * that reads it back. */
-int cvx_embed_conv31_f32(const float* x, int32_t K, const float* w_embed, int32_t ldw, const float* base, const float* dw_w,
-                         const float* dw_b, float* y, const int32_t* cu_seqlens_dev, int32_t Bt, int32_t max_T, int32_t C,
-                         cvx_stream_t s);
-
 /* v = f_c*(1+s) - s*f_n   (f_n == NULL: v = f_c)        CFG combine, acoustic.py:428
  * out = y + coef*v ; out2, out3 = optional extra copies  ODE stage update (torchdiffeq midpoint:
  * y_mid = y + f0*dt/2, y1 = y + dt*f_mid); `out` may alias `y`. */
@@ -567,23 +579,6 @@ typedef struct {
 } cvx_t2s_decoder;
 
 int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream_t stream);
-/* The same n_steps token steps as ONE persistent launch (one block per CU): phase boundaries are grid barriers instead of
- * kernel boundaries and every wave requests the weight rows of its next phase before it waits, so a step no longer pays
- * 8 * depth + 2 launch gaps and exposed weight round trips.  Same device code per phase: logits and tokens are
- * bit-identical to cvx_t2s_decode_steps.  sync_ws_dev: 2 uint32 of DEVICE memory owned by the caller for the duration of
- * the launch (zeroed by the call): [0] barrier counter, [1] error word - non-zero after the launch means a barrier timed
- * out (some block was not resident: another kernel held its CU for > 0.1 s) and the step results are invalid; the kernel
- * always terminates.  Needs heads * batch <= the device's CU count. */
-int cvx_t2s_decode_persistent(const cvx_t2s_decoder* dec, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t stream);
-/* The same token steps with ONE XCD PER UTTERANCE (round 4): 8 groups of 32 blocks, group u = the blocks b with b % 8 == u decodes
- * utterance u (batch <= 8, no guidance) on the XCD those blocks were dispatched to.  The CUs of an XCD share its L2, so a phase
- * boundary inside a group is one L2 atomic + a relaxed poll with NO cache maintenance (every activation read of the decode device
- * code bypasses L1) - against ~15 us for the device-wide hand-off of cvx_t2s_decode_persistent.  Same device code per phase:
- * logits and tokens bit-identical to cvx_t2s_decode_steps.  Block -> XCD placement is observed behaviour, not a HIP contract:
- * every block checks HW_REG_XCC_ID against its group's first block.  sync_ws_dev: 160 uint32 of DEVICE memory owned by the caller for
- * the duration of the launch (zeroed by the call); word [1] != 0 afterwards = the results are INVALID (bit 0: a barrier timed out,
- * bit 1: a group was not placed on one XCD) - run cvx_t2s_decode_steps instead.  n_steps == 0 runs the placement check alone. */
-int cvx_t2s_decode_xcd(const cvx_t2s_decoder* dec, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t stream);
 
 /* out[r, c] = h[r, c] * gelu(h[r, F + c]) for c < F, 0 for F <= c < ld_out   (GEGLU, text2semantic.py:154-157;
  * the encoder's feed-forward; ld_out >= F pads the K dimension of the following GEMM). */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB_PATH") or os.path.join(_HERE, "libcovomix_hip.so")      # CVX_LIB_PATH: dev A/B builds
 
 _f32p = C.POINTER(C.c_float)
-ABI_VERSION = 105          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
+ABI_VERSION = 106          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
 
 
 class GemmArgs(C.Structure):
@@ -183,8 +183,6 @@ SIGNATURES = {
     "cvx_mel_magnitude_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "cvx_mel_log_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "cvx_t2s_decode_steps": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p]),
-    "cvx_t2s_decode_persistent": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p, C.c_void_p]),
-    "cvx_t2s_decode_xcd": (C.c_int, [C.POINTER(T2SDecoder), C.c_int32, C.c_void_p, C.c_void_p]),
     "cvx_geglu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
     "cvx_hubert_conv0_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32]),
     "cvx_hubert_conv0_gn_gelu_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -254,6 +252,10 @@ SIGNATURES = {
     "cvx_saturation_flag_bind": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvx_saturation_flag_reset": (C.c_int, [C.c_void_p]),
     "cvx_saturation_flag_query": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.c_void_p]),
+    "cvx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "cvx_stream_destroy": (C.c_int, [C.c_void_p]),
+    "cvx_stream_set_cus": (C.c_int, [C.c_void_p, C.c_int32]),
+    "cvx_stream_cus": (C.c_int, [C.c_void_p]),
     # ragged batches (cu_seqlens)
     "cvx_attention_varlen_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_float, C.c_void_p]),
@@ -262,8 +264,6 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvx_gemm_skinny_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p]),
-    "cvx_embed_conv31_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "cvx_dwconv31_gelu_res_varlen_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                    C.c_int32, C.c_int32, C.c_void_p]),
 }

@@ -106,11 +106,6 @@ class VectorField:
             if precision == "f16x3" and w_rest.shape[1] % 32 == 0:
                 self.w_rest = w_rest.contiguous()
                 self.split["to_embed.rest"] = ops.split_f16(self.w_rest)
-        # one launch for to_embed's state columns + ConvPositionEmbed: built, bit-identical, and SLOWER than the two launches it
-        # replaces (155 vs 101 us at the bench shape: load / matrix / convolution phases of a block do not overlap with two
-        # blocks per CU) - opt-in
-        self.fused_embed = (os.environ.get("CVX_FUSED_EMBED", "0") == "1" and d["dim_out"] % 8 == 0 and d["dim_out"] <= 80
-                            and d["dim"] % 64 == 0 and sd["to_embed.weight"].stride(0) % 4 == 0)
         self._init_gain_model()
         # DEV STUDY (round 4, joules per useful flop): CVX_WLO_BITS = b keeps only the top b significand bits of every weight's lo
         # half (11 = all, 0 = lo == 0): fewer toggling operand bits in two of the three MFMA products.  Never set by the product.
@@ -122,7 +117,8 @@ class VectorField:
                     v[1].view(torch.int16).bitwise_and_(keep)
         # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
         self.split_il: Dict[str, tuple] = {}
-        self._dn_bufs: Dict[tuple, dict] = {}          # deferred norm: W diag(gamma(t)) pairs of one solve (contents rebuilt per call)
+        self._dn_bufs: Dict[tuple, dict] = {}          # deferred norm: W diag(gamma(t)) pairs per (n, depth, solver grid)
+        self._time_cache: Dict[tuple, dict] = {}       # solver grid (nfe, method) -> everything that depends on the evaluation times only
         if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
             for k, v in self.split.items():
                 if v[0].shape[0] >= 512 or k == "to_pred.weight":
@@ -178,7 +174,7 @@ class VectorField:
         return 2.0 ** max(-40, min(40, round(math.log2(x)))) if x > 0 and math.isfinite(x) else 1.0
 
     def _activation_scales(self, table: torch.Tensor) -> tuple:
-        """(S [n_eval, depth, N_KINDS], H [1]) power-of-two pre-scales from the gain model; device tensors, no host sync."""
+        """(S [n_eval, depth, N_KINDS], H [1], HS [depth, 4]) power-of-two pre-scales from the gain model; device tensors, no host sync."""
         d, gn = self.d, self.gain
         n, L, dim = table.shape[0], d["depth"], d["dim"]
         tab = table.view(n, L, 4, dim)
@@ -213,8 +209,8 @@ class VectorField:
         H = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / hmax.sqrt().clamp_min(tiny))).clamp(-40, 40)).reshape(1).contiguous()
         # the pair-only residual stream of the deferred-norm path (section 4.1d) carries ONE pre-scale PER STAGE: the stream IS those
         # pairs there, and a stage far below the largest one would sit under the full-precision window of a shared scale
-        self._stage_scales = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / torch.stack(stages).sqrt().clamp_min(tiny))).clamp(-40, 40)).contiguous()
-        return S, H
+        HS = torch.exp2(torch.round(torch.log2(self.TARGET_RMS / torch.stack(stages).sqrt().clamp_min(tiny))).clamp(-40, 40)).contiguous()
+        return S, H, HS
 
     # ------------------------------------------------------------------ workspace
     RAGGED_ROW_QUANTUM = 1024       # ragged batches: workspaces are sized in steps of this many rows and shared by every
@@ -276,9 +272,10 @@ class VectorField:
 
     # ------------------------------------------------------------------ per-call setup
     def prepare(self, phoneme_ids: torch.Tensor, cond: torch.Tensor, times: torch.Tensor, use_null: bool,
-                lengths: Optional[List[int]] = None) -> dict:
+                lengths: Optional[List[int]] = None, times_key=None) -> dict:
         """Everything that does not depend on the ODE state x:
-        time MLP + adaptive-norm tables for every evaluation time, and the step-invariant part of to_embed.
+        time MLP + adaptive-norm tables for every evaluation time (_time_tables: computed once per solver grid `times_key` and
+        model), and the step-invariant part of to_embed.
         lengths: ragged batch - phoneme_ids [M1(, S)] and cond [M1, C] hold the utterances back to back (M1 = sum(lengths));
         the null-branch rows repeat the same sequence structure behind them."""
         d, sd = self.d, self.sd
@@ -296,6 +293,47 @@ class VectorField:
             Bt = 2 * B if use_null else B
             M1 = B * T
             ws = self._workspace(Bt, T)
+        n = times.numel()
+        tt = self._time_tables(times, times_key)
+        table = tt["table"]
+        # step-invariant to_embed columns: rows [0, M1) conditional, rows [M1, 2*M1) null branch
+        g = ws["gathered"]
+        ids = phoneme_ids.to(torch.int64).contiguous()
+        ops.embed_gather(ids, d["streams"], sd["to_phoneme_emb.weight"], cond.contiguous(), None, d["dim_cond"],
+                         d["null_id"], g[:M1], M1)
+        if use_null:
+            ops.embed_gather(None, d["streams"], sd["to_phoneme_emb.weight"], None, sd["null_cond"], d["dim_cond"],
+                             d["null_id"], g[M1:], M1)
+        if "to_embed.rest" in self.split:
+            ops.gemm(g, self.w_rest, ws["base"], bias=sd["to_embed.bias"], w_split=self.split["to_embed.rest"])
+        else:
+            ops.gemm(g, sd["to_embed.weight"][:, d["dim_out"]:], ws["base"], bias=sd["to_embed.bias"])
+        ctx = dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null, M=(2 * M1 if use_null else M1), ragged=rg)
+        if "S" in tt:
+            ctx["scales"], ctx["h_scale"] = tt["S"], tt["H"]                   # keep the tensors alive as long as the pointers
+            ctx["sp"], ctx["hp"] = tt["sp"], tt["H"].data_ptr()
+            if self._defers(ctx["M"], ws):
+                if tt["dn"] is None:
+                    tt["dn"] = self._deferred_norm_tables(table, tt["HS"], times_key)
+                ctx["dn"] = tt["dn"]
+        return ctx
+
+    # ------------------------------------------------------------------ everything that depends on the evaluation times only
+    TIME_CACHE = 2          # evaluation-time grids whose tables stay resident (each holds 0.22 GB per evaluation time once a batch deferred its norms)
+
+    def _time_tables(self, times: torch.Tensor, key) -> dict:
+        """Time MLP + adaptive-norm table for every evaluation time, the activation pre-scales of the gain model and (filled in by
+        prepare() when a batch defers its norms) the deferred-norm weight tables.  All of it is a function of the CHECKPOINT and the
+        evaluation times - gamma / beta are functions of the time embedding alone (reference acoustic.py:198-204) - never of the
+        utterance, so a solver grid `key` = (nfe, method) computes it once per VectorField (= per set of weights: CoVoMixModel builds a
+        new field when its weights change) and every later call reuses it: 15 split_colscale_il + 34 weight-streaming launches and
+        ~30 torch launches less per call.  key = None: not cached.  At most TIME_CACHE grids stay resident; evicting one also
+        drops the captured graphs (they hold addresses of its tables)."""
+        d, sd = self.d, self.sd
+        if key is not None and key in self._time_cache:
+            ent = self._time_cache.pop(key)
+            self._time_cache[key] = ent                                        # most recently used last
+            return ent
         n = times.numel()
         four = torch.empty(n, d["dim"], dtype=torch.float32, device=self.device)
         ops.time_fourier(times, sd["sinu_pos_emb.0.weights"], four)
@@ -316,29 +354,19 @@ class VectorField:
             ops.gemm(temb, self.ada_w, table, bias=self.ada_b, w_split=self.split["ada"], a_split=ops.split_act_f16(temb))
         else:
             ops.gemm(temb, self.ada_w, table, bias=self.ada_b)
-        # step-invariant to_embed columns: rows [0, M1) conditional, rows [M1, 2*M1) null branch
-        g = ws["gathered"]
-        ids = phoneme_ids.to(torch.int64).contiguous()
-        ops.embed_gather(ids, d["streams"], sd["to_phoneme_emb.weight"], cond.contiguous(), None, d["dim_cond"],
-                         d["null_id"], g[:M1], M1)
-        if use_null:
-            ops.embed_gather(None, d["streams"], sd["to_phoneme_emb.weight"], None, sd["null_cond"], d["dim_cond"],
-                             d["null_id"], g[M1:], M1)
-        if "to_embed.rest" in self.split:
-            ops.gemm(g, self.w_rest, ws["base"], bias=sd["to_embed.bias"], w_split=self.split["to_embed.rest"])
-        else:
-            ops.gemm(g, sd["to_embed.weight"][:, d["dim_out"]:], ws["base"], bias=sd["to_embed.bias"])
-        ctx = dict(ws=ws, table=table, B=B, T=T, Bt=Bt, M1=M1, use_null=use_null, M=(2 * M1 if use_null else M1), ragged=rg)
+        ent = dict(table=table, dn=None)
         if self.precision in ("f16x3", "f16") and os.environ.get("CVX_ACT_SCALES", "1") == "1":
-            S, H = self._activation_scales(table)
-            ctx["scales"], ctx["h_scale"] = S, H                           # keep the tensors alive as long as the pointers
-            p0 = S.data_ptr()
-            K = self.N_KINDS
-            ctx["sp"] = [[[p0 + 4 * ((e * d["depth"] + i) * K + k) for k in range(K)] for i in range(d["depth"])] for e in range(n)]
-            ctx["hp"] = H.data_ptr()
-            if self._defers(ctx["M"], ws):
-                self._deferred_norm_tables(ctx, table)
-        return ctx
+            S, H, HS = self._activation_scales(table)
+            p0, K = S.data_ptr(), self.N_KINDS
+            ent.update(S=S, H=H, HS=HS, sp=[[[p0 + 4 * ((e * d["depth"] + i) * K + k) for k in range(K)] for i in range(d["depth"])] for e in range(n)])
+        if key is not None and not torch.cuda.is_current_stream_capturing():     # (tables made inside a capture belong to that graph's pool)
+            while len(self._time_cache) >= self.TIME_CACHE:
+                old = next(iter(self._time_cache))
+                del self._time_cache[old]
+                self._dn_bufs = {k: v for k, v in self._dn_bufs.items() if k[2] != old}
+                self.__dict__.pop("_graphs", None)
+            self._time_cache[key] = ent
+        return ent
 
     # ------------------------------------------------------------------ deferred AdaptiveRMSNorm (large batches)
     DEFER_MIN_ROWS = int(os.environ.get("CVX_DEFER_NORM_ROWS", "8192"))
@@ -352,8 +380,8 @@ class VectorField:
           needed (no fp32 store: it moves the bytes the fp32 form moved), reads its residual from that pair, and leaves the rows'
           sums of squares per 64 columns (cvx_gemm_split_io.R_hi / c_rowsq); cvx_rownorm_scale_f32 makes one factor per row;
         * the consuming GEMM (to_qkv, ff1) multiplies its accumulator rows by that factor, carries beta W^T in its bias and runs on
-          W diag(gamma(t)) - split copies of the weights for every evaluation time of the solve, rebuilt by prepare() for every call
-          (cvx_split_f16_colscale_il: 7 GB for 32 evaluation times - capacity HBM3E has - written in ~2 ms per solve).
+          W diag(gamma(t)) - split copies of the weights for every evaluation time of the solver grid, built ONCE per (model, grid)
+          (_time_tables; cvx_split_f16_colscale_il: 7 GB for 32 evaluation times - capacity HBM3E has - written in ~2 ms).
         The norm kernel (131 MB of traffic per launch at the bench shape, 16 of 17 launches per evaluation) does not run and ff2 no
         longer writes its output twice.  Only the first layer's attention norm (input from the embedding, fp32) and the final norm
         stay.  Large-problem kernel only: batches of DEFER_MIN_ROWS rows and more (CVX_DEFER_NORM=0: off)."""
@@ -374,17 +402,18 @@ class VectorField:
         medium = 0.31 * up(up(M, 128) * up(dim, 128), ncu)
         return medium >= 0.85 * large
 
-    def _deferred_norm_tables(self, ctx: dict, table: torch.Tensor) -> None:
+    def _deferred_norm_tables(self, table: torch.Tensor, HS: torch.Tensor, times_key) -> dict:
         """Per (evaluation time, layer): W diag(gamma) for to_qkv (layers 1..) and ff1 as interleaved split pairs, beta W^T as their
         bias (ff1: b1 + beta_ff W1^T), and the power of two that keeps |gamma| <= 1 inside the weight pair (divided out on the
-        accumulators through the consumer's a_scale).  Rebuilt for every call: no state survives a call."""
+        accumulators through the consumer's a_scale).  A function of the weights and the evaluation times: built once per solver
+        grid (_time_tables)."""
         d, sd = self.d, self.sd
         n, L, dim = table.shape[0], d["depth"], d["dim"]
         tab = table.view(n, L, 4, dim)
         tiny = torch.finfo(torch.float32).tiny
         gmax = tab[:, :, 0::2, :].abs().amax(dim=-1)                                     # [n, L, 2]: max |gamma_attn|, max |gamma_ff|
         gs = torch.exp2(-torch.ceil(torch.log2(gmax.clamp_min(tiny))).clamp(-40, 40)).contiguous()
-        HS = self._stage_scales                                                          # [L, 4]: stream pre-scale at a layer's input / behind its combiner / to_out / ff2
+        # HS [L, 4]: stream pre-scale at a layer's input / behind its combiner / to_out / ff2
         AS = (gs * HS[None, :, 1:3]).contiguous()                                        # pre-scale of the consumers' A pairs (stage scale) times the weights' gs
 
         def beta_w(beta_rows: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
@@ -393,9 +422,9 @@ class VectorField:
                 r1 = min(n, r0 + 32)
                 ops.gemm_skinny(beta_rows[r0:r1], w, out[r0:r1], bias=bias)
             return out
-        key = (n, L)
+        key = (n, L, times_key)
         bufs = self._dn_bufs.get(key)
-        if bufs is None:                     # (kept per evaluation count, never freed: captured HIP graphs hold their addresses; 0.22 GB per evaluation time)
+        if bufs is None:                     # (0.22 GB per evaluation time; released with the grid's cache entry, _time_tables)
             mk = lambda N: torch.empty(n, N, 2 * dim, dtype=torch.float16, device=self.device)
             bufs = dict(wq=[None if i == 0 else mk(3 * d["heads"] * 64) for i in range(L)], w1=[mk(4 * dim) for _ in range(L)])
             self._dn_bufs[key] = bufs
@@ -415,7 +444,7 @@ class VectorField:
             ops.split_f16_colscale_il(sd[nq], tab[:, i, 0, :], gs[:, i, 0], 1.0 / invq, bufs["wq"][i])
             wq.append([(bufs["wq"][i][e], invq) for e in range(n)])
         a0, h0 = AS.data_ptr(), HS.data_ptr()
-        ctx["dn"] = dict(b1p=b1p, bq=bq, wq=wq, w1=w1, gs=gs, AS=AS, HS=HS, hsp=[[h0 + 4 * (4 * i + k) for k in range(4)] for i in range(L)],
+        return dict(b1p=b1p, bq=bq, wq=wq, w1=w1, gs=gs, AS=AS, HS=HS, hsp=[[h0 + 4 * (4 * i + k) for k in range(4)] for i in range(L)],
                          asp=[[(a0 + 4 * ((e * L + i) * 2), a0 + 4 * ((e * L + i) * 2 + 1)) for i in range(L)] for e in range(n)])
 
     def _layers_pair_stream(self, ctx: dict, step: int, ws: dict, h: torch.Tensor, twin: dict, free: list, Bt: int, T: int, M: int, rg):
@@ -514,24 +543,11 @@ class VectorField:
                 out[k] = cut(v)
         return out
 
-    @staticmethod
-    def _ws_rows(ws: dict, b0: int, b1: int, T: int, heads: int) -> dict:
-        """Views restricted to sequences [b0, b1) of an equal-length batch (rows b0*T .. b1*T): an independent half-size
-        problem on the same storage, so two such parts can run concurrently on two streams."""
-        return VectorField._ws_cut(ws, b0 * T, b1 * T, vt=(b0 * heads * 64, b1 * heads * 64))
-
-    def evaluate(self, ctx: dict, step: int, part: Optional[int] = None) -> torch.Tensor:
+    def evaluate(self, ctx: dict, step: int) -> torch.Tensor:
         """Run the network on ws['xin'] (rows: cond branch then null branch) at evaluation time #step.
-        Returns ws['pred'] [Bt*T, dim_out].  part = i: only the i-th of ctx['parts'] sequence ranges (see _ws_rows)."""
+        Returns ws['pred'] [Bt*T, dim_out]."""
         d, sd, ws = self.d, self.sd, ctx["ws"]
         Bt, T, M, rg = ctx["Bt"], ctx["T"], ctx["M"], ctx.get("ragged")
-        if part is not None:
-            b0, b1 = ctx["parts"][part]
-            key = ("part_ws", part)
-            if key not in ctx:
-                ctx[key] = self._ws_rows(ws, b0, b1, T, d["heads"])
-            ws, Bt = ctx[key], b1 - b0
-            M = Bt * T
         dim = d["dim"]
         tab = ctx["table"][step]
         free: List[torch.Tensor] = list(ws["h"])
@@ -547,13 +563,10 @@ class VectorField:
             sp = self.split.get
 
         h = take()
-        if self.fused_embed:                 # state columns of to_embed + ConvPositionEmbed in one launch (h0 never reaches HBM)
-            ops.embed_conv31(ws["xin"], sd["to_embed.weight"], ws["base"], self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
-        else:
-            h0 = take()
-            ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
-            ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
-            free.append(h0)
+        h0 = take()
+        ops.gemm(ws["xin"], sd["to_embed.weight"][:, : d["dim_out"]], h0, residual=ws["base"])
+        ops.dwconv31_gelu_res(h0, self.dw_w, sd["conv_embed.dw_conv1d.0.bias"], h, Bt, T, ragged=rg)
+        free.append(h0)
         # residual-stream tensors that later feed a skip combiner (as x or as the popped skip) also get a split
         # twin, so that GEMM takes both operands pre-split (all-DMA kernel) instead of splitting on the fly
         twin = {id(b): pr for b, pr in zip(ws["h"], ws["h16"])} if split_io else None
@@ -571,7 +584,7 @@ class VectorField:
         # (2048 rows and more never split K: the call would run the same two kernels, so it stays two calls there)
         fuse_norm = split_io and M < 2048 and os.environ.get("CVX_FUSE_NORM", "1") == "1"
         normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
-        if use_dn:                           # (decided per call in prepare(): the halves of a two-chain schedule follow the whole batch)
+        if use_dn:                           # (decided per call in prepare())
             return self._layers_pair_stream(ctx, step, ws, h, twin, free, Bt, T, M, rg)
         def tab_rows(i_, k_):
             return tab[(4 * i_ + k_) * dim:(4 * i_ + k_ + 1) * dim]
@@ -682,7 +695,6 @@ class FlowMatchingSampler:
 
     def __init__(self, field: VectorField, nfe: int = 32, method: str = "midpoint"):
         self.field, self.nfe, self.method = field, nfe, method
-        self._side = None
 
     # launch-bound regime (short / single utterances): the whole solve - ~2400 kernel launches for 32 NFE - is captured
     # once per input shape into a HIP graph and replayed (env CVX_GRAPH=0 disables, CVX_GRAPH_MAX_ROWS bounds the
@@ -692,7 +704,7 @@ class FlowMatchingSampler:
     def _integrate(self, phoneme_ids, cond, y, times_dev, dts, s: float, use_null: bool, lengths=None) -> None:
         """prepare() + the fixed-grid loop; advances `y` in place (ragged batch: y, cond, ids packed, see prepare)."""
         f = self.field
-        ctx = f.prepare(phoneme_ids, cond, times_dev, use_null, lengths=lengths)
+        ctx = f.prepare(phoneme_ids, cond, times_dev, use_null, lengths=lengths, times_key=(int(self.nfe), str(self.method)))
         ws, M1 = ctx["ws"], ctx["M1"]
         xin = ws["xin"]
         x_c = xin[:M1]
@@ -700,54 +712,17 @@ class FlowMatchingSampler:
         x_c.copy_(y.reshape(M1, -1))
         if use_null:
             x_n.copy_(x_c)
-        # Large batches: the sequences are cut into two halves that run as independent kernel chains on two streams.
-        # The chains drift out of phase, so one chain's HBM-bound kernels (norms, GEMM epilogues, attention tails) run
-        # under the other's matrix work instead of every CU hitting the same phase at the same time.
-        Bt = ctx["Bt"]
-        chains = int(os.environ.get("CVX_CHAINS", "1"))
-        if (chains == 2 and ctx["ragged"] is None and Bt % 2 == 0 and (Bt // 2) * ctx["T"] >= 2048
-                and not torch.cuda.is_current_stream_capturing()):
-            ctx["parts"] = [(0, Bt // 2), (Bt // 2, Bt)]
-            # (the halves must run the kernels the whole batch would: the library's choice between the large- and the medium-problem
-            #  GEMM depends on the row count - pinned to the large one for this schedule, which is bit-identical to one chain then)
-            saved_flags = ops._GEMM_FLAGS
-            ops._GEMM_FLAGS |= 16
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=f.device)
-            side = self._side
-            ops.saturation_share(main, side)             # both chains report into this call's flag
-            full_eval = f.evaluate
-
-            skew = int(float(os.environ.get("CVX_CHAIN_SKEW_US", "0")) * 1000)      # dev: start the second chain late (ns of spin)
-
-            def evaluate2(c, step):
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    if skew:
-                        torch.cuda._sleep(skew * 2)             # ~cycles at 2 GHz
-                    full_eval(c, step, part=1)
-                full_eval(c, step, part=0)
-                main.wait_stream(side)
-                return ws["pred"]
-            evaluate = evaluate2
-        else:
-            evaluate = f.evaluate
-            saved_flags = None
+        evaluate = f.evaluate
         e = 0
-        try:
-            for dt in dts:
-                if self.method == "midpoint":
-                    pred = evaluate(ctx, e); e += 1
-                    ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, 0.5 * dt, x_c, x_n)
-                    pred = evaluate(ctx, e); e += 1
-                    ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
-                else:
-                    pred = evaluate(ctx, e); e += 1
-                    ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
-        finally:
-            if saved_flags is not None:
-                ops._GEMM_FLAGS = saved_flags
+        for dt in dts:
+            if self.method == "midpoint":
+                pred = evaluate(ctx, e); e += 1
+                ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, 0.5 * dt, x_c, x_n)
+                pred = evaluate(ctx, e); e += 1
+                ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
+            else:
+                pred = evaluate(ctx, e); e += 1
+                ops.cfg_combine_axpy(pred[:M1], pred[M1:] if use_null else None, y, s, dt, y, x_c, x_n)
         return ctx
 
     @ops.gated

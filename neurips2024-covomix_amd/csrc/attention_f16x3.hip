@@ -489,10 +489,6 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
         }
 #endif
     }
-#ifdef CVX_DEV_FLAGS          // (dev builds only: the shipped library reads no environment variable)
-    static const bool no_ks = getenv("CVX_ATT_KS") && atoi(getenv("CVX_ATT_KS")) == 0;
-    if (no_ks) ksplit = 1;
-#endif
 #define CVX_ATT_LAUNCH(NT_, NW_)                                                                                                          \
     hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_>), grid, dim3(64 * NW_), 0, reinterpret_cast<hipStream_t>(s),                       \
                        reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \

@@ -13,7 +13,7 @@ void cvx_set_error(const char* fmt, ...);
 // granted so far: function attributes are per device, so a once-per-process flag is wrong for the second GPU a process
 // uses.  Thread-safe; a map lookup after the first call.
 void cvx_allow_dynamic_lds(const void* kernel, int bytes);
-// compute units of the current device (cached per device)
+// compute units of the current device (cached per device); cvx_stream_cus(s) (covomix_hip.h): of the CUs stream s owns
 int cvx_device_cus();
 // Sticky saturation flag: one uint32 of CALLER-OWNED device memory per (device, stream), attached with
 // cvx_saturation_flag_bind (covomix_hip.h).  Every kernel that writes (fp16 hi, fp16 lo) split pairs clamps to +-65504 and ORs bit 0

@@ -54,24 +54,35 @@ int cvx_device_cus()
     }
     return n_cu[dev];
 }
-// Saturation flags are CALLER-OWNED (round 4): cvx_saturation_flag_bind attaches one uint32 of device memory to a (device,
-// stream) pair; every entry point looks up the flag of the stream it launches on.  No allocation, no per-device global: two
-// host threads / streams on one device each have their own flag, and a first launch inside a stream capture allocates nothing.
+// Per-(device, stream) bookkeeping, all CALLER-DRIVEN (no allocation, no per-device global):
+//   * the saturation flag (round 4): cvx_saturation_flag_bind attaches one uint32 of device memory to a (device, stream) pair; every
+//     entry point looks up the flag of the stream it launches on.  Two host threads / streams on one device each have their own flag,
+//     and a first launch inside a stream capture allocates nothing;
+//   * the CU count of a CU-masked stream (round 5, cvx_stream_set_cus): what the persistent grids are sized from.
 namespace {
-struct SatBinding { int dev; hipStream_t st; uint32_t* flag; };
+struct StreamInfo { int dev; hipStream_t st; uint32_t* flag; int cus; };
 std::mutex g_sat_mu;
-SatBinding g_sat[256];
+StreamInfo g_sat[256];
 int g_sat_n = 0;
+// (g_sat_mu held) entry of (dev, st), or NULL
+StreamInfo* stream_info(int dev, hipStream_t st)
+{
+    for (int i = 0; i < g_sat_n; ++i)
+        if (g_sat[i].dev == dev && g_sat[i].st == st) return &g_sat[i];
+    return nullptr;
+}
+void stream_info_drop_if_empty(StreamInfo* e)
+{
+    if (e && !e->flag && e->cus == 0) *e = g_sat[--g_sat_n];
+}
 }
 uint32_t* cvx_sat_flag_for(cvx_stream_t s)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
     std::lock_guard<std::mutex> lock(g_sat_mu);
-    for (int i = 0; i < g_sat_n; ++i)
-        if (g_sat[i].dev == dev && g_sat[i].st == st) return g_sat[i].flag;
-    return nullptr;                      // no flag bound to this stream: the kernels skip the bookkeeping
+    StreamInfo* e = stream_info(dev, reinterpret_cast<hipStream_t>(s));
+    return e ? e->flag : nullptr;        // no flag bound to this stream: the kernels skip the bookkeeping
 }
 extern "C" int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s)
 {
@@ -80,15 +91,64 @@ extern "C" int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s)
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     CVX_REQUIRE((reinterpret_cast<uintptr_t>(dev_flag) & 3) == 0, "saturation_flag_bind: the flag must be 4-byte aligned");
     std::lock_guard<std::mutex> lock(g_sat_mu);
-    for (int i = 0; i < g_sat_n; ++i)
-        if (g_sat[i].dev == dev && g_sat[i].st == st) {
-            if (dev_flag) g_sat[i].flag = dev_flag;
-            else g_sat[i] = g_sat[--g_sat_n];              // NULL unbinds
-            return CVX_OK;
-        }
+    StreamInfo* e = stream_info(dev, st);
+    if (e) {
+        e->flag = dev_flag;                                    // NULL unbinds
+        stream_info_drop_if_empty(e);
+        return CVX_OK;
+    }
     if (!dev_flag) return CVX_OK;
-    CVX_REQUIRE(g_sat_n < 256, "saturation_flag_bind: more than 256 (device, stream) bindings");
-    g_sat[g_sat_n++] = SatBinding{dev, st, dev_flag};
+    CVX_REQUIRE(g_sat_n < 256, "saturation_flag_bind: more than 256 (device, stream) entries");
+    g_sat[g_sat_n++] = StreamInfo{dev, st, dev_flag, 0};
+    return CVX_OK;
+}
+extern "C" int cvx_stream_set_cus(cvx_stream_t s, int32_t n_cus)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { cvx_set_error("stream_set_cus: no current device"); return CVX_EHIP; }
+    CVX_REQUIRE(n_cus >= 0 && n_cus <= 4096, "stream_set_cus: bad CU count %d", n_cus);
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    std::lock_guard<std::mutex> lock(g_sat_mu);
+    StreamInfo* e = stream_info(dev, st);
+    if (e) {
+        e->cus = n_cus;
+        stream_info_drop_if_empty(e);
+        return CVX_OK;
+    }
+    if (n_cus == 0) return CVX_OK;
+    CVX_REQUIRE(g_sat_n < 256, "stream_set_cus: more than 256 (device, stream) entries");
+    g_sat[g_sat_n++] = StreamInfo{dev, st, nullptr, n_cus};
+    return CVX_OK;
+}
+extern "C" int cvx_stream_cus(cvx_stream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_sat_mu);
+        const StreamInfo* e = stream_info(dev, reinterpret_cast<hipStream_t>(s));
+        if (e && e->cus > 0) return e->cus;
+    }
+    return cvx_device_cus();
+}
+extern "C" int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, cvx_stream_t* out)
+{
+    CVX_REQUIRE(mask && out && n_words > 0 && n_words <= 64, "stream_create_cu_mask: bad arguments");
+    int bits = 0;
+    for (int i = 0; i < n_words; ++i) bits += __builtin_popcount(mask[i]);
+    CVX_REQUIRE(bits > 0, "stream_create_cu_mask: empty mask");
+    hipStream_t st = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask);
+    if (e != hipSuccess) { cvx_set_error("stream_create_cu_mask: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e)); return CVX_EHIP; }
+    *out = reinterpret_cast<cvx_stream_t>(st);
+    return cvx_stream_set_cus(*out, bits);
+}
+extern "C" int cvx_stream_destroy(cvx_stream_t s)
+{
+    CVX_REQUIRE(s, "stream_destroy: the NULL stream");
+    (void)cvx_stream_set_cus(s, 0);
+    (void)cvx_saturation_flag_bind(nullptr, s);
+    const hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(s));
+    if (e != hipSuccess) { cvx_set_error("stream_destroy: %s", hipGetErrorString(e)); return CVX_EHIP; }
     return CVX_OK;
 }
 extern "C" int cvx_saturation_flag_reset(cvx_stream_t s)
@@ -301,132 +361,6 @@ __global__ __launch_bounds__(256) void dwconv31_kernel(const float* __restrict__
         if (t < T) y[base + (int64_t)t * C + c] = g2[0] + xs[o + DW_K / 2];
         if (t + 1 < T) y[base + (int64_t)(t + 1) * C + c] = g2[1] + xs[o + 1 + DW_K / 2];
     }
-}
-
-// ---------------------------------------------------------------- to_embed (state columns) + ConvPositionEmbed, fused
-// h = h0 + gelu(dwconv31(h0) + b),  h0 = x . W[:, :K]^T + base        (acoustic.py:174-176 and :60-68 per evaluation)
-// One launch instead of a [M, K = 80] x [K, C] GEMM that writes h0 (65 MB at the bench shape) and a depthwise convolution
-// that reads it back 2-3 times: a block owns EC_ROWS consecutive frames of one sequence x 64 channels,
-//   (1) stages x rows (fp32, row stride 84: conflict-free ds_read_b128) and the base tile in LDS,
-//   (2) h0 tile += x . W^T on v_mfma_f32_32x32x2_f32 - exact fp32 products; one b128 read of x feeds four MFMAs (the K order
-//       is permuted consistently in both operands: lanes g = 0 / 1 take k = 8q + j / 8q + 4 + j in step j); the W fragments of
-//       the wave's 64 channels live in registers, read once per block from L2,
-//   (3) every thread owns one channel and 25 output frames: 55-frame window from LDS, the depthwise taps in the order of
-//       dwconv31_kernel (bias first, k = 0 .. 30), GELU, + h0, coalesced store.  Frames outside the sequence count as zero.
-constexpr int EC_ROWS = 128;                   // frames of h0 per block: EC_OUT outputs + 15 either side
-constexpr int EC_OUT = EC_ROWS - (DW_K - 1);   // 98
-constexpr int EC_XLD = 84;                     // row stride of the x tile in floats (K <= 80)
-constexpr int EC_HLD = 65;                     // row stride of the h0 tile
-constexpr int EC_PER = 25;                     // output frames per thread (4 frame groups x 25 >= 98)
-__global__ __launch_bounds__(256, 2) void embed_conv31_kernel(const float* __restrict__ x, int K, const float* __restrict__ we, int ldw,
-                                                             const float* __restrict__ base_t, const float* __restrict__ dw_w,
-                                                             const float* __restrict__ dw_b, float* __restrict__ y,
-                                                             int T, int C, const int* __restrict__ cu_seqlens)
-{
-    extern __shared__ __attribute__((aligned(16))) float ec_smem[];
-    float* const xs = ec_smem;                               // [EC_ROWS][EC_XLD]
-    float* const hs = ec_smem + EC_ROWS * EC_XLD;            // [EC_ROWS][EC_HLD]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int c0 = blockIdx.x * 64;
-    const int t0 = blockIdx.y * EC_OUT;                      // first OUTPUT frame of the block; tile row r = frame t0 - 15 + r
-    int64_t row0 = (int64_t)blockIdx.z * T;
-    if (cu_seqlens) {
-        const int r0 = cu_seqlens[blockIdx.z];
-        T = cu_seqlens[blockIdx.z + 1] - r0;
-        row0 = r0;
-        if (t0 >= T) return;                                 // block-uniform
-    }
-#ifdef CVX_EC_TRACE
-    unsigned long long ts[6]; ts[0] = __builtin_amdgcn_s_memrealtime();
-#define EC_STAMP(i) ts[i] = __builtin_amdgcn_s_memrealtime();
-#else
-#define EC_STAMP(i)
-#endif
-    // W fragments of this wave's two 32-channel tiles: lane (i31, g) holds W[c0 + 32 nt + i31][8 q + 4 g .. + 3]
-    const int i31 = lane & 31, g = lane >> 5;
-    const int nq = K >> 3;                                   // K % 8 == 0, K <= 80
-    f32x4 wf[2][10];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int q = 0; q < 10; ++q)
-            wf[nt][q] = q < nq ? gload4(we + (int64_t)(c0 + 32 * nt + i31) * ldw + 8 * q + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-    // (1) stage x rows and the base tile (rows outside the sequence: zeros)
-    const int kv = K >> 2;                                   // float4 per x row
-    for (int i = tid; i < EC_ROWS * kv; i += 256) {
-        const int r = i / kv, k4 = i - r * kv, t = t0 - DW_K / 2 + r;
-        const f32x4 v = (t >= 0 && t < T) ? gload4(x + (row0 + t) * K + 4 * k4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(xs + r * EC_XLD + 4 * k4) = v;
-    }
-    for (int i = tid; i < EC_ROWS * 16; i += 256) {
-        const int r = i >> 4, c4 = i & 15, t = t0 - DW_K / 2 + r;
-        const f32x4 v = (t >= 0 && t < T) ? gload4(base_t + (row0 + t) * C + c0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hs[r * EC_HLD + 4 * c4 + e] = v[e];
-    }
-    EC_STAMP(1)
-    __syncthreads();
-    EC_STAMP(2)
-    // (2) wave wid: rows 32 wid .. + 31, both channel tiles
-    {
-        f32x16 acc[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        const float* xa = xs + (32 * wid + i31) * EC_XLD + 4 * g;
-#pragma unroll
-        for (int q = 0; q < 10; ++q) {
-            if (q < nq) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 8 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wf[0][q][j], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wf[1][q][j], acc[1], 0, 0, 0);
-                }
-            }
-        }
-        // acc[nt][r]: row (r & 3) + 8 (r >> 2) + 4 g of the wave's slab, channel 32 nt + i31 - owned by this lane alone
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * g, t = t0 - DW_K / 2 + row;
-                float* hp = hs + row * EC_HLD + 32 * nt + i31;
-                *hp = (t >= 0 && t < T) ? *hp + acc[nt][r] : 0.f;
-            }
-    }
-    EC_STAMP(3)
-    __syncthreads();
-    EC_STAMP(4)
-    // (3) channel c0 + lane, outputs o0 .. o0 + EC_PER - 1 of the tile
-    const int c = c0 + lane, o0 = wid * EC_PER;
-    float wk[DW_K];
-#pragma unroll
-    for (int k = 0; k < DW_K; ++k) wk[k] = dw_w[c * DW_K + k];
-    float win[EC_PER + DW_K - 1];
-#pragma unroll
-    for (int i = 0; i < EC_PER + DW_K - 1; ++i) win[i] = hs[min(o0 + i, EC_ROWS - 1) * EC_HLD + lane];
-    const float bc = dw_b[c];
-#pragma unroll
-    for (int o = 0; o < EC_PER; o += 2) {
-        float a0 = bc, a1 = bc;
-#pragma unroll
-        for (int k = 0; k < DW_K; ++k) { a0 = fmaf(wk[k], win[o + k], a0); if (o + 1 < EC_PER) a1 = fmaf(wk[k], win[min(o + 1 + k, EC_PER + DW_K - 2)], a1); }
-#if CVX_DWCONV_ERFF
-        const f32x2 g2 = f32x2{gelu_erf(a0), gelu_erf(a1)};
-#else
-        const f32x2 g2 = gelu_fast2(f32x2{a0, a1});
-#endif
-        const int t = t0 + o0 + o;
-        if (o0 + o < EC_OUT && t < T) y[(row0 + t) * C + c] = g2[0] + win[o + DW_K / 2];
-        if (o + 1 < EC_PER && o0 + o + 1 < EC_OUT && t + 1 < T) y[(row0 + t + 1) * C + c] = g2[1] + win[min(o + 1 + DW_K / 2, EC_PER + DW_K - 2)];
-    }
-#ifdef CVX_EC_TRACE
-    EC_STAMP(5)
-    __syncthreads();
-    if (tid == 0) { unsigned long long* d = reinterpret_cast<unsigned long long*>(y + (row0 + t0) * C + c0); for (int i = 0; i < 6; ++i) d[i] = ts[i]; }
-#endif
 }
 
 // ---------------------------------------------------------------- skinny GEMM: C[M <= 32][N] = A[M][K] . W[N][K]^T (+ bias)
@@ -763,24 +697,6 @@ extern "C" int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, 
     return CVX_OK;
 }
 
-extern "C" int cvx_embed_conv31_f32(const float* x, int32_t K, const float* w_embed, int32_t ldw, const float* base, const float* dw_w,
-                                    const float* dw_b, float* y, const int32_t* cu_seqlens_dev, int32_t Bt, int32_t max_T, int32_t C,
-                                    cvx_stream_t s)
-{
-    CVX_REQUIRE(x && w_embed && base && dw_w && dw_b && y, "embed_conv31: null pointer");
-    CVX_REQUIRE(Bt >= 0 && max_T > 0 && C > 0 && C % 64 == 0 && K > 0 && K % 8 == 0 && K <= 80 && ldw >= K && ldw % 4 == 0 && Bt <= 65535,
-                "embed_conv31: bad shape (K=%d must be a multiple of 8 up to 80, C=%d a multiple of 64, ldw=%d a multiple of 4)", K, C, ldw);
-    CVX_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_embed & 15) == 0 && ((uintptr_t)base & 15) == 0, "embed_conv31: 16-byte aligned operands");
-    if (Bt == 0) return CVX_OK;
-    const size_t lds = (size_t)(EC_ROWS * EC_XLD + EC_ROWS * EC_HLD) * sizeof(float);
-    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&embed_conv31_kernel), (int)lds);
-    dim3 grid((unsigned)(C / 64), (unsigned)((max_T + EC_OUT - 1) / EC_OUT), (unsigned)Bt);
-    hipLaunchKernelGGL(embed_conv31_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(s), x, K, w_embed, ldw, base, dw_w, dw_b, y,
-                       max_T, C, cu_seqlens_dev);
-    CVX_CHECK_LAUNCH("cvx_embed_conv31_f32");
-    return CVX_OK;
-}
-
 extern "C" int cvx_gemm_skinny_f32(const float* A, int32_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                                    int32_t M, int32_t N, int32_t K, int32_t act, cvx_stream_t s)
 {
@@ -792,7 +708,7 @@ extern "C" int cvx_gemm_skinny_f32(const float* A, int32_t lda, const float* W, 
     const size_t lds = (size_t)SK_M * (std::min(K, SK_KC) + 4) * sizeof(float);
     cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_skinny_kernel), (int)lds);
     const int64_t groups = ((int64_t)N + 127) / 128;                       // four 32-row tiles per block and trip
-    const unsigned grid = (unsigned)std::min<int64_t>(groups, (int64_t)cvx_device_cus());
+    const unsigned grid = (unsigned)std::min<int64_t>(groups, (int64_t)cvx_stream_cus(s));
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(grid), dim3(256), lds, reinterpret_cast<hipStream_t>(s), A, lda, W, ldw, bias, C, ldc, M, N, K, act);
     CVX_CHECK_LAUNCH("cvx_gemm_skinny_f32");
     return CVX_OK;

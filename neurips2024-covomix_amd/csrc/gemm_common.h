@@ -326,15 +326,11 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
 // pre-split A operand of the all-DMA kernels: (hi, lo) fp16 matrices (and the A2 pair of a K-split), row strides in halves
 struct PreSplitA { const _Float16* hi; const _Float16* lo; int64_t ld; const _Float16* hi2; const _Float16* lo2; int64_t ld2; };
 
-// gemm_f16x3_p8.hip: 256 x 256 tile, eight-phase ping-pong main loop on interleaved operands (A and W as [hi 32 | lo 32] lines).
-// Returns false when the problem does not qualify (the caller then uses the two-stage kernel).
-bool launch_gemm_f16x3_p8(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
-                          int map_mode, hipStream_t st);
-
-// gemm_f16x3_p8s.hip: the same main loop on the 16x16x32 MFMA with swapped operands and a transpose-free epilogue; only
-// problems whose epilogue can run 16-byte vectors (N % 64 == 0, aligned pointers); false -> the caller falls back
+// gemm_f16x3_p8s.hip: 256 x 256 tile, eight-phase ping-pong main loop on interleaved operands (A and W as [hi 32 | lo 32] lines),
+// 16x16x32 MFMA with swapped operands, transpose-free epilogue, persistent blocks; only problems whose epilogue can run 16-byte
+// vectors (N % 64 == 0, aligned pointers); false -> the caller falls back to the 128 x 128 kernel
 bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
-                           int map_mode, hipStream_t st);
+                           hipStream_t st);
 
 // gemm_f16x3_p8m.hip: 128 x 128 tiles, two wave groups on alternate K-tiles, for problems of fewer than 2048 rows (interleaved
 // A and W); ksplit > 1: K slices on separate blocks, scaled fp32 partial tiles to `partial` [ksplit][M][N] (the caller reduces)

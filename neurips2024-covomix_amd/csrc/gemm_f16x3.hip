@@ -375,210 +375,6 @@ __global__ __launch_bounds__(256, (STAGES <= 2 ? 2 : 1)) void gemm_f16x3_dma_ker
     gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane, so);
 }
 
-// ------------------------------------------------------------------ 256 x 256 tile, 8 waves (all-DMA, pre-split A)
-// Twice the tile edge halves the operand bytes per MFMA: the 128 x 128 kernel moves 64 KiB per K-step and CU
-// (~10 TB/s chip-wide, near what the L2 -> LDS DMA path sustains) while its MFMA pipe is only ~39 % busy.
-// 512 threads = 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers);
-// two 64 KiB stages; one block per CU.
-// WIL: the weights arrive INTERLEAVED, [N][K/32][hi 32 | lo 32] (ldw = 2K): one K-step of one row is a whole 128-byte
-// cache line, fetched by one DMA piece of 8 rows x 128 bytes (separate hi / lo matrices give 16 rows x 64 bytes = half
-// lines, which costs 6-10 % of the K-step when both operands do it).  The W tile in LDS is then [256 rows][128 bytes]
-// with the 16-byte chunk XOR-swizzled by (row >> 1) & 7.
-// AIL: the same for the activations (A and A2 interleaved, lda = 2K, A_lo == A_hi + 32): A tile in LDS [256][128 bytes].
-template <int NT, bool WIL, bool AIL>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(
-    const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ Whi, const f16* __restrict__ Wlo,
-    float acc_scale, SplitOut so, int tiles_m, int tiles_n, int map_mode)
-{
-    constexpr int TM = 4, BM = 256, BNL = 256;
-    constexpr int TILE256 = 256 * BK;                  // halves per operand tile (16 KiB)
-    constexpr int STAGE = 4 * TILE256;                 // Ahi | Alo | Whi | Wlo  (64 KiB)
-    extern __shared__ __attribute__((aligned(16))) f16 smem_h[];
-    f16* const S0 = smem_h;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
-    int tile_m, tile_n;
-    tile_of_block(tiles_m, tiles_n, map_mode, tile_m, tile_n);
-    if (tile_m >= tiles_m) return;
-    const int m0 = tile_m * BM, n0 = tile_n * BNL;
-
-    // DMA sources: wave `wid` fills rows [32*wid, +32) of each of the four tiles, 16 rows per instruction
-    const f16* pah[2]; const f16* pal[2]; const f16* pwh[2]; const f16* pwl[2];
-    int64_t jmp_h[2], jmp_l[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 32 * wid + 16 * j + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        const int64_t ra = min(m0 + r, p.M - 1), rw = min(n0 + r, p.N - 1);
-        pah[j] = A.hi + ra * A.ld + 8 * c;
-        jmp_h[j] = A.hi2 ? (A.hi2 + ra * A.ld2 + 8 * c) - (pah[j] + p.K1) : 0;
-        pwh[j] = Whi + rw * p.ldw + 8 * c;
-        if constexpr (NT == 1) {      // the "lo" slots carry the NEXT 32 k of the same fp16 operands
-            pal[j] = pah[j] + BK; jmp_l[j] = jmp_h[j]; pwl[j] = pwh[j] + BK;
-        } else {
-            pal[j] = A.lo + ra * A.ld + 8 * c;
-            jmp_l[j] = A.lo2 ? (A.lo2 + ra * A.ld2 + 8 * c) - (pal[j] + p.K1) : 0;
-            pwl[j] = Wlo + rw * p.ldw + 8 * c;
-        }
-        if constexpr (AIL) {          // as WIL below, for A (and A2): pah = piece 2j, pal = piece 2j+1
-            const int r0 = 32 * wid + 8 * (2 * j) + (lane >> 3), r1 = r0 + 8;
-            const int64_t ra0 = min(m0 + r0, p.M - 1), ra1 = min(m0 + r1, p.M - 1);
-            const int c0 = (lane & 7) ^ ((r0 >> 1) & 7), c1 = (lane & 7) ^ ((r1 >> 1) & 7);
-            pah[j] = A.hi + ra0 * A.ld + 8 * c0;
-            pal[j] = A.hi + ra1 * A.ld + 8 * c1;
-            jmp_h[j] = A.hi2 ? (A.hi2 + ra0 * A.ld2 + 8 * c0) - (pah[j] + 2 * p.K1) : 0;
-            jmp_l[j] = A.hi2 ? (A.hi2 + ra1 * A.ld2 + 8 * c1) - (pal[j] + 2 * p.K1) : 0;
-        }
-        if constexpr (WIL) {          // four pieces of 8 rows x 128 bytes: rows 32*wid + 8*q + (lane >> 3), q = 2j, 2j+1
-            const int r0 = 32 * wid + 8 * (2 * j) + (lane >> 3), r1 = r0 + 8;
-            const int64_t rw0 = min(n0 + r0, p.N - 1), rw1 = min(n0 + r1, p.N - 1);
-            pwh[j] = Whi + rw0 * p.ldw + 8 * ((lane & 7) ^ ((r0 >> 1) & 7));
-            pwl[j] = Whi + rw1 * p.ldw + 8 * ((lane & 7) ^ ((r1 >> 1) & 7));
-        }
-    }
-    constexpr int KSTEP = (NT == 1) ? 2 * BK : BK;      // k consumed per stage
-    const int dma_off = 32 * wid * BK;
-    const int switch_tile = A.hi2 ? p.K1 / KSTEP : -1;
-    const int nk = p.K / KSTEP;
-
-    auto issue = [&](int t) {
-        f16* const S = S0 + (t & 1) * STAGE + dma_off;
-        const bool live = t < nk;
-        const bool sw = live && (t == switch_tile);      // (a K slice may END exactly at the A | A2 boundary)
-        const int back = live ? 0 : KSTEP, adv = live ? KSTEP : 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int aback = AIL ? 2 * back : back, aadv = AIL ? 2 * adv : adv;     // interleaved rows hold 64 halves per K-step
-            const f16* sh = pah[j] + (sw ? jmp_h[j] : 0) - aback;
-            const f16* sl = pal[j] + (sw ? jmp_l[j] : 0) - aback;
-            const int wback = WIL ? 2 * back : back, wadv = WIL ? 2 * adv : adv;
-            const f16* wh = pwh[j] - wback;
-            const f16* wl = pwl[j] - wback;
-            if constexpr (AIL) {
-                f16* const Ad = S0 + (t & 1) * STAGE + (32 * wid + 16 * j) * 2 * BK;
-                glds16(sh, Ad);
-                glds16(sl, Ad + 8 * 2 * BK);
-            } else {
-                glds16(sh, S + 16 * j * BK);
-                glds16(sl, S + TILE256 + 16 * j * BK);
-            }
-            if constexpr (WIL) {
-                f16* const Wd = S0 + (t & 1) * STAGE + 2 * TILE256 + (32 * wid + 16 * j) * 2 * BK;
-                glds16(wh, Wd);
-                glds16(wl, Wd + 8 * 2 * BK);
-            } else {
-                glds16(wh, S + 2 * TILE256 + 16 * j * BK);
-                glds16(wl, S + 3 * TILE256 + 16 * j * BK);
-            }
-            if (live) { pah[j] = sh + aadv; pal[j] = sl + aadv; pwh[j] = wh + wadv; pwl[j] = wl + wadv; }   // a dummy re-read moves nothing
-        }
-    };
-
-    f32x16 acc[TM][2];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    const int i31 = lane & 31, g = lane >> 5, swz = (i31 >> 2) & 3;
-    int foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) foff[s] = i31 * BK + 8 * ((2 * s + g) ^ swz);
-    const int a_row0 = wm * 128 * BK, b_row0 = wn * 64 * BK;
-    int wofh[2], wofl[2], aofh[2], aofl[2];             // WIL / AIL: fragment offsets inside a [256][64 halves] tile
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int sw8 = (i31 >> 1) & 7;
-        wofh[s] = (wn * 64 + i31) * 2 * BK + 8 * ((2 * s + g) ^ sw8);
-        wofl[s] = (wn * 64 + i31) * 2 * BK + 8 * ((4 + 2 * s + g) ^ sw8);
-        aofh[s] = (wm * 128 + i31) * 2 * BK + 8 * ((2 * s + g) ^ sw8);
-        aofl[s] = (wm * 128 + i31) * 2 * BK + 8 * ((4 + 2 * s + g) ^ sw8);
-    }
-
-    issue(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(kt + 1);
-        const f16* Sc = S0 + (kt & 1) * STAGE;
-        const f16* ah = Sc + a_row0;
-        const f16* al = Sc + TILE256 + a_row0;
-        const f16* wh = Sc + 2 * TILE256 + b_row0;
-        const f16* wl = Sc + 3 * TILE256 + b_row0;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 fwh[2], fwl[2];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                if constexpr (WIL) {
-                    fwh[ni] = *reinterpret_cast<const f16x8*>(Sc + 2 * TILE256 + ni * 32 * 2 * BK + wofh[s]);
-                    fwl[ni] = *reinterpret_cast<const f16x8*>(Sc + 2 * TILE256 + ni * 32 * 2 * BK + wofl[s]);
-                } else {
-                    fwh[ni] = *reinterpret_cast<const f16x8*>(wh + ni * 32 * BK + foff[s]);
-                    fwl[ni] = *reinterpret_cast<const f16x8*>(wl + ni * 32 * BK + foff[s]);
-                }
-            }
-            // all 12 fragments of this 16-wide k slice first (in-order LDS returns let the first MFMAs start while
-            // the later reads are still in flight), then 24 back-to-back MFMAs
-            f16x8 fah[TM], fal[TM];
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                if constexpr (AIL) {
-                    fah[mi] = *reinterpret_cast<const f16x8*>(Sc + mi * 32 * 2 * BK + aofh[s]);
-                    fal[mi] = *reinterpret_cast<const f16x8*>(Sc + mi * 32 * 2 * BK + aofl[s]);
-                } else {
-                    fah[mi] = *reinterpret_cast<const f16x8*>(ah + mi * 32 * BK + foff[s]);
-                    fal[mi] = *reinterpret_cast<const f16x8*>(al + mi * 32 * BK + foff[s]);
-                }
-            }
-            // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a dependent chain on one accumulator
-            // would wait for the previous MFMA's result every time)
-            if constexpr (NT == 1) {     // plain fp16: slot "lo" is the next 32 k, one product each
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
-            } else {
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwl[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[mi], fwh[ni], acc[mi][ni], 0, 0, 0);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    acc_scale = total_acc_scale(acc_scale, so);
-    if (acc_scale != 1.0f) {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= acc_scale;
-    }
-    gemm_epilogue<TM>(p, acc, m0, n0, wm, wn, lane, so);
-}
-
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ w, f16* __restrict__ hi,
                                                        f16* __restrict__ lo, int64_t n, float scale, const float* __restrict__ scale_dev,
                                                        uint32_t* __restrict__ sat)
@@ -849,8 +645,8 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     // interleaved activations: A_lo == A_hi + 32 (and A2_lo == A2_hi + 32), lda_h >= 2K - only together with interleaved weights
     const bool a_il = io && io->A_hi && io->A_lo == io->A_hi + 32;
     if (w_il)
-        CVX_REQUIRE(!single && W_lo == W_hi + 32 && a->ldw >= 2 * (int64_t)a->K && io->A_hi && ((a->M >= 2048 && a->N >= 512) || a_il),
-                    "gemm_f16x3: interleaved weights need W_lo == W_hi + 32, ldw >= 2K, a pre-split A and - below 2048 rows or 512 columns - an interleaved A");
+        CVX_REQUIRE(!single && W_lo == W_hi + 32 && a->ldw >= 2 * (int64_t)a->K && a_il,
+                    "gemm_f16x3: interleaved weights need W_lo == W_hi + 32, ldw >= 2K and an interleaved pre-split A");
     if (a_il)
         CVX_REQUIRE(w_il && io->lda_h >= 2 * (int64_t)(a->A2 ? a->K1 : a->K) &&
                     (!a->A2 || (io->A2_lo == io->A2_hi + 32 && io->lda2_h >= 2 * (int64_t)(a->K - a->K1))),
@@ -925,14 +721,14 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     // skip at 4000 rows 2.5x faster, at 9298 rows 5 %; to_qkv / ff1 stay on the large kernel from ~4000 rows on.
     // (CVX_GEMM_FLAG_MEDIUM forces it, CVX_GEMM_FLAG_NO_MEDIUM and the A/B kernel flags keep the large kernel.)
     bool medium = a->M < 2048 || a->N < 512;
-    if (!medium && A.hi && w_il && a_il && io && !(io->flags & (CVX_GEMM_FLAG_NO_MEDIUM | CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32 | CVX_GEMM_FLAG_ONE_TILE))) {
-        const long ncu = cvx_device_cus();
+    if (!medium && A.hi && w_il && a_il && io && !(io->flags & (CVX_GEMM_FLAG_NO_MEDIUM | CVX_GEMM_FLAG_ONE_TILE))) {
+        const long ncu = cvx_stream_cus(s);
         const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
         const double large = (double)((t256 + ncu - 1) / ncu), med = 0.31 * (double)((t128 + ncu - 1) / ncu);
         medium = (io->flags & CVX_GEMM_FLAG_MEDIUM) || med < 0.97 * large;
     }
     if (dn) {
-        CVX_REQUIRE(A.hi && w_il && a_il && a->M >= 2048 && a->N >= 512 && !(io->flags & (CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32)),
+        CVX_REQUIRE(A.hi && w_il && a_il && a->M >= 2048 && a->N >= 512,
                     "gemm_f16x3: deferred norm (c_gamma_dev / c_rowsq / a_row_scale_dev) runs on the large-problem 16x16x32 kernel only: "
                     "interleaved pre-split operands, M >= 2048, N >= 512 (M=%d N=%d K=%d)", a->M, a->N, a->K);
         medium = false;
@@ -966,36 +762,19 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
             const int64_t quads = ((int64_t)a->M * a->N + 3) / 4;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, io->workspace, ksplit, *a, so);
         }
-    } else if (A.hi && a->M >= 2048 && a->N >= 512) {
-        const int tn = (a->N + 255) / 256, tm = (a->M + 255) / 256;
-        const int gm = map_mode == 1 ? ((tm + 7) / 8) * 8 : tm;
-        const size_t lds256 = (size_t)2 * 4 * 256 * BK * sizeof(f16);     // 128 KiB
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, false, false>), (int)lds256);
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, false>), (int)lds256);
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<3, true, true>), (int)lds256);
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<1, false, false>), (int)lds256);
-        const dim3 g256((unsigned)(gm * tn));
-        if (single)
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<1, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
-                               acc_scale, so, tm, tn, map_mode);
-        else if (w_il && a_il && !(io->flags & (CVX_GEMM_FLAG_TWO_STAGE | CVX_GEMM_FLAG_MFMA32)) &&
-                 cvxg::launch_gemm_f16x3_p8s(*a, A, wh, acc_scale, so, map_mode, st)) {
-            /* eight-phase ping-pong kernel on the 16x16x32 MFMA (gemm_f16x3_p8s.hip) */
-        } else if (dn) {
-            CVX_REQUIRE(false, "gemm_f16x3: deferred norm (c_gamma_dev / c_rowsq / a_row_scale_dev) needs interleaved operands and the "
-                               "16-byte vector epilogue of the 16x16x32 kernels (M=%d N=%d K=%d)", a->M, a->N, a->K);
-        } else if (w_il && a_il && !(io->flags & CVX_GEMM_FLAG_TWO_STAGE) &&
-                 cvxg::launch_gemm_f16x3_p8(*a, A, wh, acc_scale, so, map_mode, st)) {
-            /* eight-phase ping-pong kernel on the 32x32x16 MFMA (gemm_f16x3_p8.hip): ragged N, unaligned epilogues */
-        } else if (w_il && a_il)
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true, true>), g256, dim3(512), lds256, st, *a, A, wh, wl,
-                               acc_scale, so, tm, tn, map_mode);
-        else if (w_il)
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, true, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
-                               acc_scale, so, tm, tn, map_mode);
-        else
-            hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<3, false, false>), g256, dim3(512), lds256, st, *a, A, wh, wl,
-                               acc_scale, so, tm, tn, map_mode);
+    } else if (A.hi && w_il && a_il) {
+        // 2048 rows and more, 512 columns and more, interleaved operands: the eight-phase ping-pong kernel on the 16x16x32 MFMA
+        // (gemm_f16x3_p8s.hip).  Shapes it cannot take (N % 64 != 0, RoPE on other than 256-column groups, epilogue operands that are not
+        // 16-byte aligned) run on the medium-problem kernel's 128 x 128 tiles, which asks for less (N % 16 == 0, 128-column RoPE groups).
+        // (Rounds 2-4 also shipped a two-stage 256 x 256 kernel and an eight-phase form on the 32x32x16 MFMA as fallbacks and A/B
+        //  partners: superseded, removed in round 5 - HISTORY.md has their numbers.)
+        if (!cvxg::launch_gemm_f16x3_p8s(*a, A, wh, acc_scale, so, st)) {
+            CVX_REQUIRE(!dn, "gemm_f16x3: deferred norm (c_gamma_dev / c_rowsq / a_row_scale_dev) needs N %% 64 == 0 and 16-byte aligned epilogue "
+                             "operands (M=%d N=%d K=%d)", a->M, a->N, a->K);
+            CVX_REQUIRE(cvxg::launch_gemm_f16x3_p8m(*a, A, wh, acc_scale, so, 1, nullptr, st),
+                        "gemm_f16x3: interleaved operands need N %% 16 == 0 (N %% 64 == 0 with RoPE), 16-byte aligned C / residual / bias / RoPE "
+                        "tables and rope_cols %% 128 == 0 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+        }
     } else if (A.hi) {
         // Small problems (one utterance: M ~ 1000) leave most CUs with at most one block of 4 waves and nothing to hide
         // the DMA / LDS round trips behind.  Two remedies (measured on BASELINE config 2, tools/bench_c2.py):

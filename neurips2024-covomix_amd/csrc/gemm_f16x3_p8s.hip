@@ -1,19 +1,34 @@
-// Split-precision GEMM, large-problem kernel, second form: the eight-phase ping-pong main loop of gemm_f16x3_p8.hip on
-// v_mfma_f32_16x16x32_f16 with SWAPPED operands, and an epilogue that needs no register transposes.
+// Split-precision GEMM, LARGE-problem kernel (2048 rows and more, 512 columns and more): 256 x 256 block tile, eight waves, EIGHT-PHASE
+// PING-PONG main loop on v_mfma_f32_16x16x32_f16 with SWAPPED operands, persistent blocks, transpose-free epilogues.
 //
-//   * 16x16x32 instead of 32x32x16: an accumulator register is read and written once per 32 k instead of once per 16 k.
-//     The main loop of the 32x32 kernel already issues an MFMA every 32 cycles (99 % of its cycles) - what limits it is
-//     the clock the chip sustains under that load (power), and the 16x16x32 shape moves fewer register bytes per MAC.
-//   * swapped operands, D = W_frag . A_frag^T: a lane then holds 4 CONSECUTIVE COLUMNS of one output row (row = lane & 15,
-//     columns 4 * (lane >> 4) + 0..3 of a 16 x 16 tile), so every epilogue access (fp32 store, residual load, split
-//     store, bias / RoPE table loads) is a 16-byte (8-byte fp16) vector without the DPP quad transposes of the 32x32
-//     epilogue (5 VALU instructions per value there).  Blocks that own V columns of a to_qkv projection run the
-//     UN-swapped product instead: a lane then holds 4 consecutive FRAMES of one head-dim column, which is what the
-//     transposed V^T store wants.
-// Everything else (256 x 256 tile, wave groups one barrier interval apart, quarter-tile DMA ring six pieces ahead with
-// counted vmcnt, inline-asm LDS-DMA, chunk ^ ((row >> 1) & 7) swizzle) is as documented in gemm_f16x3_p8.hip.
-// Same contract as cvx_gemm_f16x3 (reference acoustic.py:225-246, :306-310); only full 64-column wave tiles with aligned
-// pointers are accepted (the launcher returns false otherwise and the 32x32 kernel takes the problem).
+// Contract of cvx_gemm_f16x3 (C = epi([A|A2] * W^T) with three MFMA products per tile on (fp16 hi, fp16 lo) operand pairs; every nn.Linear
+// of reference acoustic.py:225-246, :306-310) for INTERLEAVED operands: one K-tile (32 k) of a row of A or W is one 128-byte line
+// [hi 32 | lo 32].
+//   * the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w and w+4 share a SIMD) run ONE BARRIER INTERVAL
+//     APART: while one group issues the MFMAs of a phase the other reads its next fragments from LDS and issues its share of the
+//     LDS-DMA - the SIMD's matrix pipe always has a wave feeding it;
+//   * a K-tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each, in the order (m0,n0) (m0,n1) (m1,n1) (m1,n0), so
+//     that every phase needs at most one new operand block (A m0 + B n0, B n1, A m1, nothing) and the operand QUARTERS of a K-tile
+//     are consumed progressively;
+//   * the DMA stream runs SIX quarter-tiles (96 KiB) ahead in a two-buffer ring: a quarter (16 KiB: the rows one phase block needs,
+//     for all waves) is re-filled two intervals after its last reader, i.e. up to 9 intervals before its first one, and is retired by
+//     a COUNTED s_waitcnt vmcnt(8) (never 0) followed by a barrier;
+//   * the DMA is issued from inline asm (scalar base + 32-bit lane offset, M0 = LDS slot; gemm_p8s_epi.h dma2): hipcc puts a vmcnt(0)
+//     in front of every ds_read that follows a global_load_lds it can see;
+//   * 16x16x32 instead of 32x32x16: an accumulator register is read and written once per 32 k instead of once per 16 k; what limits
+//     the loop is the clock the chip sustains under that load (power), and this shape moves fewer register bytes per MAC;
+//   * swapped operands, D = W_frag . A_frag^T: a lane then holds 4 CONSECUTIVE COLUMNS of one output row (row = lane & 15, columns
+//     4 * (lane >> 4) + 0..3 of a 16 x 16 tile), so every epilogue access (fp32 store, residual load, split store, bias / RoPE table
+//     loads) is a 16-byte (8-byte fp16) vector without register transposes.  Blocks that own V columns of a to_qkv projection run
+//     the UN-swapped product instead: a lane then holds 4 consecutive FRAMES of one head-dim column - what the transposed V^T store
+//     wants;
+//   * PERSISTENT blocks (one per CU of the stream, cvx_stream_cus) walk tile slots of an XCD-aware map; the tail of a tile fetches the
+//     first six quarters of the next one.
+// LDS: 2 buffers x (A tile [256][128 B] | W tile [256][128 B]) = 128 KiB + 8 KiB dump area for the tail's dummy DMA.  Swizzle: 16-byte
+// chunk c of row r sits at chunk c ^ ((r >> 1) & 7), applied on the DMA source address and on the ds_read_b128 fragment address
+// (conflict-free).  Only full 64-column wave tiles with 16-byte aligned epilogue operands are accepted: the launcher returns false
+// otherwise and the 128 x 128 kernel (gemm_f16x3_p8m.hip) takes the problem.  (Rounds 2-4 shipped two more large-problem forms - a
+// two-stage 256 x 256 kernel and this main loop on the 32x32x16 MFMA: ff1 at 16,000 rows 447 / 399 us against 355 us here - removed in round 5, HISTORY.md.)
 #include "gemm_p8s_epi.h"
 
 namespace {
@@ -242,8 +257,25 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
 
 namespace cvxg {
 
+int classify_epilogue(const cvx_gemm_args& a, const SplitOut& so)
+{
+    // the specialised epilogues only have the 16-byte vector path: whole 64-column wave tiles, aligned pointers and strides
+    const bool vec = (a.N % 64 == 0) &&
+                     (!so.write_f32 || (((uintptr_t)a.C & 15) == 0 && (a.ldc & 3) == 0)) &&
+                     (!a.residual || (((uintptr_t)a.residual & 15) == 0 && (a.ldr & 3) == 0)) &&
+                     (!so.hi || ((((uintptr_t)so.hi | (uintptr_t)so.lo) & 7) == 0 && (so.ldc_h & 3) == 0));
+    if (!vec) return EPI_GENERIC;
+    const bool rope = a.rope_cos != nullptr;
+    if (rope && so.vt_hi && so.hi && !so.write_f32 && !a.bias && !a.residual && a.act == CVX_ACT_NONE) return EPI_QKV;
+    if (rope || so.vt_hi) return EPI_GENERIC;
+    if (a.residual && so.write_f32 && a.act == CVX_ACT_NONE) return EPI_RES;
+    if (a.bias && a.act == CVX_ACT_GELU && !a.residual && so.hi && !so.write_f32) return EPI_GELU_SPLIT;
+    if (a.act == CVX_ACT_NONE && !a.residual && so.write_f32 && !so.hi) return EPI_BIAS;
+    return EPI_GENERIC;
+}
+
 bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16* w_il, float acc_scale, const SplitOut& so,
-                           int map_mode, hipStream_t st)
+                           hipStream_t st)
 {
     if (a.K % 32 != 0 || (A.hi2 && a.K1 % 32 != 0) || a.N % 64 != 0) return false;
     if ((int64_t)a.M * A.ld * 2 >= (int64_t)1 << 32 || (A.hi2 && (int64_t)a.M * A.ld2 * 2 >= (int64_t)1 << 32) ||
@@ -258,10 +290,9 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     if (so.vt_hi && !(a.rope_cos && so.hi && !so.write_f32 && !a.residual && a.act == CVX_ACT_NONE)) return false;   // V^T only in QKV form
     const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
     const int n_slots = ((tm + 7) / 8) * 8 * tn;                 // XCD map: an XCD owns whole row panels (padding slots are skipped)
-    (void)map_mode;
     // persistent grid: one block per CU (136 KiB of LDS each), a multiple of 8; a next tile needs an even number of K-tiles
     // (the two LDS buffers alternate across the tile boundary), otherwise every tile gets its own block
-    const int n_cu = cvx_device_cus();                           // (mutex-protected per-device cache, cvx_common.h)
+    const int n_cu = cvx_stream_cus(st);                         // CUs this stream owns (cvx_stream_set_cus; default: the device's)
     int g = n_slots;
     if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < (n_cu / 8) * 8 ? n_slots : (n_cu / 8) * 8;
     const dim3 grid((unsigned)g);

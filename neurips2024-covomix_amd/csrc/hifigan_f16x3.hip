@@ -973,7 +973,7 @@ void launch_conv16_m16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
 void dispatch_conv16(const Conv16Args& k, int B, int n_ztiles, hipStream_t st)
 {
     if (k.Np == 256) {
-        const int cus = cvx_device_cus();
+        const int cus = cvx_stream_cus(reinterpret_cast<cvx_stream_t>(st));
         auto cost = [&](int rows) { const int64_t n = (int64_t)((k.L + rows - 1) / rows) * B * n_ztiles; return (double)((n + cus - 1) / cus * rows); };
         const double t256 = cost(256), t192 = cost(192), t160 = 1.13 * cost(160);
         if (t160 < t256 && t160 < t192) launch_conv16_m16<5, 4, 4>(k, B, n_ztiles, st);
@@ -1106,7 +1106,7 @@ extern "C" int cvx_hifigan_split_channels_last(const float* x_cl, uint16_t* z_hi
     CVX_REQUIRE(x_cl && z_hi && z_lo && n >= 0 && n % 4 == 0, "split_channels_last: bad arguments (n must be a multiple of 4)");
     if (n == 0) return CVX_OK;
     const int64_t n4 = n / 4;
-    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)cvx_device_cus() * 16);
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)cvx_stream_cus(s) * 16);
     hipLaunchKernelGGL(cl_split_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(s), x_cl,
                        reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), n4, slope, z_scale_dev, cvx_sat_flag_for(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_split_channels_last");
@@ -1151,7 +1151,7 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
                a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
                a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_for(s), a->items};
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    const int cus = cvx_device_cus();
+    const int cus = cvx_stream_cus(s);
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU
 #define CVX_LAUNCH_PAIR(TNI_, NW_)                                                                                       \
     {                                                                                                                    \

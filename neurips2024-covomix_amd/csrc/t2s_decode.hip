@@ -22,9 +22,8 @@
 // Positions: the device counter state[0]; every kernel reads it, so a captured HIP graph of N steps replays as is.
 #include "cvx_common.h"
 
-// No implicit a * b + c -> fma contraction in this file: the per-launch kernels and the persistent kernel instantiate the
-// same device functions in different contexts, and their results are REQUIRED to agree bitwise (tests/test_t2s_gpu.py);
-// every fused multiply-add below is an explicit fmaf.
+// No implicit a * b + c -> fma contraction in this file: the batch-1 / 2 / 4 / 8 instances of a kernel are REQUIRED to agree
+// bitwise per utterance (tests/test_t2s_gpu.py: batched == one-by-one tokens); every fused multiply-add below is an explicit fmaf.
 #pragma clang fp contract(off)
 
 namespace {
@@ -71,19 +70,11 @@ constexpr int PF = 4;                                      // 4 x 256 floats per
 #endif
 // weight rows: streamed once per token step by one wave each -> non-temporal loads (A/B: -DCVX_T2S_NT=0)
 __device__ __forceinline__ f32x4 wload4(const float* p) { return CVX_T2S_NT ? gload4_nt(p) : gload4(p); }
-// ACTIVATION reads (x, q, att, h, logits, the state record, cache rows) go through these.  Round 4 measured them as L1-bypassing
-// (nt) loads - what an in-kernel hand-off between CUs without an invalidate needs - and the PER-LAUNCH path lost 36 % to it (CoSingle
-// batch 1: 147.8 -> 201.2 us per step; batch 8: 28.3k -> 21.8k tokens/s, same box): plain loads, and the persistent kernels
-// invalidate their CU's L1 behind every barrier instead.  -DCVX_T2S_NT_ACT restores the nt form for A/B runs.
-#ifdef CVX_T2S_NT_ACT
-__device__ __forceinline__ float aload(const float* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ int aloadi(const int* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ f32x4 aload4(const float* p) { return gload4_nt(p); }
-#else
+// ACTIVATION reads (x, q, att, h, logits, the state record, cache rows) are plain loads (round 4 measured L1-bypassing loads at
+// -36 % on this per-launch path: 147.8 -> 201.2 us per CoSingle step)
 __device__ __forceinline__ float aload(const float* p) { return *p; }
 __device__ __forceinline__ int aloadi(const int* p) { return *p; }
 __device__ __forceinline__ f32x4 aload4(const float* p) { return gload4(p); }
-#endif
 
 // the two rows of row-pair `pair` (the pairs are chosen so that the epilogue has both members of a RoPE pair / a GEGLU
 // (value, gate) pair in one wave)
@@ -113,7 +104,7 @@ __device__ __forceinline__ bool pair_rows(const GemvArgs& a, int pair, int& r0, 
 }
 
 // the first PF chunks of the two weight rows of a pair: they do not depend on the input vector, so their HBM / MALL round
-// trip can overlap whatever precedes the dot product (staging of x; in the persistent kernel: the grid barrier)
+// trip can overlap whatever precedes the dot product (the staging of x)
 struct RowPrefetch { f32x4 pa[PF], pb[PF]; };
 template <int MODE>
 __device__ __forceinline__ void prefetch_pair(const GemvArgs& a, int pair, int lane, RowPrefetch& pf)
@@ -255,8 +246,12 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
     }
 }
 
-// PPW = row pairs per wave (1; 2 is a measured A/B, see CVX_T2S_PPW below).  Every block stages all BQ input vectors (BQ x Kin floats
-// from the L2) for its 4 x PPW row pairs.  Per-pair arithmetic does not depend on PPW: same bits.
+// PPW = row pairs per wave.  Every block stages all BQ input vectors (BQ x Kin floats from the L2) for its 4 x PPW row pairs: with one
+// pair per wave a batch-8 block reads as many bytes of x as of weights.  On the whole chip that is the fastest form all the same
+// (round 4, PPW = 2 at batch 8: 394 vs 285 us per CoSingle step - half the blocks, half the weight rows in flight, and the step is
+// bound by rows in flight); on a CU-masked side stream (pipeline.py: 32 CUs, several rounds of blocks per launch) two pairs per wave
+// win at batch 8 (CoMix step on 32 CUs, same box: 813 us with one pair, 760 with two, 942 with four; batch 4: 459 / 476 / 616) -
+// launch_gemv_b picks by the stream's CU count and the batch.  Per-pair arithmetic does not depend on PPW: same bits.
 template <int MODE, int BQ, int PPW>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
@@ -267,17 +262,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     const int pair = (blockIdx.x * 4 + wid) * PPW;                      // every wave owns TWO output rows per pair
     // weights first: their HBM / MALL round trip overlaps the staging of x below (the step is a chain of 34 dependent
     // launches; every microsecond of latency counts)
-    RowPrefetch pf;
-    prefetch_pair<MODE>(a, pair, lane, pf);
+    RowPrefetch pf[2];
+    prefetch_pair<MODE>(a, pair, lane, pf[0]);
     float inv[BQ];
     stage_input<BQ>(a, Kin, xs, red, inv);
-    if constexpr (PPW == 1) {
-        gemv_pair<MODE, BQ, true>(a, pair, xs, Kin, inv, pf);
-    } else {
-        RowPrefetch pf2;
-        prefetch_pair<MODE>(a, pair + 1, lane, pf2);
-        gemv_pair<MODE, BQ, true>(a, pair, xs, Kin, inv, pf);
-        gemv_pair<MODE, BQ, true>(a, pair + 1, xs, Kin, inv, pf2);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        if (i + 1 < PPW) prefetch_pair<MODE>(a, pair + i + 1, lane, pf[(i + 1) & 1]);
+        gemv_pair<MODE, BQ, true>(a, pair + i, xs, Kin, inv, pf[i & 1]);
     }
 }
 
@@ -461,385 +453,34 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h,
 }
 
 
-// ================================================================ persistent decode kernel
-// The per-launch path above is a chain of 8 * depth + 2 dependent launches per token; each costs ~5.7 us on the device
-// (launch gap + one exposed HBM / MALL round trip for the weights + the staging of the input vector), 34 x 5.7 = 194 of
-// the 213 us a CoSingle step takes, for 15 us worth of weight streaming.  Here ONE launch of one block per CU walks all
-// phases of n_steps token steps:
-//   * a phase boundary is a GRID BARRIER (one device-scope atomic per block on a monotonically increasing counter, then a
-//     spin on an acquire load) instead of a kernel boundary;
-//   * before it arrives at the barrier a wave requests the weight rows of ITS first row pair of the NEXT phase
-//     (prefetch_pair: registers), so the weight round trip runs under the barrier wait instead of behind it;
-//   * row pairs are dealt round-robin over all waves of the grid; attention phases run on heads x batch blocks, the sampler
-//     on `batch` blocks; every phase runs the same device code as the per-launch kernels (gemv_pair, attn_body, sample_body),
-//     so logits and tokens are BIT-IDENTICAL to that path (tests/test_t2s_gpu.py).
-// All blocks must be co-resident (the launcher sizes the grid to the CU count; 256 threads and < 64 KiB of LDS per block
-// always fit).  A barrier that is not satisfied within ~2^22 polls raises the error word next to the counter and lets the
-// block run on: the kernel terminates with garbage and the launcher's caller sees the flag - never a hung GPU.
-constexpr int T2S_MAX_DEPTH = 16;
-struct PersistArgs {
-    cvx_t2s_decoder d;
-    cvx_t2s_layer layers[T2S_MAX_DEPTH];
-    unsigned* sync;          // [0] barrier counter (zero at launch), [1] error word
-    int n_steps;
-    int lds_x_floats;        // floats of the staged-input region
-};
-
-struct GridBarrier {
-    unsigned* ctr;
-    unsigned target, nblocks;
-    bool dead;               // a wait timed out: the launch is lost (error word set); stop waiting so that it ends quickly
-    // The cache maintenance is per CACHE, not per thread: one L2 write-back (release fence) after every wave of the block
-    // has drained its stores (__syncthreads waits for vmcnt(0)), one L1 / L2 invalidate (acquire fence) after the wait, both
-    // by thread 0 (one block per CU: its fence covers the CU's L1).  The spin polls with RELAXED device-scope loads: an
-    // acquire load per poll would invalidate the XCD's L2 on every iteration of every block.
-    __device__ __forceinline__ void arrive_and_wait()
-    {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            target += nblocks;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the block's global writes -> visible device-wide
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22) || ((spins & 1023u) == 0 && __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    __hip_atomic_fetch_or(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    dead = true;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale L1 / non-local L2 lines before the next phase reads
-        }
-        __syncthreads();
-    }
-};
-
-template <int MODE, int BQ>
-__device__ __forceinline__ void phase_gemv(const GemvArgs& a, int n_pairs, float* xs, float (*red)[4], int gwave, int n_gwaves,
-                                           const RowPrefetch& pf)
-{
-    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;
-    if (gwave - (int)(threadIdx.x >> 6) >= n_pairs) return;            // no wave of this block has a pair (block-uniform)
-    float inv[BQ];
-    stage_input<BQ>(a, Kin, xs, red, inv);
-    if (gwave < n_pairs) gemv_pair<MODE, BQ, true>(a, gwave, xs, Kin, inv, pf);
-    for (int pair = gwave + n_gwaves; pair < n_pairs; pair += n_gwaves) gemv_pair<MODE, BQ, false>(a, pair, xs, Kin, inv, pf);
-}
-
-template <int BQ>
-__global__ __launch_bounds__(256) void t2s_persistent_kernel(const PersistArgs P)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const xs = lds;                                             // [BQ][Kin] of the running GEMV phase
-    float* const sc = lds;                                             // attention: scores (T2S_MAX_KEYS floats) ...
-    float (*const part)[64] = reinterpret_cast<float (*)[64]>(lds + T2S_MAX_KEYS);      // ... + 16 x 64 partial outputs
-    float* const lg = lds;                                             // sampler: 1024 logits
-    __shared__ float red[BQ][4];
-    __shared__ float red4[4];
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    __shared__ int chosen;
-
-    const cvx_t2s_decoder& d = P.d;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int bid = blockIdx.x, nblk = gridDim.x;
-    const int gwave = bid * 4 + wid, n_gwaves = nblk * 4;
-    GridBarrier bar{P.sync, 0u, (unsigned)nblk, false};
-    const float scale = 0.125f;        // dim_head ** -0.5
-    const int nb = d.batch;
-    const int64_t cache_stride = (int64_t)d.max_len * d.inner;
-
-    auto qkv_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.wqkv_s; g.ldw = d.dim; g.x = d.x; g.x_stride = d.dim; g.gamma = L.gamma_s; g.y = d.q; g.y_stride = d.inner;
-        g.N = 3 * d.inner; g.K = d.dim;
-        g.inner = d.inner; g.rope_cos = d.rope_cos; g.rope_sin = d.rope_sin; g.k_cache = L.k_cache; g.v_cache = L.v_cache;
-        g.cache_stride = cache_stride; g.state = d.state; g.max_len = d.max_len;
-        return g;
-    };
-    auto out_args = [&](const float* W) {                              // to_out of either attention: att -> x (+=)
-        GemvArgs g{};
-        g.W = W; g.ldw = d.inner; g.x = d.att; g.x_stride = d.inner; g.y = d.x; g.y_stride = d.dim; g.N = d.dim; g.K = d.inner;
-        return g;
-    };
-    auto qc_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.wq_c; g.ldw = d.dim; g.x = d.x; g.x_stride = d.dim; g.gamma = L.gamma_c; g.y = d.q; g.y_stride = d.inner;
-        g.N = d.inner; g.K = d.dim;
-        return g;
-    };
-    auto ff1_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.w1; g.ldw = d.dim; g.x = d.x; g.x_stride = d.dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d.h;
-        g.y_stride = d.ff_inner_pad; g.N = 2 * d.ff_inner; g.K = d.dim; g.y_pad = d.ff_inner_pad;
-        return g;
-    };
-    auto ff2_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.w2; g.ldw = d.ff_inner_pad; g.x = d.h; g.x_stride = d.ff_inner_pad; g.bias = L.b2; g.y = d.x; g.y_stride = d.dim;
-        g.N = d.dim; g.K = d.ff_inner_pad;
-        return g;
-    };
-    auto logit_args = [&]() {
-        GemvArgs g{};
-        g.W = d.emb; g.ldw = d.dim_emb; g.x = d.x; g.x_stride = d.dim; g.gamma = d.final_gamma; g.y = d.logits;
-        g.y_stride = d.streams * d.vocab; g.N = d.vocab; g.K = d.dim_emb; g.streams = d.streams;
-        return g;
-    };
-    const int p_qkv = 3 * d.inner / 2, p_out = (d.dim + 1) / 2, p_qc = d.inner / 2, p_ff1 = d.ff_inner_pad,
-              p_logit = d.streams * ((d.vocab + 1) / 2);
-
-    RowPrefetch pf;
-    { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
-    for (int step = 0; step < P.n_steps; ++step) {
-        for (int l = 0; l < d.depth; ++l) {
-            const cvx_t2s_layer& L = P.layers[l];
-            // ---- self-attention: q | k | v with RoPE; k, v appended to the cache at position pos
-            { const GemvArgs g = qkv_args(L); phase_gemv<MODE_QKV, BQ>(g, p_qkv, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = out_args(L.wo_s); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            if (bid < d.heads * nb) {
-                const AttnArgs at{d.q, L.k_cache, L.v_cache, d.inner, cache_stride, d.att, d.state, -1, scale, d.max_len};
-                attn_body(at, bid % d.heads, bid / d.heads, d.heads, sc, red4, part);
-            }
-            bar.arrive_and_wait();
-            { const GemvArgs g = out_args(L.wo_s); phase_gemv<MODE_RES, BQ>(g, p_out, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = qc_args(L); if (gwave < p_qc) prefetch_pair<MODE_PLAIN>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            // ---- cross-attention over [null kv | encoder context]
-            { const GemvArgs g = qc_args(L); phase_gemv<MODE_PLAIN, BQ>(g, p_qc, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = out_args(L.wo_c); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            if (bid < d.heads * nb) {
-                const AttnArgs ac{d.q, L.kv_c, L.kv_c + d.inner, 2 * (int64_t)d.inner, (int64_t)d.ctx_rows * 2 * d.inner, d.att, d.state,
-                                  d.n_ctx > 0 ? d.n_ctx : -2, scale, d.max_len};
-                attn_body(ac, bid % d.heads, bid / d.heads, d.heads, sc, red4, part);
-            }
-            bar.arrive_and_wait();
-            { const GemvArgs g = out_args(L.wo_c); phase_gemv<MODE_RES, BQ>(g, p_out, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = ff1_args(L); if (gwave < p_ff1) prefetch_pair<MODE_GEGLU>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            // ---- GEGLU feed-forward
-            { const GemvArgs g = ff1_args(L); phase_gemv<MODE_GEGLU, BQ>(g, p_ff1, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = ff2_args(L); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            { const GemvArgs g = ff2_args(L); phase_gemv<MODE_RES, BQ>(g, p_out, xs, red, gwave, n_gwaves, pf); }
-            if (l + 1 < d.depth) { const GemvArgs g = qkv_args(P.layers[l + 1]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
-            else { const GemvArgs g = logit_args(); if (gwave < p_logit) prefetch_pair<MODE_LOGITS>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-        }
-        { const GemvArgs g = logit_args(); phase_gemv<MODE_LOGITS, BQ>(g, p_logit, xs, red, gwave, n_gwaves, pf); }
-        bar.arrive_and_wait();
-        if (bid < nb) {
-            const SampleArgs sa{d.logits, d.uniforms, d.emb, d.x, d.tokens, d.state, nb, d.vocab, d.dim_emb, d.streams, d.max_len,
-                                d.top_k, d.vocab - 1, 1.0f / fmaxf(d.temperature, 1e-10f), d.cfg_scale};
-            sample_body<256>(sa, bid, lg, bv, bi, &chosen);
-        }
-        if (step + 1 < P.n_steps) { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
-        bar.arrive_and_wait();
-    }
-}
-
-// ================================================================ one XCD per utterance (round 4)
-// The whole-chip persistent kernel above loses to the launch chain because its phase boundary is a hand-off ACROSS the eight
-// non-coherent L2s: release (L2 write-back) + device-wide counter + acquire (invalidate) = ~15 us per barrier, 34 per token.
-// Inside ONE XCD the 32 CUs share the L2: a store that has completed (vmcnt) is in it - no L2 write-back, only the reading CU's
-// L1 has to be invalidated behind the barrier.  MEASURED (tools/t2s_ab.sh, same box): 366 us per CoSingle step at every batch size
-// 1..8 (batch 8: 21.1k tokens/s) against 148 us / 28.3k for the launch chain; CoMix 702 vs 196 us.  Per phase ~7 us of fixed cost (the
-// device-scope atomics and polls of the barrier go to the memory side, not to the XCD's L2; workgroup-scope atomics do not order
-// across CUs at all: the barrier then times out) + 0.38 TB/s of weight streaming (128 waves per utterance walk their row pairs
-// one after the other with one pair in flight).  A second measured negative result next to the whole-chip kernel: kept opt-in
-// (CVX_T2S_XCD=1) as an independent implementation the bit-identity test cross-checks.  Layout:
-// block b serves utterance b & 7 on "its" XCD (blocks are dispatched round-robin over the XCDs - an OBSERVATION, not a contract:
-// every block compares HW_REG_XCC_ID with the XCD of the group's first block and raises the error word on a mismatch, the caller
-// then repeats the chunk on the launch chain), with (b >> 3) as its index among the G blocks of the group; up to eight utterances
-// decode side by side, each streaming the weights through its own L2 (the 60 / 186 MB of a token step stay in the 256 MB
-// Infinity Cache between the groups).  Phases run the same device functions as the other paths with BQ = 1 and the utterance's
-// slice of every buffer: the per-utterance arithmetic - and so every logit and token - is bit-identical.
-struct XcdBarrier {
-    unsigned* ctr;           // this group's counter (own 64-byte line)
-    unsigned* err;           // the launch's error word
-    unsigned target, nblocks;
-    bool dead;
-    __device__ __forceinline__ void arrive_and_wait()
-    {
-        __syncthreads();     // every wave's stores have completed (vmcnt(0) inside): they are in the XCD's L2
-        if (threadIdx.x == 0) {
-            target += nblocks;
-#ifndef CVX_XCD_SCOPE
-#define CVX_XCD_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#ifndef CVX_T2S_SIDE_PPW
+#define CVX_T2S_SIDE_PPW 2     // row pairs per wave on a stream of at most 64 CUs, batches of more than 4 (dev A/B: 1, 2, 4)
 #endif
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, CVX_XCD_SCOPE);
-            unsigned spins = 0;
-            while (!dead && __hip_atomic_load(ctr, __ATOMIC_RELAXED, CVX_XCD_SCOPE) < target) {
-#ifndef CVX_XCD_NOSLEEP
-                __builtin_amdgcn_s_sleep(1);
-#endif
-                if (++spins > (1u << 22) || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    dead = true;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 may hold the previous step's x / q / att / h / logits lines
-        }
-        __syncthreads();
-    }
-};
-
-__global__ __launch_bounds__(256) void t2s_xcd_kernel(const PersistArgs P)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const xs = lds;
-    float* const sc = lds;
-    float (*const part)[64] = reinterpret_cast<float (*)[64]>(lds + T2S_MAX_KEYS);
-    float* const lg = lds;
-    __shared__ float red[1][4];
-    __shared__ float red4[4];
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    __shared__ int chosen;
-
-    const cvx_t2s_decoder& d = P.d;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int u = (int)blockIdx.x & 7, lb = (int)blockIdx.x >> 3, G = (int)gridDim.x >> 3;     // utterance / group, index in the group
-    if (u >= d.batch) return;
-    unsigned* const err = P.sync + 1;
-    // placement check: every block of a group must sit on the XCD of the group's block 0 (published through word 16 u + 8)
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xfu;
-    unsigned* const gctr = P.sync + 16 * (u + 1);
-    if (threadIdx.x == 0) {
-        if (lb == 0) __hip_atomic_store(gctr + 8, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    XcdBarrier bar{gctr, err, 0u, (unsigned)G, false};
-    bar.arrive_and_wait();
-    if (threadIdx.x == 0) {
-        const unsigned want = __hip_atomic_load(gctr + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (want != xcc + 1u) __hip_atomic_fetch_or(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int gwave = lb * 4 + wid, n_gwaves = G * 4;
-    const float scale = 0.125f;
-    const int64_t cache_stride = (int64_t)d.max_len * d.inner;
-    // this utterance's slice of every per-utterance buffer
-    float* const X = d.x + (int64_t)u * d.dim;
-    float* const Q = d.q + (int64_t)u * d.inner;
-    float* const ATT = d.att + (int64_t)u * d.inner;
-    float* const Hh = d.h + (int64_t)u * d.ff_inner_pad;
-    float* const LOG = d.logits + (int64_t)u * d.streams * d.vocab;
-    int* const ST = d.state + 4 * u;
-
-    auto qkv_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.wqkv_s; g.ldw = d.dim; g.x = X; g.x_stride = d.dim; g.gamma = L.gamma_s; g.y = Q; g.y_stride = d.inner;
-        g.N = 3 * d.inner; g.K = d.dim;
-        g.inner = d.inner; g.rope_cos = d.rope_cos; g.rope_sin = d.rope_sin; g.k_cache = L.k_cache + u * cache_stride;
-        g.v_cache = L.v_cache + u * cache_stride; g.cache_stride = cache_stride; g.state = ST; g.max_len = d.max_len;
-        return g;
-    };
-    auto out_args = [&](const float* W) {
-        GemvArgs g{};
-        g.W = W; g.ldw = d.inner; g.x = ATT; g.x_stride = d.inner; g.y = X; g.y_stride = d.dim; g.N = d.dim; g.K = d.inner;
-        return g;
-    };
-    auto qc_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.wq_c; g.ldw = d.dim; g.x = X; g.x_stride = d.dim; g.gamma = L.gamma_c; g.y = Q; g.y_stride = d.inner;
-        g.N = d.inner; g.K = d.dim;
-        return g;
-    };
-    auto ff1_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.w1; g.ldw = d.dim; g.x = X; g.x_stride = d.dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = Hh;
-        g.y_stride = d.ff_inner_pad; g.N = 2 * d.ff_inner; g.K = d.dim; g.y_pad = d.ff_inner_pad;
-        return g;
-    };
-    auto ff2_args = [&](const cvx_t2s_layer& L) {
-        GemvArgs g{};
-        g.W = L.w2; g.ldw = d.ff_inner_pad; g.x = Hh; g.x_stride = d.ff_inner_pad; g.bias = L.b2; g.y = X; g.y_stride = d.dim;
-        g.N = d.dim; g.K = d.ff_inner_pad;
-        return g;
-    };
-    auto logit_args = [&]() {
-        GemvArgs g{};
-        g.W = d.emb; g.ldw = d.dim_emb; g.x = X; g.x_stride = d.dim; g.gamma = d.final_gamma; g.y = LOG;
-        g.y_stride = d.streams * d.vocab; g.N = d.vocab; g.K = d.dim_emb; g.streams = d.streams;
-        return g;
-    };
-    const int p_qkv = 3 * d.inner / 2, p_out = (d.dim + 1) / 2, p_qc = d.inner / 2, p_ff1 = d.ff_inner_pad,
-              p_logit = d.streams * ((d.vocab + 1) / 2);
-    // attention: head h on local block h (the caches / context of utterance u are reached through the batch index of attn_body)
-    RowPrefetch pf;
-    { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
-    for (int step = 0; step < P.n_steps; ++step) {
-        for (int l = 0; l < d.depth; ++l) {
-            const cvx_t2s_layer& L = P.layers[l];
-            { const GemvArgs g = qkv_args(L); phase_gemv<MODE_QKV, 1>(g, p_qkv, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = out_args(L.wo_s); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            for (int h = lb; h < d.heads; h += G) {
-                const AttnArgs at{d.q, L.k_cache, L.v_cache, d.inner, cache_stride, d.att, ST, -1, scale, d.max_len};
-                attn_body(at, h, u, d.heads, sc, red4, part);
-                __syncthreads();
-            }
-            bar.arrive_and_wait();
-            { const GemvArgs g = out_args(L.wo_s); phase_gemv<MODE_RES, 1>(g, p_out, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = qc_args(L); if (gwave < p_qc) prefetch_pair<MODE_PLAIN>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            { const GemvArgs g = qc_args(L); phase_gemv<MODE_PLAIN, 1>(g, p_qc, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = out_args(L.wo_c); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            for (int h = lb; h < d.heads; h += G) {
-                const AttnArgs ac{d.q, L.kv_c, L.kv_c + d.inner, 2 * (int64_t)d.inner, (int64_t)d.ctx_rows * 2 * d.inner, d.att, d.state,
-                                  d.n_ctx > 0 ? d.n_ctx : -2, scale, d.max_len};
-                attn_body(ac, h, u, d.heads, sc, red4, part);
-                __syncthreads();
-            }
-            bar.arrive_and_wait();
-            { const GemvArgs g = out_args(L.wo_c); phase_gemv<MODE_RES, 1>(g, p_out, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = ff1_args(L); if (gwave < p_ff1) prefetch_pair<MODE_GEGLU>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            { const GemvArgs g = ff1_args(L); phase_gemv<MODE_GEGLU, 1>(g, p_ff1, xs, red, gwave, n_gwaves, pf); }
-            { const GemvArgs g = ff2_args(L); if (gwave < p_out) prefetch_pair<MODE_RES>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-            { const GemvArgs g = ff2_args(L); phase_gemv<MODE_RES, 1>(g, p_out, xs, red, gwave, n_gwaves, pf); }
-            if (l + 1 < d.depth) { const GemvArgs g = qkv_args(P.layers[l + 1]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
-            else { const GemvArgs g = logit_args(); if (gwave < p_logit) prefetch_pair<MODE_LOGITS>(g, gwave, lane, pf); }
-            bar.arrive_and_wait();
-        }
-        { const GemvArgs g = logit_args(); phase_gemv<MODE_LOGITS, 1>(g, p_logit, xs, red, gwave, n_gwaves, pf); }
-        bar.arrive_and_wait();
-        if (lb == 0) {
-            const SampleArgs sa{d.logits, d.uniforms, d.emb, d.x, d.tokens, d.state, d.batch, d.vocab, d.dim_emb, d.streams, d.max_len,
-                                d.top_k, d.vocab - 1, 1.0f / fmaxf(d.temperature, 1e-10f), 1.0f};
-            sample_body<256>(sa, u, lg, bv, bi, &chosen);
-        }
-        if (step + 1 < P.n_steps) { const GemvArgs g = qkv_args(P.layers[0]); if (gwave < p_qkv) prefetch_pair<MODE_QKV>(g, gwave, lane, pf); }
-        bar.arrive_and_wait();
-    }
-}
-
-#ifndef CVX_T2S_PPW
-#define CVX_T2S_PPW 1          // measured (round 4): 2 pairs per wave at batch 8 is SLOWER (394 vs 285 us per CoSingle step): half the blocks, half the
-#endif                         // rows in flight - the step is bound by how many weight rows are outstanding, not by the staging of x
-template <int MODE, int BQ>
-void launch_gemv_b(const GemvArgs& g, int pairs, hipStream_t st)
+template <int MODE, int BQ, int PPW>
+void launch_gemv_p(const GemvArgs& g, int pairs, hipStream_t st)
 {
     const int Kin = (MODE == MODE_LOGITS) ? g.K * g.streams : g.K;
     const size_t lds = sizeof(float) * (size_t)BQ * Kin;
-    constexpr int PPW = BQ >= 4 ? CVX_T2S_PPW : 1;
     if (lds > 48 * 1024)          // per-(device, kernel) bookkeeping, mutex-protected (cvx_common.h)
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ, PPW>), (int)lds);
     hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3((unsigned)((pairs + 4 * PPW - 1) / (4 * PPW))), dim3(256), lds, st, g);
 }
+template <int MODE, int BQ>
+void launch_gemv_b(const GemvArgs& g, int pairs, bool few_cus, hipStream_t st)
+{
+    if constexpr (BQ >= 8 && CVX_T2S_SIDE_PPW > 1) {
+        if (few_cus) { launch_gemv_p<MODE, BQ, CVX_T2S_SIDE_PPW>(g, pairs, st); return; }
+    }
+    launch_gemv_p<MODE, BQ, 1>(g, pairs, st);
+}
 
 template <int MODE>
-void launch_gemv(const GemvArgs& g, int pairs, int batch, hipStream_t st)
+void launch_gemv(const GemvArgs& g, int pairs, int batch, bool few_cus, hipStream_t st)
 {
-    if (batch <= 1) launch_gemv_b<MODE, 1>(g, pairs, st);
-    else if (batch <= 2) launch_gemv_b<MODE, 2>(g, pairs, st);
-    else if (batch <= 4) launch_gemv_b<MODE, 4>(g, pairs, st);
-    else launch_gemv_b<MODE, 8>(g, pairs, st);
+    if (batch <= 1) launch_gemv_b<MODE, 1>(g, pairs, few_cus, st);
+    else if (batch <= 2) launch_gemv_b<MODE, 2>(g, pairs, few_cus, st);
+    else if (batch <= 4) launch_gemv_b<MODE, 4>(g, pairs, few_cus, st);
+    else launch_gemv_b<MODE, 8>(g, pairs, few_cus, st);
 }
 
 }  // namespace
@@ -880,41 +521,6 @@ static int t2s_validate(const cvx_t2s_decoder* d, int32_t n_steps)
     return CVX_OK;
 }
 
-extern "C" int cvx_t2s_decode_persistent(const cvx_t2s_decoder* d, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t s)
-{
-    const int rc = t2s_validate(d, n_steps);
-    if (rc != CVX_OK) return rc;
-    CVX_REQUIRE(sync_ws_dev && d->depth <= T2S_MAX_DEPTH, "t2s_decode_persistent: needs a 2-word device workspace and depth <= %d", T2S_MAX_DEPTH);
-    if (n_steps == 0) return CVX_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    const int grid = cvx_device_cus();                 // one block per CU: all co-resident (grid barrier)
-    CVX_REQUIRE(d->heads * d->batch <= grid, "t2s_decode_persistent: heads x batch = %d exceeds the %d blocks of the grid", d->heads * d->batch, grid);
-    PersistArgs P{};
-    P.d = *d;
-    for (int l = 0; l < d->depth; ++l) P.layers[l] = d->layers[l];
-    P.d.layers = nullptr;                               // (a host pointer: the kernel uses the by-value copy)
-    P.sync = sync_ws_dev;
-    P.n_steps = n_steps;
-    int kin = d->dim > d->inner ? d->dim : d->inner;
-    if (d->ff_inner_pad > kin) kin = d->ff_inner_pad;
-    const int bq = d->batch <= 1 ? 1 : d->batch <= 2 ? 2 : d->batch <= 4 ? 4 : 8;
-    size_t floats = (size_t)bq * kin;
-    if (floats < (size_t)T2S_MAX_KEYS + 16 * 64) floats = (size_t)T2S_MAX_KEYS + 16 * 64;
-    P.lds_x_floats = (int)floats;
-    const size_t lds = floats * sizeof(float);
-    CVX_REQUIRE(lds <= 150 * 1024, "t2s_decode_persistent: %zu bytes of LDS per block", lds);
-    if (hipMemsetAsync(sync_ws_dev, 0, 2 * sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("t2s_decode_persistent: memset failed"); return CVX_EHIP; }
-#define CVX_T2S_PERSIST(BQ_)                                                                                              \
-    do {                                                                                                                  \
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&t2s_persistent_kernel<BQ_>), (int)lds);                      \
-        hipLaunchKernelGGL((t2s_persistent_kernel<BQ_>), dim3((unsigned)grid), dim3(256), lds, st, P);                    \
-    } while (0)
-    if (bq == 1) CVX_T2S_PERSIST(1); else if (bq == 2) CVX_T2S_PERSIST(2); else if (bq == 4) CVX_T2S_PERSIST(4); else CVX_T2S_PERSIST(8);
-#undef CVX_T2S_PERSIST
-    CVX_CHECK_LAUNCH("cvx_t2s_decode_persistent");
-    return CVX_OK;
-}
-
 extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, cvx_stream_t s)
 {
     const int rc = t2s_validate(d, n_steps);
@@ -922,6 +528,7 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const float scale = 0.125f;        // dim_head ** -0.5
     const int nb = d->batch;
+    const bool few = cvx_stream_cus(s) <= 64;          // a CU-masked side stream: more row pairs per wave (gemv_kernel)
     const int64_t cache_stride = (int64_t)d->max_len * d->inner;
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < d->depth; ++l) {
@@ -932,74 +539,41 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
             g.N = 3 * d->inner; g.K = d->dim;
             g.inner = d->inner; g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.k_cache = L.k_cache; g.v_cache = L.v_cache;
             g.cache_stride = cache_stride; g.state = d->state; g.max_len = d->max_len;
-            launch_gemv<MODE_QKV>(g, 3 * d->inner / 2, nb, st);
+            launch_gemv<MODE_QKV>(g, 3 * d->inner / 2, nb, few, st);
             AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, cache_stride, d->att, d->state, -1, scale, d->max_len};
             hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, at);
             g = GemvArgs{};
             g.W = L.wo_s; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
-            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, st);
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, few, st);
             // cross-attention over [null kv | encoder context]
             g = GemvArgs{};
             g.W = L.wq_c; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_c; g.y = d->q; g.y_stride = d->inner;
             g.N = d->inner; g.K = d->dim;
-            launch_gemv<MODE_PLAIN>(g, d->inner / 2, nb, st);
+            launch_gemv<MODE_PLAIN>(g, d->inner / 2, nb, few, st);
             AttnArgs ac{d->q, L.kv_c, L.kv_c + d->inner, 2 * (int64_t)d->inner, (int64_t)d->ctx_rows * 2 * d->inner, d->att, d->state,
                         d->n_ctx > 0 ? d->n_ctx : -2, scale, d->max_len};
             hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, ac);
             g = GemvArgs{};
             g.W = L.wo_c; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
-            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, st);
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, few, st);
             // GEGLU feed-forward
             g = GemvArgs{};
             g.W = L.w1; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d->h;
             g.y_stride = d->ff_inner_pad; g.N = 2 * d->ff_inner; g.K = d->dim; g.y_pad = d->ff_inner_pad;
-            launch_gemv<MODE_GEGLU>(g, d->ff_inner_pad, nb, st);
+            launch_gemv<MODE_GEGLU>(g, d->ff_inner_pad, nb, few, st);
             g = GemvArgs{};
             g.W = L.w2; g.ldw = d->ff_inner_pad; g.x = d->h; g.x_stride = d->ff_inner_pad; g.bias = L.b2; g.y = d->x; g.y_stride = d->dim;
             g.N = d->dim; g.K = d->ff_inner_pad;
-            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, st);
+            launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, few, st);
         }
         GemvArgs g{};
         g.W = d->emb; g.ldw = d->dim_emb; g.x = d->x; g.x_stride = d->dim; g.gamma = d->final_gamma; g.y = d->logits;
         g.y_stride = d->streams * d->vocab; g.N = d->vocab; g.K = d->dim_emb; g.streams = d->streams;
-        launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), nb, st);
+        launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), nb, few, st);
         SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, nb, d->vocab, d->dim_emb, d->streams, d->max_len,
                       d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f), d->cfg_scale};
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)nb), dim3(1024), 0, st, sa);
     }
     CVX_CHECK_LAUNCH("cvx_t2s_decode_steps");
-    return CVX_OK;
-}
-
-extern "C" int cvx_t2s_decode_xcd(const cvx_t2s_decoder* d, int32_t n_steps, uint32_t* sync_ws_dev, cvx_stream_t s)
-{
-    const int rc = t2s_validate(d, n_steps);
-    if (rc != CVX_OK) return rc;
-    CVX_REQUIRE(sync_ws_dev && d->depth <= T2S_MAX_DEPTH && !(d->cfg_scale > 1.f) && d->batch <= 8,
-                "t2s_decode_xcd: needs a 160-word device workspace, depth <= %d, at most 8 utterances and no guidance", T2S_MAX_DEPTH);
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    const int cus = cvx_device_cus();
-#ifndef CVX_XCD_BPC
-#define CVX_XCD_BPC 1
-#endif
-    const int G = (cus / 8 < 32 ? cus / 8 : 32) * CVX_XCD_BPC;      // blocks per group: CVX_XCD_BPC per CU of an XCD (all co-resident)
-    CVX_REQUIRE(G >= 1, "t2s_decode_xcd: %d compute units", cus);
-    PersistArgs P{};
-    P.d = *d;
-    for (int l = 0; l < d->depth; ++l) P.layers[l] = d->layers[l];
-    P.d.layers = nullptr;
-    P.sync = sync_ws_dev;
-    P.n_steps = n_steps;                                // 0: placement check only
-    int kin = d->dim > d->inner ? d->dim : d->inner;
-    if (d->ff_inner_pad > kin) kin = d->ff_inner_pad;
-    size_t floats = (size_t)kin;
-    if (floats < (size_t)T2S_MAX_KEYS + 16 * 64) floats = (size_t)T2S_MAX_KEYS + 16 * 64;
-    P.lds_x_floats = (int)floats;
-    const size_t lds = floats * sizeof(float);
-    CVX_REQUIRE(lds <= 150 * 1024, "t2s_decode_xcd: %zu bytes of LDS per block", lds);
-    if (hipMemsetAsync(sync_ws_dev, 0, 160 * sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("t2s_decode_xcd: memset failed"); return CVX_EHIP; }
-    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&t2s_xcd_kernel), (int)lds);
-    hipLaunchKernelGGL(t2s_xcd_kernel, dim3((unsigned)(8 * G)), dim3(256), lds, st, P);
-    CVX_CHECK_LAUNCH("cvx_t2s_decode_xcd");
     return CVX_OK;
 }

@@ -55,8 +55,14 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--seed", type=int, default=30, help="random seed")
     p.add_argument("--mode", type=str, choices=["covosingle", "covosinx", "covomix"], default="covosingle")
     p.add_argument("--max_batch", type=int, default=32, help="utterances per launch at most (any lengths: they are packed back to back)")
-    p.add_argument("--max_frames", type=int, default=8192, help="frames per launch (sum over its utterances): 8192 frames = 64 row "
-                   "panels of 256 rows with both CFG branches, whole rounds of GEMM tiles on 256 CUs")
+    p.add_argument("--max_frames", type=int, default=None, help="frames per launch (sum over its utterances); default: whole rounds of "
+                   "GEMM tiles - 8192 frames = 64 row panels of 256 rows with both CFG branches on 256 CUs; 7168 on the 224 CUs the "
+                   "acoustic stage owns under --pipeline on")
+    p.add_argument("--pipeline", type=str, choices=["auto", "on", "serial", "off"], default="auto",
+                   help="extension: with --t2s_ckpt, decode the text of the NEXT utterances on a CU-masked side stream while the acoustic "
+                        "model and the vocoder work on the current batch (covomix_amd/pipeline.py).  auto = on when there is text to "
+                        "decode; serial = the same batches on the same two streams one after the other (bit-identical output, for "
+                        "comparison); off = decode everything first, then one global packing (the round-4 flow)")
     p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
                    "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
     p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
@@ -293,43 +299,42 @@ def run(dialogue: bool, argv=None) -> int:
 
     names, sources, plan = utterance_plan(args.text_dir, dialogue, args.mode, t2s is not None, world)
     mine = plan[rank]
-
-    # ---- text2semantic for this rank's utterances only
     work = [(n, k, s) for n in mine for k, s in enumerate(sources[n])]
-    pred = _predict_turns(work, t2s, device, args.seed)
-    items, owner = [], []                                         # network inputs; (name, segment index) of each
-    for n in mine:
-        for seg, it in enumerate(_build_items(args.mode, dialogue, args.prompt_dir, n, [pred[(n, k)] for k in range(len(sources[n]))])):
-            items.append(it)
-            owner.append((n, seg))
-    lengths = [int(it[0].shape[0]) for it in items]
+    to_decode = sum(1 for _, _, (kind, _) in work if kind != "sem")
+    mode = args.pipeline
+    if mode == "auto":
+        mode = "on" if (t2s is not None and to_decode > 0) else "off"
+    if mode != "off" and t2s is None:
+        mode = "off"                                              # nothing to overlap: tokens come from files
+    from . import pipeline as pl
+    max_frames = args.max_frames or (pl.frames_per_launch(device) if mode != "off" else 8192)
     segments = {n: {} for n in mine}
     n_out = model._get_field().d["dim_out"]       # acoustic.py:647-650: 80 channels (twocondition_oneoutput) or as wide as cond
-    done, frames = 0, 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+
     # The reference generates one utterance at a time (monologue_generation.py:259-304); here up to --max_batch utterances
     # of ANY lengths share a launch sequence: packed back to back (no padding), every utterance attending to itself only
     # (sample_ragged), so each gets the result of its own B = 1 run.  Batches are FILLED to --max_frames (first-fit decreasing,
     # dp.pack_by_frames): the frames of a launch decide how many whole rounds of GEMM tiles it runs.
     def one_batch(batch, y0):
-        """acoustic solve + vocoder of one packed batch -> [(name, segment, int16 samples)], generated frames"""
-        if len(set(lengths[i] for i in batch)) == 1:                                     # equal lengths: the plain [B, T, .] call
-            sampled = list(model.synthesis_sample(phoneme_ids=torch.stack([items[i][0] for i in batch]).to(device),
-                                                  cond=torch.stack([items[i][1] for i in batch]).to(device),
-                                                  mask=torch.stack([items[i][2] for i in batch]).to(device),
+        """acoustic solve + vocoder of one packed batch of (inputs, (name, segment)) -> [(name, segment, int16 samples)], generated frames"""
+        its = [it for it, _ in batch]
+        lens = [int(it[0].shape[0]) for it in its]
+        if len(set(lens)) == 1:                                                          # equal lengths: the plain [B, T, .] call
+            sampled = list(model.synthesis_sample(phoneme_ids=torch.stack([it[0] for it in its]).to(device),
+                                                  cond=torch.stack([it[1] for it in its]).to(device),
+                                                  mask=torch.stack([it[2] for it in its]).to(device),
                                                   cond_scale=COND_SCALE, y0=torch.stack(y0)))
         else:
-            sampled = model.synthesis_sample(phoneme_ids=[items[i][0].to(device) for i in batch], cond=[items[i][1].to(device) for i in batch],
-                                             mask=[items[i][2] for i in batch], cond_scale=COND_SCALE, y0=y0)
+            sampled = model.synthesis_sample(phoneme_ids=[it[0].to(device) for it in its], cond=[it[1].to(device) for it in its],
+                                             mask=[it[2] for it in its], cond_scale=COND_SCALE, y0=y0)
         # vocoder: the generated frames of every utterance of the batch (:299-300: mask is a suffix) go through HiFi-GAN in
         # ONE ragged call (zero-padded to the longest, per-item lengths: every item gets its B = 1 waveform); one int16 cast
         # and one device-to-host copy per batch, sliced per utterance on the host
-        n_prompt = [int((~items[i][2]).sum()) for i in batch]
-        js = [j for j, i in enumerate(batch) if lengths[i] - n_prompt[j] > 0]
+        n_prompt = [int((~it[2]).sum()) for it in its]
+        js = [j for j in range(len(its)) if lens[j] - n_prompt[j] > 0]
         # (items of similar length only: the ragged vocoder call pads to its longest item and skips no work behind a short
         #  one, dp.group_by_padding keeps that padding below 25 % of the real frames)
-        tg_all = [lengths[batch[j]] - n_prompt[j] for j in js]
+        tg_all = [lens[j] - n_prompt[j] for j in js]
         out, nfr = [], 0
         for grp in dp.group_by_padding(tg_all):
             gj = [js[k] for k in grp]
@@ -341,13 +346,14 @@ def run(dialogue: bool, argv=None) -> int:
             pcm = ops.wav_to_int16(wav.squeeze(1).contiguous()).cpu().numpy()              # mel_decode_to_wav (:52-59), batched
             nfr += sum(tgen)
             for r, j in enumerate(gj):
-                n, seg = owner[batch[j]]
+                n, seg = batch[j][1]
                 out.append((n, seg, pcm[r, : generator.output_length(tgen[r])].copy()))
         return out, nfr
 
-    for batch in dp.pack_by_frames(list(range(len(items))), lengths, args.max_frames, args.max_batch):
-        y0 = [torch.randn(lengths[i], n_out, device=device, generator=torch.Generator(device=device).manual_seed(
-            _stable_seed(args.seed, owner[i][0], owner[i][1], 2))) for i in batch]        # acoustic.py:647-650, per utterance
+    def solve(batch):
+        """one packed batch end to end on the current stream: noise, solve, vocoder, saturation check -> generated frames"""
+        y0 = [torch.randn(int(it[0].shape[0]), n_out, device=device, generator=torch.Generator(device=device).manual_seed(
+            _stable_seed(args.seed, own[0], own[1], 2))) for it, own in batch]             # acoustic.py:647-650, per utterance
         # one saturation-flag read per batch (after the device-to-host copy that waits for the batch anyway) instead of one
         # blocking read per call; a flagged batch is repeated with the per-call checks (the stage that saturated warns and
         # re-runs in fp32, or raises under CVX_ON_SATURATION=raise)
@@ -355,9 +361,51 @@ def run(dialogue: bool, argv=None) -> int:
             res, nfr = one_batch(batch, y0)
         if guard.flagged:
             res, nfr = one_batch(batch, y0)
-        frames += nfr
         for n, seg, samples in res:
             segments[n][seg] = samples
+        return nfr
+
+    def items_of(n, pred):
+        return [(it, (n, seg)) for seg, it in enumerate(_build_items(args.mode, dialogue, args.prompt_dir, n,
+                                                                     [pred[(n, k)] for k in range(len(sources[n]))]))]
+
+    done, frames = 0, 0
+    if mode == "off":       # ---- text2semantic for this rank's utterances first (not timed, as in round 4), then ONE global packing
+        pred = _predict_turns(work, t2s, device, args.seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if mode == "off":
+        pool = [x for n in mine for x in items_of(n, pred)]
+        lengths = [int(it[0].shape[0]) for it, _ in pool]
+        for b in dp.pack_by_frames(list(range(len(pool))), lengths, max_frames, args.max_batch):
+            frames += solve([pool[i] for i in b])
+    else:
+        # ---- two-stage pipeline: stage 1 decodes the turns 8 at a time (side stream, worker thread), the collate step assembles
+        # the utterances whose turns are all there and packs them; stage 2 = solve() on the main stream.  A bin is launched when it
+        # is (nearly) full; the rest waits for more utterances - every batch is a function of the utterance list alone, so
+        # `--pipeline serial` runs exactly the same batches (bit-identical PCM).
+        groups = [work[i:i + 8] for i in range(0, len(work), 8)]
+
+        def collate(results):
+            pred, pool, pending = {}, [], list(mine)
+            for part_pred in results:
+                pred.update(part_pred)
+                while pending and all((pending[0], k) in pred for k in range(len(sources[pending[0]]))):
+                    pool.extend(items_of(pending.pop(0), pred))
+                last = not pending
+                lengths = [int(it[0].shape[0]) for it, _ in pool]
+                bins = dp.pack_by_frames(list(range(len(pool))), lengths, max_frames, args.max_batch)
+                keep = []
+                for b in bins:
+                    full = sum(lengths[i] for i in b) >= 0.9 * max_frames or len(b) >= args.max_batch
+                    if full or last:
+                        yield [pool[i] for i in b]
+                    else:
+                        keep += b
+                pool = [pool[i] for i in sorted(keep)]
+        nfr = pl.run_two_stage(groups, lambda g: _predict_turns(g, t2s, device, args.seed), solve, device,
+                               overlap=(mode == "on"), collate=collate)
+        frames = sum(nfr)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     for n in mine:
@@ -369,6 +417,6 @@ def run(dialogue: bool, argv=None) -> int:
         print("Saved wavfile", out)
         done += 1
     print(f"rank {rank}: {done} utterances, {frames} generated frames in {elapsed:.3f} s ({frames / max(elapsed, 1e-9):.1f} frames/s, "
-          f"sampling + vocoder, excluding model load and text2semantic)")
-    run.last_stats = dict(utterances=done, frames=frames, seconds=elapsed)
+          f"{'text2semantic + ' if mode != 'off' else ''}sampling + vocoder, excluding model load; --pipeline {mode})")
+    run.last_stats = dict(utterances=done, frames=frames, seconds=elapsed, pipeline=mode)
     return done

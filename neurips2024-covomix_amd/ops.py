@@ -71,21 +71,32 @@ def _pair(x, rows=None, cols=None):
     return hi.data_ptr(), _p(lo), hi.stride(0) if hi.ndim == 2 else hi.shape[-1]
 
 
-# dev A/B (read here, never inside the library): CVX_GEMM_P8 = 1 (default) eight-phase kernel on the 16x16x32 MFMA,
-# 32 = eight-phase kernel on the 32x32x16 MFMA, 0 = two-stage kernel, 1t = one tile per block.  cvx_gemm_split_io.flags.
-_GEMM_FLAGS = {"1": 0, "32": 2, "0": 1, "1t": 4}.get(__import__("os").environ.get("CVX_GEMM_P8", "1"), 0)
+# cvx_gemm_split_io.flags of every interleaved-operand GEMM (dev A/B, read here, never inside the library):
 # CVX_GEMM_MEDIUM_AUTO=0: 2048 rows and more always on the large-problem kernel (flag 16), =force: always on the medium one (8);
-# default: the library picks by how full the large kernel's last round of tiles would be
-_GEMM_FLAGS |= {"0": 16, "force": 8}.get(__import__("os").environ.get("CVX_GEMM_MEDIUM_AUTO", "1"), 0)
-_GEMM_FLAGS |= int(__import__("os").environ.get("CVX_GEMM_FLAGS_EXTRA", "0"), 0)      # dev builds (-DCVX_DEV_FLAGS): 0x10000 no K slices, 0x20000 at most two
+# default: the library picks by how full the large kernel's last round of tiles would be.  Flag 4: one tile per block (large kernel).
+_GEMM_FLAGS = {"0": 16, "force": 8}.get(_os.environ.get("CVX_GEMM_MEDIUM_AUTO", "1"), 0)
+_GEMM_FLAGS |= int(_os.environ.get("CVX_GEMM_FLAGS_EXTRA", "0"), 0)      # dev builds (-DCVX_DEV_FLAGS): 0x10000 no K slices, 0x20000 at most two
+_TL = threading.local()          # per-thread additions to the flags (gemm_flags): a schedule that pins a kernel must not leak into other threads
+
+
+@contextmanager
+def gemm_flags(extra: int):
+    """with ops.gemm_flags(16): every GEMM THIS THREAD launches inside the block carries the extra cvx_gemm_split_io.flags bits
+    (16 = CVX_GEMM_FLAG_NO_MEDIUM: the two-chain schedule pins the large-problem kernel so that its halves and the whole batch run
+    the same arithmetic).  Thread-local: another host thread's solve is not affected (round-4 advice)."""
+    old = getattr(_TL, "flags", 0)
+    _TL.flags = old | int(extra)
+    try:
+        yield
+    finally:
+        _TL.flags = old
 
 _SPLITK_WS: dict = {}
 
 
 def il_min_rows() -> int:
-    """Row count from which GEMM A operands are kept as INTERLEAVED pairs (SplitIL): 128 with the medium-problem kernel
-    (default), 2048 (large-problem kernel only) under CVX_GEMM_P8M=0 (dev A/B: the round-3 small-problem path)."""
-    return 2048 if __import__("os").environ.get("CVX_GEMM_P8M", "1") == "0" else 128
+    """Row count from which GEMM A operands are kept as INTERLEAVED pairs (SplitIL: the medium- and large-problem kernels)."""
+    return 128
 
 
 def _splitk_workspace(device) -> torch.Tensor:
@@ -245,10 +256,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         g.rope_cos, g.rope_sin, g.rope_T, g.rope_cols = None, None, 0, 0
     if isinstance(a_split, SplitIL):
         assert w_il is not None, "an interleaved A operand needs interleaved weights"
-    # interleaved weights: the large-problem kernel (M >= 2048, N >= 512; A split either way) or, with an interleaved A, the
-    # medium-problem kernel (gemm_f16x3_p8m.hip)
-    if (w_il is not None and a_split is not None and w_split is not None and w_split[1] is not None
-            and ((M >= 2048 and N >= 512) or isinstance(a_split, SplitIL))):
+    # interleaved weights go with an interleaved A: the large- (M >= 2048, N >= 512) and medium-problem kernels
+    if w_il is not None and w_split is not None and w_split[1] is not None and isinstance(a_split, SplitIL):
         il, inv_il = w_il                      # interleaved [N, 2K] copy of the same split weight (split_f16_interleaved)
         assert il.dtype == torch.float16 and il.shape == (N, 2 * K) and il.is_contiguous() and il.is_cuda
         use_il = True
@@ -256,6 +265,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
         use_il = False
     if w_split is not None and K % 32 == 0 and (M > 64 or a_split is not None or out_split is not None):
         hi, lo, inv_scale = w_split
+        ensure_saturation_bound()
         assert hi.dtype == torch.float16 and hi.shape == (N, K) and hi.stride(1) == 1 and hi.is_cuda
         assert lo is None or (lo.dtype == torch.float16 and lo.shape == (N, K) and lo.stride() == hi.stride() and lo.is_cuda)
         g.ldw = hi.stride(0)                       # rows may be padded (row stride > K)
@@ -301,7 +311,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act=
                   f"out_split={out_split is not None} vt={vt_split is not None} ws={bool(io.workspace)}", file=sys.stderr, flush=True)
         w_hi_ptr, w_lo_ptr = hi.data_ptr(), _p(lo)
         if use_il:
-            io.flags = _GEMM_FLAGS
+            io.flags = _GEMM_FLAGS | getattr(_TL, "flags", 0)
             io.w_interleaved, g.ldw = 1, 2 * K
             w_hi_ptr, w_lo_ptr, inv_scale = il.data_ptr(), il.data_ptr() + 64, inv_il
         if norm is not None:
@@ -332,6 +342,7 @@ def split_act_f16(x: torch.Tensor, hi=None, lo: Optional[torch.Tensor] = None, s
     scale: one-element fp32 CUDA tensor, the power-of-two pre-scale (the consumer GEMM's a_scale); None = 1."""
     _chk_f32(x)
     assert x.is_contiguous()
+    ensure_saturation_bound()
     if isinstance(hi, SplitIL):
         h, l, _ = _pair(hi, x.shape[0], x.shape[1])
         _lib.check(_lib.load().cvx_split_f16_dev(x.data_ptr(), h, l, x.numel(), 1.0, _sp(scale), _stream()), "cvx_split_f16")
@@ -380,6 +391,7 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
     rows = x.numel() // D
     oh, ol = (None, None)
     if out_split is not None:
+        ensure_saturation_bound()
         oh, ol, ld = _pair(out_split, rows if isinstance(out_split, SplitIL) else None, D)
         assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == x.numel())
     rpg = rows if rows_per_group is None else rows_per_group
@@ -391,6 +403,7 @@ def adarmsnorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor
 def split_f16_colscale_il(w: torch.Tensor, colscale: torch.Tensor, set_scale: Optional[torch.Tensor], scale: float, out: torch.Tensor) -> torch.Tensor:
     """out[s] = interleaved split pair of w * colscale[s][None, :] * set_scale[s] * scale for every set s (cvx_split_f16_colscale_il):
     w [N, K] fp32, colscale [n_sets, K] (row stride free), set_scale [n_sets] (stride free) or None, out [n_sets, N, 2K] fp16."""
+    ensure_saturation_bound()
     _chk_f32(w, colscale, set_scale)
     N, K = w.shape
     n_sets = colscale.shape[0]
@@ -440,19 +453,90 @@ def saturation_flag(stream: Optional["torch.cuda.Stream"] = None) -> torch.Tenso
 
 
 def saturation_share(src: "torch.cuda.Stream", dst: "torch.cuda.Stream") -> None:
-    """Kernels launched on `dst` report into the flag of `src` until further notice: the side stream of the two-chain schedule and
-    the capture stream of a HIP graph belong to the call that runs on `src` (call it before every such use)."""
+    """Kernels launched on `dst` report into the flag of `src` until further notice, and their persistent grids are sized for the
+    CUs `src` owns (cvx_stream_set_cus): the capture stream of a HIP graph - and any side stream a call opens - belongs to the call
+    that runs on `src` (call it before every such use)."""
     f = saturation_flag(src)
     skey = (src.device.index, src.cuda_stream)
     key = (dst.device.index, dst.cuda_stream)
     if key == skey:
         return
     _CAPTURE_OWNER[key] = src.cuda_stream
+    with torch.cuda.device(dst.device):
+        lib = _lib.load()
+        n = int(lib.cvx_stream_cus(src.cuda_stream))
+        full = torch.cuda.get_device_properties(dst.device).multi_processor_count
+        _lib.check(lib.cvx_stream_set_cus(dst.cuda_stream, 0 if n == full else n), "cvx_stream_set_cus")
     ent = _SAT_FLAGS.get(key)
     if ent is None or ent[0] is not f:
         _SAT_FLAGS[key] = (f, skey)
         with torch.cuda.device(dst.device):
             _bind_saturation_flag(f, dst.cuda_stream)
+
+
+def ensure_saturation_bound() -> None:
+    """The split-pair kernels skip their saturation bookkeeping on a stream nobody bound a flag to (a documented C-ABI feature for
+    callers that do not want it).  The Python front ends never want that silently (round-4 advice): every one of them that launches
+    a split-pair kernel makes sure the current stream has a flag - allocated here on first use outside a capture; inside a capture an
+    unbound stream is an error (the stream that captures must have been shared with the calling stream: saturation_share)."""
+    st = torch.cuda.current_stream()
+    if (st.device.index, st.cuda_stream) in _SAT_FLAGS:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.CovomixHipError("a split-precision kernel is being captured on a stream without a saturation flag: call "
+                                   "ops.saturation_share(calling_stream, capture_stream) before the capture")
+    saturation_flag(st)
+
+
+# ---------------------------------------------------------------- CU-partitioned streams (include/covomix_hip.h, round 5)
+class CUPartition:
+    """Two streams of one device on DISJOINT sets of compute units: `main` (the acoustic solve and the vocoder) and `side` (the
+    text2semantic decode of the next batch).  Bit k of a HIP CU mask names CU k // 8 of XCD k % 8 and consecutive indices of an XCD go
+    round its four shader engines (tools/cu_mask_probe.hip), so `side` takes the top `side_per_xcd` indices of every XCD
+    (side_per_xcd a multiple of 4: every shader engine keeps the same number of CUs, which one-block-per-CU kernels need to be
+    co-resident - tools/cu_mask_probe2.hip) and `main` the rest.  The streams live as long as the process."""
+
+    def __init__(self, device, side_per_xcd: int = 4):
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        n = torch.cuda.get_device_properties(idx).multi_processor_count
+        if side_per_xcd <= 0 or side_per_xcd % 4 or n % 8 or 8 * side_per_xcd >= n:
+            raise ValueError(f"side_per_xcd must be a positive multiple of 4 below {n // 8} (CUs per XCD), got {side_per_xcd}")
+        self.device = torch.device("cuda", idx)
+        self.n_side, self.n_main = 8 * side_per_xcd, n - 8 * side_per_xcd
+        words = (n + 31) // 32
+        lib = _lib.load()
+
+        def make(bits):
+            m = (C.c_uint32 * words)()
+            for b in bits:
+                m[b // 32] |= 1 << (b % 32)
+            out = C.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(lib.cvx_stream_create_cu_mask(m, words, C.byref(out)), "cvx_stream_create_cu_mask")
+            return torch.cuda.ExternalStream(out.value, device=self.device)
+        self.main = make(range(0, self.n_main))
+        self.side = make(range(self.n_main, n))
+
+
+_CU_PARTITIONS: dict = {}
+
+
+def cu_partition(device=None, side_per_xcd: int = 4) -> CUPartition:
+    """The (cached) CUPartition of a device."""
+    dev = torch.device(device if device is not None else "cuda")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, side_per_xcd)
+    if key not in _CU_PARTITIONS:
+        _CU_PARTITIONS[key] = CUPartition(torch.device("cuda", idx), side_per_xcd)
+    return _CU_PARTITIONS[key]
+
+
+def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:
+    """CUs the library sizes persistent grids for on `stream` (default: the current stream)."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    with torch.cuda.device(st.device):
+        return int(_lib.load().cvx_stream_cus(st.cuda_stream))
 
 
 def saturation_reset() -> None:
@@ -565,6 +649,7 @@ def attention_f16x3(qk_split, vt_split, out: Optional[torch.Tensor], Bt: int, T:
     with per-row RoPE tables [M, 32] (rope_T = M); Bt, T are ignored."""
     qh, ql = qk_split
     vh, vl = vt_split
+    ensure_saturation_bound()
     assert (ql is None) == (vl is None)
     for t in (qh, ql, vh, vl):
         assert t is None or (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous())
@@ -619,21 +704,6 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=Non
     assert w.shape[1] == K and tuple(out.shape) == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
     _lib.check(_lib.load().cvx_gemm_skinny_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(), out.stride(0),
                                                M, N, K, act, _stream()), "cvx_gemm_skinny_f32")
-    return out
-
-
-def embed_conv31(x: torch.Tensor, w_embed: torch.Tensor, base: torch.Tensor, dw_w: torch.Tensor, dw_b: torch.Tensor, out: torch.Tensor,
-                 Bt: int, T: int, ragged: Optional[Ragged] = None) -> torch.Tensor:
-    """out = h0 + gelu(dwconv31(h0) + dw_b) with h0 = x @ w_embed[:, :K].T + base, one launch (cvx_embed_conv31_f32).
-    x [rows, K]; w_embed [C, >= K] (row stride = its own, a column slice of to_embed.weight is fine); base / out [rows, C]."""
-    _chk_f32(x, w_embed, base, dw_w, dw_b, out)
-    K, C_ = x.shape[-1], base.shape[-1]
-    assert x.is_contiguous() and base.is_contiguous() and out.is_contiguous() and dw_w.is_contiguous() and dw_w.numel() == C_ * 31
-    assert w_embed.shape[0] == C_ and w_embed.shape[1] >= K and w_embed.stride(1) == 1
-    cu, n, mt = (ragged.cu.data_ptr(), ragged.n, ragged.max_T) if ragged is not None else (None, Bt, T)
-    assert x.numel() == (ragged.M if ragged is not None else Bt * T) * K
-    _lib.check(_lib.load().cvx_embed_conv31_f32(x.data_ptr(), K, w_embed.data_ptr(), w_embed.stride(0), base.data_ptr(), dw_w.data_ptr(),
-                                                dw_b.data_ptr(), out.data_ptr(), cu, n, mt, C_, _stream()), "cvx_embed_conv31_f32")
     return out
 
 
@@ -825,6 +895,7 @@ def hifigan_conv_transpose1d_f16x3(z, pk: dict, B: int, L_in: int, out: torch.Te
                                    items=None) -> torch.Tensor:
     """out (fp32 channels-last [B, Lp_out, Np_out]) = ConvTranspose1d of the activation whose split(leaky_relu(.) * z_scale) pair is
     z = (hi, lo) [B, Lp_in, Cp_in]; pk from hifigan_pack_conv_transpose1d_f16x3.  items: valid OUTPUT positions per item."""
+    ensure_saturation_bound()
     zh, zl = z
     assert zh.dtype == torch.float16 and zh.is_contiguous() and zl.is_contiguous() and zh.shape == zl.shape
     assert zh.shape[0] == B and zh.shape[2] == pk["cp_in"], (tuple(zh.shape), pk["cp_in"])
@@ -845,6 +916,7 @@ def hifigan_conv_transpose1d_f16x3(z, pk: dict, B: int, L_in: int, out: torch.Te
 
 def hifigan_split_channels_last(x_cl: torch.Tensor, z, slope: float, z_scale=None) -> None:
     """z = split(leaky_relu(x_cl, slope) * z_scale) over a whole fp32 channels-last buffer."""
+    ensure_saturation_bound()
     zh, zl = z
     assert x_cl.dtype == torch.float32 and x_cl.is_contiguous() and zh.dtype == torch.float16 and zh.is_contiguous() and zl.is_contiguous()
     assert zh.shape == x_cl.shape and zl.shape == x_cl.shape and x_cl.numel() % 4 == 0
@@ -874,6 +946,7 @@ def amax_pow2_scale(x: torch.Tensor, target: float, scale: torch.Tensor, scratch
 def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, res=None, accum=None, out_x=None,
                          out_scale: float = 1.0, out_z=None, z_slope: float = 0.1, z_scale=None, items=None) -> None:
     """z = (hi, lo) channels-last [B, Lp, Cp_in]; wpk from hifigan_pack_weight_f16x3; bias [Np] (zero padded)."""
+    ensure_saturation_bound()
     zh, zl = z
     w_hi, w_lo, inv, np_, cp = wpk
     assert zh.dtype == torch.float16 and zh.is_contiguous() and zl.is_contiguous() and zh.shape == zl.shape
@@ -903,6 +976,7 @@ def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, acc
     """One ResBlock1 (three conv pairs) through the operator-level C entry point cvx_hifigan_resblock_f16x3.
     block: list of 3 (c1, c2) pairs of objects with .w16 = hifigan_pack_weight_f16x3(...), .bias16, .k, .dil;
     scratch: dict with t, rz0, rz1 (split pairs) and r0, r1 (fp32), all [B, Lp, Np] like x_cl / z."""
+    ensure_saturation_bound()
     a = _lib.Resblock16Args()
     narrow = x_cl.shape[2] <= 64              # fused pair kernel: no split pairs in HBM (z / t / rz0 / rz1 unused)
     zh, zl = z if z is not None else (None, None)
@@ -932,6 +1006,7 @@ def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None
                                 items=None) -> None:
     """out = (c2(lrelu(c1(lrelu(x)))) + x (+ accum)) * out_scale as one kernel (cvx_hifigan_resblock_pair_f16x3; Np = 32 / 64).
     x_cl / out / accum: fp32 channels-last [B, Lp, Np]; c1, c2: objects with .w16, .bias16, .k, .dil (c2.dil == 1)."""
+    ensure_saturation_bound()
     a = _lib.Respair16Args()
     a.x = x_cl.data_ptr()
     a.B, a.L, a.Lp, a.Np, a.halo_l = B, L, x_cl.shape[1], x_cl.shape[2], HIFI_HALO_L
@@ -950,6 +1025,7 @@ def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None
 
 def hifigan_to_channels_last(x: torch.Tensor, x_cl: Optional[torch.Tensor], z, slope: float, z_scale=None) -> None:
     """x [B, C, L] fp32 channel-major -> x_cl [B, Lp, Cp] fp32 and / or z = split(leaky_relu(x)) [B, Lp, Cp]."""
+    ensure_saturation_bound()
     _chk_f32(x, x_cl)
     B, Cc, L = x.shape
     ref = x_cl if x_cl is not None else z[0]

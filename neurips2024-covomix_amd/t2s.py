@@ -7,17 +7,15 @@ forwards to (covomix/conditional_model.py:313-321).  Only what the generation sc
 
   encoder  (source transformer, once per utterance): the full-sequence kernels of the acoustic path - fp32 GEMM with
            the RoPE epilogue, flash attention, RMSNorm - plus a GEGLU kernel;
-  decoder  (one token per step): csrc/t2s_decode.hip.  Default: cvx_t2s_decode_steps, 34 launches per step replayed from a
-           HIP graph of CHUNK steps.  CVX_T2S_PERSISTENT=1 (opt-in, measured 2.7x SLOWER: 524 vs 195 us per CoSingle step):
-           cvx_t2s_decode_persistent - CHUNK token steps as ONE persistent launch (one block per CU, grid barriers between
-           the 34 phases of a step, next-phase weights requested before every barrier wait; the same device code per phase:
-           bit-identical logits and tokens).  On MI355X a grid barrier with the L2 write-back / invalidate that cross-XCD
-           visibility needs costs 4-7 us (MI355X_MICROARCH.md, barrier-counter / barrier-xcd) against 1.2-1.5 us for a
-           dependent kernel boundary, so the launch chain wins; the kernel is kept as the measured negative result.  The host
-           only looks at the eos flags (and the persistent kernel's barrier-timeout word) between chunks.  `generate_batch`
-           advances up to MAX_BATCH utterances together (the reference decodes them one by one): a token step is
-           bound by streaming the decoder weights, which a batch shares, and the per-utterance arithmetic does not
-           depend on the batch size - the tokens are bit-identical to the one-by-one decode.
+  decoder  (one token per step): csrc/t2s_decode.hip - cvx_t2s_decode_steps, 34 launches per step replayed from a HIP
+           graph of CHUNK steps.  (Two single-launch persistent forms with grid barriers were built in round 4 and measured
+           2.5-2.7x slower - a grid barrier with the L2 write-back / invalidate that cross-XCD visibility needs costs 4-7 us
+           against 1.2-1.5 us for a dependent kernel boundary; removed in round 5, numbers in HISTORY.md.)  The host only
+           looks at the eos flags between chunks.  `generate_batch` advances up to MAX_BATCH utterances together (the
+           reference decodes them one by one): a token step is bound by streaming the decoder weights, which a batch
+           shares, and the per-utterance arithmetic does not depend on the batch size - the tokens are bit-identical to
+           the one-by-one decode.  The decode is a latency chain that needs a handful of CUs: pipeline.py runs it on a
+           CU-masked side stream UNDER the acoustic solve of the previous batch.
 
 The reference's rotary embedding rotates interleaved pairs (2i, 2i+1) (rotary_embedding_torch.py:25-41); the kernels
 rotate half-split pairs (i, i+32).  Permuting the rows of to_q and to_k inside every head (the same permutation on
@@ -124,21 +122,15 @@ class TextToSemanticDecoder:
         self.buf = dict(x=f32(MAX_BATCH, d["dim_target"]), q=f32(MAX_BATCH, I), att=f32(MAX_BATCH, I), h=f32(MAX_BATCH, self.Fp),
                         logits=f32(MAX_BATCH, S, V), uniforms=f32(self.max_length * MAX_BATCH * S * V),
                         tokens=torch.zeros(MAX_BATCH, S, self.max_length, dtype=torch.int64, device=device))
-        # decode state [MAX_BATCH, 4] + one more row = the persistent kernel's workspace (barrier counter, error word): one
-        # device-to-host copy per chunk brings both
-        self._stsync = torch.zeros(MAX_BATCH + 1, 4, dtype=torch.int32, device=device)
-        self.buf["state"] = self._stsync[:MAX_BATCH]
-        self.persistent = os.environ.get("CVX_T2S_PERSISTENT", "0") == "1"
-        # one XCD per utterance (cvx_t2s_decode_xcd): CVX_T2S_XCD = 1 on / 0 off; placement is probed once (n_steps = 0)
-        self.xcd = os.environ.get("CVX_T2S_XCD", "0") == "1" and not self.persistent        # measured 2.5x slower: opt-in
-        self._xsync = torch.zeros(160, dtype=torch.int32, device=device)
-        self._xcd_ok = None
+        self.buf["state"] = torch.zeros(MAX_BATCH, 4, dtype=torch.int32, device=device)      # per utterance: pos, done, length, context rows
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
             for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
                          "k_cache", "v_cache"):
                 setattr(self._layers[i], name, L[name].data_ptr())
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self._cap = None                                   # capture stream of the decode graphs
+        self._pin = None                                   # pinned host copies of the state record (two in flight), _decode_chunks
 
     # ------------------------------------------------------------------ encoder (text2semantic.py:716-741)
     def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
@@ -189,93 +181,86 @@ class TextToSemanticDecoder:
             setattr(dec, n, b[n].data_ptr())
         return dec
 
-    def _use_xcd(self, cfg_scale: float) -> bool:
-        """One XCD per utterance?  Needs the blocks of a group to land on one XCD: checked once with an empty launch."""
-        if not self.xcd or cfg_scale > 1.0:
-            return False
-        if self._xcd_ok is None:
-            _lib.check(_lib.load().cvx_t2s_decode_xcd(C.byref(self._descriptor(1.0, 1)), 0, self._xsync.data_ptr(),
-                                                      torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_xcd")
-            self._xcd_ok = int(self._xsync[1].item()) == 0
-        return self._xcd_ok
-
-    def _check_xcd(self) -> None:
-        if int(self._xsync[1].item()) != 0:
-            self._xcd_ok = False
-            raise _lib.CovomixHipError("cvx_t2s_decode_xcd: a group barrier timed out or a group was not placed on one XCD; the tokens "
-                                       "of this chunk are invalid - set CVX_T2S_XCD=0 to use the per-launch path")
-
     def _steps(self, temperature: float, batch: int, n: int, cfg_scale: float = 1.0) -> None:
         """n token steps on the current stream without a graph."""
-        st = torch.cuda.current_stream().cuda_stream
-        if self._use_xcd(cfg_scale):
-            _lib.check(_lib.load().cvx_t2s_decode_xcd(C.byref(self._descriptor(temperature, batch)), n, self._xsync.data_ptr(), st),
-                       "cvx_t2s_decode_xcd")
-            return
-        if self.persistent:
-            _lib.check(_lib.load().cvx_t2s_decode_persistent(C.byref(self._descriptor(temperature, batch, cfg_scale)), n,
-                                                             self._stsync[MAX_BATCH].data_ptr(), st), "cvx_t2s_decode_persistent")
-        else:
-            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), n, st), "cvx_t2s_decode_steps")
+        _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), n,
+                                                    torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
 
     def _read_state(self, nb: int) -> list:
-        """state rows of the first nb utterances (the one host sync per chunk); raises if the persistent kernel reported a
-        barrier timeout."""
-        rows = self._stsync.tolist()
-        if self._xcd_ok:
-            self._check_xcd()
-        if self.persistent and rows[MAX_BATCH][1] != 0:
-            raise _lib.CovomixHipError("cvx_t2s_decode_persistent: a grid barrier timed out (a block was not resident); the decoded "
-                                       "tokens of this chunk are invalid - set CVX_T2S_PERSISTENT=0 to use the per-launch path")
-        return rows[:nb]
+        """state rows of the first nb utterances (synchronises the current stream)."""
+        return self.buf["state"].tolist()[:nb]
+
+    def _decode_chunks(self, temperature: float, nb: int, max_len: int, cfg_scale: float, watch, ignore_eos: bool = False) -> list:
+        """Graph-replayed chunks of CHUNK token steps until every utterance slot in `watch` has sampled its eos (or max_len steps).
+        The host looks at the eos flags ONE CHUNK BEHIND the device: the state record of chunk i travels to pinned host memory by an
+        asynchronous copy enqueued between the replays of chunks i and i + 1, and is examined while chunk i + 1 runs - the decode
+        chain never waits for a host round trip (nor for a host thread that is waiting for the interpreter lock while another thread
+        drives the acoustic solve, pipeline.py); the price is at most one chunk decoded past the last eos (masked afterwards like every
+        token behind an eos).  Returns the final state rows."""
+        if self._pin is None:
+            self._pin = [torch.empty(MAX_BATCH, 4, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        steps, i, pending = 0, 0, None
+        while steps < max_len:
+            self._run_chunk(temperature, nb, cfg_scale)
+            steps += CHUNK
+            self._pin[i & 1].copy_(self.buf["state"], non_blocking=True)
+            self._pin_ev[i & 1].record()
+            if pending is not None:
+                self._pin_ev[pending].synchronize()
+                st = self._pin[pending].tolist()
+                if all(st[r][1] for r in watch) and not ignore_eos:
+                    break
+            pending = i & 1
+            i += 1
+        return self._read_state(nb)
 
     def _run_chunk(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0) -> None:
-        """CHUNK token steps on the current stream (one persistent launch, or a graph replay of the per-launch path)."""
-        if self.persistent or self._use_xcd(cfg_scale):
-            self._steps(temperature, batch, CHUNK, cfg_scale)
-            return
-
+        """CHUNK token steps on the current stream (a graph replay of the per-launch path)."""
         def launch():
             _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), CHUNK,
                                                         torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
         if os.environ.get("CVX_GRAPH", "1") != "1":
             launch()
             return
-        g = self._graphs.get((temperature, batch, cfg_scale))
+        key = (temperature, batch, cfg_scale, ops.stream_cus())   # (the kernels' shape follows the CUs the stream owns)
+        g = self._graphs.get(key)
         if g is None:
             saved = {k: v.clone() for k, v in self.buf.items()}
             caches = [(L["k_cache"].clone(), L["v_cache"].clone()) for L in self.dec]
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                launch()                                   # warm-up outside capture (module load, attributes)
-            torch.cuda.current_stream().wait_stream(side)
+            launch()                                       # warm-up outside capture (module load, attributes)
+            cur = torch.cuda.current_stream()
+            if self._cap is None:
+                self._cap = torch.cuda.Stream(device=self.device)
+            ops.saturation_share(cur, self._cap)           # (the capture stream belongs to this call: flag and CU count of `cur`)
             with ops.CAPTURE_GATE.exclusive():             # (no other entry point of the package syncs / copies meanwhile)
-                torch.cuda.current_stream().synchronize()
+                cur.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
                     launch()
             for k, v in saved.items():                     # capture does not execute, the warm-up did: restore
                 self.buf[k].copy_(v)
             for L, (kc, vc) in zip(self.dec, caches):
                 L["k_cache"].copy_(kc); L["v_cache"].copy_(vc)
-            if len(self._graphs) >= 4:
+            if len(self._graphs) >= 6:
                 self._graphs.clear()
-            self._graphs[(temperature, batch, cfg_scale)] = g
+            self._graphs[key] = g
         g.replay()
 
     @ops.gated
     @torch.no_grad()          # (not inference_mode: tensors torch creates lazily during the first graph capture,
                               #  e.g. the generator's graph-safe state, would become inference tensors)
     def generate_batch(self, sources, uniforms=None, max_length: Optional[int] = None, temperature: float = 1.0,
-                       generator: Optional[torch.Generator] = None, collect_logits: bool = False, cond_scale: float = 1.0):
+                       generator: Optional[torch.Generator] = None, collect_logits: bool = False, cond_scale: float = 1.0,
+                       ignore_eos: bool = False):
         """Decode up to MAX_BATCH utterances together.  sources: list of [n] / [1, n] id tensors; uniforms: optional list
         of [steps, streams, vocab] tensors (one per utterance).  Returns a list of (flat tokens, streams[, logits])
         tuples, each exactly what `generate` returns for that utterance alone.
+        ignore_eos (benchmarks: a fixed amount of work): decode max_length steps whatever is sampled; `streams` then holds all of them.
         cond_scale > 1: classifier-free guidance (text2semantic.py:780-792; one-output models, up to MAX_BATCH / 2 utterances):
         every utterance takes two decode slots - the text context and the context masked out (cross-attention then sees the
         learned null key / value only) - and each step samples from null + (cond - null) * cond_scale; logits returned under
-        collect_logits are the conditional slot's (pre-combination)."""
+        collect_logits are the COMBINED ones, null + (cond - null) * cond_scale (what the reference filters and samples from)."""
         d, b = self.d, self.buf
         S, V = d["streams"], d["vocab"]
         cfg = float(cond_scale) > 1.0
@@ -309,24 +294,20 @@ class TextToSemanticDecoder:
                 uview[:, i].copy_(u[:max_len])
         b["x"][:nb].copy_(self.start[None, :].expand(nb, -1))
         b["state"].copy_(torch.tensor([[0, 0, 0, ctx[i] if i < nb else 1] for i in range(MAX_BATCH)], dtype=torch.int32))
-        steps = 0
         logits = []
-        while steps < max_len:
-            if collect_logits:
+        if collect_logits:                                              # (tests: one step at a time without a graph)
+            for _ in range(max_len):
                 self._steps(float(temperature), nb, 1)
                 logits.append(b["logits"][:nb].clone())
-                steps += 1
-            else:
-                self._run_chunk(float(temperature), nb)
-                steps += CHUNK
-            st = self._read_state(nb)                                   # the only host sync: once per CHUNK tokens
-            if all(row[1] for row in st):
-                break
-        st = self._read_state(nb)
+                st = self._read_state(nb)
+                if all(row[1] for row in st) and not ignore_eos:
+                    break
+        else:
+            st = self._decode_chunks(float(temperature), nb, max_len, 1.0, range(nb), ignore_eos)
         eos = V - 1
         out = []
         for i in range(nb):
-            length = min(st[i][2] if st[i][1] and st[i][2] <= max_len else max_len, max_len)
+            length = min(st[i][2] if st[i][1] and st[i][2] <= max_len and not ignore_eos else max_len, max_len)
             streams = b["tokens"][i, :, :length].clone()
             after = (streams == eos).cumsum(dim=-1) > 0                  # mask_after_eos (text2semantic.py:73-76)
             after = torch.nn.functional.pad(after, (1, -1), value=False)
@@ -368,20 +349,17 @@ class TextToSemanticDecoder:
                 uview[:, 2 * u_].copy_(u[:max_len])
         b["x"][:nb].copy_(self.start[None, :].expand(nb, -1))
         b["state"].copy_(torch.tensor([[0, 0, 0, ctx[i] if i < nb else 1] for i in range(MAX_BATCH)], dtype=torch.int32))
-        steps, logits = 0, []
-        while steps < max_len:
-            if collect_logits:
+        logits = []
+        if collect_logits:
+            for _ in range(max_len):
                 self._steps(float(temperature), nb, 1, cond_scale)
                 lg = b["logits"][:nb].clone()
                 logits.append(lg[1::2] + (lg[0::2] - lg[1::2]) * cond_scale)
-                steps += 1
-            else:
-                self._run_chunk(float(temperature), nb, cond_scale)
-                steps += CHUNK
-            st = self._read_state(nb)
-            if all(st[2 * u_][1] for u_ in range(nu)):
-                break
-        st = self._read_state(nb)
+                st = self._read_state(nb)
+                if all(st[2 * u_][1] for u_ in range(nu)):
+                    break
+        else:
+            st = self._decode_chunks(float(temperature), nb, max_len, cond_scale, [2 * u_ for u_ in range(nu)])
         eos, out = V - 1, []
         for u_ in range(nu):
             i = 2 * u_

@@ -508,3 +508,47 @@ def test_c5_pipeline_eight_dialogues_64nfe(tmp_path, monkeypatch):
             assert err.max() <= 64 and (err > 2).mean() < 0.01, (nm, err.max(), (err > 2).mean())
             checked += 1
     assert checked == 3 and n == written and written >= 6
+
+
+def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
+    """--pipeline on (text2semantic of the next utterances on the CU-masked side stream under the solve of the current batch,
+    covomix_amd/pipeline.py) writes BIT-IDENTICAL wav files to --pipeline serial (the same batches on the same two streams, one
+    after the other); --pipeline off (decode everything, one global packing: other batch compositions) agrees within 2 LSB.
+    20 dialogues = three text2semantic groups, small --max_frames = several acoustic batches with carried-over leftovers."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd import generation
+    from scipy.io.wavfile import read
+    import warnings
+    tmp = str(tmp_path)
+    _write_fixture(tmp, "vomix")
+    shapes = syn.t2s_param_shapes(two_output=True, dim=64, dim_target=128, source_depth=2, target_depth=2, heads=1, num_text=200)
+    tsd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(shapes, seed=0).items()}
+    torch.save({"state_dict": {"cfm_wrapper.model." + k: v for k, v in tsd.items()},
+                "hyper_parameters": {"text2semantic": True, "text2semantic_two_output": True}}, os.path.join(tmp, "t2s.ckpt"))
+    tdir, pdir = os.path.join(tmp, "text"), os.path.join(tmp, "prompt")
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(12)
+    names = [f"dlg{i:02d}" for i in range(20)]
+    for i, n in enumerate(names):
+        for suf in ("_1", "_2"):
+            plen = 12 + (5 * i) % 17
+            np.save(os.path.join(pdir, f"{n}{suf}.hubert_code.npy"), g.randint(0, 510, size=plen))
+            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), (g.randn(80, plen) * 2 - 6).astype(np.float32))
+        np.save(os.path.join(tdir, f"{n}.text_ids.npy"), g.randint(1, 199, size=(1, 4 + i % 7)).astype(np.int64))
+    out = {}
+    for mode in ("on", "serial", "off"):
+        sdir = os.path.join(tmp, "out_" + mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            n = generation.run(True, ["--t2s_ckpt", os.path.join(tmp, "t2s.ckpt"), "--acous_ckpt", os.path.join(tmp, "acous.ckpt"),
+                                      "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir, "--prompt_dir", pdir,
+                                      "--saved_dir", sdir, "--mode", "covomix", "--seed", "30", "--nfe", "8", "--max_frames", "300",
+                                      "--pipeline", mode])
+        assert generation.run.last_stats["pipeline"] == mode
+        out[mode] = {nm: read(os.path.join(sdir, nm + ".wav"))[1] for nm in names if os.path.isfile(os.path.join(sdir, nm + ".wav"))}
+        assert n == len(out[mode]) and n >= 15
+    assert out["on"].keys() == out["serial"].keys() == out["off"].keys()
+    for nm in out["on"]:
+        assert np.array_equal(out["on"][nm], out["serial"][nm]), nm
+        assert out["on"][nm].shape == out["off"][nm].shape
+        assert np.abs(out["on"][nm].astype(np.int32) - out["off"][nm].astype(np.int32)).max() <= 2, nm

@@ -161,41 +161,6 @@ def test_dwconv31(ops, Bt, T, C):
     assert rel_l2(y, ref) < TOL
 
 
-@pytest.mark.parametrize("Bt,T,C,K", [(2, 1000, 1024, 80), (3, 97, 128, 80), (1, 31, 64, 80), (2, 300, 256, 64), (1, 5, 64, 8)])
-def test_embed_conv31_fused(ops, Bt, T, C, K):
-    """to_embed's state columns + ConvPositionEmbed in one launch vs fp64 and vs the two-launch form it replaces (GEMM with the
-    base as residual, then the depthwise convolution); w_embed is a column slice of a wider matrix, as in the model."""
-    x, base = randn(Bt * T, K, seed=43), randn(Bt * T, C, seed=44)
-    w_full = randn(C, K + 48, seed=45) / math.sqrt(K)
-    dw, db = randn(C, 31, seed=46) / 5, randn(C, seed=47)
-    y = torch.full((Bt * T, C), float("nan"), device=dev())
-    ops.embed_conv31(x, w_full, base, dw, db, y, Bt, T)
-    h0 = (x.double() @ w_full[:, :K].double().t() + base.double()).view(Bt, T, C)
-    ref = F.gelu(F.conv1d(h0.transpose(1, 2), dw.double()[:, None, :], db.double(), padding=15, groups=C)).transpose(1, 2) + h0
-    assert rel_l2(y.view(Bt, T, C), ref) < TOL
-    h0f, y2 = torch.empty(Bt * T, C, device=dev()), torch.empty(Bt * T, C, device=dev())
-    ops.gemm(x, w_full[:, :K], h0f, residual=base)
-    ops.dwconv31_gelu_res(h0f, dw, db, y2, Bt, T)
-    assert rel_l2(y, y2.double()) < 1e-6
-
-
-def test_embed_conv31_fused_ragged(ops):
-    """Packed sequences of different length: each equals its own single-sequence call (zero padding at ITS ends)."""
-    C, K, lens = 128, 80, [130, 7, 98, 99, 260]
-    rg = ops.Ragged(lens, dev())
-    M = sum(lens)
-    x, base = randn(M, K, seed=48), randn(M, C, seed=49)
-    w, dw, db = randn(C, K, seed=45) / math.sqrt(K), randn(C, 31, seed=46) / 5, randn(C, seed=47)
-    y = torch.full((M, C), float("nan"), device=dev())
-    ops.embed_conv31(x, w, base, dw, db, y, len(lens), max(lens), ragged=rg)
-    r = 0
-    for L in lens:
-        one = torch.empty(L, C, device=dev())
-        ops.embed_conv31(x[r:r + L].contiguous(), w, base[r:r + L].contiguous(), dw, db, one, 1, L)
-        assert torch.equal(y[r:r + L], one)
-        r += L
-
-
 @pytest.mark.parametrize("M,N,K,act", [(32, 32768, 1024, 0), (7, 1000, 512, 2), (1, 9, 64, 0), (32, 130, 1024, 1), (20, 4096, 264, 0), (32, 2048, 4096, 0), (5, 333, 1032, 2)])
 def test_gemm_skinny(ops, M, N, K, act):
     """The weight-streaming GEMM for a handful of rows vs fp64 (odd N: the last wave owns one row; K not a multiple of 128)."""
@@ -726,8 +691,8 @@ def test_interleaved_activation_pairs_end_to_end(ops):
 
 @pytest.mark.parametrize("M", [2100, 2304])
 def test_gemm_large_problem_kernels_every_epilogue(ops, M):
-    """The three large-problem kernels behind cvx_gemm_f16x3 for interleaved operands - eight-phase on the 16x16x32 MFMA
-    (default), eight-phase on 32x32x16 (flag 2), two-stage (flag 1) - on every epilogue class of the transformer block,
+    """The large-problem kernel behind cvx_gemm_f16x3 for interleaved operands (eight-phase, 16x16x32 MFMA; pinned with flag 16)
+    and the library's own choice at this size (the medium-problem kernel) on every epilogue class of the transformer block,
     against fp64: QKV (RoPE + split q|k + transposed split v, T % 4 == 0 and != 0), residual (+ bias, + split twin),
     bias + GELU + split, K-split (skip combiner) + bias, plain; M = 2100 leaves a ragged last row panel."""
     dev_ = dev()
@@ -743,7 +708,7 @@ def test_gemm_large_problem_kernels_every_epilogue(ops, M):
         return w, ws, ops.split_f16_interleaved(ws)
     saved = ops._GEMM_FLAGS
     try:
-        for flags in (16, 0, 2, 1):              # large-problem 16x16 kernel pinned / the library's choice (medium kernel here) / 32x32 / two-stage
+        for flags in (16, 0):                    # large-problem kernel pinned / the library's choice (medium kernel here)
             ops._GEMM_FLAGS = flags
             # plain + bias / residual / twin
             w, ws, wil = weights(1024)
@@ -815,7 +780,7 @@ def test_gemm_large_problem_kernels_n_not_multiple_of_256(ops):
     xs = il.dense()[0].double() + il.dense()[1].double()
     saved = ops._GEMM_FLAGS
     try:
-        for flags in (16, 0, 2, 1):
+        for flags in (16, 0):
             ops._GEMM_FLAGS = flags
             for N in (576, 640):
                 w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev_)
@@ -835,7 +800,7 @@ def test_gemm_large_problem_kernels_n_not_multiple_of_256(ops):
                 assert rel_l2(oh[:M, :N].double() + ol[:M, :N].double(), F.gelu(ref + b.double())) < 1e-6, (flags, N)
                 assert bool(torch.isnan(oh[:, N:]).all()) and bool(torch.isnan(ol[:, N:]).all()) and bool(torch.isnan(oh[M]).all()), (flags, N)
                 assert bool((guard == 7.0).all())
-            # QKV with 5 heads: N = 960, rope_cols = 640 (the 16x16 kernel declines; the 32x32 / two-stage kernels take it)
+            # QKV with 5 heads: N = 960, rope_cols = 640 (the large kernel declines - RoPE groups of 256 columns; the medium kernel takes it)
             H, T = 5, 700
             Bt = M // T
             Mq = Bt * T

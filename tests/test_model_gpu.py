@@ -172,27 +172,6 @@ def test_full_size_properties():
     assert rel_l2(outp, out[perm.cuda()]) < 1e-5
 
 
-def test_two_chain_schedule_is_bit_identical(monkeypatch):
-    """CVX_CHAINS=2 cuts a large batch into two halves that run as concurrent kernel chains on two streams (opt-in
-    schedule experiment): every row's arithmetic is independent of the partition, so the sampled
-    mel must be BIT-identical to the single-chain run (this is what caught the per-instance fma contraction in the RoPE
-    epilogue)."""
-    from covomix_amd.conditional_model import CoVoMixModel
-    import covomix_amd.synthetic as syn
-    model = CoVoMixModel.from_state_dict(_state("vomix"), nfe=4).eval().to("cuda:0")
-    inp = syn.synthetic_inputs("vomix", 4, 600, 200, seed=11)           # 2 x 4 x 600 rows: halves of 2400 >= 2048
-    args = (inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
-    monkeypatch.setenv("CVX_GRAPH", "0")
-    monkeypatch.setenv("CVX_CHAINS", "1")
-    import covomix_amd.ops as ops
-    monkeypatch.setattr(ops, "_GEMM_FLAGS", ops._GEMM_FLAGS | 16)      # both runs on the large-problem GEMM (the two-chain schedule pins it)
-    one = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
-    monkeypatch.setenv("CVX_CHAINS", "2")
-    two = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
-    torch.cuda.synchronize()
-    assert torch.isfinite(one).all() and torch.equal(one, two)
-
-
 # ---------------------------------------------------------------- opt-in precision="f16" (single-term fp16 operands)
 F16_ROLL_TOL = 1e-3          # BASELINE.json north_star budget: <= 1e-3 rel-L2 on the final mel
 
@@ -295,3 +274,66 @@ def test_vocoder_repeated_calls_are_bit_identical_and_independent_of_the_previou
     gen(loud)
     third = gen(mel).clone()
     assert torch.equal(first, second) and torch.equal(first, third)
+
+
+def test_time_tables_are_cached_per_model_and_grid_not_across_checkpoints(monkeypatch):
+    """Everything that depends on the evaluation times alone (time MLP, adaLN table, activation pre-scales, deferred-norm weight
+    tables - reference acoustic.py:198-204: gamma, beta are functions of the time embedding) is computed once per (VectorField, solver
+    grid) and reused: a second call launches no table kernels and returns the same bits; another grid gets its own entry; OTHER
+    WEIGHTS (a new checkpoint in the same model object: EMA on / off) never see the old tables; at most TIME_CACHE grids stay resident."""
+    from covomix_amd.conditional_model import CoVoMixModel
+    import covomix_amd.acoustic as ac
+    import covomix_amd.ops as ops
+    import covomix_amd.synthetic as syn
+    monkeypatch.setattr(ac.VectorField, "DEFER_MIN_ROWS", 2048)          # the deferred-norm tables too (2 x 2 x 600 = 2400 rows)
+    monkeypatch.setattr(ac.VectorField, "DEFER_RULE", False)
+    monkeypatch.setenv("CVX_GRAPH", "0")
+    sd = _state("vomix")
+    model = CoVoMixModel.from_state_dict(sd, nfe=4).eval().to("cuda:0")
+    inp = syn.synthetic_inputs("vomix", 2, 600, 200, seed=5)
+    args = (inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda())
+    calls = {"skinny": 0, "colscale": 0}
+    real_sk, real_cs = ops.gemm_skinny, ops.split_f16_colscale_il
+
+    def sk(*a, **k):
+        calls["skinny"] += 1
+        return real_sk(*a, **k)
+
+    def cs(*a, **k):
+        calls["colscale"] += 1
+        return real_cs(*a, **k)
+    monkeypatch.setattr(ops, "gemm_skinny", sk)
+    monkeypatch.setattr(ops, "split_f16_colscale_il", cs)
+    one = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    f = model._get_field()
+    assert list(f._time_cache) == [(4, "midpoint")] and f._time_cache[(4, "midpoint")]["dn"] is not None
+    first = dict(calls)
+    assert first["skinny"] > 0 and first["colscale"] == 15
+    two = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    assert calls == first and torch.equal(one, two)                          # nothing rebuilt, same bits
+    model.nfe = 2
+    model.synthesis_sample(*args, 0.7, y0=inp["y0"])
+    assert list(f._time_cache) == [(4, "midpoint"), (2, "midpoint")] and calls["colscale"] == 30
+    model.nfe = 6
+    model.synthesis_sample(*args, 0.7, y0=inp["y0"])                         # a third grid evicts the least recently used one
+    assert list(f._time_cache) == [(2, "midpoint"), (6, "midpoint")]
+    assert all(k[2] in f._time_cache for k in f._dn_bufs)
+    model.nfe = 4
+    again = model.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()         # rebuilt after the eviction: same bits
+    assert torch.equal(one, again)
+    # other weights: a fresh field, fresh tables - the result is the other checkpoint's, bit for bit what a new model object gives
+    sd2 = {k: (v * 1.25 if "to_gamma" in k or "to_beta" in k else v) for k, v in sd.items()}
+    other = CoVoMixModel.from_state_dict(sd2, nfe=4).eval().to("cuda:0")
+    want = other.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    assert not torch.equal(want, one)
+    assert other._get_field() is not f and list(other._get_field()._time_cache) == [(4, "midpoint")]
+    # ... and inside ONE model object: switching the weights (EMA off -> the raw state dict) drops the field with its tables
+    from covomix_amd.conditional_model import parameter_order
+    both = CoVoMixModel(sd, ema_shadow=[sd2[n] for n in parameter_order(sd.keys())]).eval().to("cuda:0")
+    both.nfe = 4
+    ema_out = both.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    f_ema = both._get_field()
+    both.eval(no_ema=True)
+    raw_out = both.synthesis_sample(*args, 0.7, y0=inp["y0"]).clone()
+    assert both._get_field() is not f_ema
+    assert torch.equal(ema_out, want) and torch.equal(raw_out, one)

@@ -137,78 +137,11 @@ def test_batched_decode_is_bit_identical_to_one_by_one(case):
         assert torch.equal(r[0].cpu(), torch.from_numpy(g["tokens"]))
 
 
-def test_persistent_kernel_is_bit_identical_to_per_launch_path(case):
-    """cvx_t2s_decode_persistent (one launch per CHUNK steps, grid barriers, next-phase weight prefetch; opt-in) against
-    cvx_t2s_decode_steps (34 launches per step, the default): same device code per phase, so step logits and tokens must agree BITWISE -
-    batch 1 (stepwise with logits, and chunked) and a full batch of 8 with different texts."""
-    name, g, model = case
-    src, uni = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
-    S, V = uni.shape[1], uni.shape[-1]
-    gen = torch.Generator().manual_seed(23)
-    texts = [src, src[:, :5], torch.cat((src, src[:, :7]), dim=1), src[:, 2:9], src[:, 1:], src[:, :3], src, src[:, 4:]]
-    unis = [uni] + [torch.rand(uni.shape[0], S, V, generator=gen) for _ in texts[1:]]
-    assert not model.persistent
-    out = {}
-    saved_xcd, model.xcd = model.xcd, False          # (the reference point of this test is the per-launch path)
-    try:
-        for mode in (True, False):
-            model.persistent = mode
-            out[mode] = (model.generate(src, uniforms=uni, collect_logits=True),        # single steps
-                         model.generate(src, uniforms=uni, return_streams=True),         # chunks of 16 steps
-                         model.generate_batch(texts, unis),
-                         model.generate_batch(texts[:3], unis[:3], collect_logits=True))
-    finally:
-        model.persistent = False
-        model.xcd = saved_xcd
-    p, q = out[True], out[False]
-    assert torch.equal(p[0][2], q[0][2]) and torch.equal(p[0][0], q[0][0])             # logits and tokens, step by step
-    assert torch.equal(p[0][0].cpu(), torch.from_numpy(g["tokens"]))
-    assert torch.equal(p[1][0], q[1][0]) and torch.equal(p[1][1], q[1][1])
-    for a, b in zip(p[2], q[2]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for a, b in zip(p[3], q[3]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
-
-
-def test_one_xcd_per_utterance_is_bit_identical_to_per_launch_path(case):
-    """cvx_t2s_decode_xcd (round 4: 8 groups of 32 blocks, an utterance per XCD, L2-local phase barriers without cache maintenance,
-    every activation read bypassing L1) against cvx_t2s_decode_steps: step logits and tokens BITWISE, batch 1 (stepwise and
-    chunked) and a full batch of 8 different texts; the placement probe must have accepted the XCD mode on this box."""
-    name, g, model = case
-    model._xcd_ok = None                                 # (probe again: the mode is opt-in)
-    src, uni = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
-    S, V = uni.shape[1], uni.shape[-1]
-    gen = torch.Generator().manual_seed(29)
-    texts = [src, src[:, :5], torch.cat((src, src[:, :7]), dim=1), src[:, 2:9], src[:, 1:], src[:, :3], src, src[:, 4:]]
-    unis = [uni] + [torch.rand(uni.shape[0], S, V, generator=gen) for _ in texts[1:]]
-    out = {}
-    saved = model.xcd
-    try:
-        for mode in (True, False):
-            model.xcd = mode
-            out[mode] = (model.generate(src, uniforms=uni, collect_logits=True),
-                         model.generate(src, uniforms=uni, return_streams=True),
-                         model.generate_batch(texts, unis),
-                         model.generate_batch(texts[:3], unis[:3], collect_logits=True))
-            if mode:
-                assert model._xcd_ok is True, "the placement probe refused the one-XCD-per-utterance mode on this box"
-    finally:
-        model.xcd = saved
-    p, q = out[True], out[False]
-    assert torch.equal(p[0][2], q[0][2]) and torch.equal(p[0][0], q[0][0])
-    assert torch.equal(p[0][0].cpu(), torch.from_numpy(g["tokens"]))
-    assert torch.equal(p[1][0], q[1][0]) and torch.equal(p[1][1], q[1][1])
-    for a, b in zip(p[2], q[2]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for a, b in zip(p[3], q[3]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
-
-
 @pytest.mark.parametrize("name", ["cosingle_small", "cosingle"])
 def test_classifier_free_guidance_vs_reference_golden(name):
     """cond_scale = 1.5 (text2semantic.py:780-792): tokens sampled from null + (cond - null) * scale, BIT-EXACT against the
     reference built with cond_drop_prob > 0 (tests/golden/t2s_*_cfg.npz; top-2 margin >= 2e-2), the combined logits against the
-    oracle's, stepwise, graph-replayed and persistent paths alike; two utterances in one guided batch decode like each alone."""
+    oracle's, stepwise and graph-replayed alike; two utterances in one guided batch decode like each alone."""
     from covomix_amd.t2s import TextToSemanticDecoder
     _, sd = load_case(name)
     g = np.load(os.path.join(GOLDEN, f"t2s_{name}_cfg.npz"))

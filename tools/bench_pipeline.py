@@ -1,62 +1,72 @@
 #!/usr/bin/env python3
-"""Dev: BASELINE config 5 in one process - CoMix text2semantic AR decode + VoMix 64-NFE + HiFi-GAN for 8 dialogues per
-GPU (recipe weights, synthetic inputs).  Stage times and dialogues/s; the text2semantic stage runs the utterances one
-after the other at batch 1 like the reference scripts do.  TOKENS = decoded steps per utterance (eos ignored so the
-work is fixed), T = TOKENS + 400 prompt frames."""
-import os, sys, time, contextlib, torch
+"""Dev: BASELINE config 5 in one process - CoMix text2semantic AR decode + VoMix 64-NFE + HiFi-GAN (covomix_amd/config5.py; recipe
+weights, synthetic inputs, TOKENS decoded steps per dialogue with the eos ignored so the work is fixed, T = TOKENS + 400 prompt frames).
+Three schedules over the same DIALOGUES dialogues (default 56; text2semantic always decodes 8 at a time), dialogues/s each:
+  serial    the round-4 schedule: both stages on one plain stream, 8 dialogues per acoustic batch (whole GEMM rounds on 256 CUs);
+  alternate both stages on the CU partition's streams (224 + 32 CUs), one after the other, 7 per acoustic batch (whole rounds on 224 CUs);
+  pipelined the same calls with the decode of the next dialogues UNDER the solve of the current batch (covomix_amd/pipeline.py)
+and the bit-identity of `alternate` and `pipelined` (tokens and PCM), tokens identical / PCM within 1 LSB against `serial`."""
+import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import covomix_amd.synthetic as syn
+from covomix_amd.config5 import Config5
 from covomix_amd import ops
-from covomix_amd.conditional_model import CoVoMixModel
-from covomix_amd.t2s import TextToSemanticDecoder, CHUNK
-from covomix_amd.vocoder import AttrDict, Generator
+
 dev = torch.device("cuda:0")
-B, TOK, PROMPT = 8, int(os.environ.get("TOKENS", "608")), 400
-T = TOK + PROMPT
-with contextlib.redirect_stdout(sys.stderr):
-    t2s = TextToSemanticDecoder({k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(
-        syn.t2s_param_shapes(two_output=True, dim=512, dim_target=1024), seed=0).items()}, dev)
-    sd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.acoustic_param_shapes(), seed=0).items()}
-    sd["transformer.rotary_emb.inv_freq"] = torch.from_numpy(syn.rotary_inv_freq(64))
-    model = CoVoMixModel.from_state_dict(sd, nfe=64).eval().to(dev)
-    gen = Generator(AttrDict(syn.HIFIGAN_COVOMIX_CONFIG)).to(dev)
-    gen.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(syn.HIFIGAN_COVOMIX_CONFIG), seed=0).items()})
-    gen.eval(); gen.remove_weight_norm()
-inp = syn.synthetic_inputs("vomix", B, T, PROMPT, seed=1)
-ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
-texts = [torch.randint(1, 30000, (1, 64)) for _ in range(B)]
-
-T2S_BATCH = int(os.environ.get("T2S_BATCH", "8"))          # utterances decoded together (1 = one by one, like the reference)
+TOK = int(os.environ.get("TOKENS", "608"))
+ND = int(os.environ.get("DIALOGUES", "56"))
+B_SERIAL, B_PIPE = int(os.environ.get("B_SERIAL", "8")), int(os.environ.get("B_PIPE", "7"))
+c5 = Config5(dev, tokens=TOK)
+part = ops.cu_partition(dev)
+print(f"config 5, {ND} dialogues, T = {c5.T} frames ({TOK} decoded steps x 2 streams, 64 NFE); CU partition main {part.n_main} / side {part.n_side}", flush=True)
 
 
-def t2s_stage():
-    for g0 in range(0, B, T2S_BATCH):
-        group = texts[g0:g0 + T2S_BATCH]
-        nb = len(group)
-        rows = []
-        for i, src in enumerate(group):
-            enc = t2s.encode(src)
-            rows.append(enc.shape[0] + 1)
-            for L in t2s.dec:
-                L["kv_c"][i, 0].copy_(L["null"]); ops.gemm(enc, L["wkv_c"], L["kv_c"][i, 1:enc.shape[0] + 1])
-        t2s.buf["uniforms"].uniform_(1e-6, 1 - 1e-6)
-        t2s.buf["x"][:nb].copy_(t2s.start[None, :].expand(nb, -1))
-        t2s.buf["state"].copy_(torch.tensor([[0, 0, 0, rows[i] if i < nb else 1] for i in range(8)], dtype=torch.int32))
-        for _ in range(TOK // CHUNK):
-            t2s._run_chunk(1.0, nb); t2s.buf["state"].tolist()
-
-
-def acoustic_stage():
-    return model.synthesis_sample(ids, cond, mask, 0.7)
-
-def vocoder_stage(mel):
-    return ops.wav_to_int16(gen(mel.permute(0, 2, 1).contiguous()).squeeze(1).contiguous())
-
-def timed(fn, *a):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(*a); torch.cuda.synchronize()
+def timed(fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
     return r, time.perf_counter() - t0
-t2s_stage(); mel = acoustic_stage(); vocoder_stage(mel)          # warm-up (graph capture, buffers)
-_, a = timed(t2s_stage); mel, b = timed(acoustic_stage); _, c = timed(vocoder_stage, mel)
-tot = a + b + c
-print(f"config 5 per GPU, {B} dialogues, T={T} frames ({TOK} decoded steps x 2 streams): text2semantic {a*1e3:.0f} ms, "
-      f"(T2S batch {T2S_BATCH}) VoMix 64-NFE {b*1e3:.0f} ms, HiFi-GAN {c*1e3:.0f} ms -> {B/tot:.2f} dialogues/s = {B*T/tot:.0f} mel-frames/s end to end")
+
+
+def stage_times(B, s1=None, s2=None):
+    """text2semantic of 8 dialogues / acoustic + vocoder of B, each alone on its stream (ms)."""
+    cur = torch.cuda.current_stream()
+    with torch.cuda.stream(s1 or cur):
+        x, a = timed(lambda: c5.stage1([c5.dialogue(1000 + j) for j in range(8)]))
+    with torch.cuda.stream(s2 or cur):
+        _, b = timed(lambda: c5.stage2(x[:B]))
+    return a * 1e3, b * 1e3
+
+
+# warm-up of every shape on every stream (graph captures, workspaces, deferred-norm tables)
+c5.run(8, B_SERIAL, overlap=False, partitioned=False)
+c5.run(16, B_PIPE, overlap=False)
+c5.run(16, B_PIPE, overlap=True)
+
+ser, t = timed(lambda: c5.run(ND, B_SERIAL, overlap=False, partitioned=False))
+a, b = stage_times(B_SERIAL)
+print(f"serial    (one plain stream, {B_SERIAL} per solve): {ND / t:6.2f} dialogues/s = {ND * c5.T / t:7.0f} mel-frames/s  "
+      f"[text2semantic of 8: {a:.0f} ms; solve + vocoder of {B_SERIAL}: {b:.0f} ms]", flush=True)
+alt, t = timed(lambda: c5.run(ND, B_PIPE, overlap=False))
+a, b = stage_times(B_PIPE, part.side, part.main)
+print(f"alternate (CU partition, {B_PIPE} per solve):       {ND / t:6.2f} dialogues/s = {ND * c5.T / t:7.0f} mel-frames/s  "
+      f"[text2semantic of 8 on {part.n_side} CUs: {a:.0f} ms; solve + vocoder of {B_PIPE} on {part.n_main} CUs: {b:.0f} ms]", flush=True)
+walls = {"stage1": [], "stage2": []}
+for name in walls:                                    # wall time of every stage call inside the pipelined run (host view)
+    def wrap(fn, name=name):
+        def f(x):
+            t0 = time.perf_counter(); r = fn(x); torch.cuda.current_stream().synchronize(); walls[name].append(time.perf_counter() - t0)
+            return r
+        return f
+    setattr(c5, name, wrap(getattr(c5, name)))
+pip, t = timed(lambda: c5.run(ND, B_PIPE, overlap=True))
+for name in walls:
+    setattr(c5, name, getattr(Config5, name).__get__(c5))
+ms = lambda v: "/".join(f"{x * 1e3:.0f}" for x in v)
+print(f"pipelined (CU partition, {B_PIPE} per solve):       {ND / t:6.2f} dialogues/s = {ND * c5.T / t:7.0f} mel-frames/s  "
+      f"[wall per call, ms: text2semantic {ms(walls['stage1'])}; solve + vocoder {ms(walls['stage2'])}]", flush=True)
+steady = sum(walls["stage2"][1:-1]) / max(len(walls["stage2"]) - 2, 1)
+print(f"          steady state (a full solve + vocoder call per {B_PIPE} dialogues, the decode hidden): {B_PIPE / steady:.2f} dialogues/s; "
+      f"this run pays one un-overlapped decode ({walls['stage1'][0] * 1e3:.0f} ms) to fill the pipeline")
+same = all(torch.equal(x["streams"], y["streams"]) and torch.equal(x["pcm"], y["pcm"]) for x, y in zip(alt, pip))
+print("tokens and PCM of the pipelined schedule bit-identical to the alternate one:", same)
+tok_same = all(torch.equal(x["streams"], y["streams"]) for x, y in zip(ser, pip))
+lsb = max(int((x["pcm"].int() - y["pcm"].int()).abs().max()) for x, y in zip(ser, pip))
+print(f"against the serial single-stream schedule: tokens identical: {tok_same}; PCM max |difference| {lsb} LSB")

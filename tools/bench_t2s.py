@@ -6,8 +6,12 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import covomix_amd.synthetic as syn
 from covomix_amd.t2s import TextToSemanticDecoder, CHUNK
+from covomix_amd import ops
 dev = torch.device("cuda:0")
 N = int(os.environ.get("TOKENS", "512"))
+if os.environ.get("SIDE", "0") == "1":          # on the 32-CU side stream of the CU partition (pipeline.py)
+    torch.cuda.set_stream(ops.cu_partition(dev).side)
+    print("on the side stream of the CU partition:", ops.stream_cus(), "CUs")
 for name, kw in [("cosingle", dict(two_output=False, dim=512, dim_target=512)), ("comix", dict(two_output=True, dim=512, dim_target=1024))]:
     sd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(syn.t2s_param_shapes(**kw), seed=0).items()}
     m = TextToSemanticDecoder(sd, dev, max_length=2048)
