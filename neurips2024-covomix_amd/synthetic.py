@@ -146,11 +146,28 @@ def _rule(name: str, shape) -> Tuple[float, float]:
     return 1.0 / np.sqrt(max(fan_in, 1)), 0.0
 
 
+_ARRAY_CACHE: "OrderedDict" = OrderedDict()      # (name, shape, seed) -> array: the recipe is deterministic and RandomState is slow
+_ARRAY_CACHE_BYTES = [0]                          # (the 250 M parameters of VoMix take 3-10 s; tests and bench.py ask for them again and again)
+_ARRAY_CACHE_LIMIT = 5 << 30
+
+
 def synth_array(name: str, shape, seed: int = 0) -> np.ndarray:
+    """One recipe tensor.  Results are kept in a process-wide cache of at most 5 GB (least recently used first out) and the SAME
+    array is handed out again: treat it as read-only (copy before writing into it - every caller in this repo does)."""
+    key = (name, tuple(shape), int(seed))
+    hit = _ARRAY_CACHE.get(key)
+    if hit is not None:
+        _ARRAY_CACHE.move_to_end(key)
+        return hit
     rs = np.random.RandomState((zlib.crc32(name.encode()) ^ seed) & 0xFFFFFFFF)
     scale, shift = _rule(name, tuple(shape))
-    a = rs.standard_normal(tuple(shape)) * scale + shift
-    return a.astype(np.float32)
+    a = (rs.standard_normal(tuple(shape)) * scale + shift).astype(np.float32)
+    _ARRAY_CACHE[key] = a
+    _ARRAY_CACHE_BYTES[0] += a.nbytes
+    while _ARRAY_CACHE_BYTES[0] > _ARRAY_CACHE_LIMIT and len(_ARRAY_CACHE) > 1:
+        _, old = _ARRAY_CACHE.popitem(last=False)
+        _ARRAY_CACHE_BYTES[0] -= old.nbytes
+    return a
 
 
 def synth_state_dict(shapes: Shapes, seed: int = 0) -> "Dict[str, np.ndarray]":
