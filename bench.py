@@ -237,6 +237,48 @@ def config2(dev, calls: int = 5):
             "frac": round(500 / dt * flop_per_frame / PEAK_F16_MFMA, 4), "vs_f32_mfma_peak": round(500 / dt * flop_per_frame / PEAK_F32_MFMA, 4)}
 
 
+def config5(dev, dialogues: int = 28):
+    """BASELINE config 5 next to the headline (extra key `c5`, N = 1 only): CoMix text2semantic AR decode (608 steps per dialogue, eos
+    ignored so the work is fixed) + VoMix 64-NFE + HiFi-GAN on 1008-frame dialogues (covomix_amd/config5.py), dialogues/s of
+      serial    - the reference's order of stages (dialogue_generation.py:272-329) on one stream, 8 dialogues per acoustic batch, and
+      pipelined - the decode of the next dialogues on a CU-masked side stream UNDER the solve of the current batch (7 per acoustic
+                  batch: whole GEMM rounds on the 224 CUs the solve keeps; covomix_amd/pipeline.py),
+    with the bit-identity of the pipelined output to the same calls run alternately.  A bounded sample: `dialogues` per schedule."""
+    from covomix_amd.config5 import Config5
+    c5 = Config5(dev)
+    c5.run(8, 8, overlap=False, partitioned=False)            # warm-up of every shape on every stream
+    c5.run(14, 7, overlap=False)
+    c5.run(14, 7, overlap=True)
+
+    def timed(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+    n_ser = max(8, dialogues // 8 * 8)
+    _, ts = timed(lambda: c5.run(n_ser, 8, overlap=False, partitioned=False))
+    alt, ta = timed(lambda: c5.run(dialogues, 7, overlap=False))
+    walls = []
+    inner = c5.stage2
+
+    def stage2(x):
+        t0 = time.perf_counter(); r = inner(x); walls.append(time.perf_counter() - t0)
+        return r
+    c5.stage2 = stage2
+    pip, tp = timed(lambda: c5.run(dialogues, 7, overlap=True))
+    same = all(torch.equal(a["streams"], b["streams"]) and torch.equal(a["pcm"], b["pcm"]) for a, b in zip(alt, pip))
+    steady = sorted(walls[1:])[len(walls[1:]) // 2] if len(walls) > 1 else walls[0]
+    from covomix_amd import ops
+    part = ops.cu_partition(dev)
+    return {"workload": f"CoMix text2semantic (608 steps) + VoMix 64-NFE + HiFi-GAN, T = {c5.T} frames per dialogue, recipe weights",
+            "cu_partition": {"main": part.n_main, "side": part.n_side},
+            "serial_dialogues_per_s": round(n_ser / ts, 3), "serial_dialogues": n_ser,
+            "alternate_dialogues_per_s": round(dialogues / ta, 3),
+            "pipelined_dialogues_per_s": round(dialogues / tp, 3), "pipelined_dialogues": dialogues,
+            "pipelined_mel_frames_per_s": round(dialogues * c5.T / tp, 1),
+            "pipelined_steady_state_dialogues_per_s": round(7 / steady, 3),
+            "speedup_vs_serial": round((dialogues / tp) / (n_ser / ts), 4),
+            "pipelined_bits_equal_alternate": bool(same)}
+
+
 def make_models(dev, rank, world, precision=None):
     import covomix_amd.synthetic as syn
     from covomix_amd import dp
@@ -345,6 +387,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="skip the BASELINE config-2 figure (extra key `c2`, N = 1 only)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE config-5 figure (extra key `c5`, N = 1 only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): 8 utterances per GPU per step.  strong: BASELINE config 4 literally - 64 utterances per step "
                          "dealt over the N ranks (N must divide 8), i.e. 64/N per GPU in batches of 8")
@@ -501,6 +544,10 @@ def main():
         if world == 1 and not args.no_c2 and model_precision == "f16x3":
             with contextlib.redirect_stdout(sys.stderr):
                 out["c2"] = config2(dev)
+        if world == 1 and not args.no_c5 and model_precision == "f16x3":
+            torch.cuda.empty_cache()
+            with contextlib.redirect_stdout(sys.stderr):
+                out["c5"] = config5(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_sd)
         print(json.dumps(out), flush=True)
@@ -508,5 +555,28 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _guarded_main():
+    """main(), and at N > 1 a line that says WHICH rank failed and how when one does (an RCCL abort takes the process down without a
+    Python exception: the launcher's per-rank stderr tails cover that, covomix_amd/dp.launch_ranks; a Python-level failure is reported
+    here) - rank 0 still prints ONE JSON line (value null, the error, what dp.INFO knows about the start-up) so that a failed scaling
+    run is diagnosable from the record alone."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:          # noqa: BLE001
+        import traceback
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        tb = traceback.format_exc()
+        print(f"[bench.py rank {rank}/{world}] FAILED: {type(e).__name__}: {e}\n{tb[-2000:]}", file=sys.stderr, flush=True)
+        if world > 1 and rank == 0:
+            from covomix_amd import dp
+            print(json.dumps({"metric": "mel-frames/sec (VoMix 32-step + HiFi-GAN, Bx1000x80)", "value": None, "unit": "mel-frames/s",
+                              "n_gpus": world, "error": f"rank 0: {type(e).__name__}: {str(e)[:500]}",
+                              "ranks": {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in dp.INFO.items()}}),
+                  flush=True)
+        raise
+
+
 if __name__ == "__main__":
-    main()
+    _guarded_main()

@@ -98,28 +98,18 @@ class VectorField:
             # per solve) - 0.74 ms on the fp32 pipe at the bench shape
             # the adaptive-norm table GEMM - [n evaluation times, dim] x the packed [4 depth dim, dim] matrix: pure weight
             # streaming at 32 rows - 1.35 ms per solve on the fp32 kernel inside the model (cold weights), 0.76 ms here
-            # (rocprofv3; CVX_ADA_F16X3=0 for A/B).  Neither is close to the 134 MB / HBM rate = 30 us: DESIGN 4.4
-            if (precision == "f16x3" and self.ada_w.shape[1] % 32 == 0 and os.environ.get("CVX_ADA_F16X3", "1") == "1"
-                    and os.environ.get("CVX_SKINNY", "1") != "1"):       # (solves of > 32 evaluations build it on demand)
-                self.split["ada"] = ops.split_f16(self.ada_w)
+            # (rocprofv3).  Neither is close to the 134 MB / HBM rate = 30 us: DESIGN 4.4
+            # (solves of more than 32 evaluation times build self.split["ada"] on demand: _time_tables)
             w_rest = sd["to_embed.weight"][:, d["dim_out"]:]
             if precision == "f16x3" and w_rest.shape[1] % 32 == 0:
                 self.w_rest = w_rest.contiguous()
                 self.split["to_embed.rest"] = ops.split_f16(self.w_rest)
         self._init_gain_model()
-        # DEV STUDY (round 4, joules per useful flop): CVX_WLO_BITS = b keeps only the top b significand bits of every weight's lo
-        # half (11 = all, 0 = lo == 0): fewer toggling operand bits in two of the three MFMA products.  Never set by the product.
-        wlo_bits = int(os.environ.get("CVX_WLO_BITS", "11"))
-        if precision == "f16x3" and wlo_bits < 11:
-            keep = torch.tensor(-(1 << (11 - wlo_bits)) if wlo_bits > 0 else 0, dtype=torch.int16, device=device)
-            for k, v in self.split.items():
-                if v[1] is not None:
-                    v[1].view(torch.int16).bitwise_and_(keep)
         # interleaved copies ([hi 32 | lo 32] per K-step: whole cache lines for the DMA) for the large-problem kernel
         self.split_il: Dict[str, tuple] = {}
         self._dn_bufs: Dict[tuple, dict] = {}          # deferred norm: W diag(gamma(t)) pairs per (n, depth, solver grid)
         self._time_cache: Dict[tuple, dict] = {}       # solver grid (nfe, method) -> everything that depends on the evaluation times only
-        if precision == "f16x3" and os.environ.get("CVX_GEMM_WIL", "1") == "1":
+        if precision == "f16x3":
             for k, v in self.split.items():
                 if v[0].shape[0] >= 512 or k == "to_pred.weight":
                     self.split_il[k] = ops.split_f16_interleaved(v)
@@ -247,7 +237,7 @@ class VectorField:
             # GEMM A operands: for the large-problem kernel (M >= 2048, interleaved weights available) as INTERLEAVED pairs
             # ([hi 32 | lo 32] per K-step: whole cache lines for the DMA), otherwise as two separate fp16 tensors
             a16 = h16
-            if lo_too and (ragged_rows or M) >= ops.il_min_rows() and self.split_il and d["dim"] >= 512 and os.environ.get("CVX_GEMM_AIL", "1") == "1":
+            if lo_too and (ragged_rows or M) >= ops.il_min_rows() and self.split_il and d["dim"] >= 512:
                 a16 = lambda rows, cols: ops.SplitIL(rows, cols, dev)
             ws["normed16"], ws["att16"], ws["ff16"] = a16(M, d["dim"]), a16(M, d["heads"] * 64), a16(M, 4 * d["dim"])
             # final norm -> to_pred (N = 80): the medium-problem kernel takes it (interleaved pair; K slices below 2048 rows)
@@ -340,7 +330,7 @@ class VectorField:
         temb = torch.empty(n, d["time_hidden"], dtype=torch.float32, device=self.device)
         # products with n <= 32 rows are weight streaming: cvx_gemm_skinny_f32 (the table, 537 MB of weights: 1.35 ms on the tiled fp32
         # kernel, 0.79 on the split-precision one, 0.25 here)
-        skinny = lambda w: n <= 32 and w.shape[1] % 8 == 0 and os.environ.get("CVX_SKINNY", "1") == "1"
+        skinny = lambda w: n <= 32 and w.shape[1] % 8 == 0
         if skinny(sd["sinu_pos_emb.1.weight"]):
             ops.gemm_skinny(four, sd["sinu_pos_emb.1.weight"], temb, bias=sd["sinu_pos_emb.1.bias"], act=ops.ACT_SILU)
         else:
@@ -348,14 +338,14 @@ class VectorField:
         table = torch.empty(n, self.ada_w.shape[0], dtype=torch.float32, device=self.device)
         if skinny(self.ada_w):
             ops.gemm_skinny(temb, self.ada_w, table, bias=self.ada_b)
-        elif "ada" in self.split or (self.precision == "f16x3" and self.ada_w.shape[1] % 32 == 0 and os.environ.get("CVX_ADA_F16X3", "1") == "1"):
+        elif "ada" in self.split or (self.precision == "f16x3" and self.ada_w.shape[1] % 32 == 0):
             if "ada" not in self.split:
                 self.split["ada"] = ops.split_f16(self.ada_w)
             ops.gemm(temb, self.ada_w, table, bias=self.ada_b, w_split=self.split["ada"], a_split=ops.split_act_f16(temb))
         else:
             ops.gemm(temb, self.ada_w, table, bias=self.ada_b)
         ent = dict(table=table, dn=None)
-        if self.precision in ("f16x3", "f16") and os.environ.get("CVX_ACT_SCALES", "1") == "1":
+        if self.precision in ("f16x3", "f16"):
             S, H, HS = self._activation_scales(table)
             p0, K = S.data_ptr(), self.N_KINDS
             ent.update(S=S, H=H, HS=HS, sp=[[[p0 + 4 * ((e * d["depth"] + i) * K + k) for k in range(K)] for i in range(d["depth"])] for e in range(n)])
@@ -370,7 +360,9 @@ class VectorField:
 
     # ------------------------------------------------------------------ deferred AdaptiveRMSNorm (large batches)
     DEFER_MIN_ROWS = int(os.environ.get("CVX_DEFER_NORM_ROWS", "8192"))
-    DEFER_RULE = os.environ.get("CVX_DEFER_NORM_RULE", "1") == "1"       # 0: every batch of DEFER_MIN_ROWS rows and more (tests, A/B)
+    DEFER_RULE = False       # (round 4 kept batches whose 256-row rounds came out part-empty - 18,000 / 20,480 rows - off this path; with the
+                             #  large-problem kernel's 192-row tiles, round 5, the path wins at every size from 8192 rows: tools/defer_rows_bench.py,
+                             #  20,480 rows 448.7 vs 470.1 ms, 18,000 rows 404.2 vs 417.5, 9,300 rows 232.8 vs 242.1)
 
     def _defers(self, M: int, ws: dict) -> bool:
         """Large batches run WITHOUT the norm kernel and with the residual stream as split pairs only.  An AdaptiveRMSNorm is one
@@ -388,19 +380,7 @@ class VectorField:
         if not (self.precision == "f16x3" and M >= self.DEFER_MIN_ROWS and isinstance(ws.get("normed16"), ops.SplitIL)
                 and self.d["dim"] % 64 == 0 and 512 <= self.d["dim"] <= 4096 and os.environ.get("CVX_DEFER_NORM", "1") == "1"):
             return False
-        if not self.DEFER_RULE:
-            return True
-        # The deferred forms exist on the large-problem kernel only, whose N = dim products run in rounds of 256 x 256 tiles: where
-        # the library would hand those products to the medium-problem kernel (cvx_gemm_f16x3's rule: 128 x 128 tiles at 0.31 of a
-        # large tile's time) because the rounds come out part-empty, forcing the large kernel costs more than the norm saves.
-        # Measured (tools/defer_rows_bench.py, 32-NFE solve, ms with / without): 10,000 rows 260.2 / 265.8, 12,000 294.8 / 302.7,
-        # 16,000 352.6 / 361.1, 24,000 555.4 / 583.7 - and 20,480 rows (a full bin of the CLI: two rounds at 62 %) 497.7 / 491.5.
-        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        dim = self.d["dim"]
-        up = lambda a, b: -(-a // b)
-        large = up(up(M, 256) * up(dim, 256), ncu)
-        medium = 0.31 * up(up(M, 128) * up(dim, 128), ncu)
-        return medium >= 0.85 * large
+        return True
 
     def _deferred_norm_tables(self, table: torch.Tensor, HS: torch.Tensor, times_key) -> dict:
         """Per (evaluation time, layer): W diag(gamma) for to_qkv (layers 1..) and ff1 as interleaved split pairs, beta W^T as their
@@ -580,9 +560,9 @@ class VectorField:
             ops.split_act_f16(h, tw, scale=h0s) if isinstance(tw, ops.SplitIL) else ops.split_act_f16(h, *tw, scale=h0s)
 
         # every to_out / ff2 / skip-combiner product is followed by a norm of its output: one call (ops.gemm(norm=...)), so that
-        # problems on the split-K path (one utterance) normalise inside the reduction.  CVX_FUSE_NORM=0: separate launches (A/B)
+        # problems on the split-K path (one utterance) normalise inside the reduction
         # (2048 rows and more never split K: the call would run the same two kernels, so it stays two calls there)
-        fuse_norm = split_io and M < 2048 and os.environ.get("CVX_FUSE_NORM", "1") == "1"
+        fuse_norm = split_io and M < 2048
         normed_ahead = False                 # the attention norm of the layer about to start was produced by the previous GEMM
         if use_dn:                           # (decided per call in prepare())
             return self._layers_pair_stream(ctx, step, ws, h, twin, free, Bt, T, M, rg)

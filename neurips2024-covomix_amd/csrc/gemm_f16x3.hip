@@ -676,6 +676,8 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         so.dbg = 0; so.trace = nullptr;
 #endif
         if (io->flags & CVX_GEMM_FLAG_ONE_TILE) so.dbg |= 8;      // scheduling only: same arithmetic, bit-identical results
+        if (io->flags & CVX_GEMM_FLAG_TILE192) so.dbg |= 16;      // tile height of the large-problem kernel pinned (same bits either way)
+        if (io->flags & CVX_GEMM_FLAG_TILE256) so.dbg |= 32;
         if (io->Vt_hi || io->Vt_lo) {
             CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
                         (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= ((a->rope_T + 15) / 16) * 16 && io->vt_ld % 8 == 0 &&
@@ -723,8 +725,11 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     bool medium = a->M < 2048 || a->N < 512;
     if (!medium && A.hi && w_il && a_il && io && !(io->flags & (CVX_GEMM_FLAG_NO_MEDIUM | CVX_GEMM_FLAG_ONE_TILE))) {
         const long ncu = cvx_stream_cus(s);
-        const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
-        const double large = (double)((t256 + ncu - 1) / ncu), med = 0.31 * (double)((t128 + ncu - 1) / ncu);
+        const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t192 = (long)((a->M + 191) / 192) * ((a->N + 255) / 256);
+        const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+        // (the large kernel picks 192-row tiles - 0.75 of a 256-row tile's time - where that gives fewer, shorter rounds: gemm_f16x3_p8s.hip)
+        const double r256 = (double)((t256 + ncu - 1) / ncu), r192 = 0.75 * (double)((t192 + ncu - 1) / ncu);
+        const double large = r192 < r256 ? r192 : r256, med = 0.31 * (double)((t128 + ncu - 1) / ncu);
         medium = (io->flags & CVX_GEMM_FLAG_MEDIUM) || med < 0.97 * large;
     }
     if (dn) {

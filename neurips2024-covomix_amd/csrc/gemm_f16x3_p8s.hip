@@ -44,11 +44,20 @@ constexpr int LDS_B = DUMP_B + 8 * 1024;
 // PERM (the deferred-norm instances): LDS row rho of the W tile holds weight row perm32(rho) (a permutation inside every 32 rows, free:
 // the DMA's source address is per lane) so that a lane's accumulators of a tile PAIR are 8 consecutive output columns - 16-byte
 // split-pair loads / stores in the epilogue instead of 8-byte ones (gemm_p8s_epi.h)
-template <bool HAS_A2, bool SWAP, bool PERM = false>
+// MI (8 or 6): 16-row accumulator tiles per wave = tile HEIGHT 32 * MI (256 or 192 rows; round 5).  The 192-row form runs the same
+// loop with three instead of four A tiles per M half: 72 instead of 96 MFMAs per K-tile and wave, 24 instead of 32 A pieces (the
+// waves whose A slots fall past row 192 issue dummy pieces so that the counted vmcnt holds) - a tile costs 0.75 of a 256-row one, and
+// the launcher takes it where fewer, shorter rounds of tiles come out (9,298 rows x N = 1024: 196 tiles of 192 rows = one round at 0.75
+// against 148 tiles of 256 rows = one round at 1.0).  Every output element is the same sum in the same order: same bits.
+template <bool HAS_A2, bool SWAP, bool PERM = false, int MI = 8>
 __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreSplitA& A, const f16* __restrict__ W, char* smem,
                                               int m0, int n0, int m0n, int n0n, bool first, int lane, int wid, int wr, int wc,
-                                              f32x4 (&acc)[8][4], const float a2_ratio = 1.f)
+                                              f32x4 (&acc)[MI][4], const float a2_ratio = 1.f)
 {
+    constexpr int MH = MI / 2;                                   // 16-row tiles per M half of a wave
+    constexpr int RG = MI * 16, RH = RG / 2;                     // rows per wave group / per M half of a group
+    constexpr int A_PIECES = 2 * RH / 8;                         // 8-row DMA pieces per A quarter (16 issue slots: 2 per wave)
+    const bool a_slot = 2 * wid < A_PIECES;                      // this wave's two A slots hold rows of the tile (wave-uniform)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     uint32_t offA[2][2], offA2[2][2], offW[2][2];                // per-lane source byte offsets of the tile being FETCHED
     uint32_t dstA[2][2], dstW[2][2];                             // LDS byte offsets inside a buffer (wave-uniform)
@@ -57,8 +66,8 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     auto set_offsets = [&](int h, int mm, int nn) {               // quarters A_h / W_h of the tile at (mm, nn)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pr0 = 8 * (2 * wid + j);
-            const int ra0 = (pr0 >> 6) * 128 + h * 64 + (pr0 & 63);
+            const int slot = 2 * wid + j, pr0 = 8 * slot;
+            const int ra0 = a_slot ? (slot / (RH / 8)) * RG + h * RH + (slot % (RH / 8)) * 8 : 0;
             const int rb0 = (pr0 >> 5) * 64 + h * 32 + (pr0 & 31);
             const int ra = ra0 + (lane >> 3), rb = rb0 + (lane >> 3);
             const uint32_t ca = (uint32_t)(((lane & 7) ^ ((ra >> 1) & 7)) * 16);
@@ -94,8 +103,9 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
         if constexpr (HAS_A2) {
             if (u >= t_sw) { base = a2base + (int64_t)(u - t_sw) * 128; v0 = offA2[h][0]; v1 = offA2[h][1]; }
         }
-        if (!live) { base = wbase; v0 = 0u; v1 = 0u; }
-        dma2(v0, v1, live ? b + dstA[h][0] : dump, live ? b + dstA[h][1] : dump, base);
+        const bool put = live && a_slot;
+        if (!put) { base = wbase; v0 = 0u; v1 = 0u; }
+        dma2(v0, v1, put ? b + dstA[h][0] : dump, put ? b + dstA[h][1] : dump, base);
     };
     auto issue_W = [&](int h, int tt) {
         const bool cur = tt < nk;
@@ -108,8 +118,8 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
 
     // fragment addresses: row (lane & 15) of a 16-row MFMA tile, k chunk (lane >> 4) for hi / 4 + (lane >> 4) for lo
     const int lr = lane & 15, kg = lane >> 4, sw8 = lr >> 1;
-    const int aoh = (wr * 128 + lr) * 128 + 16 * (kg ^ sw8);
-    const int aol = (wr * 128 + lr) * 128 + 16 * ((4 + kg) ^ sw8);
+    const int aoh = (wr * RG + lr) * 128 + 16 * (kg ^ sw8);
+    const int aol = (wr * RG + lr) * 128 + 16 * ((4 + kg) ^ sw8);
     const int boh = TILE_B + (wc * 64 + lr) * 128 + 16 * (kg ^ sw8);
     const int bol = TILE_B + (wc * 64 + lr) * 128 + 16 * ((4 + kg) ^ sw8);
 
@@ -120,13 +130,13 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     }
     if (wr == 1) CVX_P8_BARRIER();                      // group 1 runs one interval behind group 0
 
-    f16x8 fah[4], fal[4];                               // A fragments of the current M half (4 tiles of 16 rows)
+    f16x8 fah[MH], fal[MH];                             // A fragments of the current M half (MH tiles of 16 rows)
     f16x8 fbh[2][2], fbl[2][2];                         // W fragments: [n half][tile]
 
 #define CVX_P8S_READ_A(buf, mh)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
-        fah[i] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((mh) * 4 + i) * 16 * 128 + aoh);        \
-        fal[i] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((mh) * 4 + i) * 16 * 128 + aol);        \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) {                                                             \
+        fah[i] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((mh) * MH + i) * 16 * 128 + aoh);       \
+        fal[i] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((mh) * MH + i) * 16 * 128 + aol);       \
     }
 #define CVX_P8S_READ_B(buf, nh)                                                                                  \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
@@ -134,16 +144,16 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
         fbl[nh][j] = *reinterpret_cast<const f16x8*>(smem + (buf) * BUF_B + ((nh) * 2 + j) * 16 * 128 + bol);    \
     }
 #define CVX_P8S_MM(x, y, c) (SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(y, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0))
-    // quadrant (mh, nh): 4 x 2 tiles x three terms = 24 MFMAs, term-major (consecutive MFMAs hit different accumulators)
+    // quadrant (mh, nh): MH x 2 tiles x three terms = 24 (18) MFMAs, term-major (consecutive MFMAs hit different accumulators)
 #define CVX_P8S_MFMA(mh, nh)                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
-        acc[(mh) * 4 + i][(nh) * 2 + j] = CVX_P8S_MM(fal[i], fbh[nh][j], acc[(mh) * 4 + i][(nh) * 2 + j]);       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
-        acc[(mh) * 4 + i][(nh) * 2 + j] = CVX_P8S_MM(fah[i], fbl[nh][j], acc[(mh) * 4 + i][(nh) * 2 + j]);       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
-        acc[(mh) * 4 + i][(nh) * 2 + j] = CVX_P8S_MM(fah[i], fbh[nh][j], acc[(mh) * 4 + i][(nh) * 2 + j]);       \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
+        acc[(mh) * MH + i][(nh) * 2 + j] = CVX_P8S_MM(fal[i], fbh[nh][j], acc[(mh) * MH + i][(nh) * 2 + j]);     \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
+        acc[(mh) * MH + i][(nh) * 2 + j] = CVX_P8S_MM(fah[i], fbl[nh][j], acc[(mh) * MH + i][(nh) * 2 + j]);     \
+    _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
+        acc[(mh) * MH + i][(nh) * 2 + j] = CVX_P8S_MM(fah[i], fbh[nh][j], acc[(mh) * MH + i][(nh) * 2 + j]);     \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     CVX_P8_BARRIER();
@@ -158,7 +168,7 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     {                                                                                                            \
         if (has_next && (t) == nk - 2 + (buf)) set_offsets((buf), m0n, n0n);                                     \
         if (HAS_A2 && a2_ratio != 1.f && (t) == t_sw) {          /* the A2 pairs carry another pre-scale: bring the sums so far to it */ \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] *= a2_ratio;    \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] *= a2_ratio;   \
         }                                                                                                        \
         CVX_P8S_READ_B(buf, 0) CVX_P8S_READ_A(buf, 0)                                                            \
         issue_W(1, (t) + 1);                                                                                     \
@@ -188,7 +198,7 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
     if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tail's dummy pieces before LDS is released
 }
 
-template <bool HAS_A2, int EPI>
+template <bool HAS_A2, int EPI, int MI = 8>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ W, float acc_scale, SplitOut so,
     int tiles_m, int tiles_n, int n_slots)
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
     auto tile_of_slot = [&](int s, int& m0, int& n0) {          // -> false for the padding slots of the XCD map
         const int xcd = s & 7, q = s >> 3;
         const int tm = xcd + 8 * (q / tiles_n), tn = q % tiles_n;
-        m0 = tm * 256; n0 = tn * 256;
+        m0 = tm * (32 * MI); n0 = tn * 256;
         return tm < tiles_m;
     };
     auto next_slot = [&](int s) {                                // next slot of this block that holds a real tile, or -1
@@ -228,21 +238,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
         int m0n = -1, n0n = -1;
         if (nslot >= 0) tile_of_slot(nslot, m0n, n0n);
 
-        f32x4 acc[8][4];
+        f32x4 acc[MI][4];
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+        const int row0 = m0 + wr * (16 * MI), col0 = n0 + wc * 64;
         bool v_block = false;
         if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_RS) v_block = n0 >= p.rope_cols;          // block-uniform: this tile holds V columns
         constexpr bool PERM = epi_perm(EPI);
         if (v_block) {
-            tile_mainloop<HAS_A2, false, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc, a2_ratio);
-            if (!(so.dbg & 1)) epilogue_vt<8, false, EPI == EPI_QKV_RS, PERM>(p, acc, row0, col0, lane, so, acc_scale);
+            tile_mainloop<HAS_A2, false, PERM, MI>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc, a2_ratio);
+            if (!(so.dbg & 1)) epilogue_vt<MI, false, EPI == EPI_QKV_RS, PERM>(p, acc, row0, col0, lane, so, acc_scale);
         } else {
-            tile_mainloop<HAS_A2, true, PERM>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc, a2_ratio);
-            if (!(so.dbg & 1)) epilogue_rows<EPI>(p, acc, row0, col0, lane, so, acc_scale);      // (dbg bit 0: main loop only, timing)
+            tile_mainloop<HAS_A2, true, PERM, MI>(p, A, W, smem_p8s, m0, n0, m0n, n0n, first, lane, wid, wr, wc, acc, a2_ratio);
+            if (!(so.dbg & 1)) epilogue_rows<EPI, MI>(p, acc, row0, col0, lane, so, acc_scale);  // (dbg bit 0: main loop only, timing)
         }
         if (nslot < 0) break;
         // the epilogue's own loads / stores share the vmcnt counter with the DMA: start the next tile from a clean count
@@ -288,13 +298,20 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
                      (!a.rope_cos || ((((uintptr_t)a.rope_cos | (uintptr_t)a.rope_sin) & 15) == 0 && a.rope_cols % 256 == 0));
     if (!vec) return false;
     if (so.vt_hi && !(a.rope_cos && so.hi && !so.write_f32 && !a.residual && a.act == CVX_ACT_NONE)) return false;   // V^T only in QKV form
-    const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
+    const int tn = (a.N + 255) / 256;
+    const int n_cu = cvx_stream_cus(st);                         // CUs this stream owns (cvx_stream_set_cus; default: the device's)
+    // tile height: 256 rows, or 192 where rounds x height comes out smaller (a launch runs in rounds of one tile per CU and a tile's
+    // time goes with its height).  so.dbg bits 16 / 32 pin 192 / 256 (CVX_GEMM_FLAG_TILE192 / _TILE256: A/B, bit-identity tests).
+    const int cus8 = (n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8;
+    auto cost = [&](int h) { const long t = (long)((a.M + h - 1) / h) * tn; return ((t + cus8 - 1) / cus8) * (long)h; };
+    const bool h192 = (so.dbg & 16) ? true : (so.dbg & 32) ? false : cost(192) < cost(256);
+    const int th = h192 ? 192 : 256;
+    const int tm = (a.M + th - 1) / th;
     const int n_slots = ((tm + 7) / 8) * 8 * tn;                 // XCD map: an XCD owns whole row panels (padding slots are skipped)
     // persistent grid: one block per CU (136 KiB of LDS each), a multiple of 8; a next tile needs an even number of K-tiles
     // (the two LDS buffers alternate across the tile boundary), otherwise every tile gets its own block
-    const int n_cu = cvx_stream_cus(st);                         // CUs this stream owns (cvx_stream_set_cus; default: the device's)
     int g = n_slots;
-    if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < (n_cu / 8) * 8 ? n_slots : (n_cu / 8) * 8;
+    if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < cus8 ? n_slots : cus8;
     const dim3 grid((unsigned)g);
     int epi = classify_epilogue(a, so);
     if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;
@@ -314,11 +331,13 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
                           (so.res_hi && (so.res_ld & 7) != 0))) return false;
     if (epi == EPI_GENERIC && so.vt_hi) return false;
     if (so.a2_scale && !(epi == EPI_BIAS_TW && so.a_scale)) return false;
-#define CVX_P8S_LAUNCH(A2, E)                                                                                           \
+#define CVX_P8S_LAUNCH_MI(A2, E, MI_)                                                                                   \
     do {                                                                                                                \
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8s_kernel<A2, E>), LDS_B);                     \
-        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, n_slots); \
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8s_kernel<A2, E, MI_>), LDS_B);                \
+        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E, MI_>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, n_slots); \
     } while (0)
+#define CVX_P8S_LAUNCH(A2, E)                                                                                           \
+    do { if (h192) CVX_P8S_LAUNCH_MI(A2, E, 6); else CVX_P8S_LAUNCH_MI(A2, E, 8); } while (0)
     if (A.hi2) {
         if (epi == EPI_BIAS) CVX_P8S_LAUNCH(true, EPI_BIAS); else if (epi == EPI_BIAS_TW) CVX_P8S_LAUNCH(true, EPI_BIAS_TW); else CVX_P8S_LAUNCH(true, EPI_GENERIC);
     } else {
@@ -334,6 +353,7 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
         }
     }
 #undef CVX_P8S_LAUNCH
+#undef CVX_P8S_LAUNCH_MI
     return true;
 }
 

@@ -32,13 +32,28 @@ def launch_ranks(script: str, argv: Sequence[str], n: int) -> int:
     """Run `script argv...` as n ranks of ONE node under torch.distributed.run (one process per GPU, rendezvous on
     127.0.0.1 at a free port) and return its exit code.  What `bench.py --gpus N` / the generation scripts do when they are
     started from a plain shell - the reference's multi-GPU entry point spawns its own ranks too (hifi-gan/train.py:268-278)."""
+    import glob
     import subprocess
     import sys
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), script, *argv]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
-    return subprocess.call(cmd, env=env)
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="covomix_ranks_") as logs:
+        # --tee 3: every rank's stdout / stderr still stream through, and a copy per rank lands under `logs`, so that a rank that
+        # dies (an RCCL abort is not a Python exception: nothing else would say which rank and why) can be reported below
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "--tee", "3", "--log-dir", logs, script, *argv]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+        rc = subprocess.call(cmd, env=env)
+        if rc != 0:
+            print(f"[covomix_amd.dp] {n} ranks of {os.path.basename(script)} ended with exit code {rc}; stderr tail per rank:", file=sys.stderr)
+            for path in sorted(glob.glob(os.path.join(logs, "**", "stderr.log"), recursive=True)):
+                try:
+                    tail = open(path, errors="replace").read().strip().splitlines()[-12:]
+                except OSError:
+                    continue
+                rank = os.path.basename(os.path.dirname(path))
+                print(f"--- rank {rank} ---\n" + "\n".join(tail), file=sys.stderr)
+        return rc
 
 
 # what happened at start-up, for the `ranks` block of the bench line / the CLI log: which transport carried the weight broadcast,
@@ -64,8 +79,9 @@ def pin_host_threads(local: int, local_world: int) -> int:
     torch.set_num_threads(share)
     if local_world > 1 and len(cpus) >= 2 * local_world:
         per = len(cpus) // local_world
+        slot = int(os.environ.get("LOCAL_RANK", local)) % local_world      # (the REAL local rank: the one-device test modes pass local = 0 for every rank)
         try:
-            os.sched_setaffinity(0, cpus[local * per:(local + 1) * per])
+            os.sched_setaffinity(0, cpus[slot * per:(slot + 1) * per])
         except Exception:
             pass
     INFO["host_threads_per_rank"] = share
@@ -126,19 +142,43 @@ def rccl_group():
                                     ": weights staged through host memory)"
         return None
     import datetime
+
+    def agreed(ok: float) -> bool:
+        flag = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)           # (default group = gloo)
+        return float(flag.item()) >= 1.0
     ok, err, g = 1.0, None, None
+    timeout = datetime.timedelta(seconds=float(os.environ.get("CVX_DP_RCCL_TIMEOUT_S", "180")))
+    # A communicator that cannot come up on ONE rank leaves the others inside the probe: the default handling of that is the
+    # process-group watchdog aborting the process (not an exception).  For the probe only: blocking waits that raise on time-out and
+    # no watchdog abort - both are read when the group is constructed.  UNTESTED with more than one GPU (no such node was available
+    # in rounds 1-5): README says so.
+    saved = {k: os.environ.get(k) for k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_BLOCKING_WAIT")}
+    os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"], os.environ["TORCH_NCCL_BLOCKING_WAIT"] = "0", "1"
     try:
-        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("CVX_DP_RCCL_TIMEOUT_S", "180"))))
-        probe = torch.ones(1, device="cuda")
-        dist.all_reduce(probe, group=g)
-        torch.cuda.synchronize()
-        if float(probe.item()) != float(dist.get_world_size()):
-            raise RuntimeError(f"RCCL all-reduce probe returned {float(probe.item())}")
-    except Exception as e:                                    # noqa: BLE001
-        ok, err = 0.0, f"{type(e).__name__}: {str(e)[:300]}"
-    flag = torch.tensor([ok], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)               # (default group = gloo)
-    if float(flag.item()) < 1.0:
+        try:
+            g = dist.new_group(backend="nccl", timeout=timeout)
+        except Exception as e:                                # noqa: BLE001
+            ok, err = 0.0, f"{type(e).__name__}: {str(e)[:300]}"
+        if agreed(ok):                                        # every rank has a group object: only now does anyone enter an RCCL collective
+            try:
+                probe = torch.ones(1, device="cuda")
+                work = dist.all_reduce(probe, group=g, async_op=True)
+                work.wait(timeout)
+                torch.cuda.synchronize()
+                if float(probe.item()) != float(dist.get_world_size()):
+                    raise RuntimeError(f"RCCL all-reduce probe returned {float(probe.item())}")
+            except Exception as e:                            # noqa: BLE001
+                ok, err = 0.0, f"{type(e).__name__}: {str(e)[:300]}"
+        else:
+            ok = 0.0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if not agreed(ok):
         INFO["rccl_error"] = err or "another rank failed to bring RCCL up"
         g = None
     INFO["broadcast_backend"] = "nccl (RCCL)" if g is not None else "gloo (RCCL unavailable: weights staged through host memory)"
@@ -216,6 +256,37 @@ def pack_by_frames(indices: Sequence[int], lengths: Sequence[int], max_frames: i
             bins.append([i])
             room.append(max(0, max_frames - t))
     return bins
+
+
+def launch_cost(frames: int, cus: int = 256, dim: int = 1024) -> float:
+    """Relative time of the transformer GEMMs of ONE packed launch of `frames` frames (both CFG branches: 2 x frames rows) in units
+    of one round of 256 x 256 tiles at K = dim: the large-problem kernel runs in rounds of one tile per CU, with 256- or 192-row
+    tiles, whichever gives fewer, shorter rounds (gemm_f16x3_p8s.hip); per layer to_qkv (12 column tiles), to_out (4), ff1 (16), ff2
+    (4, K = 4 dim) and a skip combiner in every other layer (4, K = 2 dim).  A cost model for the packing only."""
+    rows = 2 * int(frames)
+    up = lambda a, b: -(-a // b)
+    ct = lambda n: up(n, 256)
+
+    def rounds(tn):
+        return min(up(up(rows, 256) * tn, cus), 0.75 * up(up(rows, 192) * tn, cus))
+    n1 = ct(dim)
+    return rounds(3 * n1) + rounds(n1) + rounds(4 * n1) + 4 * rounds(n1) + 0.5 * 2 * rounds(n1)
+
+
+def choose_max_frames(lengths: Sequence[int], max_batch: int, cus: int = 256, candidates: Sequence[int] = (8192, 12288, 16384, 24576)) -> int:
+    """Frames per launch for a directory: the candidate cap (scaled to the CUs the acoustic stage owns) whose first-fit-decreasing
+    packing costs least under launch_cost - a directory whose tail would make a part-empty second launch is better off as one larger
+    launch (more rounds: finer quantisation), e.g. 12,799 frames: 8,150 + 4,649 frames cost 13 + 9.75 units, one launch of 12,799 frames
+    20.25.  Ties go to the smaller cap (less workspace).  Deterministic in the lengths: every rank chooses alike."""
+    best, best_cost = None, None
+    idx = list(range(len(lengths)))
+    for c in candidates:
+        cap = max(256, c * cus // 256)
+        bins = pack_by_frames(idx, lengths, cap, max_batch)
+        cost = sum(launch_cost(sum(int(lengths[i]) for i in b), cus) for b in bins)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = cap, cost
+    return int(best)
 
 
 def group_by_padding(lengths: Sequence[int], max_waste: float = 0.25, max_group: int = 32) -> List[List[int]]:

@@ -55,9 +55,9 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--seed", type=int, default=30, help="random seed")
     p.add_argument("--mode", type=str, choices=["covosingle", "covosinx", "covomix"], default="covosingle")
     p.add_argument("--max_batch", type=int, default=32, help="utterances per launch at most (any lengths: they are packed back to back)")
-    p.add_argument("--max_frames", type=int, default=None, help="frames per launch (sum over its utterances); default: whole rounds of "
-                   "GEMM tiles - 8192 frames = 64 row panels of 256 rows with both CFG branches on 256 CUs; 7168 on the 224 CUs the "
-                   "acoustic stage owns under --pipeline on")
+    p.add_argument("--max_frames", type=int, default=None, help="frames per launch (sum over its utterances); default: chosen from the "
+                   "directory's lengths among 8192 / 12288 / 16384 / 24576 by the cost of the packing in rounds of GEMM tiles "
+                   "(dp.choose_max_frames); 14336 under --pipeline on (two rounds on the 224 CUs the acoustic stage owns)")
     p.add_argument("--pipeline", type=str, choices=["auto", "on", "serial", "off"], default="auto",
                    help="extension: with --t2s_ckpt, decode the text of the NEXT utterances on a CU-masked side stream while the acoustic "
                         "model and the vocoder work on the current batch (covomix_amd/pipeline.py).  auto = on when there is text to "
@@ -307,7 +307,9 @@ def run(dialogue: bool, argv=None) -> int:
     if mode != "off" and t2s is None:
         mode = "off"                                              # nothing to overlap: tokens come from files
     from . import pipeline as pl
-    max_frames = args.max_frames or (pl.frames_per_launch(device) if mode != "off" else 8192)
+    # frames per launch: pipelined - two rounds of the N = 1024 products' tiles on the acoustic stage's CUs (the batches form while the
+    # text is still being decoded: the lengths are not known up front); otherwise chosen from the directory's lengths below
+    max_frames = args.max_frames or (2 * pl.frames_per_launch(device) if mode != "off" else None)
     segments = {n: {} for n in mine}
     n_out = model._get_field().d["dim_out"]       # acoustic.py:647-650: 80 channels (twocondition_oneoutput) or as wide as cond
 
@@ -377,6 +379,8 @@ def run(dialogue: bool, argv=None) -> int:
     if mode == "off":
         pool = [x for n in mine for x in items_of(n, pred)]
         lengths = [int(it[0].shape[0]) for it, _ in pool]
+        if max_frames is None:               # the cap whose packing costs least in rounds of GEMM tiles (dp.choose_max_frames)
+            max_frames = dp.choose_max_frames(lengths, args.max_batch, ops.stream_cus())
         for b in dp.pack_by_frames(list(range(len(pool))), lengths, max_frames, args.max_batch):
             frames += solve([pool[i] for i in b])
     else:

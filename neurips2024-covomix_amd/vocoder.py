@@ -71,10 +71,9 @@ class Generator:
         if self.precision not in ("f16x3", "fp32"):
             raise ValueError(f"vocoder precision must be 'f16x3' or 'fp32', got {self.precision!r}")
         self._cl: Dict[tuple, dict] = {}
-        self.act_scales = os.environ.get("CVX_ACT_SCALES", "1") == "1"
+        self.act_scales = True               # measured per-stage power-of-two pre-scales of the split pairs
         # channels-last pipeline (round 3): the upsamplers on the split pipe too, no layout converters between the stages
-        # (CVX_VOCODER_CL=0: ConvTranspose1d on the fp32 kernel, channel-major between the stages - the round-2 flow)
-        self.cl_pipeline = os.environ.get("CVX_VOCODER_CL", "1") == "1"
+        self.cl_pipeline = True
         self.h = h
         self.num_kernels = len(h["resblock_kernel_sizes"])
         self.num_upsamples = len(h["upsample_rates"])

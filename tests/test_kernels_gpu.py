@@ -1020,3 +1020,74 @@ def test_gemm_deferred_norm_producer_and_consumers(ops, M):
                  c_gamma=gamma, c_rowsq=rowsq)
     with pytest.raises(ops._lib.CovomixHipError):
         ops.gemm(x, w, c, w_split=ws, w_il=wil, a_split=il, a_row_scale=rs)            # fp32 store with a row factor: not a consumer form
+
+
+@pytest.mark.parametrize("M", [2100, 9298])
+def test_gemm_192_row_tiles_are_bit_identical_to_256_row_tiles(ops, M):
+    """Round 5: the large-problem kernel in its 192-row form (three instead of four A tiles per M half; taken where rounds x height
+    come out smaller, e.g. 9,298 rows x N = 1024: 196 tiles of 192 rows instead of 148 of 256) - every output element is the same
+    sum in the same order, so EVERY epilogue class must give the same bits as the 256-row form (flags 64 / 128 pin the height): plain,
+    residual + twin, bias + GELU + split, A | A2 + bias with two pre-scales, QKV (RoPE, V^T; T % 4 != 0), the deferred-norm producer
+    (pair residual in place, row sums) and consumer (factor per row); also against fp64, and the library's own choice at these sizes."""
+    dev_ = dev()
+    g = torch.Generator().manual_seed(M)
+    K, H = 1024, 4
+    x = torch.randn(M, K, generator=g).to(dev_)
+    il = ops.SplitIL(M, K, dev_); ops.split_act_f16(x, il)
+    xs = il.dense()[0].double() + il.dense()[1].double()
+    pair = lambda t: t.dense()[0].double() + t.dense()[1].double()
+
+    def weights(N, Kw=K):
+        w = (torch.randn(N, Kw, generator=g) / math.sqrt(Kw)).to(dev_)
+        ws = ops.split_f16(w)
+        return w, ws, ops.split_f16_interleaved(ws)
+    W1, W2, WA2, WQ = weights(1024), weights(2048), weights(1024, 2 * K), weights(3 * H * 64)
+    b1, b2 = torch.randn(1024, generator=g).to(dev_), torch.randn(2048, generator=g).to(dev_)
+    r = torch.randn(M, 1024, generator=g).to(dev_)
+    rs = (0.5 + torch.rand(M, generator=g)).to(dev_)
+    sa, sb, hs = (torch.tensor([v], device=dev_) for v in (2.0, 32.0, 8.0))
+    ila, ilb = ops.SplitIL(M, K, dev_), ops.SplitIL(M, K, dev_)
+    ops.split_act_f16(x, ila, scale=sa); ops.split_act_f16(x, ilb, scale=sb)
+    T = M // 3
+    Mq = 3 * T
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(T).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(dev_).contiguous(), ang.sin().to(dev_).contiguous()
+    ilq = ops.SplitIL(Mq, K, dev_); ops.split_act_f16(x[:Mq].contiguous(), ilq)
+
+    def run(flags):
+        out = []
+        with ops.gemm_flags(flags):
+            c = torch.full((M, 1024), float("nan"), device=dev_)
+            ops.gemm(x, W1[0], c, w_split=W1[1], w_il=W1[2], a_split=il); out.append(c.clone())
+            tw = ops.SplitIL(M, 1024, dev_)
+            ops.gemm(x, W1[0], c, w_split=W1[1], w_il=W1[2], a_split=il, bias=b1, residual=r, out_split=tw); out += [c.clone(), tw.buf.clone()]
+            o = ops.SplitIL(M, 2048, dev_)
+            ops.gemm(x, W2[0], torch.empty(M, 2048, device=dev_), w_split=W2[1], w_il=W2[2], a_split=il, bias=b2, act=1, out_split=o, write_f32=False)
+            out.append(o.buf.clone())
+            ops.gemm(x, WA2[0], c, w_split=WA2[1], w_il=WA2[2], a_split=ila, a2=x, a2_split=ilb, a_scale=sa, a2_scale=sb, bias=b1,
+                     out_split=tw, c_rowsq=torch.empty(M, 16, device=dev_)); out += [c.clone(), tw.buf.clone()]
+            qk = (torch.empty(Mq, 2 * H * 64, dtype=torch.float16, device=dev_), torch.empty(Mq, 2 * H * 64, dtype=torch.float16, device=dev_))
+            Tp = (T + 31) // 32 * 32
+            vt = (torch.zeros(3 * H * 64, Tp, dtype=torch.float16, device=dev_), torch.zeros(3 * H * 64, Tp, dtype=torch.float16, device=dev_))
+            ops.gemm(x[:Mq], WQ[0], torch.empty(Mq, 3 * H * 64, device=dev_), w_split=WQ[1], w_il=WQ[2], a_split=ilq, rope=(cos, sin),
+                     rope_cols=2 * H * 64, out_split=qk, vt_split=vt, write_f32=False)
+            out += [qk[0].clone(), qk[1].clone(), vt[0].clone(), vt[1].clone()]
+            rp = ops.SplitIL(M, 1024, dev_); ops.split_act_f16(r, rp, scale=hs)
+            rowsq = torch.full((M, 16), float("nan"), device=dev_)
+            ops.gemm(x, W1[0], c, w_split=W1[1], w_il=W1[2], a_split=il, bias=b1, res_split=rp, res_scale=hs, out_split=rp, c_scale=hs,
+                     c_rowsq=rowsq, write_f32=False); out += [rp.buf.clone(), rowsq.clone()]
+            o2 = ops.SplitIL(M, 2048, dev_)
+            ops.gemm(x, W2[0], torch.empty(M, 2048, device=dev_), w_split=W2[1], w_il=W2[2], a_split=il, bias=b2, act=1, out_split=o2,
+                     write_f32=False, a_row_scale=rs); out.append(o2.buf.clone())
+        torch.cuda.synchronize()
+        return out
+    t256, t192, auto = run(16 | 128), run(16 | 64), run(16)
+    assert len(t256) == len(t192) == 13
+    for k, (a, b, c_) in enumerate(zip(t256, t192, auto)):
+        assert torch.equal(a, b), k
+        assert torch.equal(a, c_), k
+    assert rel_l2(t192[0], xs @ W1[0].double().T) < 1e-6
+    assert rel_l2(t192[1], xs @ W1[0].double().T + b1.double() + r.double()) < 1e-6
+    o_pair = t192[3].view(M, 64, 2, 32)
+    assert rel_l2(o_pair[:, :, 0].reshape(M, 2048).double() + o_pair[:, :, 1].reshape(M, 2048).double(), F.gelu(xs @ W2[0].double().T + b2.double())) < 1e-6

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Dev: the large-problem GEMM on the transformer shapes of BASELINE config 3 WITH THE MODEL'S EPILOGUES (qkv: RoPE +
 split q|k + transposed split v; out: residual; ff1: bias + GELU + split, no fp32 store; ff2: bias + residual + split twin;
-skip: K-split A|A2 + bias), interleaved A and W.  Columns: two-stage kernel, eight-phase kernel, eight-phase main loop
-only (epilogue skipped: timing experiment).  Env: M=16000, SHAPES=qkv,ff2, ZERO=1 (power probe), REPS=20."""
+skip: K-split A|A2 + bias), interleaved A and W.  Columns = cvx_gemm_split_io.flags values (VARIANTS=, default "144,80,16,8"):
+16 + 128 large-problem kernel with 256-row tiles, 16 + 64 with 192-row tiles, 16 its own choice of height, 8 medium-problem kernel,
+0 the library's choice of kernel (+ 4 one tile per block; dev builds: + 256 main loop only).
+Env: M=16000, SHAPES=qkv,ff2, ZERO=1 (power probe), REPS=20."""
 import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from covomix_amd import ops
@@ -16,9 +18,11 @@ def timeit(fn, iters=int(os.environ.get("REPS", "20")), warm=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 M = int(os.environ.get("M", "16000"))
-T = 1000
+T = int(os.environ.get("T", "1000"))
+if M % T:
+    T = M                                   # (one sequence: the RoPE table covers every row)
 only = os.environ.get("SHAPES")
-variants = [int(v) for v in os.environ.get("VARIANTS", "2,0,256").split(",")]       # flags: 1 two-stage, 2 eight-phase 32x32, 0 eight-phase 16x16 (default), +256 without epilogue
+variants = [int(v) for v in os.environ.get("VARIANTS", "144,80,16,8").split(",")]
 tot = {v: 0.0 for v in variants}
 inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
 ang = torch.arange(T).float()[:, None] * inv[None, :]
@@ -50,7 +54,8 @@ for (N, K, K1, name, cnt) in [(3072, 1024, 0, "qkv", 8), (1024, 1024, 0, "out", 
     c = torch.zeros(M, N, device=dev)
     if name == "qkv":
         qk = (torch.empty(M, 2048, dtype=torch.float16, device=dev), torch.empty(M, 2048, dtype=torch.float16, device=dev))
-        vt = (torch.zeros(16 * 16 * 64, 1024, dtype=torch.float16, device=dev), torch.zeros(16 * 16 * 64, 1024, dtype=torch.float16, device=dev))
+        Tp = (T + 31) // 32 * 32
+        vt = (torch.zeros((M // T) * 16 * 64, Tp, dtype=torch.float16, device=dev), torch.zeros((M // T) * 16 * 64, Tp, dtype=torch.float16, device=dev))
         kw.update(rope=rope, rope_cols=2048, out_split=qk, vt_split=vt, write_f32=False)
     elif name == "out":
         kw.update(residual=res)

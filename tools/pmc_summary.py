@@ -14,6 +14,9 @@ import sys
 from collections import defaultdict
 
 
+EPI = {0: "generic", 1: "qkv", 2: "res", 3: "gelu_split", 4: "bias", 5: "res_tw", 6: "bias_tw", 7: "gelu_rs", 8: "qkv_rs"}    # gemm_common.h
+
+
 def short(name: str) -> str:
     m = re.search(r"_GLOBAL__N_1(\d\d)(\w+)", name)          # mangled: _ZN12_GLOBAL__N_1<len><name>...
     if m:
@@ -22,15 +25,28 @@ def short(name: str) -> str:
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
+def instance(name: str) -> str:
+    """The template instance of the GEMM kernels, e.g. gemm_f16x3_p8s_kernel<a2=0,epi=res_tw>: one row per epilogue, so that the
+    traffic ratio of the dominant kernel can be attributed to a shape (round-4 review: all eight instances were one row)."""
+    k = short(name)
+    if not k.startswith("gemm_f16x3_p8"):
+        return k
+    m = re.search(re.escape(k) + r"ILb([01])ELi(\d+)E", name) or re.search(re.escape(k) + r"<(true|false|[01]), *(\d+)", name)
+    if not m:
+        return k
+    a2 = {"true": 1, "false": 0}.get(m.group(1), m.group(1))
+    return f"{k}<a2={a2},epi={EPI.get(int(m.group(2)), m.group(2))}>"
+
+
 def load(path, counter):
     acc = defaultdict(lambda: [0.0, 0])
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            k = short(row["Kernel_Name"])
-            acc[k][0] += float(row["Counter_Value"])
-            acc[k][1] += 1
+            for k in {short(row["Kernel_Name"]), instance(row["Kernel_Name"])}:      # the kernel as a whole and its template instance
+                acc[k][0] += float(row["Counter_Value"])
+                acc[k][1] += 1
     return acc
 
 
