@@ -37,10 +37,11 @@ def launch_ranks(script: str, argv: Sequence[str], n: int) -> int:
     import sys
     import tempfile
     with tempfile.TemporaryDirectory(prefix="covomix_ranks_") as logs:
-        # --tee 3: every rank's stdout / stderr still stream through, and a copy per rank lands under `logs`, so that a rank that
-        # dies (an RCCL abort is not a Python exception: nothing else would say which rank and why) can be reported below
+        # --tee 2: every rank's stderr still streams through (stdout is untouched: rank 0's JSON line stays ONE bare line) and a copy
+        # per rank lands under `logs`, so that a rank that dies (an RCCL abort is not a Python exception: nothing else would say which
+        # rank and why) can be reported below
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), "--tee", "3", "--log-dir", logs, script, *argv]
+               "--master-port", str(free_port()), "--tee", "2", "--log-dir", logs, script, *argv]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
         rc = subprocess.call(cmd, env=env)

@@ -360,6 +360,29 @@ torch.distributed.destroy_process_group()
     assert r.returncode != 0 and "MASTER_PORT" in r.stderr
 
 
+def test_launch_ranks_reports_the_rank_that_failed(tmp_path, capfd):
+    """A rank that dies takes the job down; launch_ranks then prints every rank's stderr tail so that the first multi-GPU run is
+    diagnosable from its log (round-4 review item 8) - and a healthy rank's stdout stays untouched (rank 0's JSON line is ONE bare line)."""
+    from covomix_amd import dp
+    script = tmp_path / "ranks_fail.py"
+    script.write_text(f"""
+import sys, os
+sys.path.insert(0, {ROOT!r})
+rank = int(os.environ["RANK"])
+if rank == 0:
+    print('{{"n_gpus": 2}}', flush=True)
+if rank == 1:
+    print("rank one could not bring its communicator up: simulated", file=sys.stderr, flush=True)
+    os._exit(17)                     # (an abort, not a Python exception)
+import time; time.sleep(1.0)
+""")
+    rc = dp.launch_ranks(str(script), [], 2)
+    out, err = capfd.readouterr()
+    assert rc != 0
+    assert '{"n_gpus": 2}' in out.splitlines()
+    assert "--- rank 1 ---" in err and "rank one could not bring its communicator up: simulated" in err.split("--- rank 1 ---")[1]
+
+
 def test_every_python_source_compiles():
     """Host modules that only run on a GPU box (t2s, hubert, generation, tools) are still byte-compiled here, so a syntax
     error cannot reach the GPU tier unnoticed."""
