@@ -528,8 +528,36 @@ def cu_partition(device=None, side_per_xcd: int = 4) -> CUPartition:
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, side_per_xcd)
     if key not in _CU_PARTITIONS:
+        if not _CU_PARTITIONS:
+            import atexit
+            atexit.register(_destroy_partitions)      # while the HIP runtime is still up (a masked stream that outlives it crashed rocprofv3's finaliser)
         _CU_PARTITIONS[key] = CUPartition(torch.device("cuda", idx), side_per_xcd)
     return _CU_PARTITIONS[key]
+
+
+def _destroy_partitions() -> None:
+    lib = _lib.load()
+    for part in list(_CU_PARTITIONS.values()):
+        try:
+            with torch.cuda.device(part.device):
+                torch.cuda.synchronize()
+                # torch's pinned-memory allocator keeps events of the streams its blocks were last copied on (the decode's state
+                # record travels by non_blocking copies on the side stream): give the blocks back BEFORE their stream goes, or the
+                # allocator touches a dead stream at process exit (SIGSEGV, tools/cu_mask_exit_probe.py)
+                if hasattr(torch._C, "_host_emptyCache"):
+                    torch._C._host_emptyCache()
+                for st in (part.main, part.side):
+                    st.synchronize()
+                    lib.cvx_stream_destroy(st.cuda_stream)
+        except Exception:               # noqa: BLE001 - interpreter shutdown: nothing left to report to
+            pass
+    _CU_PARTITIONS.clear()
+
+
+def is_partition_stream(stream: Optional["torch.cuda.Stream"] = None) -> bool:
+    """Is `stream` (default: the current one) one of the CU-masked streams of a CUPartition?"""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    return any(st.cuda_stream in (p.main.cuda_stream, p.side.cuda_stream) for p in _CU_PARTITIONS.values())
 
 
 def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:

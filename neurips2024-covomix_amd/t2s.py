@@ -130,7 +130,7 @@ class TextToSemanticDecoder:
                 setattr(self._layers[i], name, L[name].data_ptr())
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self._cap = None                                   # capture stream of the decode graphs
-        self._pin = None                                   # pinned host copies of the state record (two in flight), _decode_chunks
+        self._stage = None                                 # staging copies of the state record (two in flight), _decode_chunks
 
     # ------------------------------------------------------------------ encoder (text2semantic.py:716-741)
     def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
@@ -192,26 +192,45 @@ class TextToSemanticDecoder:
 
     def _decode_chunks(self, temperature: float, nb: int, max_len: int, cfg_scale: float, watch, ignore_eos: bool = False) -> list:
         """Graph-replayed chunks of CHUNK token steps until every utterance slot in `watch` has sampled its eos (or max_len steps).
-        The host looks at the eos flags ONE CHUNK BEHIND the device: the state record of chunk i travels to pinned host memory by an
-        asynchronous copy enqueued between the replays of chunks i and i + 1, and is examined while chunk i + 1 runs - the decode
+        The host looks at the eos flags ONE CHUNK BEHIND the device: the state record of chunk i is copied to a device-side staging
+        record between the replays of chunks i and i + 1 and read through a helper stream while chunk i + 1 runs - the decode
         chain never waits for a host round trip (nor for a host thread that is waiting for the interpreter lock while another thread
         drives the acoustic solve, pipeline.py); the price is at most one chunk decoded past the last eos (masked afterwards like every
         token behind an eos).  Returns the final state rows."""
-        if self._pin is None:
+        if self._stage is None:
+            self._stage = [torch.empty_like(self.buf["state"]) for _ in range(2)]
             self._pin = [torch.empty(MAX_BATCH, 4, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._stage_ev = [torch.cuda.Event(), torch.cuda.Event()]
             self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._helper = torch.cuda.Stream(device=self.device)
+        # How the record reaches the host.  On an ordinary stream: a non_blocking copy into pinned memory on the decode stream itself.
+        # On a CU-masked stream of ops.CUPartition that form is NOT used: torch's pinned-memory allocator remembers the stream of such a
+        # copy, and a masked stream destroyed at exit before the block is freed takes the process down (tools/cu_mask_exit_probe.py) -
+        # there the record is copied device-to-device on the decode stream and a plain helper stream brings it to the host.  (The
+        # helper form on the legacy null stream measured 3.4x slower per decode - 941 vs 274 ms - in one process layout and not in another:
+        # it is confined to the streams that need it.)
+        via_helper = ops.is_partition_stream()
         steps, i, pending = 0, 0, None
         while steps < max_len:
             self._run_chunk(temperature, nb, cfg_scale)
             steps += CHUNK
-            self._pin[i & 1].copy_(self.buf["state"], non_blocking=True)
-            self._pin_ev[i & 1].record()
+            k = i & 1
+            if via_helper:
+                self._stage[k].copy_(self.buf["state"])                 # (device to device, behind chunk i on this stream)
+                self._stage_ev[k].record()
+                with torch.cuda.stream(self._helper):                   # the helper waits for chunk i only
+                    self._helper.wait_event(self._stage_ev[k])
+                    self._pin[k].copy_(self._stage[k], non_blocking=True)
+                    self._pin_ev[k].record()
+            else:
+                self._pin[k].copy_(self.buf["state"], non_blocking=True)
+                self._pin_ev[k].record()
             if pending is not None:
                 self._pin_ev[pending].synchronize()
                 st = self._pin[pending].tolist()
                 if all(st[r][1] for r in watch) and not ignore_eos:
                     break
-            pending = i & 1
+            pending = k
             i += 1
         return self._read_state(nb)
 

@@ -40,7 +40,18 @@ c5.run(8, B_SERIAL, overlap=False, partitioned=False)
 c5.run(16, B_PIPE, overlap=False)
 c5.run(16, B_PIPE, overlap=True)
 
+_w = {"stage1": [], "stage2": []}
+for _n in _w:
+    def _wrap(fn, _n=_n):
+        def f(x):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(x); torch.cuda.synchronize(); _w[_n].append(time.perf_counter() - t0)
+            return r
+        return f
+    setattr(c5, _n, _wrap(getattr(c5, _n)))
 ser, t = timed(lambda: c5.run(ND, B_SERIAL, overlap=False, partitioned=False))
+for _n in _w:
+    setattr(c5, _n, getattr(Config5, _n).__get__(c5))
+print("serial, per call [ms]: text2semantic " + "/".join(f"{x * 1e3:.0f}" for x in _w["stage1"]) + "; solve + vocoder " + "/".join(f"{x * 1e3:.0f}" for x in _w["stage2"]), flush=True)
 a, b = stage_times(B_SERIAL)
 print(f"serial    (one plain stream, {B_SERIAL} per solve): {ND / t:6.2f} dialogues/s = {ND * c5.T / t:7.0f} mel-frames/s  "
       f"[text2semantic of 8: {a:.0f} ms; solve + vocoder of {B_SERIAL}: {b:.0f} ms]", flush=True)
@@ -49,13 +60,18 @@ a, b = stage_times(B_PIPE, part.side, part.main)
 print(f"alternate (CU partition, {B_PIPE} per solve):       {ND / t:6.2f} dialogues/s = {ND * c5.T / t:7.0f} mel-frames/s  "
       f"[text2semantic of 8 on {part.n_side} CUs: {a:.0f} ms; solve + vocoder of {B_PIPE} on {part.n_main} CUs: {b:.0f} ms]", flush=True)
 walls = {"stage1": [], "stage2": []}
+spans = {"stage1": [], "stage2": []}                  # (start, end) HIP events of every stage call ON ITS OWN STREAM: the device's view
+base = torch.cuda.Event(enable_timing=True)
 for name in walls:                                    # wall time of every stage call inside the pipelined run (host view)
     def wrap(fn, name=name):
         def f(x):
-            t0 = time.perf_counter(); r = fn(x); torch.cuda.current_stream().synchronize(); walls[name].append(time.perf_counter() - t0)
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter(); a_.record(); r = fn(x); b_.record(); torch.cuda.current_stream().synchronize()
+            walls[name].append(time.perf_counter() - t0); spans[name].append((a_, b_))
             return r
         return f
     setattr(c5, name, wrap(getattr(c5, name)))
+torch.cuda.synchronize(); base.record(); torch.cuda.synchronize()
 pip, t = timed(lambda: c5.run(ND, B_PIPE, overlap=True))
 for name in walls:
     setattr(c5, name, getattr(Config5, name).__get__(c5))
@@ -65,6 +81,15 @@ print(f"pipelined (CU partition, {B_PIPE} per solve):       {ND / t:6.2f} dialog
 steady = sum(walls["stage2"][1:-1]) / max(len(walls["stage2"]) - 2, 1)
 print(f"          steady state (a full solve + vocoder call per {B_PIPE} dialogues, the decode hidden): {B_PIPE / steady:.2f} dialogues/s; "
       f"this run pays one un-overlapped decode ({walls['stage1'][0] * 1e3:.0f} ms) to fill the pipeline")
+# the two queues on the device's clock: when was a decode group running, when a solve batch, when both
+iv = {k: [(base.elapsed_time(a_), base.elapsed_time(b_)) for a_, b_ in v] for k, v in spans.items()}
+both = sum(max(0.0, min(e1, e2) - max(s1, s2)) for s1, e1 in iv["stage1"] for s2, e2 in iv["stage2"])
+dec, sol = sum(e - s_ for s_, e in iv["stage1"]), sum(e - s_ for s_, e in iv["stage2"])
+end = max(e for v in iv.values() for _, e in v)
+print(f"          device timeline (HIP events on each stage's own stream): decode stream busy {dec:.0f} ms, solve stream busy {sol:.0f} ms of {end:.0f} ms; "
+      f"BOTH busy {both:.0f} ms = {100 * both / dec:.0f} % of the decode hidden under a solve")
+print("          decode groups [ms]: " + " ".join(f"{s_:.0f}-{e:.0f}" for s_, e in iv["stage1"]))
+print("          solve batches [ms]: " + " ".join(f"{s_:.0f}-{e:.0f}" for s_, e in iv["stage2"]))
 same = all(torch.equal(x["streams"], y["streams"]) and torch.equal(x["pcm"], y["pcm"]) for x, y in zip(alt, pip))
 print("tokens and PCM of the pipelined schedule bit-identical to the alternate one:", same)
 tok_same = all(torch.equal(x["streams"], y["streams"]) for x, y in zip(ser, pip))
