@@ -727,8 +727,8 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         const long ncu = cvx_stream_cus(s);
         const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t192 = (long)((a->M + 191) / 192) * ((a->N + 255) / 256);
         const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
-        // (the large kernel picks 192-row tiles - 0.75 of a 256-row tile's time - where that gives fewer, shorter rounds: gemm_f16x3_p8s.hip)
-        const double r256 = (double)((t256 + ncu - 1) / ncu), r192 = 0.75 * (double)((t192 + ncu - 1) / ncu);
+        // (the large kernel picks 192-row tiles - 0.8 of a 256-row tile's time - where that gives fewer, shorter rounds: gemm_f16x3_p8s.hip)
+        const double r256 = (double)((t256 + ncu - 1) / ncu), r192 = 0.8 * (double)((t192 + ncu - 1) / ncu);
         const double large = r192 < r256 ? r192 : r256, med = 0.31 * (double)((t128 + ncu - 1) / ncu);
         medium = (io->flags & CVX_GEMM_FLAG_MEDIUM) || med < 0.97 * large;
     }

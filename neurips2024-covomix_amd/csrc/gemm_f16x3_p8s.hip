@@ -46,7 +46,7 @@ constexpr int LDS_B = DUMP_B + 8 * 1024;
 // split-pair loads / stores in the epilogue instead of 8-byte ones (gemm_p8s_epi.h)
 // MI (8 or 6): 16-row accumulator tiles per wave = tile HEIGHT 32 * MI (256 or 192 rows; round 5).  The 192-row form runs the same
 // loop with three instead of four A tiles per M half: 72 instead of 96 MFMAs per K-tile and wave, 24 instead of 32 A pieces (the
-// waves whose A slots fall past row 192 issue dummy pieces so that the counted vmcnt holds) - a tile costs 0.75 of a 256-row one, and
+// waves whose A slots fall past row 192 issue dummy pieces so that the counted vmcnt holds) - a tile costs 0.8 of a 256-row one (0.75 of the MFMAs, the same W stream), and
 // the launcher takes it where fewer, shorter rounds of tiles come out (9,298 rows x N = 1024: 196 tiles of 192 rows = one round at 0.75
 // against 148 tiles of 256 rows = one round at 1.0).  Every output element is the same sum in the same order: same bits.
 template <bool HAS_A2, bool SWAP, bool PERM = false, int MI = 8>
@@ -303,7 +303,9 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     // tile height: 256 rows, or 192 where rounds x height comes out smaller (a launch runs in rounds of one tile per CU and a tile's
     // time goes with its height).  so.dbg bits 16 / 32 pin 192 / 256 (CVX_GEMM_FLAG_TILE192 / _TILE256: A/B, bit-identity tests).
     const int cus8 = (n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8;
-    auto cost = [&](int h) { const long t = (long)((a.M + h - 1) / h) * tn; return ((t + cus8 - 1) / cus8) * (long)h; };
+    // (a 192-row tile measures 0.81 of a 256-row one - 65.6 vs 81.3 us at 9,298 rows x N = 1024, one round each; W traffic per flop is 4/3 - so
+    //  it is priced at 0.8, not at its 0.75 of the rows: 5 rounds of 192 do not beat 4 of 256)
+    auto cost = [&](int h) { const long t = (long)((a.M + h - 1) / h) * tn; return ((t + cus8 - 1) / cus8) * (long)(h == 192 ? 205 : 256); };
     const bool h192 = (so.dbg & 16) ? true : (so.dbg & 32) ? false : cost(192) < cost(256);
     const int th = h192 ? 192 : 256;
     const int tm = (a.M + th - 1) / th;

@@ -269,7 +269,7 @@ def launch_cost(frames: int, cus: int = 256, dim: int = 1024) -> float:
     ct = lambda n: up(n, 256)
 
     def rounds(tn):
-        return min(up(up(rows, 256) * tn, cus), 0.75 * up(up(rows, 192) * tn, cus))
+        return min(up(up(rows, 256) * tn, cus), 0.8 * up(up(rows, 192) * tn, cus))
     n1 = ct(dim)
     return rounds(3 * n1) + rounds(n1) + rounds(4 * n1) + 4 * rounds(n1) + 0.5 * 2 * rounds(n1)
 

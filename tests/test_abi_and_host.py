@@ -360,6 +360,24 @@ torch.distributed.destroy_process_group()
     assert r.returncode != 0 and "MASTER_PORT" in r.stderr
 
 
+def test_launch_cost_model_and_frames_per_launch():
+    """dp.launch_cost: rounds of GEMM tiles of a packed launch (one tile per CU and round; 256-row tiles, or 192-row ones at 0.8 where
+    they give fewer / shorter rounds) - the model behind dp.choose_max_frames.  Whole rounds cost least per frame; the cap is chosen from
+    the directory's lengths, deterministically, and scales with the CUs the acoustic stage owns."""
+    from covomix_amd import dp
+    full = dp.launch_cost(8192)                    # 16384 rows = 64 row panels: qkv 3 + out 1 + ff1 4 + ff2 4 + skip 1 rounds
+    assert full == 13.0
+    assert dp.launch_cost(8150) == 13.0            # (the last panel is ragged: same rounds)
+    assert dp.launch_cost(4649) == pytest.approx(2 + 0.8 + 3 + 4 * 0.8 + 0.8)      # N = 1024 products on 192-row tiles: one round at 0.8
+    assert dp.launch_cost(4649) / 4649 > full / 8192                               # a part-empty launch costs more per frame
+    assert dp.launch_cost(7168, cus=224) == 13.0                                   # the same whole rounds on 224 CUs
+    lengths = [400, 1200, 451, 1149, 503, 1097, 555, 1044, 607, 993, 659, 941, 711, 889, 763, 837]      # the ragged test directory
+    assert dp.choose_max_frames(lengths, 32) == 8192
+    assert dp.choose_max_frames(lengths, 32, cus=224) in (7168, 10752, 14336, 21504)
+    assert dp.choose_max_frames([1000] * 24, 32) == 8192                           # 24,000 frames: three whole-round launches tie any bigger one: smallest cap
+    assert dp.choose_max_frames(lengths, 32) == dp.choose_max_frames(list(lengths), 32)
+
+
 def test_launch_ranks_reports_the_rank_that_failed(tmp_path, capfd):
     """A rank that dies takes the job down; launch_ranks then prints every rank's stderr tail so that the first multi-GPU run is
     diagnosable from its log (round-4 review item 8) - and a healthy rank's stdout stays untouched (rank 0's JSON line is ONE bare line)."""
