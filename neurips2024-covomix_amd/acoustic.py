@@ -730,7 +730,7 @@ class FlowMatchingSampler:
         times, dts = evaluation_times(self.nfe, self.method)
         rows = (2 * B if use_null else B) * T
         if os.environ.get("CVX_GRAPH", "1") == "0" or rows > int(os.environ.get("CVX_GRAPH_MAX_ROWS", "8192")):
-            self._integrate(phoneme_ids, cond, y, times.to(dev), dts, s, use_null)
+            self._integrate(phoneme_ids, cond, y, ops.h2d(times, dev), dts, s, use_null)
             return y
         main = torch.cuda.current_stream()
         # (the saturation flag of the launching stream is a kernel argument of the captured launches: one graph per stream)
@@ -738,7 +738,7 @@ class FlowMatchingSampler:
         cache = f.__dict__.setdefault("_graphs", {})
         ent = cache.get(key)
         if ent is None:
-            st = dict(ids=phoneme_ids.clone(), cond=cond.clone(), y=y.clone(), times=times.to(dev))
+            st = dict(ids=phoneme_ids.clone(), cond=cond.clone(), y=y.clone(), times=ops.h2d(times, dev))
             ctx = self._integrate(st["ids"], st["cond"], st["y"], st["times"], dts, s, use_null)   # eager warm-up
             st["ws"] = ctx["ws"]             # keep this shape's workspace alive for as long as the graph is
             # (thread-local capture mode + the package's capture gate: another host thread driving its own model on this device
@@ -794,6 +794,6 @@ class FlowMatchingSampler:
             y = torch.cat([t.to(device=dev, dtype=torch.float32) for t in y0]).contiguous().clone()
         use_null = float(cond_scale) != 1.0          # acoustic.py:423
         times, dts = evaluation_times(self.nfe, self.method)
-        self._integrate(ids_p, cond_p, y, times.to(dev), dts, float(cond_scale), use_null, lengths=lengths)
+        self._integrate(ids_p, cond_p, y, ops.h2d(times, dev), dts, float(cond_scale), use_null, lengths=lengths)
         return list(torch.split(y, lengths))
 

@@ -273,6 +273,7 @@ def run(dialogue: bool, argv=None) -> int:
     generator.load_state_dict(state_dict_g["generator"])
     generator.eval()
     generator.remove_weight_norm()
+    generator.pack()                           # (part of loading the model, not of the first batch)
     model = CoVoMixModel.load_from_checkpoint(args.acous_ckpt, base_dir="", batch_size=16, num_workers=0)
     model.eval()
     model = model.to(device)
@@ -317,17 +318,20 @@ def run(dialogue: bool, argv=None) -> int:
     # of ANY lengths share a launch sequence: packed back to back (no padding), every utterance attending to itself only
     # (sample_ragged), so each gets the result of its own B = 1 run.  Batches are FILLED to --max_frames (first-fit decreasing,
     # dp.pack_by_frames): the frames of a launch decide how many whole rounds of GEMM tiles it runs.
-    def one_batch(batch, y0):
-        """acoustic solve + vocoder of one packed batch of (inputs, (name, segment)) -> [(name, segment, int16 samples)], generated frames"""
+    def one_batch(batch, y0, defer=False):
+        """acoustic solve + vocoder of one packed batch of (inputs, (name, segment)) -> parts, generated frames.  parts: one
+        (int16 PCM [items, samples] on the HOST, [(name, segment, samples of that item)]) per vocoder call; defer: the PCM travels by
+        an asynchronous copy into pinned memory - valid once the stream has got there (_finish)."""
         its = [it for it, _ in batch]
         lens = [int(it[0].shape[0]) for it in its]
+        up = lambda t: ops.h2d(t, device)          # (through pinned memory: a pageable copy would make the host wait for the stream)
         if len(set(lens)) == 1:                                                          # equal lengths: the plain [B, T, .] call
-            sampled = list(model.synthesis_sample(phoneme_ids=torch.stack([it[0] for it in its]).to(device),
-                                                  cond=torch.stack([it[1] for it in its]).to(device),
-                                                  mask=torch.stack([it[2] for it in its]).to(device),
+            sampled = list(model.synthesis_sample(phoneme_ids=up(torch.stack([it[0] for it in its])),
+                                                  cond=up(torch.stack([it[1] for it in its])),
+                                                  mask=torch.stack([it[2] for it in its]),
                                                   cond_scale=COND_SCALE, y0=torch.stack(y0)))
         else:
-            sampled = model.synthesis_sample(phoneme_ids=[it[0].to(device) for it in its], cond=[it[1].to(device) for it in its],
+            sampled = model.synthesis_sample(phoneme_ids=[up(it[0]) for it in its], cond=[up(it[1]) for it in its],
                                              mask=[it[2] for it in its], cond_scale=COND_SCALE, y0=y0)
         # vocoder: the generated frames of every utterance of the batch (:299-300: mask is a suffix) go through HiFi-GAN in
         # ONE ragged call (zero-padded to the longest, per-item lengths: every item gets its B = 1 waveform); one int16 cast
@@ -337,7 +341,7 @@ def run(dialogue: bool, argv=None) -> int:
         # (items of similar length only: the ragged vocoder call pads to its longest item and skips no work behind a short
         #  one, dp.group_by_padding keeps that padding below 25 % of the real frames)
         tg_all = [lens[j] - n_prompt[j] for j in js]
-        out, nfr = [], 0
+        parts, nfr = [], 0
         for grp in dp.group_by_padding(tg_all):
             gj = [js[k] for k in grp]
             tgen = [tg_all[k] for k in grp]
@@ -345,39 +349,75 @@ def run(dialogue: bool, argv=None) -> int:
             for r, j in enumerate(gj):
                 mel[r, :, : tgen[r]] = sampled[j][n_prompt[j]:, :].T
             wav = generator(mel, lengths=tgen) if len(set(tgen)) > 1 else generator(mel)
-            pcm = ops.wav_to_int16(wav.squeeze(1).contiguous()).cpu().numpy()              # mel_decode_to_wav (:52-59), batched
+            pcm_dev = ops.wav_to_int16(wav.squeeze(1).contiguous())                        # mel_decode_to_wav (:52-59), batched
+            if defer:
+                pcm = torch.empty(pcm_dev.shape, dtype=pcm_dev.dtype, pin_memory=True)
+                pcm.copy_(pcm_dev, non_blocking=True)
+            else:
+                pcm = pcm_dev.cpu()
             nfr += sum(tgen)
-            for r, j in enumerate(gj):
-                n, seg = batch[j][1]
-                out.append((n, seg, pcm[r, : generator.output_length(tgen[r])].copy()))
-        return out, nfr
+            parts.append((pcm, [(batch[j][1][0], batch[j][1][1], generator.output_length(tgen[r])) for r, j in enumerate(gj)]))
+        return parts, nfr
+
+    def _store(parts):
+        for pcm, owners in parts:
+            pcm = pcm.numpy()
+            for r, (n, seg, ns) in enumerate(owners):
+                segments[n][seg] = pcm[r, :ns].copy()
+
+    # The host runs ONE BATCH AHEAD of the device: solve() enqueues a batch - inputs through pinned memory, the solve, the vocoder, the
+    # PCM and the saturation flag into pinned memory, an event - and only then waits for the batch BEFORE it.  File-to-tensor work,
+    # packing, the per-utterance copies around the vocoder and the Python between the launches (7 % of the device's time on a directory
+    # of 16 utterances when every batch ended in a blocking copy) then happen under the previous batch's kernels.
+    pending: list = []
+
+    def _finish(entry):
+        batch, y0, parts, flag, ev, nfr = entry
+        ev.synchronize()
+        if flag is not None and int(flag[0]) != 0:
+            # a flagged batch is repeated with the per-call checks (the stage that saturated warns and re-runs in fp32, or raises
+            # under CVX_ON_SATURATION=raise)
+            parts, nfr = one_batch(batch, y0)
+        _store(parts)
+        now = time.perf_counter()
+        batch_log.append((len(batch), sum(int(it[0].shape[0]) for it, _ in batch), nfr, now - batch_log_t[0]))
+        batch_log_t[0] = now
 
     def solve(batch):
-        """one packed batch end to end on the current stream: noise, solve, vocoder, saturation check -> generated frames"""
+        """one packed batch on the current stream: noise, solve, vocoder, saturation flag -> generated frames (its PCM is collected when
+        the NEXT batch has been enqueued, or by drain())"""
         y0 = [torch.randn(int(it[0].shape[0]), n_out, device=device, generator=torch.Generator(device=device).manual_seed(
             _stable_seed(args.seed, own[0], own[1], 2))) for it, own in batch]             # acoustic.py:647-650, per utterance
-        # one saturation-flag read per batch (after the device-to-host copy that waits for the batch anyway) instead of one
-        # blocking read per call; a flagged batch is repeated with the per-call checks (the stage that saturated warns and
-        # re-runs in fp32, or raises under CVX_ON_SATURATION=raise)
-        with ops.saturation_deferred() as guard:
-            res, nfr = one_batch(batch, y0)
-        if guard.flagged:
-            res, nfr = one_batch(batch, y0)
-        for n, seg, samples in res:
-            segments[n][seg] = samples
+        with ops.saturation_deferred(read=False):          # one flag read per batch instead of one blocking read per call
+            parts, nfr = one_batch(batch, y0, defer=True)
+        flag = ops.saturation_snapshot()
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((batch, y0, parts, flag, ev, nfr))
+        while len(pending) > 1:
+            _finish(pending.pop(0))
         return nfr
+
+    def drain():
+        while pending:
+            _finish(pending.pop(0))
 
     def items_of(n, pred):
         return [(it, (n, seg)) for seg, it in enumerate(_build_items(args.mode, dialogue, args.prompt_dir, n,
                                                                      [pred[(n, k)] for k in range(len(sources[n]))]))]
 
     done, frames = 0, 0
+    batch_log_t = [0.0]
+    batch_log: list = []                     # (utterances, frames in the launch, generated frames, seconds) per batch -> last_stats
+    load_s = 0.0
     if mode == "off":       # ---- text2semantic for this rank's utterances first (not timed, as in round 4), then ONE global packing
         pred = _predict_turns(work, t2s, device, args.seed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    batch_log_t[0] = t0
     if mode == "off":
         pool = [x for n in mine for x in items_of(n, pred)]
+        load_s = time.perf_counter() - t0                         # prompt files -> model inputs (host only)
         lengths = [int(it[0].shape[0]) for it, _ in pool]
         if max_frames is None:               # the cap whose packing costs least in rounds of GEMM tiles (dp.choose_max_frames)
             max_frames = dp.choose_max_frames(lengths, args.max_batch, ops.stream_cus())
@@ -410,6 +450,7 @@ def run(dialogue: bool, argv=None) -> int:
         nfr = pl.run_two_stage(groups, lambda g: _predict_turns(g, t2s, device, args.seed), solve, device,
                                overlap=(mode == "on"), collate=collate)
         frames = sum(nfr)
+    drain()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     for n in mine:
@@ -422,5 +463,6 @@ def run(dialogue: bool, argv=None) -> int:
         done += 1
     print(f"rank {rank}: {done} utterances, {frames} generated frames in {elapsed:.3f} s ({frames / max(elapsed, 1e-9):.1f} frames/s, "
           f"{'text2semantic + ' if mode != 'off' else ''}sampling + vocoder, excluding model load; --pipeline {mode})")
-    run.last_stats = dict(utterances=done, frames=frames, seconds=elapsed, pipeline=mode)
+    run.last_stats = dict(utterances=done, frames=frames, seconds=elapsed, pipeline=mode, load_seconds=load_s, batches=batch_log,
+                          max_frames=max_frames)
     return done

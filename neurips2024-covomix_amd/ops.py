@@ -618,6 +618,29 @@ class saturation_deferred:
         return False
 
 
+def h2d(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
+    """Host tensor -> device through pinned memory, asynchronously on the current stream.  A copy from PAGEABLE memory makes the host
+    wait for everything the stream still has to do before it (the runtime stages it behind the queue and waits): one small tensor
+    made with torch.tensor(..., device=...) in the middle of a call is enough to keep the host from running ahead of the device."""
+    if t.device.type != "cpu":
+        return t.to(device=device, dtype=dtype) if dtype is not None else t.to(device)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
+def saturation_snapshot():
+    """The current stream's saturation flag as it stands after everything enqueued so far, WITHOUT waiting: an asynchronous copy into a
+    pinned int32 tensor (read element 0 once an event recorded after this call has completed).  For callers that run the host ahead
+    of the device - `with saturation_deferred(read=False): ...calls...; snap = saturation_snapshot()` - and look at the batch later.
+    None under CVX_SAT_CHECK=0."""
+    if _os.environ.get("CVX_SAT_CHECK", "1") != "1":
+        return None
+    snap = torch.zeros(1, dtype=torch.int32).pin_memory()
+    snap.copy_(saturation_flag(), non_blocking=True)
+    return snap
+
+
 class Ragged:
     """A packed batch of sequences of different length: sequence i owns rows [cu[i], cu[i+1]) of every [M, width] tensor.
     cu: int32 CUDA tensor [n + 1]; lengths: the python list (host side: grid sizes, slicing)."""
@@ -631,7 +654,7 @@ class Ragged:
         for t in self.lengths:
             cu.append(cu[-1] + t)
         self.cu_host = cu
-        self.cu = torch.tensor(cu, dtype=torch.int32, device=device)
+        self.cu = h2d(torch.tensor(cu, dtype=torch.int32), device)
 
     def positions(self) -> torch.Tensor:
         """Position of every packed row inside its own sequence (fp32, on the device)."""

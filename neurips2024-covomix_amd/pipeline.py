@@ -34,14 +34,18 @@ class _Failure:
 
 
 def run_two_stage(items: Iterable, stage1: Callable, stage2: Callable, device=None, overlap: bool = True, depth: int = 2,
-                  partition: Optional[ops.CUPartition] = None, collate: Optional[Callable] = None) -> List:
+                  partition: Optional[ops.CUPartition] = None, collate: Optional[Callable] = None,
+                  finish: Optional[Callable] = None) -> List:
     """[stage2(y) for y in collate(stage1(item) for item in items)], stage1 on the side stream of the device's CU partition and
     stage2 on its main stream.  collate (default: identity) is a generator function that turns the stream of stage-1 results into
     stage-2 inputs - the two stages need not batch alike (text2semantic decodes 8 utterances per pass whatever the acoustic batch is).
     overlap=True: stage1 runs in a worker thread, at most `depth` results ahead of stage2; overlap=False: the same calls on the same
     streams one after the other (the reference point of the bit-identity tests and of the speed-up).  A stage-1 result is handed over
     after its stream has drained (device tensors in it are safe to read on the main stream); stage2's results are returned after
-    the main stream has drained.  An exception in either stage is re-raised in the calling thread."""
+    the main stream has drained.  An exception in either stage is re-raised in the calling thread.
+    finish: stage2 only ENQUEUES its batch and returns a handle (results on their way into pinned memory behind an event);
+    finish(handle) -> result is called after the NEXT batch has been enqueued, so the host work between two batches (assembly, input
+    copies, the Python of ~2,500 launches) happens under the previous batch's kernels instead of between them."""
     part = partition if partition is not None else ops.cu_partition(device)
     dev = part.device
     out: List = []
@@ -49,8 +53,17 @@ def run_two_stage(items: Iterable, stage1: Callable, stage2: Callable, device=No
     def consume(results):
         feed = collate(results) if collate is not None else results
         with torch.cuda.device(dev), torch.cuda.stream(part.main):
+            pend = None
             for y in feed:
-                out.append(stage2(y))
+                h = stage2(y)
+                if finish is None:
+                    out.append(h)
+                    continue
+                if pend is not None:
+                    out.append(finish(pend[0]))
+                pend = (h,)
+            if pend is not None:
+                out.append(finish(pend[0]))
         part.main.synchronize()
 
     if not overlap:

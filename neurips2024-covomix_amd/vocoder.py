@@ -142,6 +142,13 @@ class Generator:
             c.bias16[: c.cout] = c.bias
         return c
 
+    def pack(self) -> "Generator":
+        """Fold weight norm and lay the weights out for the kernels NOW (otherwise the first forward does it - with host-to-device
+        copies that wait behind whatever the stream is still running, e.g. the solve whose mel this call is about to vocode)."""
+        if self._packed is None:
+            self._pack()
+        return self
+
     def _pack(self):
         if self._sd is None:
             raise RuntimeError("Generator: load_state_dict() has not been called")
@@ -249,7 +256,7 @@ class Generator:
         if lengths is not None:
             if len(lengths) != x.shape[0] or min(lengths) < 1 or max(lengths) > x.shape[2]:
                 raise ValueError(f"lengths must hold one frame count in [1, {x.shape[2]}] per batch item")
-            lens = torch.tensor([int(t) for t in lengths], dtype=torch.int32, device=self.device)
+            lens = ops.h2d(torch.tensor([int(t) for t in lengths], dtype=torch.int32), self.device)
         it = lambda: None if lens is None else (lens, mul, add)
         mul, add = self._affine(pk["pre"], mul, add)
         x = self._run(pk["pre"], x, items=it())

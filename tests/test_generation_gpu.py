@@ -296,7 +296,7 @@ def test_cli_dialogue_turn_modes(tmp_path, mode, monkeypatch):
 
 def test_cli_rate_matches_bench_path(tmp_path):
     """The CLI is the bench path (round-1 verdict item 6): 16 synthetic utterances of 1000 frames (600 generated) through
-    generation.run on the full-width VoMix + config_covomix HiFi-GAN must generate frames at >= 85 % of the rate the same
+    generation.run on the full-width VoMix + config_covomix HiFi-GAN must generate frames at >= 88 % of the rate (round 5, host one batch ahead of the device: 0.93) the same
     model reaches when driven like bench.py (8 utterances per launch, vocoder batched, one device-to-host copy per batch)."""
     import time
     import covomix_amd.synthetic as syn
@@ -332,8 +332,9 @@ def test_cli_rate_matches_bench_path(tmp_path):
         cli_rate = 0.0
         for _ in range(3):                                       # best of three: a wall-clock ratio on a shared host
             assert generation.run(True, argv) == N
-            cli = generation.run.last_stats
-            cli_rate = max(cli_rate, cli["frames"] / cli["seconds"])
+            if generation.run.last_stats["frames"] / generation.run.last_stats["seconds"] > cli_rate:
+                cli = generation.run.last_stats
+                cli_rate = cli["frames"] / cli["seconds"]
     # the bench-style loop on the same shapes: 8 x 1000 frames per launch, vocoder on the 600 generated frames
     model = CoVoMixModel.from_state_dict(sd, nfe=32).eval().to("cuda:0")
     gen = Generator(AttrDict(h)).to("cuda:0"); gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
@@ -359,7 +360,7 @@ def test_cli_rate_matches_bench_path(tmp_path):
 def test_cli_rate_on_ragged_directory(tmp_path):
     """Round-2 verdict item 2: a REAL directory has utterances of all different lengths.  16 utterances of distinct
     T in [400, 1200] (40 % prompt, like the bench shape) through generation.run on the full-width VoMix + config_covomix
-    HiFi-GAN must generate frames at >= 85 % of the rate of the bench-style loop on 8 x 1000 equal-length frames (with
+    HiFi-GAN must generate frames at >= 88 % of the rate (round 5, host one batch ahead of the device: 0.93) of the bench-style loop on 8 x 1000 equal-length frames (with
     equal-length-only batching this directory ran at the B = 1 rate, about 0.4)."""
     import time
     import covomix_amd.synthetic as syn
@@ -422,7 +423,9 @@ def test_cli_rate_on_ragged_directory(tmp_path):
         torch.cuda.synchronize()
         bench_rate = max(bench_rate, 2 * 8 * (T - P) / (time.perf_counter() - t0))
     print(f"ragged directory: CLI {cli_rate:.0f} generated frames/s vs bench-style loop {bench_rate:.0f}: ratio {cli_rate / bench_rate:.3f}")
-    assert cli["frames"] == gen_frames and cli_rate >= 0.85 * bench_rate
+    print(f"  {cli['seconds'] * 1e3:.1f} ms = inputs from files {cli['load_seconds'] * 1e3:.1f} ms + batches (utterances, frames, ms): "
+          + ", ".join(f"({n}, {fr}, {sec * 1e3:.1f})" for n, fr, _, sec in cli["batches"]) + f"; max_frames {cli['max_frames']}")
+    assert cli["frames"] == gen_frames and cli_rate >= 0.88 * bench_rate
 
 
 
@@ -552,3 +555,38 @@ def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
         assert np.array_equal(out["on"][nm], out["serial"][nm]), nm
         assert out["on"][nm].shape == out["off"][nm].shape
         assert np.abs(out["on"][nm].astype(np.int32) - out["off"][nm].astype(np.int32)).max() <= 2, nm
+
+
+def test_cli_batch_outside_the_window_is_repeated_in_fp32_while_the_host_runs_ahead(tmp_path, monkeypatch):
+    """generation.run enqueues batch k + 1 before it looks at batch k (PCM and saturation flag arrive through pinned memory behind
+    an event).  A prompt mel far outside the split pairs' window in the MIDDLE batch of a directory must still never come back
+    silently: the CLI warns, repeats that batch with the per-call checks (exact-fp32 re-run, conditional_model.py) and every wav -
+    the batches before and after it too - equals the wav of an all-fp32 run of the same directory within 2 LSB."""
+    import warnings
+    from covomix_amd import generation
+    from scipy.io.wavfile import read
+    tmp = str(tmp_path)
+    _write_fixture(tmp, "vomix")
+    tdir, pdir = os.path.join(tmp, "text"), os.path.join(tmp, "prompt")
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(3)
+    names = [f"u{i}" for i in range(6)]
+    for i, n in enumerate(names):
+        P = 20 + 3 * i
+        for suf in ("_1", "_2"):
+            np.save(os.path.join(pdir, f"{n}{suf}.hubert_code.npy"), g.randint(0, 500, size=P))
+            mel = (g.randn(80, P) * 2 - 6).astype(np.float32)
+            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), mel * (30000.0 if i == 3 else 1.0))
+        np.save(os.path.join(tdir, f"{n}.semantic.npy"), g.randint(0, 500, size=(2, 30 + 2 * i)))
+    base = ["--acous_ckpt", os.path.join(tmp, "acous.ckpt"), "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir,
+            "--prompt_dir", pdir, "--mode", "covomix", "--seed", "4", "--nfe", "4", "--max_frames", "130"]
+    with pytest.warns(UserWarning, match="saturat"):
+        assert generation.run(True, base + ["--saved_dir", os.path.join(tmp, "a")]) == 6
+    assert len(generation.run.last_stats["batches"]) >= 3
+    monkeypatch.setenv("CVX_PRECISION", "fp32")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert generation.run(True, base + ["--saved_dir", os.path.join(tmp, "b")]) == 6
+    for n in names:
+        a, b = read(os.path.join(tmp, "a", n + ".wav"))[1], read(os.path.join(tmp, "b", n + ".wav"))[1]
+        assert a.shape == b.shape and np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2, n

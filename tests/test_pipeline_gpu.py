@@ -91,6 +91,12 @@ def test_two_stage_runner_order_errors_and_overlap():
     with pytest.raises(ValueError, match="stage two failed"):
         pipeline.run_two_stage(range(50), lambda i: i, bad2, dev)
     assert pipeline.run_two_stage(range(3), lambda i: i, lambda x: x + 1, dev) == [1, 2, 3]      # (and the runner is reusable afterwards)
+    # finish: stage 2 only enqueues and hands back a handle; the handle of batch k is finished after batch k + 1 was enqueued
+    log = []
+    out = pipeline.run_two_stage(range(4), lambda i: i, lambda x: (log.append(("launch", x)), x)[1], dev,
+                                 finish=lambda h: (log.append(("finish", h)), 10 * h)[1])
+    assert out == [0, 10, 20, 30]
+    assert log == [("launch", 0), ("launch", 1), ("finish", 0), ("launch", 2), ("finish", 1), ("launch", 3), ("finish", 2), ("finish", 3)]
 
 
 @pytest.fixture(scope="module")
