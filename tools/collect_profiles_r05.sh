@@ -5,13 +5,18 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py (2 timed steps + 1 warm-up), of tools/bench_c2.py and of the config-5 pipeline
 #      (tools/bench_pipeline.py: serial / alternate / pipelined schedules in one trace; the kernel trace keeps the queue ids)
 #   3. --pmc SQ pass (GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES) of bench.py and config 2
+#   5. config 5 (56 dialogues) and the ragged test directory without a profiler, the ragged directory's device idle gaps (gap_summary.py)
 #   4. --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (separate; pmc_summary.py: one row per GEMM epilogue instance)
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof5
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+DIALOGUES=56 python tools/bench_pipeline.py > $OUT/c5_pipeline.txt 2>&1
+PASSES=3 python tools/ragged_dir.py > $OUT/ragged_dir.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
+PASSES=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/ragged -- python $REPO/tools/ragged_dir.py > $OUT/ragged_trace.log 2>&1
+f=$(find $OUT/ragged -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $REPO/tools/gap_summary.py $f 12 -$(grep -o "[0-9.]* ms = files" $OUT/ragged_trace.log | head -1 | cut -d" " -f1) > $OUT/ragged_gaps.txt 2>&1
 B="python $REPO/bench.py --no-cpu-baseline --no-fp32-exact --no-c2 --no-c5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B --steps 2 --warmup 1 > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_stats -- python $REPO/tools/bench_c2.py > $OUT/c2_stats.log 2>&1
