@@ -254,8 +254,9 @@ def config5(dev, dialogues: int = 28):
         torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
         return r, time.perf_counter() - t0
     n_ser = max(8, dialogues // 8 * 8)
-    _, ts = timed(lambda: c5.run(n_ser, 8, overlap=False, partitioned=False))
-    alt, ta = timed(lambda: c5.run(dialogues, 7, overlap=False))
+    recs = [c5.dialogue(j) for j in range(max(n_ser, dialogues))]          # synthetic inputs: made outside the timed regions
+    _, ts = timed(lambda: c5.run(n_ser, 8, overlap=False, partitioned=False, recs=recs[:n_ser]))
+    alt, ta = timed(lambda: c5.run(dialogues, 7, overlap=False, recs=recs[:dialogues]))
     spans = []                     # the solve is only ENQUEUED by stage2_launch (the host runs a batch ahead): HIP events on its stream
     inner = c5.stage2_launch
 
@@ -264,7 +265,7 @@ def config5(dev, dialogues: int = 28):
         a.record(); r = inner(x); b.record(); spans.append((a, b))
         return r
     c5.stage2_launch = launch
-    pip, tp = timed(lambda: c5.run(dialogues, 7, overlap=True))
+    pip, tp = timed(lambda: c5.run(dialogues, 7, overlap=True, recs=recs[:dialogues]))
     walls = [a.elapsed_time(b) * 1e-3 for a, b in spans]
     same = all(torch.equal(a["streams"], b["streams"]) and torch.equal(a["pcm"], b["pcm"]) for a, b in zip(alt, pip))
     steady = sorted(walls[1:])[len(walls[1:]) // 2] if len(walls) > 1 else walls[0]

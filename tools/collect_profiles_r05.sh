@@ -3,7 +3,8 @@
 # judged live under profiles/r05_* (copied after a look).  PMC passes are their own runs with --kernel-trace only.
 #   1. bench.py (default): JSON line with roofline (+ power / sclk), kernel classes, c2, c5, fp32_exact, cpu_baseline
 #   2. rocprofv3 --kernel-trace --stats of bench.py (2 timed steps + 1 warm-up), of tools/bench_c2.py and of the config-5 pipeline
-#      (tools/bench_pipeline.py: serial / alternate / pipelined schedules in one trace; the kernel trace keeps the queue ids)
+#      (tools/bench_pipeline.py: serial / alternate / pipelined schedules in one trace; the overlap of the two stages is in its own
+#      HIP-event device timeline, c5_pipeline.txt - a profiler's trace slows the decode chain and merges the three schedules)
 #   3. --pmc SQ pass (GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES) of bench.py and config 2
 #   5. config 5 (56 dialogues) and the ragged test directory without a profiler, the ragged directory's device idle gaps (gap_summary.py)
 #   4. --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (separate; pmc_summary.py: one row per GEMM epilogue instance)
@@ -29,7 +30,6 @@ cd $REPO
 for d in stats c2_stats c5_stats; do
   f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${d}_kernel_stats.csv && python tools/stats_summary.py $f > $OUT/${d}_summary.txt 2>&1
 done
-f=$(find $OUT/c5_stats -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/queue_overlap.py $f > $OUT/c5_queue_overlap.txt 2>&1
 f=$(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python tools/sq_summary.py $f $OUT/sq_counters.json > $OUT/sq_counters.txt 2>&1
 f=$(find $OUT/c2_pmc_sq -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python tools/sq_summary.py $f $OUT/c2_sq_counters.json > $OUT/c2_sq_counters.txt 2>&1
 ff=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); fw=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
