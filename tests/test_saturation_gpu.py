@@ -276,6 +276,52 @@ def test_deferred_check_reads_the_flag_once_for_a_block_of_calls():
         model.synthesis_sample(ids, (inp["cond"] * 4000.0).cuda(), mask, 0.7, y0=inp["y0"])
 
 
+def test_snapshot_reads_the_flag_without_waiting_and_h2d_goes_through_pinned_memory():
+    """Round 5, host one batch ahead of the device: ops.saturation_snapshot() is an asynchronous copy of the stream's flag into pinned
+    memory - two batches enqueued back to back (deferred, no read), each followed by its snapshot and an event: the first snapshot
+    says 'saturated', the second 'clean' (the reset of the second block sits between them in stream order), with no flag query in
+    between.  ops.h2d copies host tensors through pinned memory (values and dtype conversion intact, device tensors pass through)."""
+    import covomix_amd.ops as ops
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    dev = torch.device("cuda:0")
+    x = torch.arange(12, dtype=torch.int64).reshape(3, 4)
+    d = ops.h2d(x, dev)
+    assert d.device.type == "cuda" and d.dtype == torch.int64 and torch.equal(d.cpu(), x)
+    d32 = ops.h2d(x[:, ::2], dev, dtype=torch.float32)            # (non-contiguous source, conversion)
+    assert d32.dtype == torch.float32 and torch.equal(d32.cpu(), x[:, ::2].float())
+    assert ops.h2d(d, dev) is d
+    sd = _full_width_state()
+    inp = syn.synthetic_inputs("vomix", 1, 80, 40, seed=5)
+    model = CoVoMixModel.from_state_dict(sd, nfe=2).eval().to(dev)
+    ids, mask = inp["phoneme_ids"].cuda(), inp["mask"].cuda()
+    good = model.synthesis_sample(ids, inp["cond"].cuda(), mask, 0.7, y0=inp["y0"])
+    q0, queries = ops.saturation_query, [0]
+
+    def counting(*a, **k):
+        queries[0] += 1
+        return q0(*a, **k)
+    ops.saturation_query = counting
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            with ops.saturation_deferred(read=False):
+                model.synthesis_sample(ids, (inp["cond"] * 4000.0).cuda(), mask, 0.7, y0=inp["y0"])
+            snap_hot = ops.saturation_snapshot()
+            ev_hot = torch.cuda.Event(); ev_hot.record()
+            with ops.saturation_deferred(read=False):
+                mel = model.synthesis_sample(ids, inp["cond"].cuda(), mask, 0.7, y0=inp["y0"])
+            snap_ok = ops.saturation_snapshot()
+            ev_ok = torch.cuda.Event(); ev_ok.record()
+        ev_hot.synchronize()
+        assert int(snap_hot[0]) != 0 and snap_hot.is_pinned()
+        ev_ok.synchronize()
+        assert int(snap_ok[0]) == 0 and queries[0] == 0
+        assert torch.equal(mel, good)
+    finally:
+        ops.saturation_query = q0
+
+
 def _vocoder(h, vsd, precision=None):
     from covomix_amd.vocoder import AttrDict, Generator
     gen = Generator(AttrDict(h), precision=precision).to("cuda:0")
