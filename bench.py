@@ -488,7 +488,7 @@ def main():
         split = model.precision in ("f16x3", "f16")
         terms = {"f16x3": 3, "f16": 1, "fp32": 1}[model.precision]
         p8 = model.precision == "f16x3" and ops._GEMM_FLAGS == 0
-        kname = ("gemm_f16x3_p8s_kernel" if p8 else "gemm_f16x3_dma256_kernel") if split else "gemm_f32_glds_kernel"
+        kname = ("gemm_f16x3_p8s_kernel" if p8 else "gemm_f16x3_dma_kernel") if split else "gemm_f32_glds_kernel"
         mfma = "v_mfma_f32_16x16x32_f16" if p8 else "v_mfma_f32_32x32x16_f16"
         peak = PEAK_F16_MFMA if split else PEAK_F32_MFMA
         traffic = None

@@ -474,8 +474,7 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
     uint32_t* sat = cvx_sat_flag_for(s);
     // key-split groups for short launches (see the kernel): fewer than 2048 query rows = at most one 128-query block per CU (96 KiB of
-    // LDS with three groups).  The halves of the two-chain schedule (>= 2048 rows each) and the whole batch always agree on the
-    // variant, so that schedule stays bit-identical to the single chain.
+    // LDS with three groups).
     int ksplit = 1, nwk = 4;
     const int64_t q_rows = cu_seqlens_dev ? cols : (int64_t)Bt * T;             // query rows of the launch
     if (nw == 4 && T >= 4 * KT && q_rows < 2048) {

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const cvx_gemm_args 
 // tiles are requested STAGES-1 steps ahead and retired with a COUNTED vmcnt + a raw s_barrier, so loads stay in
 // flight across barriers (a 24-MFMA step is only ~770 cycles - far shorter than an L2/HBM round trip, which a
 // 2-stage scheme cannot hide).  No staging VGPRs, no split VALU work, no ds_write in the loop.
-// (PreSplitA lives in gemm_common.h: shared with gemm_f16x3_p8.hip)
+// (PreSplitA lives in gemm_common.h: shared with gemm_f16x3_p8s.hip / _p8m.hip)
 
 // Split-K (ksplit > 1, small problems only): blockIdx.y selects a K slice of k_per columns; the block writes its raw
 // partial sums (fp32, no epilogue) to `partial` [ksplit][M][N] and splitk_reduce_kernel finishes the job.

@@ -82,8 +82,8 @@ _TL = threading.local()          # per-thread additions to the flags (gemm_flags
 @contextmanager
 def gemm_flags(extra: int):
     """with ops.gemm_flags(16): every GEMM THIS THREAD launches inside the block carries the extra cvx_gemm_split_io.flags bits
-    (16 = CVX_GEMM_FLAG_NO_MEDIUM: the two-chain schedule pins the large-problem kernel so that its halves and the whole batch run
-    the same arithmetic).  Thread-local: another host thread's solve is not affected (round-4 advice)."""
+    (16 = CVX_GEMM_FLAG_NO_MEDIUM pins the large-problem kernel, 64 / 128 its tile height: A/B measurements and the bit-identity
+    tests).  Thread-local: another host thread's solve is not affected (round-4 advice)."""
     old = getattr(_TL, "flags", 0)
     _TL.flags = old | int(extra)
     try:

@@ -378,7 +378,7 @@ def test_flags_are_per_stream_and_caller_owned(ops):
     """Round-3 review: the flag was ONE library-owned word per device, so a reset on one stream could clear what another
     stream's kernels had raised.  Now the caller owns one word per (device, stream) (cvx_saturation_flag_bind): a saturating
     launch on stream A flags A only, a reset / clean launch / query on stream B neither sees nor clears it, a stream without a
-    flag runs without bookkeeping, and a shared flag (two-chain side stream, capture stream) collects both streams."""
+    flag runs without bookkeeping, and a shared flag (capture stream, side stream) collects both streams."""
     dev_ = dev()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(300, 256, generator=g).to(dev_)

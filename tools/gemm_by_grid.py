@@ -5,9 +5,9 @@ from collections import defaultdict
 acc = defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if "dma256" not in n and "p8_kernel" not in n and "p8s_kernel" not in n:
+    if "p8s_kernel" not in n:
         continue
-    tag = ("p8s" + n.split("p8s_kernel")[1][:14]) if "p8s_kernel" in n else ("p8" + n.split("p8_kernel")[1][:12]) if "p8_kernel" in n else n.split("dma256_kernel")[1][:24]
+    tag = "p8s" + n.split("p8s_kernel")[1][:14]
     k = (tag, r.get("Grid_Size") or r.get("Grid_Size_X"))
     acc[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; acc[k][1] += 1
 for k, (s, n) in sorted(acc.items()):

@@ -1,4 +1,4 @@
-// Dev probe: pure v_mfma_f32_32x32x16_f16 rate with the dma256 kernel's register shape (8 accumulators / wave, 8 waves / CU).
+// Dev probe: pure v_mfma_f32_32x32x16_f16 rate with 8 accumulators per wave, 8 waves per CU (the register shape of the round-2 large-problem kernel).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
