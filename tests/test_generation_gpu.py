@@ -517,7 +517,9 @@ def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
     """--pipeline on (text2semantic of the next utterances on the CU-masked side stream under the solve of the current batch,
     covomix_amd/pipeline.py) writes BIT-IDENTICAL wav files to --pipeline serial (the same batches on the same two streams, one
     after the other); --pipeline off (decode everything, one global packing: other batch compositions) agrees within 2 LSB.
-    20 dialogues = three text2semantic groups, small --max_frames = several acoustic batches with carried-over leftovers."""
+    20 dialogues = three text2semantic groups, small --max_frames = several acoustic batches with carried-over leftovers.  One
+    dialogue's prompt lies outside the split pairs' window: every schedule must warn and repeat that batch on the exact-fp32 kernels
+    (the host runs a batch ahead: the flag arrives through a pinned snapshot taken on the CU-masked stream)."""
     import covomix_amd.synthetic as syn
     from covomix_amd import generation
     from scipy.io.wavfile import read
@@ -536,13 +538,14 @@ def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
         for suf in ("_1", "_2"):
             plen = 12 + (5 * i) % 17
             np.save(os.path.join(pdir, f"{n}{suf}.hubert_code.npy"), g.randint(0, 510, size=plen))
-            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), (g.randn(80, plen) * 2 - 6).astype(np.float32))
+            # (dialogue 7: a prompt far outside the split pairs' window - its batch is flagged through the pinned snapshot taken on
+            #  the CU-masked stream and repeated with the per-call checks, in every schedule)
+            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), ((g.randn(80, plen) * 2 - 6) * (30000.0 if i == 7 else 1.0)).astype(np.float32))
         np.save(os.path.join(tdir, f"{n}.text_ids.npy"), g.randint(1, 199, size=(1, 4 + i % 7)).astype(np.int64))
     out = {}
     for mode in ("on", "serial", "off"):
         sdir = os.path.join(tmp, "out_" + mode)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
+        with pytest.warns(UserWarning, match="saturat"):
             n = generation.run(True, ["--t2s_ckpt", os.path.join(tmp, "t2s.ckpt"), "--acous_ckpt", os.path.join(tmp, "acous.ckpt"),
                                       "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir, "--prompt_dir", pdir,
                                       "--saved_dir", sdir, "--mode", "covomix", "--seed", "30", "--nfe", "8", "--max_frames", "300",
