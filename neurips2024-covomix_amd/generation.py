@@ -73,6 +73,7 @@ def build_parser() -> ArgumentParser:
     return p
 
 
+HEAD_START = 24     # utterances read before the first launch of a large directory (generation.run, --pipeline off)
 _HUBERT = None      # HubertTokenizer, built by main() when --hubert_ckpt / --km_path are given
 
 
@@ -415,7 +416,28 @@ def run(dialogue: bool, argv=None) -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     batch_log_t[0] = t0
-    if mode == "off":
+    head_start = mode == "off" and len(mine) >= 2 * HEAD_START
+    if head_start:
+        # ---- a large directory: the model inputs of the first HEAD_START utterances are read, their fullest first-fit-decreasing bin
+        # is ENQUEUED, and the rest of the directory is read while the device works on it (reading is Python + numpy, ~0.7 ms per
+        # utterance: 2-3 % of the run when it all happens before the first launch; a reader THREAD was tried first and fought the
+        # enqueueing thread for the interpreter lock - 40 utterances in 224-295 ms instead of 40, the first launch enqueued in
+        # 200-390 ms instead of 60); then one global packing of everything that is left.  Every batch is a function of the
+        # utterance list alone.
+        if max_frames is None:
+            max_frames = max(256, 32 * ops.stream_cus())          # two rounds of the N = 1024 products' tiles (8192 on 256 CUs)
+        head = [x for n in mine[:HEAD_START] for x in items_of(n, pred)]
+        load_s = time.perf_counter() - t0
+        lengths = [int(it[0].shape[0]) for it, _ in head]
+        bins = dp.pack_by_frames(list(range(len(head))), lengths, max_frames, args.max_batch)
+        first = max(range(len(bins)), key=lambda b: (sum(lengths[i] for i in bins[b]), -b))
+        frames += solve([head[i] for i in bins[first]])
+        taken = set(bins[first])
+        pool = [x for i, x in enumerate(head) if i not in taken] + [x for n in mine[HEAD_START:] for x in items_of(n, pred)]
+        lengths = [int(it[0].shape[0]) for it, _ in pool]
+        for b in dp.pack_by_frames(list(range(len(pool))), lengths, max_frames, args.max_batch):
+            frames += solve([pool[i] for i in b])
+    elif mode == "off":
         pool = [x for n in mine for x in items_of(n, pred)]
         load_s = time.perf_counter() - t0                         # prompt files -> model inputs (host only)
         lengths = [int(it[0].shape[0]) for it, _ in pool]
@@ -464,5 +486,5 @@ def run(dialogue: bool, argv=None) -> int:
     print(f"rank {rank}: {done} utterances, {frames} generated frames in {elapsed:.3f} s ({frames / max(elapsed, 1e-9):.1f} frames/s, "
           f"{'text2semantic + ' if mode != 'off' else ''}sampling + vocoder, excluding model load; --pipeline {mode})")
     run.last_stats = dict(utterances=done, frames=frames, seconds=elapsed, pipeline=mode, load_seconds=load_s, batches=batch_log,
-                          max_frames=max_frames)
+                          max_frames=max_frames, head_start=bool(head_start))
     return done

@@ -593,3 +593,42 @@ def test_cli_batch_outside_the_window_is_repeated_in_fp32_while_the_host_runs_ah
     for n in names:
         a, b = read(os.path.join(tmp, "a", n + ".wav"))[1], read(os.path.join(tmp, "b", n + ".wav"))[1]
         assert a.shape == b.shape and np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2, n
+
+
+def test_cli_large_directory_reads_the_rest_of_its_files_under_the_first_launch(tmp_path, monkeypatch):
+    """A directory of 2 x HEAD_START utterances and more: generation.run reads the first HEAD_START, enqueues their fullest bin and
+    reads the rest while the device works on it, then packs everything that is left.  Other batches
+    than one global packing, so every wav equals the global-packing run's within 2 LSB (each utterance attends to itself only);
+    every utterance is generated exactly once, and the run is repeatable bit for bit."""
+    import warnings
+    from covomix_amd import generation
+    from scipy.io.wavfile import read
+    tmp = str(tmp_path)
+    _write_fixture(tmp, "vomix")
+    tdir, pdir = os.path.join(tmp, "text"), os.path.join(tmp, "prompt")
+    os.makedirs(tdir); os.makedirs(pdir)
+    g = np.random.RandomState(11)
+    names = [f"u{i:02d}" for i in range(2 * generation.HEAD_START + 5)]
+    for i, n in enumerate(names):
+        P = 16 + (7 * i) % 19
+        for suf in ("_1", "_2"):
+            np.save(os.path.join(pdir, f"{n}{suf}.hubert_code.npy"), g.randint(0, 500, size=P))
+            np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), (g.randn(80, P) * 2 - 6).astype(np.float32))
+        np.save(os.path.join(tdir, f"{n}.semantic.npy"), g.randint(0, 500, size=(2, 20 + (11 * i) % 23)))
+    base = ["--acous_ckpt", os.path.join(tmp, "acous.ckpt"), "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir,
+            "--prompt_dir", pdir, "--mode", "covomix", "--seed", "9", "--nfe", "4", "--max_frames", "400"]
+
+    def run(out):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert generation.run(True, base + ["--saved_dir", os.path.join(tmp, out)]) == len(names)
+        st = generation.run.last_stats
+        return {n: read(os.path.join(tmp, out, n + ".wav"))[1] for n in names}, [b[0] for b in st["batches"]], st["head_start"]
+    a, ba, ha = run("a")
+    a2, ba2, _ = run("a2")
+    monkeypatch.setattr(generation, "HEAD_START", 10 ** 9)
+    b, bb, hb = run("b")
+    assert sum(ba) == sum(bb) == len(names) and ba == ba2 and ha and not hb
+    for n in names:
+        assert np.array_equal(a[n], a2[n]), n
+        assert a[n].shape == b[n].shape and np.abs(a[n].astype(np.int32) - b[n].astype(np.int32)).max() <= 2, n
