@@ -73,7 +73,7 @@ def build_parser() -> ArgumentParser:
     return p
 
 
-HEAD_START = 24     # utterances read before the first launch of a large directory (generation.run, --pipeline off)
+HEAD_START = 16     # utterances read before the first launch of a large directory (generation.run, --pipeline off)
 _HUBERT = None      # HubertTokenizer, built by main() when --hubert_ckpt / --km_path are given
 
 
