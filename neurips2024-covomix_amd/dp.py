@@ -40,11 +40,24 @@ def launch_ranks(script: str, argv: Sequence[str], n: int) -> int:
         # --tee 2: every rank's stderr still streams through (stdout is untouched: rank 0's JSON line stays ONE bare line) and a copy
         # per rank lands under `logs`, so that a rank that dies (an RCCL abort is not a Python exception: nothing else would say which
         # rank and why) can be reported below
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), "--tee", "2", "--log-dir", logs, script, *argv]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
-        rc = subprocess.call(cmd, env=env)
+        rc = 1
+        for attempt in range(2):
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(free_port()), "--tee", "2", "--log-dir", os.path.join(logs, f"try{attempt}"), script, *argv]
+            # (the launcher's own stderr is kept apart from the ranks': a rendezvous port that someone took between free_port() and
+            #  the store's bind is the one failure worth a second attempt)
+            proc = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True, errors="replace")
+            seen = []
+            for line in proc.stderr:                                # forwarded as it comes, remembered for the check below
+                sys.stderr.write(line)
+                seen.append(line)
+                del seen[:-200]
+            rc = proc.wait()
+            if rc == 0 or not any(k in ln for ln in seen for k in ("Address already in use", "EADDRINUSE", "address already in use")):
+                break
+            print("[covomix_amd.dp] the rendezvous port was taken: trying once more on another port", file=sys.stderr)
         if rc != 0:
             print(f"[covomix_amd.dp] {n} ranks of {os.path.basename(script)} ended with exit code {rc}; stderr tail per rank:", file=sys.stderr)
             for path in sorted(glob.glob(os.path.join(logs, "**", "stderr.log"), recursive=True)):
