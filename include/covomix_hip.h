@@ -40,8 +40,10 @@ typedef void* cvx_stream_t;   /* hipStream_t */
  * streams (cvx_stream_create_cu_mask / _destroy / cvx_stream_set_cus / cvx_stream_cus); the library reads no environment
  * variable in any build; REMOVED (measured slower, numbers in
  * HISTORY.md): cvx_t2s_decode_persistent, cvx_t2s_decode_xcd, cvx_embed_conv31_f32, CVX_GEMM_FLAG_TWO_STAGE / _MFMA32 (the superseded
- * large-problem GEMM forms: shapes the eight-phase kernel cannot take run on the 128 x 128 kernel). */
-#define CVX_ABI_VERSION 106
+ * large-problem GEMM forms: shapes the eight-phase kernel cannot take run on the 128 x 128 kernel).  107: round 6 - text2semantic
+ * decode of up to 64 slots at independent positions with an on-device dialogue queue (continuous batching): cvx_t2s_decoder grew
+ * uniform_steps / queue / dialogues / start, slot records are int32[8], uniforms and tokens are indexed by dialogue. */
+#define CVX_ABI_VERSION 107
 int         cvx_version(void);
 const char* cvx_last_error_string(void);
 
@@ -539,23 +541,34 @@ int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_stream_t s);
  * cross-attention over [learned null k/v | encoder context] (:253-262), the GEGLU FeedForward (:154-167), then
  * final RMSNorm (:143-151), tied logits (:545), top_k (:126-132) + gumbel_sample (:105-113) from the caller's
  * U(0,1) draws, eos bookkeeping (:803-818) and the embedding of the sampled ids as the next input.
- * No host synchronisation: the position lives in state[0] on the device, so a captured graph replays.
+ * No host synchronisation: positions live in the slot records on the device, so a captured graph replays.
  *
  * Host packing contract (neurips2024-covomix_amd/t2s.py):
  *   wqkv_s [3*inner, dim] = to_q | to_k | to_v rows; inside every 64-row head of to_q and to_k the rows are
  *       permuted (0,2,..,62,1,3,..,63) so the reference's interleaved rotary pairs become half-split pairs;
- *   kv_c   [batch, ctx_rows, 2, inner]: row 0 = null_kv, rows 1.. = to_kv(encoder output), computed once per utterance;
- *   k_cache / v_cache [batch, max_len, inner]; every per-utterance buffer below is [batch, ...];
+ *   kv_c   [dialogues, ctx_rows, 2, inner]: row 0 = null_kv, rows 1.. = to_kv(encoder output), computed once per dialogue
+ *       (dialogue = utterance; without a queue dialogue b is decoded by slot b);
+ *   k_cache / v_cache [slots, max_len, inner]; every per-slot buffer below is [slots, ...] with slots = batch for batch in
+ *       {1, 2, 4} and batch rounded up to a multiple of 8 otherwise (the kernels work on groups of 8 slots);
  *   w2     [dim, ff_inner_pad]: the K dimension zero-padded to a multiple of 4;
  *   rope_cos / rope_sin [max_len, 32]: cos / sin(position * freqs[i]);
- *   uniforms [max_len, batch, streams, vocab]; tokens [batch, streams, max_len] int64;
- *   batch (1..8) utterances advance together; a weight row is read once per step for all of them, and the
- *   arithmetic per utterance does not depend on the batch size (results are bit-identical to batch 1);
- *   state int32[batch][4]: [0] position (= tokens produced so far), [1] 1 once an eos was sampled in any stream,
- *       [2] number of steps at that moment, [3] context rows (null row included) used when n_ctx == 0, so that one
- *       captured graph serves utterances of different text length; x must hold start_token and state[0..2]
- *       zeros before the first step.
- * The caller must not ask for more than max_len steps in total (extra steps are ignored on the device).
+ *   uniforms [dialogues, uniform_steps, streams, vocab]; tokens [dialogues, streams, max_len] int64;
+ *   batch (1..64) slots advance together, EACH AT ITS OWN POSITION; a weight row is read once per step and group of 8
+ *   slots, and the arithmetic per utterance does not depend on the batch size, the slot or the other slots' positions
+ *   (results are bit-identical to batch 1);
+ *   state int32[slots][8] (slot records): [0] position (= tokens produced so far), [1] 1 once an eos was sampled in any
+ *       stream, [2] number of steps at that moment, [3] context rows (null row included) used when n_ctx == 0, so that one
+ *       captured graph serves utterances of different text length, [4] the dialogue the slot decodes (indexes kv_c, uniforms,
+ *       tokens; the caller writes the slot number there when there is no queue), [5] step limit and [6] flags of that
+ *       dialogue (queue only; bit 0: an eos does not end it), [7] reserved; x must hold start_token and state[0..2] zeros
+ *       before a slot's first step.
+ *   Continuous batching (queue != NULL; reference loop per dialogue: text2semantic.py:749-848, its exit :803-818): queue
+ *       int32[2] = {next pending dialogue, number of dialogues}; dialogues int32[n][8]: the caller writes [0] context rows,
+ *       [1] step limit (<= uniform_steps, <= max_len), [2] flags; the device writes [3] status (0 pending, 1 running, 2 ended
+ *       by its eos, 3 by its limit), [4] steps decoded, [5] the slot it ran in.  A slot whose dialogue ends takes the next
+ *       pending one inside the sampling kernel of the same step (position 0, `start` as input) or idles when none is left;
+ *       the caller fills the first `batch` slots itself (slot b <- dialogue b, queue[0] = batch).  Not with guidance.
+ * The caller must not ask for more than max_len steps per slot without a queue (extra steps are ignored on the device).
  */
 typedef struct {
     const float *gamma_s, *wqkv_s, *wo_s;        /* self-attention: norm.gamma, packed to_q|to_kv, to_out [dim, inner] */
@@ -567,7 +580,7 @@ typedef struct {
 
 typedef struct {
     int32_t dim, inner, heads, ff_inner, ff_inner_pad, depth, streams, vocab, dim_emb, n_ctx, max_len, top_k;
-    int32_t batch, ctx_rows;                     /* utterances decoded together (1..8); kv_c rows allocated per utterance */
+    int32_t batch, ctx_rows;                     /* slots decoded together (1..64); kv_c rows allocated per dialogue */
     float temperature;
     const cvx_t2s_layer* layers;                 /* HOST array of `depth` entries */
     const float *final_gamma, *emb, *rope_cos, *rope_sin, *uniforms;
@@ -578,6 +591,10 @@ typedef struct {
                                                   * even: slot 2u decodes with the text context, slot 2u + 1 with the context masked out
                                                   * (state[3] = 1: the null key / value row only); every step samples slot 2u's token from
                                                   * null + (cond - null) * cfg_scale (uniforms of slot 2u) and feeds it to both slots */
+    int32_t uniform_steps;                       /* steps of uniforms allocated per dialogue */
+    int32_t* queue;                              /* NULL: slot b decodes dialogue b until the caller stops.  Else continuous batching (above) */
+    int32_t* dialogues;
+    const float* start;                          /* [dim] start token: the input of a slot that takes a new dialogue (queue != NULL) */
 } cvx_t2s_decoder;
 
 int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream_t stream);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB_PATH") or os.path.join(_HERE, "libcovomix_hip.so")      # CVX_LIB_PATH: dev A/B builds
 
 _f32p = C.POINTER(C.c_float)
-ABI_VERSION = 106          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
+ABI_VERSION = 107          # == cvx_version(): bumped whenever an argument struct or an entry point's meaning changes
 
 
 class GemmArgs(C.Structure):
@@ -136,7 +136,8 @@ class T2SDecoder(C.Structure):
                                          "dim_emb", "n_ctx", "max_len", "top_k", "batch", "ctx_rows")] + \
                [("temperature", C.c_float), ("layers", C.POINTER(T2SLayer))] + \
                [(n, C.c_void_p) for n in ("final_gamma", "emb", "rope_cos", "rope_sin", "uniforms",
-                                          "x", "q", "att", "h", "logits", "tokens", "state")] + [("cfg_scale", C.c_float)]
+                                          "x", "q", "att", "h", "logits", "tokens", "state")] + [("cfg_scale", C.c_float)] + \
+               [("uniform_steps", C.c_int32), ("queue", C.c_void_p), ("dialogues", C.c_void_p), ("start", C.c_void_p)]
 
 
 class ResblockArgs(C.Structure):

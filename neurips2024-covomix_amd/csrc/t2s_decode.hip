@@ -3,9 +3,13 @@
 //
 // One new position per step: every projection is a matrix-VECTOR product, so the step is bound by streaming the
 // decoder weights (CoSingle 60 MB, CoMix 186 MB of fp32 per token step) - an HBM/MALL-bound path, not an MFMA one.
-// BATCH: up to 8 utterances advance together (same position, own context / cache / eos): a weight row is read once
-// and multiplied with every utterance's vector, so the step costs about the same as for one utterance.  The arithmetic
-// per utterance (summation order included) does not depend on the batch size: results are bit-identical to batch 1.
+// BATCH: up to 64 decode SLOTS advance together (each at its OWN position, with its own context / cache / eos): a weight row
+// is read once per group of 8 slots and multiplied with every slot's vector.  The chain of 34 dependent launches is latency-bound,
+// so a step at batch 32 costs little more than at batch 8.  The arithmetic per utterance (summation order included) does not
+// depend on the batch size, the slot or the position of the other slots: results are bit-identical to batch 1.
+// CONTINUOUS BATCHING (round 6): with a dialogue queue (cvx_t2s_decoder.queue) a slot whose dialogue has sampled its eos (or
+// reached its step limit) takes the next pending dialogue INSIDE sample_kernel - no host round trip, no idle slot-steps; the
+// per-dialogue buffers (context k/v, uniforms, tokens) are indexed by the dialogue number the slot record carries.
 // Kernels (all fp32, fp32 accumulate):
 //   gemv_kernel<MODE>   block = 4 waves, every wave owns TWO output rows (the pairs are chosen so that the epilogue
 //                       has both members of a RoPE pair / a GEGLU (value, gate) pair in one wave); the input vector is
@@ -19,7 +23,7 @@
 // (rotary_embedding_torch.py:146-157); rotating a key once at its own position when it enters the cache is the same
 // arithmetic.  Interleaved pairs (2i, 2i+1) become half-split pairs (i, i+32) by permuting the rows of to_q / to_k
 // inside every head at load time (q.k is invariant under a common permutation) - done by the host packer.
-// Positions: the device counter state[0]; every kernel reads it, so a captured HIP graph of N steps replays as is.
+// Positions: the device-side slot records (state[slot][0]); every kernel reads them, so a captured HIP graph of N steps replays as is.
 #include "cvx_common.h"
 
 // No implicit a * b + c -> fma contraction in this file: the batch-1 / 2 / 4 / 8 instances of a kernel are REQUIRED to agree
@@ -30,6 +34,8 @@ namespace {
 
 constexpr int T2S_MAX_KEYS = 4096;
 constexpr int T2S_MAX_DIM = 4096;     // floats of the staged input vector (16 KiB of LDS)
+constexpr int SR = 8;                 // int32 per slot record / dialogue record (cvx_t2s_decoder.state / .dialogues)
+constexpr int T2S_MAX_BATCH = 64;
 
 enum { MODE_QKV = 0, MODE_PLAIN = 1, MODE_RES = 2, MODE_GEGLU = 3, MODE_LOGITS = 4 };
 
@@ -49,8 +55,11 @@ struct GemvArgs {
     const float* rope_sin;
     float* k_cache;          // [max_len, inner]
     float* v_cache;
-    const int* state;        // state[0] = pos
+    const int* state;        // slot records: state[SR * slot + 0] = pos
     int max_len;             // positions >= max_len are clamped (the host never asks for them; keeps a stray call in bounds)
+    // slot groups (batch > 8): the batch is ceil(batch / 8) groups of BQ = 8 slots; a block works on `gl` consecutive groups (the
+    // weight rows of its pairs stay in registers) and `gy` blocks share a row block (dispatched back to back on one XCD: L2 hits)
+    int gy, gl, n_blocks;
     // MODE_GEGLU: rows j (value) and j + F (gate), F = N / 2; y[j] for j < F, zero fill up to y_pad
     int y_pad;
     // MODE_LOGITS: `streams` independent slices of the normalised vector: y[s*N + n] = W[n,:] . xn[s*K .. (s+1)*K)
@@ -125,8 +134,9 @@ __device__ __forceinline__ void prefetch_pair(const GemvArgs& a, int pair, int l
 // stage (and RMS-normalise) the input vectors of a GEMV into LDS: xs[b][k] = x[b][k] * gamma[k]; inv[b] = the per-vector
 // normalisation factor (1 without gamma).  All threads of the block; contains block barriers.
 template <int BQ>
-__device__ __forceinline__ void stage_input(const GemvArgs& a, int Kin, float* xs, float (*red)[4], float (&inv)[BQ])
+__device__ __forceinline__ void stage_input(const GemvArgs& a, int bofs, int Kin, float* xs, float (*red)[4], float (&inv)[BQ])
 {
+    const float* const xg = a.x + (int64_t)bofs * a.x_stride;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float ss[BQ];
 #pragma unroll
@@ -135,7 +145,7 @@ __device__ __forceinline__ void stage_input(const GemvArgs& a, int Kin, float* x
         const float gk = a.gamma ? a.gamma[k] : 1.f;
         float v[BQ];
 #pragma unroll
-        for (int b = 0; b < BQ; ++b) v[b] = aload(a.x + (int64_t)b * a.x_stride + k);
+        for (int b = 0; b < BQ; ++b) v[b] = aload(xg + (int64_t)b * a.x_stride + k);
 #pragma unroll
         for (int b = 0; b < BQ; ++b) { ss[b] = fmaf(v[b], v[b], ss[b]); xs[b * Kin + k] = v[b] * gk; }
     }
@@ -161,9 +171,10 @@ __device__ __forceinline__ void stage_input(const GemvArgs& a, int Kin, float* x
 // one row pair: dot products with every staged vector (fixed summation order: lane-strided 4-vectors, then the wave
 // reduction - independent of the batch size and of which kernel runs it) + the MODE epilogue (lane 0)
 template <int MODE, int BQ, bool PRE>
-__device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const float* xs, int Kin, const float (&inv)[BQ],
+__device__ __forceinline__ void gemv_pair(const GemvArgs& a, int bofs, int pair, const float* xs, int Kin, const float (&inv)[BQ],
                                           const RowPrefetch& pf)
 {
+    float* const yg = a.y + (int64_t)bofs * a.y_stride;
     const int lane = threadIdx.x & 63;
     int r0, r1, sidx;
     const bool valid = pair_rows<MODE>(a, pair, r0, r1, sidx);
@@ -171,7 +182,7 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
         if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
             const int F = a.N / 2;
             if (pair >= F && pair < a.y_pad && lane == 0)
-                for (int b = 0; b < BQ; ++b) a.y[(int64_t)b * a.y_stride + pair] = 0.f;
+                for (int b = 0; b < BQ; ++b) yg[(int64_t)b * a.y_stride + pair] = 0.f;
         }
         return;
     }
@@ -214,11 +225,12 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
 #pragma unroll
     for (int b = 0; b < BQ; ++b) { acc0[b] = wave_sum(acc0[b]) * inv[b]; acc1[b] = wave_sum(acc1[b]) * inv[b]; }
     if (lane != 0) return;
-    const int pos = (MODE == MODE_QKV) ? min(aloadi(a.state), a.max_len - 1) : 0;
 #pragma unroll
     for (int b = 0; b < BQ; ++b) {
         float s0 = acc0[b], s1 = acc1[b];
-        float* const yb = a.y + (int64_t)b * a.y_stride;
+        float* const yb = yg + (int64_t)b * a.y_stride;
+        // every slot decodes at its own position (continuous batching: slots are refilled at different steps)
+        const int pos = (MODE == MODE_QKV) ? min(aloadi(a.state + SR * (bofs + b)), a.max_len - 1) : 0;
         if (a.bias) { s0 += a.bias[r0]; if (has1) s1 += a.bias[r1]; }
 
         if (MODE == MODE_QKV) {
@@ -228,7 +240,7 @@ __device__ __forceinline__ void gemv_pair(const GemvArgs& a, int pair, const flo
                 const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
                 s0 = n0; s1 = n1;
             }
-            float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + b * a.cache_stride + (int64_t)pos * a.inner;
+            float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + (bofs + b) * a.cache_stride + (int64_t)pos * a.inner;
             dst[c0] = s0;
             dst[c0 + 32] = s1;
         } else if (MODE == MODE_RES) {
@@ -259,29 +271,41 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     __shared__ float red[BQ][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per utterance
-    const int pair = (blockIdx.x * 4 + wid) * PPW;                      // every wave owns TWO output rows per pair
+    // block -> (row block, first slot group).  More than one block per row block (gy > 1): the gy blocks of a row block are
+    // consecutive ON ONE XCD (blocks are dealt to the 8 XCDs round robin), so the first one brings the rows into that XCD's L2
+    int rb = blockIdx.x, g0 = 0;
+    if (a.gy > 1) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        rb = (i / a.gy) * 8 + xcd;
+        g0 = (i % a.gy) * a.gl;
+        if (rb >= a.n_blocks) return;                                   // (block-uniform)
+    }
+    const int pair = (rb * 4 + wid) * PPW;                              // every wave owns TWO output rows per pair
     // weights first: their HBM / MALL round trip overlaps the staging of x below (the step is a chain of 34 dependent
     // launches; every microsecond of latency counts)
-    RowPrefetch pf[2];
-    prefetch_pair<MODE>(a, pair, lane, pf[0]);
-    float inv[BQ];
-    stage_input<BQ>(a, Kin, xs, red, inv);
+    RowPrefetch pf[PPW];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        if (i + 1 < PPW) prefetch_pair<MODE>(a, pair + i + 1, lane, pf[(i + 1) & 1]);
-        gemv_pair<MODE, BQ, true>(a, pair + i, xs, Kin, inv, pf[i & 1]);
+    for (int i = 0; i < PPW; ++i) prefetch_pair<MODE>(a, pair + i, lane, pf[i]);
+    for (int g = 0; g < a.gl; ++g) {
+        const int bofs = (g0 + g) * BQ;
+        if (g) __syncthreads();                                        // (xs / red of the previous group are free)
+        float inv[BQ];
+        stage_input<BQ>(a, bofs, Kin, xs, red, inv);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) gemv_pair<MODE, BQ, true>(a, bofs, pair + i, xs, Kin, inv, pf[i]);
     }
 }
 
 // ---------------------------------------------------------------- attention of ONE query over n cached keys
 struct AttnArgs {
     const float* q;          // [batch][heads*64]
-    const float* k;          // key j of head h of utterance b at k + b*batch_stride + j*stride + h*64
-    const float* v;
+    const float* k;          // key j of head h at k + B*batch_stride + j*stride + h*64; B = the slot (self-attention cache) or the
+    const float* v;          // dialogue the slot is decoding (cross-attention context, n_fixed == -2 / by_dialogue)
     int64_t stride, batch_stride;
     float* out;              // [batch][heads*64]
-    const int* state;        // [batch][4]
-    int n_fixed;             // >= 0: that many keys; -1: state[0] + 1 (self-attention); -2: state[3] (context length)
+    const int* state;        // [batch][SR]
+    int n_fixed;             // >= 0: that many keys; -1: state[slot][0] + 1 (self-attention); -2: state[slot][3] (context length)
+    int by_dialogue;         // 1: k / v are per DIALOGUE (state[slot][4]), not per slot
     float scale;
     int max_len;
 };
@@ -292,9 +316,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int HD64 = heads * 64;
     const int n = a.n_fixed >= 0 ? a.n_fixed
-                                 : (a.n_fixed == -1 ? min(aloadi(a.state) + 1, a.max_len) : min(aloadi(a.state + 4 * b + 3), T2S_MAX_KEYS));
-    const float* const kb = a.k + b * a.batch_stride;
-    const float* const vb = a.v + b * a.batch_stride;
+                                 : (a.n_fixed == -1 ? min(aloadi(a.state + SR * b) + 1, a.max_len) : min(aloadi(a.state + SR * b + 3), T2S_MAX_KEYS));
+    const int64_t kvb = a.by_dialogue ? aloadi(a.state + SR * b + 4) : b;
+    const float* const kb = a.k + kvb * a.batch_stride;
+    const float* const vb = a.v + kvb * a.batch_stride;
     const int sub = tid & 15, grp = tid >> 4;              // 16 lanes per key, 16 keys per pass
     const f32x4 q4 = aload4(a.q + (int64_t)b * HD64 + h * 64 + 4 * sub);
     float mx = -3.0e38f;
@@ -350,12 +375,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a)
 // ---------------------------------------------------------------- top-k + Gumbel argmax, eos bookkeeping, next input
 struct SampleArgs {
     const float* logits;     // [batch][streams, V]
-    const float* uniforms;   // [max_len][batch][streams, V]
+    const float* uniforms;   // [dialogue][uniform_steps][streams, V]
     const float* emb;        // [V, dim_emb]
     float* x;                // [batch][streams * dim_emb]  next step's input (residual stream)
-    int64_t* tokens;         // [batch][streams, max_len]
-    int* state;              // [batch][4]: [0] pos  [1] done  [2] length at the first eos  [3] context rows
-    int batch;
+    int64_t* tokens;         // [dialogue][streams, max_len]
+    int* state;              // [batch][SR]: [0] pos  [1] done  [2] length at the first eos  [3] context rows  [4] dialogue  [5] step limit
+                             //              [6] flags (bit 0: the eos does not end the dialogue)
+    int* queue;              // NULL, or {next pending dialogue, number of dialogues}: continuous batching
+    int* dialogues;          // [n][SR] (queue != NULL): in [0] context rows [1] step limit [2] flags; out [3] status (0 pending, 1 running,
+                             //   2 ended by its eos, 3 by its limit) [4] steps decoded [5] the slot it ran in
+    const float* start;      // [streams * dim_emb] start token (queue != NULL): the input of a refilled slot
+    int batch, uniform_steps;
     int V, dim_emb, streams, max_len, top_k, eos_id;
     float inv_temp;
     float cfg_scale;         // > 1: classifier-free guidance (text2semantic.py:780-792) - slots 2u (text context) and 2u + 1 (context
@@ -372,9 +402,10 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const bool cfg = a.cfg_scale > 1.0f;
     if (cfg && (b & 1)) return;                     // the null-context slot follows its partner (block-uniform)
-    int* const state = a.state + 4 * b;
+    int* const state = a.state + SR * b;
     const int pos = aloadi(state);
-    if (pos >= a.max_len) return;                   // (block-uniform)
+    if (pos >= a.max_len) return;                   // (block-uniform; also: an idle slot of a drained queue)
+    const int64_t dlg = aloadi(state + 4);          // the dialogue this slot decodes (== b without a queue)
     bool eos = false;
     for (int s = 0; s < a.streams; ++s) {
         for (int i = tid; i < a.V; i += NT) {
@@ -392,7 +423,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
             int cnt = 0;
             for (int j = 0; j < a.V; ++j) cnt += (lg[j] > me) ? 1 : 0;
             if (cnt < a.top_k) {
-                const float u = a.uniforms[(((int64_t)pos * a.batch + b) * a.streams + s) * a.V + i];
+                const float u = a.uniforms[((dlg * a.uniform_steps + pos) * a.streams + s) * a.V + i];
                 const float g = -logf(fmaxf(-logf(fmaxf(u, 1e-20f)), 1e-20f));
                 const float v = me * a.inv_temp + g;
                 if (v > val) { val = v; idx = i; }   // (ascending i: the lowest index wins ties)
@@ -412,7 +443,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
             for (int w = 1; w < NT / 64; ++w)
                 if (bv[w] > best || (bv[w] == best && bi[w] < bt)) { best = bv[w]; bt = bi[w]; }
             *chosen = bt;
-            a.tokens[((int64_t)b * a.streams + s) * a.max_len + pos] = bt;
+            a.tokens[(dlg * a.streams + s) * a.max_len + pos] = bt;
         }
         __syncthreads();
         const int tok = *chosen;
@@ -422,14 +453,47 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
             a.x[((int64_t)b * a.streams + s) * a.dim_emb + d] = e;
             if (cfg) a.x[((int64_t)(b + 1) * a.streams + s) * a.dim_emb + d] = e;
         }
-        if (cfg && tid == 0) a.tokens[((int64_t)(b + 1) * a.streams + s) * a.max_len + pos] = tok;
+        if (cfg && tid == 0) a.tokens[((dlg + 1) * a.streams + s) * a.max_len + pos] = tok;
         __syncthreads();
     }
+    if (a.queue == nullptr) {
+        if (tid == 0) {
+            int done = aloadi(state + 1), len = aloadi(state + 2);
+            if (eos && done == 0) { done = 1; len = pos + 1; state[1] = 1; state[2] = len; }
+            state[0] = pos + 1;
+            if (cfg) { int* const sn = state + SR; sn[1] = done; sn[2] = len; sn[0] = pos + 1; }
+        }
+        return;
+    }
+    // continuous batching: the dialogue ends with its first eos (text2semantic.py:803-818) or at its step limit; the slot then
+    // takes the next pending dialogue: position 0, the start token as input, that dialogue's context / uniforms / token rows
+    const bool ends_eos = eos && !(aloadi(state + 6) & 1);
+    const bool ends = ends_eos || pos + 1 >= aloadi(state + 5);        // (block-uniform: `eos` comes from LDS, the record is read by all)
+    if (!ends) {
+        if (tid == 0) state[0] = pos + 1;
+        return;
+    }
     if (tid == 0) {
-        int done = aloadi(state + 1), len = aloadi(state + 2);
-        if (eos && done == 0) { done = 1; len = pos + 1; state[1] = 1; state[2] = len; }
-        state[0] = pos + 1;
-        if (cfg) { int* const sn = state + 4; sn[1] = done; sn[2] = len; sn[0] = pos + 1; }
+        int* const dr = a.dialogues + SR * dlg;
+        dr[4] = pos + 1;
+        dr[5] = b;
+        __threadfence();
+        dr[3] = ends_eos ? 2 : 3;
+        const int nxt = atomicAdd(a.queue, 1);
+        *chosen = nxt < aloadi(a.queue + 1) ? nxt : -1;
+    }
+    __syncthreads();
+    const int nxt = *chosen;
+    if (nxt < 0) {                                  // nothing pending: the slot idles (every kernel clamps / skips at max_len)
+        if (tid == 0) { state[0] = a.max_len; state[1] = 1; }
+        return;
+    }
+    for (int d = tid; d < a.dim_emb * a.streams; d += NT) a.x[(int64_t)b * a.streams * a.dim_emb + d] = a.start[d];
+    if (tid == 0) {
+        int* const dn = a.dialogues + SR * nxt;
+        state[0] = 0; state[1] = 0; state[2] = 0; state[3] = dn[0]; state[4] = nxt; state[5] = dn[1]; state[6] = dn[2];
+        dn[5] = b;
+        dn[3] = 1;
     }
 }
 
@@ -456,31 +520,41 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h,
 #ifndef CVX_T2S_SIDE_PPW
 #define CVX_T2S_SIDE_PPW 2     // row pairs per wave on a stream of at most 64 CUs, batches of more than 4 (dev A/B: 1, 2, 4)
 #endif
+#ifndef CVX_T2S_GROUP_LOOP
+#define CVX_T2S_GROUP_LOOP 1   // slot groups one block walks with its weight rows in registers (dev A/B: 1, 2, 4, 8); the rest as blocks
+#endif
 template <int MODE, int BQ, int PPW>
-void launch_gemv_p(const GemvArgs& g, int pairs, hipStream_t st)
+void launch_gemv_p(GemvArgs g, int pairs, int groups, hipStream_t st)
 {
     const int Kin = (MODE == MODE_LOGITS) ? g.K * g.streams : g.K;
     const size_t lds = sizeof(float) * (size_t)BQ * Kin;
     if (lds > 48 * 1024)          // per-(device, kernel) bookkeeping, mutex-protected (cvx_common.h)
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ, PPW>), (int)lds);
-    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3((unsigned)((pairs + 4 * PPW - 1) / (4 * PPW))), dim3(256), lds, st, g);
+    g.n_blocks = (pairs + 4 * PPW - 1) / (4 * PPW);
+    g.gl = 1;
+    while (g.gl < CVX_T2S_GROUP_LOOP && groups % (2 * g.gl) == 0) g.gl *= 2;
+    g.gy = groups / g.gl;
+    const unsigned grid = g.gy > 1 ? (unsigned)((g.n_blocks + 7) / 8 * 8 * g.gy) : (unsigned)g.n_blocks;
+    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3(grid), dim3(256), lds, st, g);
 }
 template <int MODE, int BQ>
-void launch_gemv_b(const GemvArgs& g, int pairs, bool few_cus, hipStream_t st)
+void launch_gemv_b(const GemvArgs& g, int pairs, int groups, bool few_cus, hipStream_t st)
 {
     if constexpr (BQ >= 8 && CVX_T2S_SIDE_PPW > 1) {
-        if (few_cus) { launch_gemv_p<MODE, BQ, CVX_T2S_SIDE_PPW>(g, pairs, st); return; }
+        if (few_cus) { launch_gemv_p<MODE, BQ, CVX_T2S_SIDE_PPW>(g, pairs, groups, st); return; }
     }
-    launch_gemv_p<MODE, BQ, 1>(g, pairs, st);
+    launch_gemv_p<MODE, BQ, 1>(g, pairs, groups, st);
 }
 
+// batch 1 / 2 / 4 / 8: one group of that many slots; above: ceil(batch / 8) groups of 8 (the per-slot buffers of the caller hold
+// whole groups; the slots past `batch` compute on whatever they hold and nothing reads them)
 template <int MODE>
 void launch_gemv(const GemvArgs& g, int pairs, int batch, bool few_cus, hipStream_t st)
 {
-    if (batch <= 1) launch_gemv_b<MODE, 1>(g, pairs, few_cus, st);
-    else if (batch <= 2) launch_gemv_b<MODE, 2>(g, pairs, few_cus, st);
-    else if (batch <= 4) launch_gemv_b<MODE, 4>(g, pairs, few_cus, st);
-    else launch_gemv_b<MODE, 8>(g, pairs, few_cus, st);
+    if (batch <= 1) launch_gemv_b<MODE, 1>(g, pairs, 1, few_cus, st);
+    else if (batch <= 2) launch_gemv_b<MODE, 2>(g, pairs, 1, few_cus, st);
+    else if (batch <= 4) launch_gemv_b<MODE, 4>(g, pairs, 1, few_cus, st);
+    else launch_gemv_b<MODE, 8>(g, pairs, (batch + 7) / 8, few_cus, st);
 }
 
 }  // namespace
@@ -503,7 +577,8 @@ static int t2s_validate(const cvx_t2s_decoder* d, int32_t n_steps)
                 d->streams >= 1 && d->streams <= 2 && d->dim_emb * d->streams == d->dim && d->vocab > 0 && d->vocab <= 1024 &&
                 d->ff_inner > 0 && d->ff_inner_pad >= d->ff_inner && d->ff_inner_pad % 4 == 0 && d->ff_inner_pad <= T2S_MAX_DIM &&
                 d->n_ctx >= 0 && d->n_ctx <= T2S_MAX_KEYS && d->max_len > 0 && d->max_len <= T2S_MAX_KEYS &&
-                d->top_k > 0 && d->top_k <= d->vocab && d->temperature >= 0.f && d->batch >= 1 && d->batch <= 8 &&
+                d->top_k > 0 && d->top_k <= d->vocab && d->temperature >= 0.f && d->batch >= 1 && d->batch <= T2S_MAX_BATCH &&
+                d->uniform_steps > 0 &&
                 d->ctx_rows > 0 && d->ctx_rows <= T2S_MAX_KEYS && d->n_ctx <= d->ctx_rows,
                 "t2s_decode: bad dimensions (dim=%d inner=%d heads=%d streams=%d dim_emb=%d vocab=%d ff=%d/%d n_ctx=%d/%d max_len=%d batch=%d)",
                 d->dim, d->inner, d->heads, d->streams, d->dim_emb, d->vocab, d->ff_inner, d->ff_inner_pad, d->n_ctx, d->ctx_rows,
@@ -511,6 +586,8 @@ static int t2s_validate(const cvx_t2s_decoder* d, int32_t n_steps)
     CVX_REQUIRE(!(d->cfg_scale > 1.f) || (d->streams == 1 && d->batch % 2 == 0 && d->n_ctx == 0),
                 "t2s_decode: guidance (cfg_scale > 1) needs a one-output model, an even batch (context / null-context slot pairs) and "
                 "per-slot context rows (n_ctx == 0)");
+    CVX_REQUIRE(!d->queue || (d->dialogues && d->start && !(d->cfg_scale > 1.f) && d->n_ctx == 0),
+                "t2s_decode: a dialogue queue needs the dialogue records and the start token, per-dialogue context rows (n_ctx == 0) and no guidance");
     CVX_REQUIRE(d->final_gamma && d->emb && d->rope_cos && d->rope_sin && d->uniforms && d->x && d->q && d->att && d->h &&
                 d->logits && d->tokens && d->state, "t2s_decode: null buffer");
     for (int l = 0; l < d->depth; ++l) {
@@ -540,7 +617,7 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
             g.inner = d->inner; g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.k_cache = L.k_cache; g.v_cache = L.v_cache;
             g.cache_stride = cache_stride; g.state = d->state; g.max_len = d->max_len;
             launch_gemv<MODE_QKV>(g, 3 * d->inner / 2, nb, few, st);
-            AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, cache_stride, d->att, d->state, -1, scale, d->max_len};
+            AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, cache_stride, d->att, d->state, -1, 0, scale, d->max_len};
             hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, at);
             g = GemvArgs{};
             g.W = L.wo_s; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
@@ -551,7 +628,7 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
             g.N = d->inner; g.K = d->dim;
             launch_gemv<MODE_PLAIN>(g, d->inner / 2, nb, few, st);
             AttnArgs ac{d->q, L.kv_c, L.kv_c + d->inner, 2 * (int64_t)d->inner, (int64_t)d->ctx_rows * 2 * d->inner, d->att, d->state,
-                        d->n_ctx > 0 ? d->n_ctx : -2, scale, d->max_len};
+                        d->n_ctx > 0 ? d->n_ctx : -2, 1, scale, d->max_len};
             hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, ac);
             g = GemvArgs{};
             g.W = L.wo_c; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
@@ -570,8 +647,9 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
         g.W = d->emb; g.ldw = d->dim_emb; g.x = d->x; g.x_stride = d->dim; g.gamma = d->final_gamma; g.y = d->logits;
         g.y_stride = d->streams * d->vocab; g.N = d->vocab; g.K = d->dim_emb; g.streams = d->streams;
         launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), nb, few, st);
-        SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, nb, d->vocab, d->dim_emb, d->streams, d->max_len,
-                      d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f), d->cfg_scale};
+        SampleArgs sa{d->logits, d->uniforms, d->emb, d->x, d->tokens, d->state, d->queue, d->dialogues, d->start, nb, d->uniform_steps,
+                      d->vocab, d->dim_emb, d->streams, d->max_len, d->top_k, d->vocab - 1, 1.0f / fmaxf(d->temperature, 1e-10f),
+                      d->cfg_scale};
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)nb), dim3(1024), 0, st, sa);
     }
     CVX_CHECK_LAUNCH("cvx_t2s_decode_steps");

@@ -11,11 +11,13 @@ forwards to (covomix/conditional_model.py:313-321).  Only what the generation sc
            graph of CHUNK steps.  (Two single-launch persistent forms with grid barriers were built in round 4 and measured
            2.5-2.7x slower - a grid barrier with the L2 write-back / invalidate that cross-XCD visibility needs costs 4-7 us
            against 1.2-1.5 us for a dependent kernel boundary; removed in round 5, numbers in HISTORY.md.)  The host only
-           looks at the eos flags between chunks.  `generate_batch` advances up to MAX_BATCH utterances together (the
-           reference decodes them one by one): a token step is bound by streaming the decoder weights, which a batch
-           shares, and the per-utterance arithmetic does not depend on the batch size - the tokens are bit-identical to
-           the one-by-one decode.  The decode is a latency chain that needs a handful of CUs: pipeline.py runs it on a
-           CU-masked side stream UNDER the acoustic solve of the previous batch.
+           looks at the eos flags between chunks.  `generate_batch` advances up to MAX_BATCH (64) utterances together (the
+           reference decodes them one by one): a token step is a latency chain of dependent launches whose time barely
+           depends on the batch, and the per-utterance arithmetic does not depend on the batch size - the tokens are
+           bit-identical to the one-by-one decode.  `generate_many` decodes ANY number of utterances through a fixed number
+           of decode slots with CONTINUOUS BATCHING: an utterance that has sampled its eos (text2semantic.py:803-818) frees
+           its slot, and the sampling kernel of that very step hands the slot the next pending utterance (device-side
+           queue, no host round trip) - real dialogues end at different steps, and a lock-step batch would run half empty.
 
 The reference's rotary embedding rotates interleaved pairs (2i, 2i+1) (rotary_embedding_torch.py:25-41); the kernels
 rotate half-split pairs (i, i+32).  Permuting the rows of to_q and to_k inside every head (the same permutation on
@@ -33,7 +35,9 @@ from . import _lib, ops
 PAD_ID = -1                    # semantic_pad_id (conditional_model.py:126)
 TOP_K_THRES = 0.1              # top_k default (text2semantic.py:126)
 CHUNK = 16                     # token steps per graph replay / host check
-MAX_BATCH = 8                  # utterances per decode step (kernel limit)
+MAX_BATCH = 64                 # decode slots per step (kernel limit)
+WINDOW = 256                   # utterances queued on the device at a time (generate_many)
+SR = 8                         # int32 per slot / dialogue record (include/covomix_hip.h, cvx_t2s_decoder)
 
 
 def _dims(sd: Dict[str, torch.Tensor]) -> dict:
@@ -110,27 +114,62 @@ class TextToSemanticDecoder:
                                  gamma_c=sd[p + ".1.norm.gamma"], wq_c=wq_c, wkv_c=wkv_c, wo_c=sd[p + ".1.to_out.weight"],
                                  null=torch.cat((nkv[0].reshape(I), nkv[1].reshape(I))).contiguous(),
                                  gamma_f=sd[p + ".2.0.gamma"], w1=sd[p + ".2.1.weight"], b1=sd[p + ".2.1.bias"],
-                                 w2=_pad_cols(sd[p + ".2.4.weight"]), b2=sd[p + ".2.4.bias"],
-                                 kv_c=f32(MAX_BATCH, self.max_source + 2, 2 * I), k_cache=f32(MAX_BATCH, self.max_length, I),
-                                 v_cache=f32(MAX_BATCH, self.max_length, I)))
+                                 w2=_pad_cols(sd[p + ".2.4.weight"]), b2=sd[p + ".2.4.bias"]))
         self.dec_final = sd["target_transformer.final_norm.gamma"]
         pos = torch.arange(self.max_length, device=device, dtype=torch.float32)
         ang = pos[:, None] * sd["target_transformer.layers.0.0.rotary_emb.freqs"][None, :]
         self.rope = (ang.cos().contiguous(), ang.sin().contiguous())
-        S, V = d["streams"], d["vocab"]
-        self.top_k = math.ceil(TOP_K_THRES * V)
-        self.buf = dict(x=f32(MAX_BATCH, d["dim_target"]), q=f32(MAX_BATCH, I), att=f32(MAX_BATCH, I), h=f32(MAX_BATCH, self.Fp),
-                        logits=f32(MAX_BATCH, S, V), uniforms=f32(self.max_length * MAX_BATCH * S * V),
-                        tokens=torch.zeros(MAX_BATCH, S, self.max_length, dtype=torch.int64, device=device))
-        self.buf["state"] = torch.zeros(MAX_BATCH, 4, dtype=torch.int32, device=device)      # per utterance: pos, done, length, context rows
+        self.top_k = math.ceil(TOP_K_THRES * d["vocab"])
+        self.buf: Dict[str, torch.Tensor] = {}
+        self._slots = self._dialogues = self._steps = 0   # capacities of the decode buffers (_ensure)
+        self._gen = 0                                      # bumped when they are re-allocated (captured graphs hold their addresses)
         self._layers = (_lib.T2SLayer * d["target_depth"])()
         for i, L in enumerate(self.dec):
-            for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c", "gamma_f", "w1", "b1", "w2", "b2",
-                         "k_cache", "v_cache"):
+            for name in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "gamma_f", "w1", "b1", "w2", "b2"):
                 setattr(self._layers[i], name, L[name].data_ptr())
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self._cap = None                                   # capture stream of the decode graphs
         self._stage = None                                 # staging copies of the state record (two in flight), _decode_chunks
+        self._ensure(8, 8, 0)
+
+    @staticmethod
+    def _slot_capacity(n: int) -> int:
+        """per-slot buffers hold whole kernel groups: 1 / 2 / 4 slots, or a multiple of 8 (include/covomix_hip.h)"""
+        return n if n in (1, 2, 4) else (n + 7) // 8 * 8
+
+    def _ensure(self, slots: int, dialogues: int, steps: int) -> None:
+        """Decode buffers for `slots` decode slots (x, q, att, h, logits, slot records, the self-attention caches), `dialogues`
+        utterances in flight or queued (context k/v, token rows, dialogue records) and `steps` uniform draws per dialogue.  They only
+        grow; growing re-allocates (and drops the captured graphs, which hold the old addresses)."""
+        d, dev = self.d, self.device
+        S, V, I = d["streams"], d["vocab"], d["inner"]
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        slots = max(8, self._slot_capacity(slots))
+        grown = False
+        if slots > self._slots:
+            self.buf.update(x=f32(slots, d["dim_target"]), q=f32(slots, I), att=f32(slots, I), h=f32(slots, self.Fp), logits=f32(slots, S, V),
+                            state=torch.zeros(slots, SR, dtype=torch.int32, device=dev))
+            for i, L in enumerate(self.dec):
+                L["k_cache"], L["v_cache"] = f32(slots, self.max_length, I), f32(slots, self.max_length, I)
+                self._layers[i].k_cache, self._layers[i].v_cache = L["k_cache"].data_ptr(), L["v_cache"].data_ptr()
+            self._slots, grown = slots, True
+        if dialogues > self._dialogues:
+            dialogues = max(dialogues, 8)
+            for i, L in enumerate(self.dec):
+                L["kv_c"] = f32(dialogues, self.max_source + 2, 2 * I)
+                self._layers[i].kv_c = L["kv_c"].data_ptr()
+            self.buf.update(tokens=torch.zeros(dialogues, S, self.max_length, dtype=torch.int64, device=dev),
+                            dialogues=torch.zeros(dialogues, SR, dtype=torch.int32, device=dev),
+                            queue=torch.zeros(2, dtype=torch.int32, device=dev))
+            self._dialogues, grown = dialogues, True
+        if steps > self._steps or "uniforms" not in self.buf or self.buf["uniforms"].numel() < self._dialogues * self._steps * S * V:
+            self._steps = max(self._steps, steps, 1)
+            self.buf["uniforms"] = f32(self._dialogues * self._steps * S * V)
+            grown = True
+        if grown:
+            self._graphs.clear()
+            self._stage = None
+            self._gen += 1
 
     # ------------------------------------------------------------------ encoder (text2semantic.py:716-741)
     def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
@@ -165,7 +204,7 @@ class TextToSemanticDecoder:
         return enc
 
     # ------------------------------------------------------------------ decoder
-    def _descriptor(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0) -> "_lib.T2SDecoder":
+    def _descriptor(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0, queue: bool = False) -> "_lib.T2SDecoder":
         d, b = self.d, self.buf
         dec = _lib.T2SDecoder()
         dec.batch, dec.ctx_rows = batch, self.max_source + 2
@@ -179,92 +218,143 @@ class TextToSemanticDecoder:
         dec.rope_cos, dec.rope_sin = self.rope[0].data_ptr(), self.rope[1].data_ptr()
         for n in ("uniforms", "x", "q", "att", "h", "logits", "tokens", "state"):
             setattr(dec, n, b[n].data_ptr())
+        dec.uniform_steps = self._steps
+        if queue:
+            dec.queue, dec.dialogues, dec.start = b["queue"].data_ptr(), b["dialogues"].data_ptr(), self.start.data_ptr()
         return dec
 
-    def _steps(self, temperature: float, batch: int, n: int, cfg_scale: float = 1.0) -> None:
+    def _run_steps(self, temperature: float, batch: int, n: int, cfg_scale: float = 1.0, queue: bool = False) -> None:
         """n token steps on the current stream without a graph."""
-        _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), n,
+        _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale, queue)), n,
                                                     torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
 
+    def _uniform_view(self, n: int) -> torch.Tensor:
+        """[n, steps, streams, vocab] view of the uniform draws of the first n dialogues"""
+        S, V = self.d["streams"], self.d["vocab"]
+        return self.buf["uniforms"][: n * self._steps * S * V].view(n, self._steps, S, V)
+
+    def _slot_records(self, ctx, limit: int = 0, flags: int = 0) -> torch.Tensor:
+        """slot records [slots, SR] (CPU): slot b decodes dialogue b from position 0; slots past len(ctx) idle at max_length"""
+        rows = [[0, 0, 0, ctx[i], i, limit, flags, 0] if i < len(ctx) else [self.max_length, 1, 0, 1, 0, 0, 0, 0] for i in range(self._slots)]
+        return torch.tensor(rows, dtype=torch.int32)
+
+
     def _read_state(self, nb: int) -> list:
-        """state rows of the first nb utterances (synchronises the current stream)."""
+        """slot records of the first nb slots (synchronises the current stream)."""
         return self.buf["state"].tolist()[:nb]
 
-    def _decode_chunks(self, temperature: float, nb: int, max_len: int, cfg_scale: float, watch, ignore_eos: bool = False) -> list:
-        """Graph-replayed chunks of CHUNK token steps until every utterance slot in `watch` has sampled its eos (or max_len steps).
-        The host looks at the eos flags ONE CHUNK BEHIND the device: the state record of chunk i is copied to a device-side staging
-        record between the replays of chunks i and i + 1 and read through a helper stream while chunk i + 1 runs - the decode
-        chain never waits for a host round trip (nor for a host thread that is waiting for the interpreter lock while another thread
-        drives the acoustic solve, pipeline.py); the price is at most one chunk decoded past the last eos (masked afterwards like every
-        token behind an eos).  Returns the final state rows."""
+    # ---- the host looks at device-side records ONE CHUNK BEHIND the device
+    def _mirror_setup(self) -> None:
         if self._stage is None:
-            self._stage = [torch.empty_like(self.buf["state"]) for _ in range(2)]
-            self._pin = [torch.empty(MAX_BATCH, 4, dtype=torch.int32).pin_memory() for _ in range(2)]
+            rows = max(self._slots, self._dialogues)
+            self._stage = [torch.empty(rows, SR, dtype=torch.int32, device=self.device) for _ in range(2)]
+            self._pin = [torch.empty(rows, SR, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._stage_ev = [torch.cuda.Event(), torch.cuda.Event()]
             self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
             self._helper = torch.cuda.Stream(device=self.device)
-        # How the record reaches the host.  On an ordinary stream: a non_blocking copy into pinned memory on the decode stream itself.
-        # On a CU-masked stream of ops.CUPartition that form is NOT used: torch's pinned-memory allocator remembers the stream of such a
-        # copy, and a masked stream destroyed at exit before the block is freed takes the process down (tools/cu_mask_exit_probe.py) -
-        # there the record is copied device-to-device on the decode stream and a plain helper stream brings it to the host.  (The
-        # helper form on the legacy null stream measured 3.4x slower per decode - 941 vs 274 ms - in one process layout and not in another:
-        # it is confined to the streams that need it.)
+
+    def _mirror_push(self, k: int, src: torch.Tensor, via_helper: bool) -> None:
+        """enqueue a copy of the records `src` [rows, SR] into pinned buffer k behind everything the current stream holds.
+        On an ordinary stream: a non_blocking copy into pinned memory on the decode stream itself.  On a CU-masked stream of
+        ops.CUPartition that form is NOT used: torch's pinned-memory allocator remembers the stream of such a copy, and a masked stream
+        destroyed at exit before the block is freed takes the process down (tools/cu_mask_exit_probe.py) - there the record is copied
+        device-to-device on the decode stream and a plain helper stream brings it to the host."""
+        rows = src.shape[0]
+        if via_helper:
+            self._stage[k][:rows].copy_(src)
+            self._stage_ev[k].record()
+            with torch.cuda.stream(self._helper):
+                self._helper.wait_event(self._stage_ev[k])
+                self._pin[k][:rows].copy_(self._stage[k][:rows], non_blocking=True)
+                self._pin_ev[k].record()
+        else:
+            self._pin[k][:rows].copy_(src, non_blocking=True)
+            self._pin_ev[k].record()
+
+    def _mirror_pull(self, k: int, rows: int) -> list:
+        self._pin_ev[k].synchronize()
+        return self._pin[k][:rows].tolist()
+
+    def _decode_chunks(self, temperature: float, nb: int, max_len: int, cfg_scale: float, watch, ignore_eos: bool = False) -> list:
+        """Graph-replayed chunks of CHUNK token steps until every utterance slot in `watch` has sampled its eos (or max_len steps).
+        The host looks at the eos flags ONE CHUNK BEHIND the device: the slot records of chunk i are copied between the replays of
+        chunks i and i + 1 and read while chunk i + 1 runs - the decode chain never waits for a host round trip (nor for a host
+        thread that is waiting for the interpreter lock while another thread drives the acoustic solve, pipeline.py); the price is
+        at most one chunk decoded past the last eos (masked afterwards like every token behind an eos).  Returns the final records."""
+        self._mirror_setup()
         via_helper = ops.is_partition_stream()
         steps, i, pending = 0, 0, None
         while steps < max_len:
             self._run_chunk(temperature, nb, cfg_scale)
             steps += CHUNK
             k = i & 1
-            if via_helper:
-                self._stage[k].copy_(self.buf["state"])                 # (device to device, behind chunk i on this stream)
-                self._stage_ev[k].record()
-                with torch.cuda.stream(self._helper):                   # the helper waits for chunk i only
-                    self._helper.wait_event(self._stage_ev[k])
-                    self._pin[k].copy_(self._stage[k], non_blocking=True)
-                    self._pin_ev[k].record()
-            else:
-                self._pin[k].copy_(self.buf["state"], non_blocking=True)
-                self._pin_ev[k].record()
+            self._mirror_push(k, self.buf["state"][:nb], via_helper)
             if pending is not None:
-                self._pin_ev[pending].synchronize()
-                st = self._pin[pending].tolist()
+                st = self._mirror_pull(pending, nb)
                 if all(st[r][1] for r in watch) and not ignore_eos:
                     break
             pending = k
             i += 1
+        if pending is not None:
+            self._pin_ev[pending].synchronize()      # (the helper stream's last copy: the buffers are reused by the next call)
         return self._read_state(nb)
 
-    def _run_chunk(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0) -> None:
-        """CHUNK token steps on the current stream (a graph replay of the per-launch path)."""
-        def launch():
-            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale)), CHUNK,
-                                                        torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
-        if os.environ.get("CVX_GRAPH", "1") != "1":
-            launch()
-            return
-        key = (temperature, batch, cfg_scale, ops.stream_cus())   # (the kernels' shape follows the CUs the stream owns)
+    def _graph(self, temperature: float, batch: int, cfg_scale: float = 1.0, queue: bool = False):
+        """The captured graph of CHUNK token steps for this (batch, stream CU count, mode); captured on first use.  Capturing runs the
+        steps once outside the capture (module load, kernel attributes): callers get their graph BEFORE they set up the decode state -
+        the warm-up runs on idle slot records (position max_length: the sampling kernel returns at once, every other kernel clamps)."""
+        key = (temperature, batch, cfg_scale, ops.stream_cus(), queue, self._gen)   # (the kernels' shape follows the CUs the stream owns)
         g = self._graphs.get(key)
-        if g is None:
-            saved = {k: v.clone() for k, v in self.buf.items()}
-            caches = [(L["k_cache"].clone(), L["v_cache"].clone()) for L in self.dec]
-            launch()                                       # warm-up outside capture (module load, attributes)
-            cur = torch.cuda.current_stream()
-            if self._cap is None:
-                self._cap = torch.cuda.Stream(device=self.device)
-            ops.saturation_share(cur, self._cap)           # (the capture stream belongs to this call: flag and CU count of `cur`)
-            with ops.CAPTURE_GATE.exclusive():             # (no other entry point of the package syncs / copies meanwhile)
-                cur.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
-                    launch()
-            for k, v in saved.items():                     # capture does not execute, the warm-up did: restore
-                self.buf[k].copy_(v)
-            for L, (kc, vc) in zip(self.dec, caches):
-                L["k_cache"].copy_(kc); L["v_cache"].copy_(vc)
-            if len(self._graphs) >= 6:
-                self._graphs.clear()
-            self._graphs[key] = g
-        g.replay()
+        if g is not None:
+            return g
+
+        def launch():
+            _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale, queue)), CHUNK,
+                                                        torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+        self.buf["state"].copy_(self._slot_records([]))
+        launch()                                       # warm-up outside capture
+        cur = torch.cuda.current_stream()
+        if self._cap is None:
+            self._cap = torch.cuda.Stream(device=self.device)
+        ops.saturation_share(cur, self._cap)           # (the capture stream belongs to this call: flag and CU count of `cur`)
+        with ops.CAPTURE_GATE.exclusive():             # (no other entry point of the package syncs / copies meanwhile)
+            cur.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
+                launch()
+        if len(self._graphs) >= 8:
+            self._graphs.clear()
+        self._graphs[key] = g
+        return g
+
+    def _run_chunk(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0, queue: bool = False) -> None:
+        """CHUNK token steps on the current stream: a graph replay of the per-launch path (the graph must exist - `_graph` - unless
+        CVX_GRAPH=0 asks for plain launches)."""
+        if os.environ.get("CVX_GRAPH", "1") != "1":
+            self._run_steps(temperature, batch, CHUNK, cfg_scale, queue)
+            return
+        self._graph(temperature, batch, cfg_scale, queue).replay()
+
+    def _context(self, j: int, src: torch.Tensor) -> int:
+        """encoder + the cross-attention k/v of one utterance into dialogue row j: [null | to_kv(enc)] -> context rows"""
+        if src.ndim == 2 and src.shape[0] != 1:
+            raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
+        enc = self.encode(src)
+        n = enc.shape[0]
+        for L in self.dec:
+            L["kv_c"][j, 0].copy_(L["null"])
+            ops.gemm(enc, L["wkv_c"], L["kv_c"][j, 1:n + 1])
+        return n + 1
+
+    def _cut(self, j: int, length: int, logits=None):
+        """(flat tokens, streams[, logits]) of dialogue row j after `length` steps: mask_after_eos (text2semantic.py:73-76)"""
+        eos = self.d["vocab"] - 1
+        streams = self.buf["tokens"][j, :, :length].clone()
+        after = (streams == eos).cumsum(dim=-1) > 0
+        after = torch.nn.functional.pad(after, (1, -1), value=False)
+        flat = streams.masked_fill(after, PAD_ID).reshape(-1)
+        item = (flat[flat != PAD_ID], streams)
+        return item if logits is None else item + (logits[:length],)
 
     @ops.gated
     @torch.no_grad()          # (not inference_mode: tensors torch creates lazily during the first graph capture,
@@ -272,9 +362,10 @@ class TextToSemanticDecoder:
     def generate_batch(self, sources, uniforms=None, max_length: Optional[int] = None, temperature: float = 1.0,
                        generator: Optional[torch.Generator] = None, collect_logits: bool = False, cond_scale: float = 1.0,
                        ignore_eos: bool = False):
-        """Decode up to MAX_BATCH utterances together.  sources: list of [n] / [1, n] id tensors; uniforms: optional list
-        of [steps, streams, vocab] tensors (one per utterance).  Returns a list of (flat tokens, streams[, logits])
-        tuples, each exactly what `generate` returns for that utterance alone.
+        """Decode up to MAX_BATCH utterances together IN LOCK STEP (all start at position 0; the batch runs until the last one has
+        sampled its eos).  sources: list of [n] / [1, n] id tensors; uniforms: optional list of [steps, streams, vocab] tensors (one
+        per utterance).  Returns a list of (flat tokens, streams[, logits]) tuples, each exactly what `generate` returns for that
+        utterance alone.  (`generate_many`: any number of utterances through continuously refilled slots.)
         ignore_eos (benchmarks: a fixed amount of work): decode max_length steps whatever is sampled; `streams` then holds all of them.
         cond_scale > 1: classifier-free guidance (text2semantic.py:780-792; one-output models, up to MAX_BATCH / 2 utterances):
         every utterance takes two decode slots - the text context and the context masked out (cross-attention then sees the
@@ -292,55 +383,43 @@ class TextToSemanticDecoder:
         if not 1 <= nb <= MAX_BATCH:
             raise ValueError(f"1..{MAX_BATCH} utterances per decode batch, got {nb}")
         max_len = min(int(max_length or self.max_length), self.max_length)
+        us = None
         if uniforms is not None:
             us = [u.to(self.device, torch.float32).reshape(u.shape[0], S, V) for u in uniforms]
             max_len = min([max_len] + [u.shape[0] for u in us])
-        ctx = []
-        for i, src in enumerate(sources):
-            if src.ndim == 2 and src.shape[0] != 1:
-                raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
-            enc = self.encode(src)
-            n = enc.shape[0]
-            ctx.append(n + 1)
-            for L in self.dec:                                          # context k/v once: [null | to_kv(enc)]
-                L["kv_c"][i, 0].copy_(L["null"])
-                ops.gemm(enc, L["wkv_c"], L["kv_c"][i, 1:n + 1])
-        uview = b["uniforms"][: max_len * nb * S * V].view(max_len, nb, S, V)
-        if uniforms is None:
-            uview.copy_(torch.rand(max_len, nb, S, V, device=self.device, generator=generator))
+        self._ensure(nb, nb, max_len)
+        b = self.buf
+        if not collect_logits and max_len > 0:
+            self._graph(float(temperature), nb)
+        ctx = [self._context(i, src) for i, src in enumerate(sources)]
+        uview = self._uniform_view(nb)
+        if us is None:            # (drawn step-major, as the [steps, batch, streams, vocab] buffer of earlier versions was: same seeds, same tokens)
+            uview[:, :max_len].copy_(torch.rand(max_len, nb, S, V, device=self.device, generator=generator).permute(1, 0, 2, 3))
         else:
             for i, u in enumerate(us):
-                uview[:, i].copy_(u[:max_len])
+                uview[i, :max_len].copy_(u[:max_len])
         b["x"][:nb].copy_(self.start[None, :].expand(nb, -1))
-        b["state"].copy_(torch.tensor([[0, 0, 0, ctx[i] if i < nb else 1] for i in range(MAX_BATCH)], dtype=torch.int32))
+        b["state"].copy_(self._slot_records(ctx))
         logits = []
+        st = self._slot_records(ctx).tolist()[:nb]
         if collect_logits:                                              # (tests: one step at a time without a graph)
             for _ in range(max_len):
-                self._steps(float(temperature), nb, 1)
+                self._run_steps(float(temperature), nb, 1)
                 logits.append(b["logits"][:nb].clone())
                 st = self._read_state(nb)
                 if all(row[1] for row in st) and not ignore_eos:
                     break
-        else:
+        elif max_len > 0:
             st = self._decode_chunks(float(temperature), nb, max_len, 1.0, range(nb), ignore_eos)
-        eos = V - 1
         out = []
         for i in range(nb):
             length = min(st[i][2] if st[i][1] and st[i][2] <= max_len and not ignore_eos else max_len, max_len)
-            streams = b["tokens"][i, :, :length].clone()
-            after = (streams == eos).cumsum(dim=-1) > 0                  # mask_after_eos (text2semantic.py:73-76)
-            after = torch.nn.functional.pad(after, (1, -1), value=False)
-            flat = streams.masked_fill(after, PAD_ID).reshape(-1)
-            item = (flat[flat != PAD_ID], streams)
-            if collect_logits:
-                item = item + (torch.stack([lg[i] for lg in logits])[:length],)
-            out.append(item)
+            out.append(self._cut(i, length, torch.stack([lg[i] for lg in logits]) if collect_logits and logits else None))
         return out
 
     def _generate_guided(self, sources, uniforms, max_length, temperature, generator, collect_logits, cond_scale):
         """generate_batch with cond_scale > 1: slots 2u (text context) / 2u + 1 (null context) per utterance u."""
-        d, b = self.d, self.buf
-        V, nu = d["vocab"], len(sources)
+        V, nu = self.d["vocab"], len(sources)
         nb = 2 * nu
         if not 1 <= nu <= MAX_BATCH // 2:
             raise ValueError(f"1..{MAX_BATCH // 2} utterances per guided decode batch, got {nu}")
@@ -349,48 +428,128 @@ class TextToSemanticDecoder:
         if uniforms is not None:
             us = [u.to(self.device, torch.float32).reshape(u.shape[0], 1, V) for u in uniforms]
             max_len = min([max_len] + [u.shape[0] for u in us])
+        self._ensure(nb, nb, max_len)
+        b = self.buf
+        if not collect_logits and max_len > 0:
+            self._graph(float(temperature), nb, cond_scale)
         ctx = []
         for u_, src in enumerate(sources):
-            if src.ndim == 2 and src.shape[0] != 1:
-                raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
-            enc = self.encode(src)
-            n = enc.shape[0]
-            ctx += [n + 1, 1]                                            # the null slot: row 0 (null k/v) only = every context key masked
+            ctx += [self._context(2 * u_, src), 1]                       # the null slot: row 0 (null k/v) only = every context key masked out
             for L in self.dec:
-                L["kv_c"][2 * u_, 0].copy_(L["null"])
-                ops.gemm(enc, L["wkv_c"], L["kv_c"][2 * u_, 1:n + 1])
                 L["kv_c"][2 * u_ + 1, 0].copy_(L["null"])
-        uview = b["uniforms"][: max_len * nb * V].view(max_len, nb, 1, V)
+        uview = self._uniform_view(nb)
         if us is None:
-            uview[:, 0::2].copy_(torch.rand(max_len, nu, 1, V, device=self.device, generator=generator))
+            uview[0::2, :max_len].copy_(torch.rand(max_len, nu, 1, V, device=self.device, generator=generator).permute(1, 0, 2, 3))
         else:
             for u_, u in enumerate(us):
-                uview[:, 2 * u_].copy_(u[:max_len])
+                uview[2 * u_, :max_len].copy_(u[:max_len])
         b["x"][:nb].copy_(self.start[None, :].expand(nb, -1))
-        b["state"].copy_(torch.tensor([[0, 0, 0, ctx[i] if i < nb else 1] for i in range(MAX_BATCH)], dtype=torch.int32))
+        b["state"].copy_(self._slot_records(ctx))
         logits = []
+        st = self._slot_records(ctx).tolist()[:nb]
         if collect_logits:
             for _ in range(max_len):
-                self._steps(float(temperature), nb, 1, cond_scale)
+                self._run_steps(float(temperature), nb, 1, cond_scale)
                 lg = b["logits"][:nb].clone()
                 logits.append(lg[1::2] + (lg[0::2] - lg[1::2]) * cond_scale)
                 st = self._read_state(nb)
                 if all(st[2 * u_][1] for u_ in range(nu)):
                     break
-        else:
+        elif max_len > 0:
             st = self._decode_chunks(float(temperature), nb, max_len, cond_scale, [2 * u_ for u_ in range(nu)])
-        eos, out = V - 1, []
+        out = []
         for u_ in range(nu):
             i = 2 * u_
             length = min(st[i][2] if st[i][1] and st[i][2] <= max_len else max_len, max_len)
-            streams = b["tokens"][i, :, :length].clone()
-            after = (streams == eos).cumsum(dim=-1) > 0
-            after = torch.nn.functional.pad(after, (1, -1), value=False)
-            flat = streams.masked_fill(after, PAD_ID).reshape(-1)
-            item = (flat[flat != PAD_ID], streams)
-            if collect_logits:
-                item = item + (torch.stack([lg[u_] for lg in logits])[:length],)
-            out.append(item)
+            out.append(self._cut(i, length, torch.stack([lg[u_] for lg in logits]) if collect_logits and logits else None))
+        return out
+
+    @ops.gated
+    @torch.no_grad()
+    def generate_many(self, sources, uniforms=None, max_length: Optional[int] = None, temperature: float = 1.0,
+                      generator: Optional[torch.Generator] = None, slots: int = 32, ignore_eos: bool = False, limits=None, on_done=None):
+        """Decode ANY number of utterances through `slots` decode slots with continuous batching: every utterance runs the
+        reference's loop (text2semantic.py:749-848) from position 0 to its first eos (:803-818) or its step limit, and the slot it
+        ran in takes the next pending utterance in the sampling kernel of that very step (cvx_t2s_decoder.queue) - utterances end
+        at different steps, and a lock-step batch would run half empty.  Every utterance gets exactly the tokens it gets alone.
+        sources / uniforms as generate_batch; limits: optional per-utterance step limits (default max_length for all).
+        on_done(j, (flat, streams)): called for utterance j as soon as the host has seen it finish (the host reads the dialogue
+        records one chunk of CHUNK steps behind the device) - the next pipeline stage can start on the first results while the
+        rest decodes.  Returns the list of (flat tokens, streams) in input order."""
+        d = self.d
+        S, V = d["streams"], d["vocab"]
+        n = len(sources)
+        if n == 0:
+            return []
+        if n > WINDOW:            # (the context k/v, uniforms and token rows of every queued utterance are resident: bounded windows)
+            out = []
+            for w in range(0, n, WINDOW):
+                out += self.generate_many(sources[w:w + WINDOW], None if uniforms is None else uniforms[w:w + WINDOW], max_length, temperature,
+                                          generator, slots, ignore_eos, None if limits is None else limits[w:w + WINDOW],
+                                          None if on_done is None else (lambda j, r, w=w: on_done(w + j, r)))
+            return out
+        nb = max(1, min(int(slots), MAX_BATCH, n))
+        nb = nb if nb in (1, 2, 4) else min((nb + 7) // 8 * 8, MAX_BATCH)      # whole kernel groups (idle slots cost nothing)
+        max_len = min(int(max_length or self.max_length), self.max_length)
+        us = None
+        if uniforms is not None:
+            us = [u.to(self.device, torch.float32).reshape(u.shape[0], S, V) for u in uniforms]
+            max_len = min([max_len] + [u.shape[0] for u in us])
+        lim = [max_len] * n if limits is None else [max(1, min(int(x), max_len)) for x in limits]
+        if max_len <= 0:
+            raise ValueError("generate_many needs at least one step")
+        self._ensure(nb, n, max_len)
+        b = self.buf
+        temperature = float(temperature)
+        self._graph(temperature, nb, 1.0, True)
+        ctx = [self._context(j, src) for j, src in enumerate(sources)]
+        uview = self._uniform_view(n)
+        if us is None:
+            uview[:, :max_len].copy_(torch.rand(n, max_len, S, V, device=self.device, generator=generator))
+        else:
+            for j, u in enumerate(us):
+                uview[j, :max_len].copy_(u[:max_len])
+        flags = 1 if ignore_eos else 0
+        first = min(nb, n)
+        rec = torch.tensor([[ctx[j], lim[j], flags, 1 if j < first else 0, 0, j if j < first else 0, 0, 0] for j in range(n)], dtype=torch.int32)
+        b["dialogues"][:n].copy_(rec)
+        b["queue"].copy_(torch.tensor([first, n], dtype=torch.int32))
+        slot = self._slot_records(ctx[:first]).clone()
+        for j in range(first):
+            slot[j, 5], slot[j, 6] = lim[j], flags
+        b["state"].copy_(slot)
+        b["x"][:first].copy_(self.start[None, :].expand(first, -1))
+        self._mirror_setup()
+        via_helper = ops.is_partition_stream()
+        out: list = [None] * n
+        left = n
+
+        def collect(records):
+            nonlocal left
+            self.last_records = records          # (tests / tools: status, steps and slot of every utterance)
+            for j in range(n):
+                if out[j] is None and records[j][3] >= 2:
+                    out[j] = self._cut(j, records[j][4])
+                    left -= 1
+                    if on_done is not None:
+                        on_done(j, out[j])
+
+        i, pending = 0, None
+        cap = (sum(lim) + CHUNK - 1) // CHUNK + 4          # (one slot decoding everything: cannot be reached)
+        while left > 0 and i < cap:
+            self._run_chunk(temperature, nb, 1.0, True)
+            k = i & 1
+            self._mirror_push(k, b["dialogues"][:n], via_helper)
+            if pending is not None:
+                collect(self._mirror_pull(pending, n))
+            pending = k
+            i += 1
+        if left > 0 and pending is not None:
+            collect(self._mirror_pull(pending, n))
+        if pending is not None:
+            self._pin_ev[pending].synchronize()
+        if left > 0:
+            raise RuntimeError(f"text2semantic continuous decode: {left} of {n} utterances did not finish in {i} chunks")
         return out
 
     @ops.gated

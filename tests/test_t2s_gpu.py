@@ -137,6 +137,68 @@ def test_batched_decode_is_bit_identical_to_one_by_one(case):
         assert torch.equal(r[0].cpu(), torch.from_numpy(g["tokens"]))
 
 
+def _varied(g, n, steps, seed):
+    """n utterances: texts of different length cut from the golden one, own uniform draws"""
+    src = torch.from_numpy(g["source_ids"])
+    uni = torch.from_numpy(g["uniforms"])
+    S, V = uni.shape[1], uni.shape[-1]
+    gen = torch.Generator().manual_seed(seed)
+    L = src.shape[1]
+    srcs, unis = [], []
+    for i in range(n):
+        a = int(torch.randint(0, max(1, L // 2), (1,), generator=gen))
+        e = int(torch.randint(a + 3, L + 1, (1,), generator=gen))
+        srcs.append(src[:, a:e] if i % 5 else torch.cat((src, src[:, : 1 + i % 7]), dim=1))
+        unis.append(torch.rand(steps, S, V, generator=gen))
+    return srcs, unis
+
+
+@pytest.mark.parametrize("nb", [16, 32, 64])
+def test_large_decode_batches_are_bit_identical_to_one_by_one(case, nb):
+    """Round 6: 16 / 32 / 64 decode slots per step (groups of 8 slots; the kernels read every slot's own position).  Every
+    utterance must get exactly the tokens it gets alone - the golden utterance in slot nb - 3 against the reference's tokens."""
+    name, g, model = case
+    if nb > 16 and not name.endswith("_small") and name != "comix":
+        pytest.skip("the wide batches run on both small fixtures and on the full CoMix shape")
+    steps = g["uniforms"].shape[0]          # (a lock-step batch runs as many steps as its shortest list of draws)
+    srcs, unis = _varied(g, nb, steps, seed=100 + nb)
+    slot = nb - 3
+    srcs[slot], unis[slot] = torch.from_numpy(g["source_ids"]), torch.from_numpy(g["uniforms"])
+    res = model.generate_batch(srcs, unis)
+    assert torch.equal(res[slot][0].cpu(), torch.from_numpy(g["tokens"]))
+    for i in sorted({0, 1, 7, 8, 9, nb // 2, nb - 9, nb - 1}):
+        alone = model.generate(srcs[i], uniforms=unis[i], return_streams=True)
+        assert torch.equal(res[i][0], alone[0]) and torch.equal(res[i][1], alone[1]), (name, nb, i)
+
+
+@pytest.mark.parametrize("slots", [8, 32])
+def test_continuous_batching_tokens_equal_one_by_one(case, slots):
+    """generate_many: utterances that end at DIFFERENT steps (their own eos, text2semantic.py:803-818, or their step limit) run
+    through continuously refilled decode slots - the sampling kernel hands a finished slot the next pending utterance on the
+    device.  Every utterance gets exactly the tokens the one-by-one decode gives it, whatever slot and neighbours it had."""
+    name, g, model = case
+    n, steps = 44, 96
+    srcs, unis = _varied(g, n, steps, seed=7)
+    gold = torch.from_numpy(g["uniforms"])[:, :, 0, :]
+    srcs[5], unis[5] = torch.from_numpy(g["source_ids"]), torch.cat((gold, unis[5][gold.shape[0]:]))
+    gen = torch.Generator().manual_seed(1)
+    limits = torch.randint(10, steps + 1, (n,), generator=gen).tolist()
+    limits[5] = gold.shape[0]
+    done = []
+    res = model.generate_many(srcs, unis, slots=slots, limits=limits, on_done=lambda j, r: done.append(j))
+    assert sorted(done) == list(range(n))
+    rec = model.last_records
+    by_eos = sum(1 for j in range(n) if rec[j][3] == 2)
+    by_limit = sum(1 for j in range(n) if rec[j][3] == 3)
+    used = {rec[j][5] for j in range(n)}
+    print(name, f"{slots} slots: {by_eos} utterances ended by their eos, {by_limit} by their limit; slots used: {len(used)}")
+    assert by_eos + by_limit == n and by_limit > 0 and len(used) == min(slots, n)
+    for j in range(n):
+        alone = model.generate(srcs[j], uniforms=unis[j][: limits[j]], return_streams=True)
+        assert torch.equal(res[j][0], alone[0]) and torch.equal(res[j][1], alone[1]), (name, slots, j, rec[j])
+    assert torch.equal(res[5][0].cpu(), torch.from_numpy(g["tokens"]))          # the reference's tokens for the golden utterance
+
+
 @pytest.mark.parametrize("name", ["cosingle_small", "cosingle"])
 def test_classifier_free_guidance_vs_reference_golden(name):
     """cond_scale = 1.5 (text2semantic.py:780-792): tokens sampled from null + (cond - null) * scale, BIT-EXACT against the
