@@ -595,6 +595,9 @@ typedef struct {
     int32_t* queue;                              /* NULL: slot b decodes dialogue b until the caller stops.  Else continuous batching (above) */
     int32_t* dialogues;
     const float* start;                          /* [dim] start token: the input of a slot that takes a new dialogue (queue != NULL) */
+    int32_t group_loop;                          /* tuning hint, 0 = the library's choice: groups of 8 slots one thread block walks with its
+                                                  * weight rows in registers (1, 2, 4, 8); the other groups run as blocks of their own */
+    int32_t pairs_per_wave;                      /* tuning hint, 0 = the library's choice: output row pairs per wavefront (1 or 2) */
 } cvx_t2s_decoder;
 
 int cvx_t2s_decode_steps(const cvx_t2s_decoder* dec, int32_t n_steps, cvx_stream_t stream);

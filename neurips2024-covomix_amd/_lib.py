@@ -137,7 +137,8 @@ class T2SDecoder(C.Structure):
                [("temperature", C.c_float), ("layers", C.POINTER(T2SLayer))] + \
                [(n, C.c_void_p) for n in ("final_gamma", "emb", "rope_cos", "rope_sin", "uniforms",
                                           "x", "q", "att", "h", "logits", "tokens", "state")] + [("cfg_scale", C.c_float)] + \
-               [("uniform_steps", C.c_int32), ("queue", C.c_void_p), ("dialogues", C.c_void_p), ("start", C.c_void_p)]
+               [("uniform_steps", C.c_int32), ("queue", C.c_void_p), ("dialogues", C.c_void_p), ("start", C.c_void_p),
+                ("group_loop", C.c_int32), ("pairs_per_wave", C.c_int32)]
 
 
 class ResblockArgs(C.Structure):

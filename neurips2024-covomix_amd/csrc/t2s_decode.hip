@@ -112,165 +112,198 @@ __device__ __forceinline__ bool pair_rows(const GemvArgs& a, int pair, int& r0, 
     return r0 < a.N;
 }
 
-// the first PF chunks of the two weight rows of a pair: they do not depend on the input vector, so their HBM / MALL round
-// trip can overlap whatever precedes the dot product (the staging of x)
-struct RowPrefetch { f32x4 pa[PF], pb[PF]; };
+// One CHUNK = 1024 consecutive floats of the input vector(s) = PF x 256-float strips; lane l of a wave works on the 4-vectors
+// 4 l + 256 i of every row (fixed summation order: lane-strided 4-vectors in ascending k, then the lane tree below).
+struct RowChunk { f32x4 pa[PF], pb[PF]; };
+struct PairInfo { const float *w0, *w1; int r0, r1, sidx; bool valid, has1; };
+
 template <int MODE>
-__device__ __forceinline__ void prefetch_pair(const GemvArgs& a, int pair, int lane, RowPrefetch& pf)
+__device__ __forceinline__ PairInfo pair_info(const GemvArgs& a, int pair)
 {
-    int r0, r1, sidx;
-    const bool valid = pair_rows<MODE>(a, pair, r0, r1, sidx);
-    const bool has1 = valid && r1 < a.N;
-    const float* w0 = a.W + (int64_t)(valid ? r0 : 0) * a.ldw;
-    const float* w1 = a.W + (int64_t)(has1 ? r1 : (valid ? r0 : 0)) * a.ldw;
-    const int K4 = a.K & ~3;
+    PairInfo p;
+    p.valid = pair_rows<MODE>(a, pair, p.r0, p.r1, p.sidx);
+    p.has1 = p.valid && p.r1 < a.N;
+    p.w0 = a.W + (int64_t)(p.valid ? p.r0 : 0) * a.ldw;
+    p.w1 = a.W + (int64_t)(p.has1 ? p.r1 : (p.valid ? p.r0 : 0)) * a.ldw;
+    return p;
+}
+
+// chunk c of the two weight rows of a pair: independent of the input vectors, so the HBM / MALL round trip overlaps whatever
+// precedes the dot product (the staging of x).  Strips are classified with WAVE-UNIFORM conditions (whole / partial / absent): the
+// common whole strip carries no lane masks (a lane-wise guard on every strip cost 290 selects and 220 spilled mask registers).
+__device__ __forceinline__ void load_chunk(const GemvArgs& a, const PairInfo& p, int c, int lane, RowChunk& w)
+{
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        const int k = 4 * lane + 256 * i;
-        if (k < K4) { pf.pa[i] = wload4(w0 + k); pf.pb[i] = wload4(w1 + k); }
+        const int kb = 1024 * c + 256 * i, k = kb + 4 * lane;
+        if (kb + 256 <= a.K) { w.pa[i] = wload4(p.w0 + k); w.pb[i] = wload4(p.w1 + k); }
+        else if (kb < a.K) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            w.pa[i] = z; w.pb[i] = z;
+            if (k < a.K) { w.pa[i] = wload4(p.w0 + k); w.pb[i] = wload4(p.w1 + k); }
+        }
     }
 }
 
-// stage (and RMS-normalise) the input vectors of a GEMV into LDS: xs[b][k] = x[b][k] * gamma[k]; inv[b] = the per-vector
-// normalisation factor (1 without gamma).  All threads of the block; contains block barriers.
+// Lane tree: the xor butterfly 32, 16, 8, 4, 2, 1 ("v += shfl_xor(v, o)").  For BQ values per lane it runs as a reduce-scatter - at
+// the first log2(BQ) steps a lane keeps half of its values and hands the other half to its partner - which computes, for every value,
+// exactly the sums of the plain butterfly (own + partner's, fp addition commutes) with 2 BQ + ... instead of 6 BQ exchanges: the same
+// bits for every BQ.  Afterwards value b sits in the lanes with (lane >> (6 - log2 BQ)) == b.
+template <int H, int N>
+__device__ __forceinline__ void tree_step(float (&v)[N], int lane, int o)
+{
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {                     // (H is a template constant: v is indexed statically and stays in registers)
+        const float send = up ? v[j] : v[j + H];
+        const float keep = up ? v[j + H] : v[j];
+        v[j] = keep + __shfl_xor(send, o, 64);
+    }
+}
 template <int BQ>
-__device__ __forceinline__ void stage_input(const GemvArgs& a, int bofs, int Kin, float* xs, float (*red)[4], float (&inv)[BQ])
+__device__ __forceinline__ void lane_tree(float (&v)[BQ], int lane)
 {
-    const float* const xg = a.x + (int64_t)bofs * a.x_stride;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float ss[BQ];
+    if constexpr (BQ == 8) { tree_step<4>(v, lane, 32); tree_step<2>(v, lane, 16); tree_step<1>(v, lane, 8); }
+    if constexpr (BQ == 4) { tree_step<2>(v, lane, 32); tree_step<1>(v, lane, 16); }
+    if constexpr (BQ == 2) { tree_step<1>(v, lane, 32); }
+    constexpr int first = BQ == 8 ? 4 : BQ == 4 ? 8 : BQ == 2 ? 16 : 32;
 #pragma unroll
-    for (int b = 0; b < BQ; ++b) ss[b] = 0.f;
-    for (int k = tid; k < Kin; k += 256) {      // (k outer, utterances inner: the loads of one k are independent)
-        const float gk = a.gamma ? a.gamma[k] : 1.f;
-        float v[BQ];
+    for (int o = first; o > 0; o >>= 1) v[0] += __shfl_xor(v[0], o, 64);
+}
+template <int BQ> struct SlotShift { static constexpr int value = BQ == 8 ? 3 : BQ == 4 ? 4 : BQ == 2 ? 5 : 6; };
+
+// LDS image of one chunk of the BQ input vectors.  BQ >= 2: slots interleaved in pairs, xs[(b >> 1)][k][b & 1], so that the two
+// slots of a pair sit in one 64-bit register pair and a v_pk_fma_f32 advances both (two independent fp32 FMAs: the bits of fmaf).
+template <int BQ>
+__device__ __forceinline__ void stage_chunk(const GemvArgs& a, int bofs, int c, int Kin, float* xs, float (&ss)[BQ])
+{
+    const int k = 1024 * c + 4 * (int)threadIdx.x;
+    const float* const xg = a.x + (int64_t)bofs * a.x_stride + k;
+    f32x4 v[BQ];
+    f32x4 gk = {1.f, 1.f, 1.f, 1.f};
+    if (k < Kin) {                                    // (Kin is a multiple of 4; wave-uniform whenever it is a multiple of 256)
 #pragma unroll
-        for (int b = 0; b < BQ; ++b) v[b] = aload(xg + (int64_t)b * a.x_stride + k);
+        for (int b = 0; b < BQ; ++b) v[b] = aload4(xg + (int64_t)b * a.x_stride);      // (independent loads: one L2 round trip)
+        if (a.gamma) gk = aload4(a.gamma + k);
+    } else {                                          // zero padding of the last chunk: a partial strip multiplies it with zero weights
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < BQ; ++b) { ss[b] = fmaf(v[b], v[b], ss[b]); xs[b * Kin + k] = v[b] * gk; }
+        for (int b = 0; b < BQ; ++b) v[b] = z;
     }
-    if (a.gamma) {
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) ss[b] = wave_sum(ss[b]);
-        if (lane == 0) {
-#pragma unroll
-            for (int b = 0; b < BQ; ++b) red[b][wid] = ss[b];
-        }
-    }
-    __syncthreads();
 #pragma unroll
     for (int b = 0; b < BQ; ++b) {
-        inv[b] = 1.f;
-        if (a.gamma) {
-            const float tot = red[b][0] + red[b][1] + red[b][2] + red[b][3];
-            inv[b] = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize(eps = 1e-12) * sqrt(dim)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss[b] = fmaf(v[b][e], v[b][e], ss[b]);
+        v[b] = v[b] * gk;
+    }
+    const int t4 = 4 * (int)threadIdx.x;
+    if (BQ == 1) {
+        *reinterpret_cast<f32x4*>(xs + t4) = v[0];
+    } else {
+#pragma unroll
+        for (int bp = 0; bp < BQ / 2; ++bp) {
+            const f32x4 lo = {v[2 * bp][0], v[2 * bp + 1][0], v[2 * bp][1], v[2 * bp + 1][1]};
+            const f32x4 hi = {v[2 * bp][2], v[2 * bp + 1][2], v[2 * bp][3], v[2 * bp + 1][3]};
+            float* const d = xs + ((size_t)bp * 1024 + t4) * 2;
+            *reinterpret_cast<f32x4*>(d) = lo;
+            *reinterpret_cast<f32x4*>(d + 4) = hi;
         }
     }
 }
 
-// one row pair: dot products with every staged vector (fixed summation order: lane-strided 4-vectors, then the wave
-// reduction - independent of the batch size and of which kernel runs it) + the MODE epilogue (lane 0)
-template <int MODE, int BQ, bool PRE>
-__device__ __forceinline__ void gemv_pair(const GemvArgs& a, int bofs, int pair, const float* xs, int Kin, const float (&inv)[BQ],
-                                          const RowPrefetch& pf)
-{
-    float* const yg = a.y + (int64_t)bofs * a.y_stride;
-    const int lane = threadIdx.x & 63;
-    int r0, r1, sidx;
-    const bool valid = pair_rows<MODE>(a, pair, r0, r1, sidx);
-    if (!valid) {
-        if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
-            const int F = a.N / 2;
-            if (pair >= F && pair < a.y_pad && lane == 0)
-                for (int b = 0; b < BQ; ++b) yg[(int64_t)b * a.y_stride + pair] = 0.f;
-        }
-        return;
-    }
-    const bool has1 = r1 < a.N;
-    const float* w0 = a.W + (int64_t)r0 * a.ldw;
-    const float* w1 = a.W + (int64_t)(has1 ? r1 : r0) * a.ldw;
-    const int K4 = a.K & ~3;
-    const float* xv = xs + ((MODE == MODE_LOGITS) ? sidx * a.K : 0);
-    float acc0[BQ], acc1[BQ];
+// accumulators of one output row over the BQ slots of a group: slot pairs as 64-bit register pairs (v_pk_fma_f32 operands)
+template <int BQ> struct Acc {
+    f32x2 p[(BQ + 1) / 2];
+    __device__ __forceinline__ void zero() {
 #pragma unroll
-    for (int b = 0; b < BQ; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
+        for (int i = 0; i < (BQ + 1) / 2; ++i) p[i] = f32x2{0.f, 0.f};
+    }
+    __device__ __forceinline__ void unpack(float (&v)[BQ]) const {
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) v[b] = p[b >> 1][b & 1];
+    }
+};
+
+// one 256-float strip of a row pair against the staged vectors of the BQ slots
+template <int BQ>
+__device__ __forceinline__ void dot_strip(const float* xs, int xk, const f32x4 a0, const f32x4 a1, Acc<BQ>& acc0, Acc<BQ>& acc1)
+{
+    if (BQ == 1) {
+        const f32x4 xw = *reinterpret_cast<const f32x4*>(xs + xk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc0.p[0][0] = fmaf(a0[e], xw[e], acc0.p[0][0]); acc1.p[0][0] = fmaf(a1[e], xw[e], acc1.p[0][0]); }
+    } else {
+#pragma unroll
+        for (int bp = 0; bp < BQ / 2; ++bp) {
+            const float* const sp = xs + ((size_t)bp * 1024 + xk) * 2;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
+            const f32x2 xe[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0.p[bp] = fma2(splat2(a0[e]), xe[e], acc0.p[bp]); acc1.p[bp] = fma2(splat2(a1[e]), xe[e], acc1.p[bp]); }
+        }
+    }
+}
+
+// dot products of one row pair with one staged chunk: acc0 row 0, acc1 row 1 (strips past K are skipped wave-uniformly; inside a
+// partial strip the lanes past K multiply zero weights with the zero padding stage_chunk wrote)
+template <int BQ>
+__device__ __forceinline__ void dot_chunk(const GemvArgs& a, int c, int xoff, const float* xs, const RowChunk& w, int lane,
+                                          Acc<BQ>& acc0, Acc<BQ>& acc1)
+{
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        const int k = 4 * lane + 256 * i;
-        if (k < K4) {
-            const f32x4 a0 = PRE ? pf.pa[i] : wload4(w0 + k);
-            const f32x4 a1 = PRE ? pf.pb[i] : wload4(w1 + k);
-#pragma unroll
-            for (int b = 0; b < BQ; ++b) {
-                const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { acc0[b] = fmaf(a0[e], xw[e], acc0[b]); acc1[b] = fmaf(a1[e], xw[e], acc1[b]); }
-            }
-        }
-    }
-    for (int k = 4 * lane + 256 * PF; k < K4; k += 256) {
-        const f32x4 a0 = wload4(w0 + k);
-        const f32x4 a1 = wload4(w1 + k);
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) {
-            const f32x4 xw = *reinterpret_cast<const f32x4*>(xv + b * Kin + k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { acc0[b] = fmaf(a0[e], xw[e], acc0[b]); acc1[b] = fmaf(a1[e], xw[e], acc1[b]); }
-        }
-    }
-    for (int k = K4 + lane; k < a.K; k += 64) {
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) { acc0[b] = fmaf(w0[k], xv[b * Kin + k], acc0[b]); acc1[b] = fmaf(w1[k], xv[b * Kin + k], acc1[b]); }
-    }
-#pragma unroll
-    for (int b = 0; b < BQ; ++b) { acc0[b] = wave_sum(acc0[b]) * inv[b]; acc1[b] = wave_sum(acc1[b]) * inv[b]; }
-    if (lane != 0) return;
-#pragma unroll
-    for (int b = 0; b < BQ; ++b) {
-        float s0 = acc0[b], s1 = acc1[b];
-        float* const yb = yg + (int64_t)b * a.y_stride;
-        // every slot decodes at its own position (continuous batching: slots are refilled at different steps)
-        const int pos = (MODE == MODE_QKV) ? min(aloadi(a.state + SR * (bofs + b)), a.max_len - 1) : 0;
-        if (a.bias) { s0 += a.bias[r0]; if (has1) s1 += a.bias[r1]; }
-
-        if (MODE == MODE_QKV) {
-            const int sec = r0 / a.inner, c0 = r0 - sec * a.inner;        // column inside q / k / v
-            if (sec < 2) {                                                // half-split RoPE on the (i, i+32) pair
-                const float c = a.rope_cos[pos * 32 + (c0 & 31)], s = a.rope_sin[pos * 32 + (c0 & 31)];
-                const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
-                s0 = n0; s1 = n1;
-            }
-            float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + (bofs + b) * a.cache_stride + (int64_t)pos * a.inner;
-            dst[c0] = s0;
-            dst[c0 + 32] = s1;
-        } else if (MODE == MODE_RES) {
-            yb[r0] = aload(yb + r0) + s0;
-            if (has1) yb[r1] = aload(yb + r1) + s1;
-        } else if (MODE == MODE_GEGLU) {
-            yb[r0] = s0 * gelu_erf(s1);                                   // F.gelu(gate) * x, text2semantic.py:154-157
-        } else if (MODE == MODE_LOGITS) {
-            yb[sidx * a.N + r0] = s0;
-            if (has1) yb[sidx * a.N + r1] = s1;
-        } else {
-            yb[r0] = s0;
-            if (has1) yb[r1] = s1;
-        }
+        if (1024 * c + 256 * i < a.K) dot_strip<BQ>(xs, xoff + 4 * lane + 256 * i, w.pa[i], w.pb[i], acc0, acc1);
     }
 }
 
-// PPW = row pairs per wave.  Every block stages all BQ input vectors (BQ x Kin floats from the L2) for its 4 x PPW row pairs: with one
-// pair per wave a batch-8 block reads as many bytes of x as of weights.  On the whole chip that is the fastest form all the same
-// (round 4, PPW = 2 at batch 8: 394 vs 285 us per CoSingle step - half the blocks, half the weight rows in flight, and the step is
-// bound by rows in flight); on a CU-masked side stream (pipeline.py: 32 CUs, several rounds of blocks per launch) two pairs per wave
-// win at batch 8 (CoMix step on 32 CUs, same box: 813 us with one pair, 760 with two, 942 with four; batch 4: 459 / 476 / 616) -
-// launch_gemv_b picks by the stream's CU count and the batch.  Per-pair arithmetic does not depend on PPW: same bits.
+// the MODE epilogue of one (row pair, slot): s0 / s1 = the two rows' finished dot products
+template <int MODE>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const PairInfo& p, int slot, float s0, float s1)
+{
+    float* const yb = a.y + (int64_t)slot * a.y_stride;
+    const int r0 = p.r0, r1 = p.r1;
+    if (a.bias) { s0 += a.bias[r0]; if (p.has1) s1 += a.bias[r1]; }
+    if (MODE == MODE_QKV) {
+        // every slot decodes at its own position (continuous batching: slots are refilled at different steps)
+        const int pos = min(aloadi(a.state + SR * slot), a.max_len - 1);
+        const int sec = r0 / a.inner, c0 = r0 - sec * a.inner;        // column inside q / k / v
+        if (sec < 2) {                                                // half-split RoPE on the (i, i+32) pair
+            const float c = a.rope_cos[pos * 32 + (c0 & 31)], s = a.rope_sin[pos * 32 + (c0 & 31)];
+            const float n0 = s0 * c - s1 * s, n1 = s1 * c + s0 * s;
+            s0 = n0; s1 = n1;
+        }
+        float* dst = sec == 0 ? yb : (sec == 1 ? a.k_cache : a.v_cache) + slot * a.cache_stride + (int64_t)pos * a.inner;
+        dst[c0] = s0;
+        dst[c0 + 32] = s1;
+    } else if (MODE == MODE_RES) {
+        yb[r0] = aload(yb + r0) + s0;
+        if (p.has1) yb[r1] = aload(yb + r1) + s1;
+    } else if (MODE == MODE_GEGLU) {
+        yb[r0] = s0 * gelu_erf(s1);                                   // F.gelu(gate) * x, text2semantic.py:154-157
+    } else if (MODE == MODE_LOGITS) {
+        yb[p.sidx * a.N + r0] = s0;
+        if (p.has1) yb[p.sidx * a.N + r1] = s1;
+    } else {
+        yb[r0] = s0;
+        if (p.has1) yb[r1] = s1;
+    }
+}
+
+// y[slot] = epilogue(W . norm(x[slot])) for the slots of the block's groups.  PPW = row pairs per wave (the wave's weight strips stay in
+// registers for every group of slots it walks); BQ = slots per group.  The input vectors go through LDS in chunks of 1024 floats (32
+// KiB at BQ = 8: four blocks per CU whatever K is), staged with ONE 16-byte load per thread and slot - the launch is one link of a
+// chain of 34 dependent launches per token, and its critical path is [weight strip | x chunk] -> FMAs -> lane tree -> store.
+// (Round 5 staged scalar-wise, four dependent L2 round trips per 1024 floats, ran the lane tree once per value - 96 exchanges per
+// pair at BQ = 8 against 20 now - and left the epilogue of all slots to lane 0.)  Per-(row, slot) arithmetic does not depend on BQ, PPW
+// or the grouping: same bits.
 template <int MODE, int BQ, int PPW>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float xs[];         // [BQ][Kin] (Kin a multiple of 4)
+    __shared__ __attribute__((aligned(16))) float xs[BQ * 1024];
     __shared__ float red[BQ][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per utterance
+    const int Kin = (MODE == MODE_LOGITS) ? a.K * a.streams : a.K;     // staged length per slot
+    const int nchunk = (Kin + 1023) >> 10;
     // block -> (row block, first slot group).  More than one block per row block (gy > 1): the gy blocks of a row block are
     // consecutive ON ONE XCD (blocks are dealt to the 8 XCDs round robin), so the first one brings the rows into that XCD's L2
     int rb = blockIdx.x, g0 = 0;
@@ -280,19 +313,65 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         g0 = (i % a.gy) * a.gl;
         if (rb >= a.n_blocks) return;                                   // (block-uniform)
     }
-    const int pair = (rb * 4 + wid) * PPW;                              // every wave owns TWO output rows per pair
-    // weights first: their HBM / MALL round trip overlaps the staging of x below (the step is a chain of 34 dependent
-    // launches; every microsecond of latency counts)
-    RowPrefetch pf[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) prefetch_pair<MODE>(a, pair + i, lane, pf[i]);
+    PairInfo pi[PPW];
+    RowChunk w[PPW];                                                    // the current chunk of the wave's weight rows (K <= 1024: all of them,
+#pragma unroll                                                          // loaded once for every group of slots the block walks)
+    for (int p = 0; p < PPW; ++p) {
+        pi[p] = pair_info<MODE>(a, (rb * 4 + wid) * PPW + p);
+        load_chunk(a, pi[p], 0, lane, w[p]);                            // weights first: in flight under the staging of x
+    }
+    constexpr int SH = SlotShift<BQ>::value;
+    const int myb = BQ == 1 ? 0 : lane >> SH;                          // the slot (of a group) whose results the lane tree leaves here
+    const bool writer = (lane & ((1 << SH) - 1)) == 0;
+#pragma unroll 1
     for (int g = 0; g < a.gl; ++g) {
         const int bofs = (g0 + g) * BQ;
-        if (g) __syncthreads();                                        // (xs / red of the previous group are free)
-        float inv[BQ];
-        stage_input<BQ>(a, bofs, Kin, xs, red, inv);
+        Acc<BQ> acc0[PPW], acc1[PPW];
+        float ss[BQ];
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) gemv_pair<MODE, BQ, true>(a, bofs, pair + i, xs, Kin, inv, pf[i]);
+        for (int b = 0; b < BQ; ++b) ss[b] = 0.f;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) { acc0[p].zero(); acc1[p].zero(); }
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
+            if (c > 0 || (g > 0 && nchunk > 1)) {
+#pragma unroll
+                for (int p = 0; p < PPW; ++p) load_chunk(a, pi[p], c, lane, w[p]);
+            }
+            if (g | c) __syncthreads();                                 // (xs / red of the previous chunk / group are free)
+            stage_chunk<BQ>(a, bofs, c, Kin, xs, ss);
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PPW; ++p) {
+                // LOGITS: the staged vector holds `streams` slices; the pair's slice starts at sidx * K (one chunk: Kin <= 1024)
+                const int xoff = (MODE == MODE_LOGITS) ? pi[p].sidx * a.K : 0;
+                dot_chunk<BQ>(a, c, xoff, xs, w[p], lane, acc0[p], acc1[p]);
+            }
+        }
+        float inv = 1.f;
+        if (a.gamma) {                                                  // F.normalize(eps = 1e-12) * sqrt(dim)
+            lane_tree<BQ>(ss, lane);
+            if (writer) red[myb][wid] = ss[0];
+            __syncthreads();
+            const float tot = red[myb][0] + red[myb][1] + red[myb][2] + red[myb][3];
+            inv = sqrtf((float)Kin) / fmaxf(sqrtf(tot), 1e-12f);
+        }
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            if (!pi[p].valid) {
+                if (MODE == MODE_GEGLU) {      // zero the K padding of the consumer GEMV
+                    const int pair = (rb * 4 + wid) * PPW + p;
+                    if (pair >= a.N / 2 && pair < a.y_pad && lane < BQ) a.y[(int64_t)(bofs + lane) * a.y_stride + pair] = 0.f;
+                }
+                continue;
+            }
+            float v0[BQ], v1[BQ];
+            acc0[p].unpack(v0);
+            acc1[p].unpack(v1);
+            lane_tree<BQ>(v0, lane);
+            lane_tree<BQ>(v1, lane);
+            if (writer) gemv_epilogue<MODE>(a, pi[p], bofs + myb, v0[0] * inv, v1[0] * inv);
+        }
     }
 }
 
@@ -323,17 +402,25 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
     const int sub = tid & 15, grp = tid >> 4;              // 16 lanes per key, 16 keys per pass
     const f32x4 q4 = aload4(a.q + (int64_t)b * HD64 + h * 64 + 4 * sub);
     float mx = -3.0e38f;
-    for (int j0 = 0; j0 < n; j0 += 16) {
-        const int j = j0 + grp;
-        float d = 0.f;
-        if (j < n) {
-            const f32x4 k4 = aload4(kb + (int64_t)j * a.stride + h * 64 + 4 * sub);
-            d = k4[0] * q4[0] + k4[1] * q4[1] + k4[2] * q4[2] + k4[3] * q4[3];
+    // four key rows per thread in flight (the loop is a chain of cache round trips otherwise: one 16-byte load, four shuffles and a
+    // compare per trip - 38 dependent trips at 600 keys); the arithmetic per key is unchanged
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        f32x4 k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 16 * u + grp;
+            if (j < n) k4[u] = aload4(kb + (int64_t)j * a.stride + h * 64 + 4 * sub);
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-        d *= a.scale;
-        if (j < n) { if (sub == 0) sc[j] = d; mx = fmaxf(mx, d); }
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 16 * u + grp;
+            float d = 0.f;
+            if (j < n) d = k4[u][0] * q4[0] + k4[u][1] * q4[1] + k4[u][2] * q4[2] + k4[u][3] * q4[3];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            d *= a.scale;
+            if (j < n) { if (sub == 0) sc[j] = d; mx = fmaxf(mx, d); }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -348,11 +435,18 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
     __syncthreads();
     sum = red[0] + red[1] + red[2] + red[3];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j = grp; j < n; j += 16) {
-        const f32x4 v4 = aload4(vb + (int64_t)j * a.stride + h * 64 + 4 * sub);
-        const float p = sc[j];
+    for (int j0 = grp; j0 < n; j0 += 64) {              // (value rows four at a time; accumulated in ascending key order as before)
+        f32x4 v4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, v4[e], acc[e]);
+        for (int u = 0; u < 4; ++u) if (j0 + 16 * u < n) v4[u] = aload4(vb + (int64_t)(j0 + 16 * u) * a.stride + h * 64 + 4 * sub);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + 16 * u < n) {
+                const float p = sc[j0 + 16 * u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, v4[u][e], acc[e]);
+            }
+        }
     }
     *reinterpret_cast<f32x4*>(&part[grp][4 * sub]) = acc;
     __syncthreads();
@@ -415,13 +509,17 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
                 lg[i] = n + (c - n) * a.cfg_scale;
             } else lg[i] = c;
         }
+        if (tid < 4 && a.V + tid < ((a.V + 3) & ~3)) lg[a.V + tid] = -INFINITY;      // (the rank count below reads whole 4-vectors)
         __syncthreads();
         float val = -INFINITY;
         int idx = tid;
         for (int i = tid; i < a.V; i += NT) {
             const float me = lg[i];
             int cnt = 0;
-            for (int j = 0; j < a.V; ++j) cnt += (lg[j] > me) ? 1 : 0;
+            for (int j = 0; j < a.V; j += 4) {       // rank of entry i = number of larger logits (exact: any order gives the same count)
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lg + j);
+                cnt += (l4[0] > me ? 1 : 0) + (l4[1] > me ? 1 : 0) + (l4[2] > me ? 1 : 0) + (l4[3] > me ? 1 : 0);
+            }
             if (cnt < a.top_k) {
                 const float u = a.uniforms[((dlg * a.uniform_steps + pos) * a.streams + s) * a.V + i];
                 const float g = -logf(fmaxf(-logf(fmaxf(u, 1e-20f)), 1e-20f));
@@ -499,7 +597,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, int b, float* l
 
 __global__ __launch_bounds__(1024) void sample_kernel(const SampleArgs a)
 {
-    __shared__ float lg[1024];
+    __shared__ __attribute__((aligned(16))) float lg[1024];
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ int chosen;
@@ -517,31 +615,24 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h,
 }
 
 
-#ifndef CVX_T2S_SIDE_PPW
-#define CVX_T2S_SIDE_PPW 2     // row pairs per wave on a stream of at most 64 CUs, batches of more than 4 (dev A/B: 1, 2, 4)
-#endif
-#ifndef CVX_T2S_GROUP_LOOP
-#define CVX_T2S_GROUP_LOOP 1   // slot groups one block walks with its weight rows in registers (dev A/B: 1, 2, 4, 8); the rest as blocks
-#endif
+constexpr int T2S_TWO_PAIRS_BATCH = 40;           // (CoMix, whole chip: 32 slots 366 vs 365 us per step, 64 slots 575 vs 489)
+constexpr int T2S_GROUP_LOOP = 1;   // default of cvx_t2s_decoder.group_loop: slot groups one block walks with its weight rows in registers
 template <int MODE, int BQ, int PPW>
 void launch_gemv_p(GemvArgs g, int pairs, int groups, hipStream_t st)
 {
-    const int Kin = (MODE == MODE_LOGITS) ? g.K * g.streams : g.K;
-    const size_t lds = sizeof(float) * (size_t)BQ * Kin;
-    if (lds > 48 * 1024)          // per-(device, kernel) bookkeeping, mutex-protected (cvx_common.h)
-        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemv_kernel<MODE, BQ, PPW>), (int)lds);
     g.n_blocks = (pairs + 4 * PPW - 1) / (4 * PPW);
+    const int want = g.gl > 0 ? g.gl : T2S_GROUP_LOOP;
     g.gl = 1;
-    while (g.gl < CVX_T2S_GROUP_LOOP && groups % (2 * g.gl) == 0) g.gl *= 2;
+    while (g.gl < want && groups % (2 * g.gl) == 0) g.gl *= 2;
     g.gy = groups / g.gl;
     const unsigned grid = g.gy > 1 ? (unsigned)((g.n_blocks + 7) / 8 * 8 * g.gy) : (unsigned)g.n_blocks;
-    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3(grid), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3(grid), dim3(256), 0, st, g);
 }
 template <int MODE, int BQ>
-void launch_gemv_b(const GemvArgs& g, int pairs, int groups, bool few_cus, hipStream_t st)
+void launch_gemv_b(const GemvArgs& g, int pairs, int groups, bool two, hipStream_t st)
 {
-    if constexpr (BQ >= 8 && CVX_T2S_SIDE_PPW > 1) {
-        if (few_cus) { launch_gemv_p<MODE, BQ, CVX_T2S_SIDE_PPW>(g, pairs, groups, st); return; }
+    if constexpr (BQ >= 8) {
+        if (two) { launch_gemv_p<MODE, BQ, 2>(g, pairs, groups, st); return; }
     }
     launch_gemv_p<MODE, BQ, 1>(g, pairs, groups, st);
 }
@@ -574,7 +665,8 @@ static int t2s_validate(const cvx_t2s_decoder* d, int32_t n_steps)
 {
     CVX_REQUIRE(d && d->layers && n_steps >= 0, "t2s_decode: null decoder");
     CVX_REQUIRE(d->dim > 0 && d->dim % 4 == 0 && d->dim <= T2S_MAX_DIM && d->inner == d->heads * 64 && d->depth > 0 &&
-                d->streams >= 1 && d->streams <= 2 && d->dim_emb * d->streams == d->dim && d->vocab > 0 && d->vocab <= 1024 &&
+                d->streams >= 1 && d->streams <= 2 && d->dim_emb * d->streams == d->dim && d->dim_emb % 4 == 0 &&
+                (d->streams == 1 || d->dim <= 1024) && d->vocab > 0 && d->vocab <= 1024 &&
                 d->ff_inner > 0 && d->ff_inner_pad >= d->ff_inner && d->ff_inner_pad % 4 == 0 && d->ff_inner_pad <= T2S_MAX_DIM &&
                 d->n_ctx >= 0 && d->n_ctx <= T2S_MAX_KEYS && d->max_len > 0 && d->max_len <= T2S_MAX_KEYS &&
                 d->top_k > 0 && d->top_k <= d->vocab && d->temperature >= 0.f && d->batch >= 1 && d->batch <= T2S_MAX_BATCH &&
@@ -605,12 +697,15 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
     hipStream_t st = reinterpret_cast<hipStream_t>(s);
     const float scale = 0.125f;        // dim_head ** -0.5
     const int nb = d->batch;
-    const bool few = cvx_stream_cus(s) <= 64;          // a CU-masked side stream: more row pairs per wave (gemv_kernel)
+    // two row pairs per wave (half the blocks, each staging the input vectors for twice the rows): on a CU-masked side stream (several
+    // rounds of blocks per launch at batch 8) and from T2S_TWO_PAIRS_BATCH slots up; cvx_t2s_decoder.pairs_per_wave overrides
+    const bool few = d->pairs_per_wave > 0 ? d->pairs_per_wave >= 2 : (cvx_stream_cus(s) <= 64 || d->batch >= T2S_TWO_PAIRS_BATCH);
     const int64_t cache_stride = (int64_t)d->max_len * d->inner;
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < d->depth; ++l) {
             const cvx_t2s_layer& L = d->layers[l];
             GemvArgs g{};
+            g.gl = d->group_loop;
             // self-attention: q | k | v with RoPE; k, v appended to the cache at position pos
             g.W = L.wqkv_s; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_s; g.y = d->q; g.y_stride = d->inner;
             g.N = 3 * d->inner; g.K = d->dim;
@@ -620,10 +715,12 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
             AttnArgs at{d->q, L.k_cache, L.v_cache, d->inner, cache_stride, d->att, d->state, -1, 0, scale, d->max_len};
             hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, at);
             g = GemvArgs{};
+            g.gl = d->group_loop;
             g.W = L.wo_s; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
             launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, few, st);
             // cross-attention over [null kv | encoder context]
             g = GemvArgs{};
+            g.gl = d->group_loop;
             g.W = L.wq_c; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_c; g.y = d->q; g.y_stride = d->inner;
             g.N = d->inner; g.K = d->dim;
             launch_gemv<MODE_PLAIN>(g, d->inner / 2, nb, few, st);
@@ -631,19 +728,23 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
                         d->n_ctx > 0 ? d->n_ctx : -2, 1, scale, d->max_len};
             hipLaunchKernelGGL(attn_kernel, dim3((unsigned)d->heads, (unsigned)nb), dim3(256), 0, st, ac);
             g = GemvArgs{};
+            g.gl = d->group_loop;
             g.W = L.wo_c; g.ldw = d->inner; g.x = d->att; g.x_stride = d->inner; g.y = d->x; g.y_stride = d->dim; g.N = d->dim; g.K = d->inner;
             launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, few, st);
             // GEGLU feed-forward
             g = GemvArgs{};
+            g.gl = d->group_loop;
             g.W = L.w1; g.ldw = d->dim; g.x = d->x; g.x_stride = d->dim; g.gamma = L.gamma_f; g.bias = L.b1; g.y = d->h;
             g.y_stride = d->ff_inner_pad; g.N = 2 * d->ff_inner; g.K = d->dim; g.y_pad = d->ff_inner_pad;
             launch_gemv<MODE_GEGLU>(g, d->ff_inner_pad, nb, few, st);
             g = GemvArgs{};
+            g.gl = d->group_loop;
             g.W = L.w2; g.ldw = d->ff_inner_pad; g.x = d->h; g.x_stride = d->ff_inner_pad; g.bias = L.b2; g.y = d->x; g.y_stride = d->dim;
             g.N = d->dim; g.K = d->ff_inner_pad;
             launch_gemv<MODE_RES>(g, (d->dim + 1) / 2, nb, few, st);
         }
         GemvArgs g{};
+        g.gl = d->group_loop;
         g.W = d->emb; g.ldw = d->dim_emb; g.x = d->x; g.x_stride = d->dim; g.gamma = d->final_gamma; g.y = d->logits;
         g.y_stride = d->streams * d->vocab; g.N = d->vocab; g.K = d->dim_emb; g.streams = d->streams;
         launch_gemv<MODE_LOGITS>(g, d->streams * ((d->vocab + 1) / 2), nb, few, st);

@@ -172,36 +172,49 @@ class TextToSemanticDecoder:
             self._gen += 1
 
     # ------------------------------------------------------------------ encoder (text2semantic.py:716-741)
-    def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
-        d = self.d
-        ids = source_ids.reshape(-1).to(self.device, torch.int64)
+    def _source_rows(self, source_ids: torch.Tensor) -> torch.Tensor:
+        if source_ids.ndim == 2 and source_ids.shape[0] != 1:
+            raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
+        ids = source_ids.reshape(-1).to(torch.int64)
         if bool((ids == 0).any()):
             raise NotImplementedError("padded text batches (id 0) are not supported: one un-padded utterance per call")
         if ids.numel() + 1 > self.max_source:
             raise ValueError(f"text of {ids.numel()} tokens exceeds max_source = {self.max_source}")
-        src = torch.cat((ids, torch.tensor([d["text_eos"]], device=self.device)))          # set_eos_id, no padding
-        n, H, I, D = src.numel(), d["heads"], d["inner"], d["dim"]
+        return torch.cat((ids.cpu(), torch.tensor([self.d["text_eos"]])))                    # set_eos_id, no padding
+
+    def encode_many(self, sources):
+        """The source transformer over SEVERAL texts as one packed batch (rows of text i: [cu[i], cu[i + 1]); attention and rotary
+        positions per text): the reference encodes one utterance per call, and a 65-token text alone is 19 GEMM launches of 30 us
+        each on a handful of CUs - 64 dialogues encoded one by one cost a quarter of their decode.  Row results do not depend on the
+        other rows of the batch.  -> (encoder output [M, dim], ops.Ragged)"""
+        d = self.d
+        rows = [self._source_rows(s_) for s_ in sources]
+        rg = ops.Ragged([r.numel() for r in rows], self.device)
+        src = ops.h2d(torch.cat(rows), self.device)
+        M, H, I, D = rg.M, d["heads"], d["inner"], d["dim"]
         x = self.emb_text.index_select(0, src).contiguous()
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
-        normed, qkv, att = f(n, D), f(n, 3 * I), f(n, I)
+        normed, qkv, att = f(M, D), f(M, 3 * I), f(M, I)
         F_ = d["ff_src"]
         Fp = (F_ + 3) // 4 * 4
-        h2, hg = f(n, 2 * F_), f(n, Fp)
-        pos = torch.arange(n, device=self.device, dtype=torch.float32)
-        ang = pos[:, None] * self.freqs_src[None, :]
-        rope = (ang.cos().contiguous(), ang.sin().contiguous())
+        h2, hg = f(M, 2 * F_), f(M, Fp)
+        ang = rg.positions()[:, None] * self.freqs_src[None, :]
+        rope = (ang.cos().contiguous(), ang.sin().contiguous())          # per-row tables (rope_T = M)
         for L in self.enc:
             ops.adarmsnorm(x, L["gamma_a"], None, normed)
             ops.gemm(normed, L["wqkv"], qkv, rope=rope, rope_cols=2 * I)
-            ops.attention(qkv, att, 1, n, H, 64 ** -0.5)
+            ops.attention(qkv, att, 1, M, H, 64 ** -0.5, ragged=rg)
             ops.gemm(att, L["wo"], x, residual=x)
             ops.adarmsnorm(x, L["gamma_f"], None, normed)
             ops.gemm(normed, L["w1"], h2, bias=L["b1"])
             ops.geglu(h2, hg, F_)
             ops.gemm(hg, L["w2"], x, bias=L["b2"], residual=x)
-        enc = f(n, D)
+        enc = f(M, D)
         ops.adarmsnorm(x, self.enc_final, None, enc)
-        return enc
+        return enc, rg
+
+    def encode(self, source_ids: torch.Tensor) -> torch.Tensor:
+        return self.encode_many([source_ids])[0]
 
     # ------------------------------------------------------------------ decoder
     def _descriptor(self, temperature: float, batch: int = 1, cfg_scale: float = 1.0, queue: bool = False) -> "_lib.T2SDecoder":
@@ -219,6 +232,8 @@ class TextToSemanticDecoder:
         for n in ("uniforms", "x", "q", "att", "h", "logits", "tokens", "state"):
             setattr(dec, n, b[n].data_ptr())
         dec.uniform_steps = self._steps
+        dec.group_loop = int(os.environ.get("CVX_T2S_GROUP_LOOP", "0"))          # dev A/B
+        dec.pairs_per_wave = int(os.environ.get("CVX_T2S_PPW", "0"))              # dev A/B
         if queue:
             dec.queue, dec.dialogues, dec.start = b["queue"].data_ptr(), b["dialogues"].data_ptr(), self.start.data_ptr()
         return dec
@@ -335,16 +350,23 @@ class TextToSemanticDecoder:
             return
         self._graph(temperature, batch, cfg_scale, queue).replay()
 
-    def _context(self, j: int, src: torch.Tensor) -> int:
-        """encoder + the cross-attention k/v of one utterance into dialogue row j: [null | to_kv(enc)] -> context rows"""
-        if src.ndim == 2 and src.shape[0] != 1:
-            raise NotImplementedError("one utterance per entry (the generation scripts run batch 1)")
-        enc = self.encode(src)
-        n = enc.shape[0]
+    def _contexts(self, sources, rows=None) -> list:
+        """encoder + the cross-attention k/v of the utterances into dialogue rows `rows` (default 0, 1, ...): [null | to_kv(enc)]
+        -> context rows per utterance.  One packed encoder pass and one to_kv GEMM per decoder layer for all of them."""
+        n = len(sources)
+        rows = list(range(n)) if rows is None else list(rows)
+        enc, rg = self.encode_many(sources)
+        R = self.max_source + 2
+        dst = torch.cat([torch.arange(t, dtype=torch.int64) + (rows[i] * R + 1) for i, t in enumerate(rg.lengths)])
+        dst = ops.h2d(dst, self.device)
+        first = ops.h2d(torch.tensor([r * R for r in rows], dtype=torch.int64), self.device)
+        kv = torch.empty(rg.M, 2 * self.d["inner"], dtype=torch.float32, device=self.device)
         for L in self.dec:
-            L["kv_c"][j, 0].copy_(L["null"])
-            ops.gemm(enc, L["wkv_c"], L["kv_c"][j, 1:n + 1])
-        return n + 1
+            ops.gemm(enc, L["wkv_c"], kv)
+            flat = L["kv_c"].view(-1, kv.shape[1])
+            flat.index_copy_(0, dst, kv)
+            flat.index_copy_(0, first, L["null"][None, :].expand(n, -1))
+        return [t + 1 for t in rg.lengths]
 
     def _cut(self, j: int, length: int, logits=None):
         """(flat tokens, streams[, logits]) of dialogue row j after `length` steps: mask_after_eos (text2semantic.py:73-76)"""
@@ -391,7 +413,7 @@ class TextToSemanticDecoder:
         b = self.buf
         if not collect_logits and max_len > 0:
             self._graph(float(temperature), nb)
-        ctx = [self._context(i, src) for i, src in enumerate(sources)]
+        ctx = self._contexts(sources)
         uview = self._uniform_view(nb)
         if us is None:            # (drawn step-major, as the [steps, batch, streams, vocab] buffer of earlier versions was: same seeds, same tokens)
             uview[:, :max_len].copy_(torch.rand(max_len, nb, S, V, device=self.device, generator=generator).permute(1, 0, 2, 3))
@@ -433,10 +455,10 @@ class TextToSemanticDecoder:
         if not collect_logits and max_len > 0:
             self._graph(float(temperature), nb, cond_scale)
         ctx = []
-        for u_, src in enumerate(sources):
-            ctx += [self._context(2 * u_, src), 1]                       # the null slot: row 0 (null k/v) only = every context key masked out
-            for L in self.dec:
-                L["kv_c"][2 * u_ + 1, 0].copy_(L["null"])
+        for c in self._contexts(sources, range(0, nb, 2)):
+            ctx += [c, 1]                                                # the null slot: row 0 (null k/v) only = every context key masked out
+        for L in self.dec:
+            L["kv_c"][1:nb:2, 0].copy_(L["null"][None, :].expand(nu, -1))
         uview = self._uniform_view(nb)
         if us is None:
             uview[0::2, :max_len].copy_(torch.rand(max_len, nu, 1, V, device=self.device, generator=generator).permute(1, 0, 2, 3))
@@ -475,7 +497,8 @@ class TextToSemanticDecoder:
         sources / uniforms as generate_batch; limits: optional per-utterance step limits (default max_length for all).
         on_done(j, (flat, streams)): called for utterance j as soon as the host has seen it finish (the host reads the dialogue
         records one chunk of CHUNK steps behind the device) - the next pipeline stage can start on the first results while the
-        rest decodes.  Returns the list of (flat tokens, streams) in input order."""
+        rest decodes.  Returns the list of (flat tokens, streams) in input order - int64 tensors ON THE HOST (they travel through pinned
+        memory on a helper stream so that nothing makes the decode stream wait)."""
         d = self.d
         S, V = d["streams"], d["vocab"]
         n = len(sources)
@@ -502,7 +525,7 @@ class TextToSemanticDecoder:
         b = self.buf
         temperature = float(temperature)
         self._graph(temperature, nb, 1.0, True)
-        ctx = [self._context(j, src) for j, src in enumerate(sources)]
+        ctx = self._contexts(sources)
         uview = self._uniform_view(n)
         if us is None:
             uview[:, :max_len].copy_(torch.rand(n, max_len, S, V, device=self.device, generator=generator))
@@ -522,21 +545,44 @@ class TextToSemanticDecoder:
         self._mirror_setup()
         via_helper = ops.is_partition_stream()
         out: list = [None] * n
-        left = n
+        seen = [False] * n
+        # token rows of finished utterances reach the host through the helper stream into pinned memory (a dialogue's rows are final
+        # once the host has SEEN it finished: any stream may read them) and are cut on the host - nothing here makes the decode
+        # stream wait, so the chunks stay back to back (a device-side boolean index per utterance cost a stream sync each: 64
+        # utterances on 64 slots ran 996 ms against 746 ms in lock step)
+        tok_pin = torch.empty(n, S, max_len, dtype=torch.int64).pin_memory()
+        copies: list = []                                  # (j, steps, event) in flight on the helper stream
+        eos = V - 1
+
+        def finish(block: bool):
+            while copies and (block or copies[0][2].query()):
+                j, length, ev = copies.pop(0)
+                ev.synchronize()
+                streams = tok_pin[j, :, :length].clone()
+                after = (streams == eos).cumsum(dim=-1) > 0          # mask_after_eos (text2semantic.py:73-76)
+                after = torch.nn.functional.pad(after, (1, -1), value=False)
+                flat = streams.masked_fill(after, PAD_ID).reshape(-1)
+                out[j] = (flat[flat != PAD_ID], streams)
+                if on_done is not None:
+                    on_done(j, out[j])
 
         def collect(records):
-            nonlocal left
             self.last_records = records          # (tests / tools: status, steps and slot of every utterance)
-            for j in range(n):
-                if out[j] is None and records[j][3] >= 2:
-                    out[j] = self._cut(j, records[j][4])
-                    left -= 1
-                    if on_done is not None:
-                        on_done(j, out[j])
+            fresh = [j for j in range(n) if not seen[j] and records[j][3] >= 2]
+            if fresh:
+                with torch.cuda.stream(self._helper):
+                    for j in fresh:
+                        seen[j] = True
+                        length = records[j][4]
+                        tok_pin[j, :, :length].copy_(b["tokens"][j, :, :length], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        copies.append((j, length, ev))
+            finish(False)
 
         i, pending = 0, None
         cap = (sum(lim) + CHUNK - 1) // CHUNK + 4          # (one slot decoding everything: cannot be reached)
-        while left > 0 and i < cap:
+        while not all(seen) and i < cap:
             self._run_chunk(temperature, nb, 1.0, True)
             k = i & 1
             self._mirror_push(k, b["dialogues"][:n], via_helper)
@@ -544,12 +590,13 @@ class TextToSemanticDecoder:
                 collect(self._mirror_pull(pending, n))
             pending = k
             i += 1
-        if left > 0 and pending is not None:
+        if not all(seen) and pending is not None:
             collect(self._mirror_pull(pending, n))
         if pending is not None:
             self._pin_ev[pending].synchronize()
-        if left > 0:
-            raise RuntimeError(f"text2semantic continuous decode: {left} of {n} utterances did not finish in {i} chunks")
+        finish(True)
+        if not all(seen):
+            raise RuntimeError(f"text2semantic continuous decode: {seen.count(False)} of {n} utterances did not finish in {i} chunks")
         return out
 
     @ops.gated

@@ -195,7 +195,7 @@ def test_continuous_batching_tokens_equal_one_by_one(case, slots):
     assert by_eos + by_limit == n and by_limit > 0 and len(used) == min(slots, n)
     for j in range(n):
         alone = model.generate(srcs[j], uniforms=unis[j][: limits[j]], return_streams=True)
-        assert torch.equal(res[j][0], alone[0]) and torch.equal(res[j][1], alone[1]), (name, slots, j, rec[j])
+        assert torch.equal(res[j][0], alone[0].cpu()) and torch.equal(res[j][1], alone[1].cpu()), (name, slots, j, rec[j])
     assert torch.equal(res[5][0].cpu(), torch.from_numpy(g["tokens"]))          # the reference's tokens for the golden utterance
 
 

@@ -29,7 +29,7 @@ for name in which:
     for nb in BATCHES:                                      # slots decoded together, lock step
         m._ensure(nb, nb, N)
         m._graph(1.0, nb)
-        ctx = [m._context(i, src) for i in range(nb)]
+        ctx = m._contexts([src] * nb)
         m.buf["uniforms"].uniform_(1e-6, 1 - 1e-6)
         m.buf["x"][:nb].copy_(m.start[None, :].expand(nb, -1))
         m.buf["state"].copy_(m._slot_records(ctx))
@@ -45,7 +45,7 @@ for name in which:
         lims = torch.randint(100, 609, (n,), generator=g).tolist()
         srcs = [torch.randint(1, 30000, (1, 48), generator=g) for _ in range(n)]
         for slots in (8, 32, 64):
-            m.generate_many(srcs[:slots], max_length=32, slots=slots, ignore_eos=True)      # graph + buffers
+            m.generate_many(srcs, max_length=608, slots=slots, ignore_eos=True, limits=[20] * n)      # graph + buffers of the timed shape
             torch.cuda.synchronize(); t0 = time.perf_counter()
             m.generate_many(srcs, max_length=608, slots=slots, ignore_eos=True, limits=lims)
             torch.cuda.synchronize(); t_many = time.perf_counter() - t0
