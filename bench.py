@@ -211,7 +211,7 @@ class PowerSampler:
                 "power_samples": len(sel), "power_source": src}
 
 
-def config2(dev, calls: int = 5):
+def config2(dev, calls: int = 20):
     """BASELINE config 2 next to the headline: VoSingle, 32 NFE, ONE 500-frame utterance (200-frame prompt) per call - the
     reference's own calling pattern (monologue_generation.py:259-304).  ms per utterance, frames/s and the fraction of the dense
     fp16 MFMA peak its algorithmic FLOPs (15.18 GFLOP per frame) reach."""
@@ -225,61 +225,106 @@ def config2(dev, calls: int = 5):
     ids, cond, mask = inp["phoneme_ids"].to(dev), inp["cond"].to(dev), inp["mask"].to(dev)
     for _ in range(2):
         model.synthesis_sample(ids, cond, mask, COND_SCALE)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        model.synthesis_sample(ids, cond, mask, COND_SCALE)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / calls
+
+    def loop():
+        for _ in range(calls):
+            model.synthesis_sample(ids, cond, mask, COND_SCALE)
+    _, dt, pw = timed_region(loop, dev.index or 0)
+    dt /= calls
     flop_per_frame = 64 * 237_139_968
+    # config 2 is ~2,400 dependent launches of 5-40 us per call: besides the shader clock of a lightly loaded chip (sclk_mhz above), the
+    # box's cost of one dependent launch inside a graph decides it - measured here on a chain of 2,000 one-element kernels
+    x = torch.zeros(1, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        x.add_(1.0)
+        side.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            for _ in range(2000):
+                x.add_(1.0)
+        gr.replay(); side.synchronize()
+        t0 = time.perf_counter(); gr.replay(); side.synchronize()
+        floor_us = (time.perf_counter() - t0) / 2000 * 1e6
+    pw["dependent_launch_us"] = round(floor_us, 3)
     return {"workload": "VoSingle 32-NFE, B=1, T=500 (200-frame prompt), acoustic model only", "calls": calls,
             "ms_per_utterance": round(dt * 1e3, 3), "frames_per_s": round(500 / dt, 1),
-            "frac": round(500 / dt * flop_per_frame / PEAK_F16_MFMA, 4), "vs_f32_mfma_peak": round(500 / dt * flop_per_frame / PEAK_F32_MFMA, 4)}
+            "frac": round(500 / dt * flop_per_frame / PEAK_F16_MFMA, 4), "vs_f32_mfma_peak": round(500 / dt * flop_per_frame / PEAK_F32_MFMA, 4), **pw}
 
 
-def config5(dev, dialogues: int = 28):
+def timed_region(fn, dev_index=0):
+    """fn() between two device synchronisations -> (result, seconds, {power_w, sclk_mhz, ...} of THAT region): boxes of the pool
+    differ by several per cent, and every figure of the line must say which box state it was measured in."""
+    power = PowerSampler(device_index=dev_index)
+    power.start()
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); t1 = time.perf_counter()
+    info = power.stop(t0, t1)
+    return r, t1 - t0, {k: info.get(k) for k in ("power_w", "sclk_mhz", "power_samples")}
+
+
+def config5(dev, dialogues: int = 56):
     """BASELINE config 5 next to the headline (extra key `c5`, N = 1 only): CoMix text2semantic AR decode (608 steps per dialogue, eos
     ignored so the work is fixed) + VoMix 64-NFE + HiFi-GAN on 1008-frame dialogues (covomix_amd/config5.py), dialogues/s of
-      serial    - the reference's order of stages (dialogue_generation.py:272-329) on one stream, 8 dialogues per acoustic batch, and
-      pipelined - the decode of the next dialogues on a CU-masked side stream UNDER the solve of the current batch (7 per acoustic
-                  batch: whole GEMM rounds on the 224 CUs the solve keeps; covomix_amd/pipeline.py),
-    with the bit-identity of the pipelined output to the same calls run alternately.  A bounded sample: `dialogues` per schedule."""
+      serial_64 - THE SCHEDULE THE CLI RUNS (`--pipeline auto`): 64 dialogues per text2semantic pass on the whole chip (the decode is a
+                  latency chain whose step time barely depends on the batch: 4.7 ms per dialogue at 64 slots, 20 at 8), then 8 dialogues
+                  per acoustic batch, everything on one stream in the reference's order of stages (dialogue_generation.py:272-329);
+      serial_8  - the same with 8 dialogues per decode pass (the round-5 serial schedule; tokens and PCM must be IDENTICAL);
+      pipelined - the decode of the next 8 dialogues on a CU-masked side stream UNDER the solve of the current batch (7 per acoustic
+                  batch: whole GEMM rounds on the 224 CUs the solve keeps; covomix_amd/pipeline.py) - the round-5 schedule,
+    and `ragged_eos`: the decode stage alone on dialogues that END at different steps (100 ... 608) through continuously refilled decode
+    slots (t2s.generate_many) against the same slots in lock step and against the fixed-length case."""
     from covomix_amd.config5 import Config5
     c5 = Config5(dev)
     c5.run(8, 8, overlap=False, partitioned=False)            # warm-up of every shape on every stream
-    c5.run(14, 7, overlap=False)
+    c5.run(64, 8, overlap=False, partitioned=False, B1=64)
     c5.run(14, 7, overlap=True)
-
-    def timed(fn):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
-        return r, time.perf_counter() - t0
-    n_ser = max(8, dialogues // 8 * 8)
-    recs = [c5.dialogue(j) for j in range(max(n_ser, dialogues))]          # synthetic inputs: made outside the timed regions
-    _, ts = timed(lambda: c5.run(n_ser, 8, overlap=False, partitioned=False, recs=recs[:n_ser]))
-    alt, ta = timed(lambda: c5.run(dialogues, 7, overlap=False, recs=recs[:dialogues]))
-    spans = []                     # the solve is only ENQUEUED by stage2_launch (the host runs a batch ahead): HIP events on its stream
-    inner = c5.stage2_launch
-
-    def launch(x):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); r = inner(x); b.record(); spans.append((a, b))
-        return r
-    c5.stage2_launch = launch
-    pip, tp = timed(lambda: c5.run(dialogues, 7, overlap=True, recs=recs[:dialogues]))
-    walls = [a.elapsed_time(b) * 1e-3 for a, b in spans]
-    same = all(torch.equal(a["streams"], b["streams"]) and torch.equal(a["pcm"], b["pcm"]) for a, b in zip(alt, pip))
-    steady = sorted(walls[1:])[len(walls[1:]) // 2] if len(walls) > 1 else walls[0]
+    idx = dev.index or 0
+    recs = [c5.dialogue(j) for j in range(dialogues)]          # synthetic inputs: made outside the timed regions
+    big, tb, pb = timed_region(lambda: c5.run(dialogues, 8, overlap=False, partitioned=False, recs=recs, B1=64), idx)
+    ser, ts, ps = timed_region(lambda: c5.run(dialogues, 8, overlap=False, partitioned=False, recs=recs, B1=8), idx)
+    n_pip = min(dialogues, 28)
+    pip, tp, pp = timed_region(lambda: c5.run(n_pip, 7, overlap=True, recs=recs[:n_pip]), idx)
+    same = all(torch.equal(a["streams"], b["streams"]) and torch.equal(a["pcm"], b["pcm"]) for a, b in zip(ser, big))
+    tok = all(torch.equal(a["streams"], b["streams"]) for a, b in zip(ser, pip))
     from covomix_amd import ops
     part = ops.cu_partition(dev)
     return {"workload": f"CoMix text2semantic (608 steps) + VoMix 64-NFE + HiFi-GAN, T = {c5.T} frames per dialogue, recipe weights",
-            "cu_partition": {"main": part.n_main, "side": part.n_side},
-            "serial_dialogues_per_s": round(n_ser / ts, 3), "serial_dialogues": n_ser,
-            "alternate_dialogues_per_s": round(dialogues / ta, 3),
-            "pipelined_dialogues_per_s": round(dialogues / tp, 3), "pipelined_dialogues": dialogues,
-            "pipelined_mel_frames_per_s": round(dialogues * c5.T / tp, 1),
-            "pipelined_steady_state_dialogues_per_s": round(7 / steady, 3),
-            "speedup_vs_serial": round((dialogues / tp) / (n_ser / ts), 4),
-            "pipelined_bits_equal_alternate": bool(same)}
+            "best_schedule": "serial_64: 64 dialogues per text2semantic pass on the whole chip, 8 per acoustic batch, one stream (= --pipeline auto)",
+            "dialogues_per_s": round(dialogues / tb, 3), "dialogues": dialogues, "mel_frames_per_s": round(dialogues * c5.T / tb, 1),
+            "serial_64": dict(dialogues_per_s=round(dialogues / tb, 3), dialogues=dialogues, **pb),
+            "serial_8": dict(dialogues_per_s=round(dialogues / ts, 3), dialogues=dialogues, **ps),
+            "pipelined_8": dict(dialogues_per_s=round(n_pip / tp, 3), dialogues=n_pip, cu_partition={"main": part.n_main, "side": part.n_side}, **pp),
+            "serial_64_tokens_and_pcm_equal_serial_8": bool(same), "pipelined_tokens_equal_serial_8": bool(tok),
+            "ragged_eos": c5.decode_ragged()}
+
+
+def config1(dev, calls: int = 150):
+    """BASELINE config 1's shape on the GPU (extra key `c1`, N = 1 only): HiFi-GAN config_covomix on ONE unbatched [80, 1000] mel - what
+    the reference's scripts call per utterance (monologue_generation.py:300 -> mel_decode_to_wav :52-59), int16 cast included.
+    ms per call, mel frames/s and the fraction of the dense fp16 MFMA peak its 281.4 MFLOP per frame reach."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd import ops
+    from covomix_amd.vocoder import AttrDict, Generator
+    gen = Generator(AttrDict(syn.HIFIGAN_COVOMIX_CONFIG)).to(dev)
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(syn.HIFIGAN_COVOMIX_CONFIG), seed=0).items()})
+    gen.eval(); gen.remove_weight_norm()
+    g = torch.Generator().manual_seed(1234)
+    mel = (torch.randn(80, 1000, generator=g) * 2.0 - 6.0).clamp(-11.52, 2.0).to(dev)          # SURVEY.md section 8(d): C1 input statistics
+
+    def call():
+        return ops.wav_to_int16(gen(mel).squeeze(0).contiguous())
+    for _ in range(3):
+        pcm = call()
+    assert pcm.shape == (160 * 1000 + 32,)
+
+    def loop():
+        for _ in range(calls):
+            call()
+    _, dt, pw = timed_region(loop, dev.index or 0)
+    dt /= calls
+    return {"workload": "HiFi-GAN config_covomix, ONE unbatched [80, 1000] mel -> int16 PCM (monologue_generation.py:300)", "calls": calls,
+            "ms_per_call": round(dt * 1e3, 3), "frames_per_s": round(1000 / dt, 1), "frac": round(1000 / dt * 281_398_000 / PEAK_F16_MFMA, 5),
+            "vs_f32_mfma_peak": round(1000 / dt * 281_398_000 / PEAK_F32_MFMA, 4), **pw}
 
 
 def make_models(dev, rank, world, precision=None):
@@ -372,14 +417,13 @@ def fp32_exact(dev, rank, world, steps: int = 2):
         mel = model.synthesis_sample(ids, cond, mask, COND_SCALE, y0=torch.randn(B, T, 80, device=dev))
         return ops.wav_to_int16(gen(mel.permute(0, 2, 1).contiguous()).squeeze(1).contiguous())
     step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def loop():
+        for _ in range(steps):
+            step()
+    _, dt, pw = timed_region(loop, dev.index or 0)
     return {"value": round(B * T * steps / dt, 2), "unit": "mel-frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-            "dtype": "f32 (v_mfma_f32_32x32x2_f32 GEMM / attention / vocoder)"}
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32 GEMM / attention / vocoder)", **pw}
 
 
 def main():
@@ -390,6 +434,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="skip the BASELINE config-2 figure (extra key `c2`, N = 1 only)")
+    ap.add_argument("--no-c1", action="store_true", help="skip the BASELINE config-1 figure (extra key `c1`, N = 1 only)")
     ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE config-5 figure (extra key `c5`, N = 1 only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): 8 utterances per GPU per step.  strong: BASELINE config 4 literally - 64 utterances per step "
@@ -462,10 +507,12 @@ def main():
         power.start()
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                           # CPU seconds of this process, all its threads
     for _ in range(args.steps):
         pcm = step()
     barrier()
     t1 = time.perf_counter()
+    host_cpu = time.process_time() - cpu0
     elapsed = t1 - t0
     timer.remove()
     for c in classes.values():
@@ -476,10 +523,12 @@ def main():
     frames, elapsed = dp.reduce_metric(float(B * T * args.steps * batches_per_step), elapsed, dev)
     per_rank = [my_elapsed]
     loads = [t_load]
+    cpus = [host_cpu]
     if world > 1:                                        # diagnosis of the first hardware scaling runs: who was slow, and where
-        allb = dp.gather_floats([my_elapsed, t_load], dev)
+        allb = dp.gather_floats([my_elapsed, t_load, host_cpu], dev)
         per_rank = [b[0] for b in allb]
         loads = [b[1] for b in allb]
+        cpus = [b[2] for b in allb]
 
     if rank == 0:
         value = frames / elapsed
@@ -530,6 +579,15 @@ def main():
                          "ms_per_step": round(gemm_s / launches * all_launches / args.steps * 1e3, 3)},
         }
         out["roofline"].update(power_info)          # power_w, sclk_mhz, power_cap_w of the timed region (rank 0's GPU)
+        # host budget: a rank drives ~10k launches/s from Python; `busy_cores` = CPU seconds of the process (all threads, the power
+        # sampler included) per second of the timed region.  A rank whose share of the cgroup quota is below what it needs is
+        # host-bound however fast the GPU is - the first thing to rule out when an N > 1 line comes in low.
+        busy = [c / max(e, 1e-9) for c, e in zip(cpus, per_rank)]
+        need = max(1.5, -(-busy[0] // 0.5) * 0.5)     # cores a rank needs: what rank 0 used here (launching thread + event brackets + sampler), rounded up
+        share = dp.INFO.get("host_threads_per_rank") or host_cores()
+        out["host"] = {"cpu_s_per_step": round(host_cpu / args.steps, 4), "busy_cores": [round(b, 3) for b in busy],
+                       "cores_needed_per_rank": need, "host_cores_quota": host_cores(), "host_threads_per_rank": share,
+                       "warning": (f"only {share} host thread(s) per rank for {need} needed: the ranks are host-bound" if share < need else None)}
         out["kernel_classes_ms_per_step"] = {k: c.result(args.steps) for k, c in classes.items()}
         voc_ms = sum(a.elapsed_time(b) for a, b in voc_events) / max(len(voc_events), 1)
         out["kernel_classes_ms_per_step"]["vocoder"] = {"launches_per_step": 1, "timed": len(voc_events), "avg_launch_ms": round(voc_ms, 4),
@@ -547,6 +605,9 @@ def main():
         if world == 1 and not args.no_c2 and model_precision == "f16x3":
             with contextlib.redirect_stdout(sys.stderr):
                 out["c2"] = config2(dev)
+        if world == 1 and not args.no_c1 and model_precision == "f16x3":
+            with contextlib.redirect_stdout(sys.stderr):
+                out["c1"] = config1(dev)
         if world == 1 and not args.no_c5 and model_precision == "f16x3":
             torch.cuda.empty_cache()
             with contextlib.redirect_stdout(sys.stderr):

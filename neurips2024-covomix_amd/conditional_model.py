@@ -226,12 +226,13 @@ class CoVoMixModel:
     @ops.gated
     @torch.no_grad()
     def synthesis_sample_text2semantic(self, grapheme_token_ids, temprature=1.0, cond_scale=1.0, beam_search_decode=False,
-                                       prompt_mel=None, uniforms=None, generator=None, max_length=None):
+                                       prompt_mel=None, uniforms=None, generator=None, max_length=None, slots=64):
         """reference conditional_model.py:313-321 -> TextToSemanticWrapper.sample (text2semantic.py:1237-1251): the
         sampled semantic tokens as one flat int64 tensor (two-output models: stream 1 then stream 2) on the input's
         device.  (`temprature` is the reference's spelling.)  `uniforms` / `generator` (optional) fix the U(0,1) draws
-        behind the Gumbel noise; parity is defined given them.  A LIST of id tensors (up to 8) is decoded as one batch and
-        returns a list (the reference decodes utterances one by one; the tokens are the same)."""
+        behind the Gumbel noise; parity is defined given them.  A LIST of id tensors (any number) is decoded through `slots`
+        continuously refilled decode slots (t2s.generate_many) and returns a list (the reference decodes utterances one by
+        one; the tokens are the same)."""
         if not self.is_text2semantic:
             raise TypeError("this checkpoint is an acoustic model: use synthesis_sample")
         assert cond_scale >= 1., "cond_scale >= 1 (text2semantic.py:683)"
@@ -245,7 +246,14 @@ class CoVoMixModel:
         self._get_t2s()
         ids = grapheme_token_ids
         if isinstance(ids, (list, tuple)):          # extension: several utterances decoded together (bit-identical tokens)
-            res = self._t2s.generate_batch(list(ids), uniforms, max_length, float(temprature), generator, cond_scale=float(cond_scale))
+            ids = list(ids)
+            if float(cond_scale) > 1.0:             # guidance: slot pairs in lock step, up to 32 utterances per pass
+                res = []
+                for w in range(0, len(ids), 32):
+                    res += self._t2s.generate_batch(ids[w:w + 32], None if uniforms is None else list(uniforms[w:w + 32]), max_length,
+                                                    float(temprature), generator, cond_scale=float(cond_scale))
+            else:                                   # any number of utterances through 64 continuously refilled decode slots
+                res = self._t2s.generate_many(ids, uniforms, max_length, float(temprature), generator, slots=slots)
             return [r[0].to(i.device) for r, i in zip(res, ids)]
         out = self._t2s.generate(ids, uniforms=uniforms, max_length=max_length, temperature=float(temprature), generator=generator,
                                  cond_scale=float(cond_scale))

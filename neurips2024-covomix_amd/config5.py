@@ -3,7 +3,7 @@ one GPU (recipe weights, seeded inputs - there are no trained weights upstream).
 key and tests/test_pipeline_gpu.py; the generation scripts run the same two stages on real files (generation.py).
 
 Stage 1 (text2semantic, reference dialogue_generation.py:297-320 comix_pred): `tokens` decoded steps per dialogue with the eos ignored so
-that the work is fixed; up to 8 dialogues decode together (bit-identical to one by one, t2s.py) whatever the acoustic batch size is.
+that the work is fixed; up to 64 dialogues decode together (bit-identical to one by one, t2s.py) whatever the acoustic batch size is.
 Stage 2 (reference :306-329 covomix + mel_decode_to_wav): prompt + predicted token assembly (assembly.py), the 64-NFE solve on the
 [B, tokens + prompt, .] batch, HiFi-GAN on the generated frames, int16 cast."""
 from __future__ import annotations
@@ -45,7 +45,7 @@ class Config5:
         return dict(j=j, text=text, sem=sem, mel=mel)
 
     def stage1(self, group: list) -> list:
-        """text2semantic of up to 8 dialogues together on the current stream -> their records + `streams` (int64 CPU [2, tokens])."""
+        """text2semantic of up to 64 dialogues together on the current stream -> their records + `streams` (int64 CPU [2, tokens])."""
         d = self.t2s.d
         unis = []
         for rec in group:
@@ -54,6 +54,31 @@ class Config5:
         res = self.t2s.generate_batch([rec["text"] for rec in group], unis, max_length=self.tokens, ignore_eos=True)
         streams = torch.stack([r[1] for r in res]).cpu()
         return [dict(rec, streams=streams[i]) for i, rec in enumerate(group)]
+
+    def decode_ragged(self, n: int = 128, slots: int = 16, seed: int = 3) -> dict:
+        """Stage 1 alone on dialogues that END at different steps - real dialogues sample their eos anywhere (text2semantic.py:803-818);
+        here: step limits spread over [100, tokens], the eos itself ignored so that the work is a function of the seed.  Useful
+        tokens/s of the continuously refilled slots (t2s.generate_many) against the same slots in lock step (generate_batch: a batch
+        runs until its longest dialogue ends) and against the fixed-length case (every dialogue `tokens` steps)."""
+        import time
+        g = torch.Generator().manual_seed(seed)
+        lims = torch.randint(100, self.tokens + 1, (n,), generator=g).tolist()
+        srcs = [torch.randint(1, 30000, (1, 64), generator=g) for _ in range(n)]
+        t2s = self.t2s
+
+        def timed(fn):
+            torch.cuda.synchronize(self.device); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(self.device)
+            return time.perf_counter() - t0
+        t2s.generate_many(srcs, max_length=self.tokens, slots=slots, ignore_eos=True, limits=[20] * n)       # graph + buffers of the timed shape
+        t_many = timed(lambda: t2s.generate_many(srcs, max_length=self.tokens, slots=slots, ignore_eos=True, limits=lims))
+        t_lock = timed(lambda: [t2s.generate_batch(srcs[w:w + slots], max_length=max(lims[w:w + slots]), ignore_eos=True)
+                                for w in range(0, n, slots)])
+        t_fix = timed(lambda: [t2s.generate_batch(srcs[w:w + slots], max_length=self.tokens, ignore_eos=True) for w in range(0, n, slots)])
+        useful = sum(lims)
+        return {"dialogues": n, "slots": slots, "steps_per_dialogue": f"100..{self.tokens}, {useful} in total",
+                "continuous_tokens_per_s": round(useful / t_many, 1), "lock_step_tokens_per_s": round(useful / t_lock, 1),
+                "fixed_length_tokens_per_s": round(n * self.tokens / t_fix, 1),
+                "continuous_vs_lock_step": round(t_lock / t_many, 3), "continuous_vs_fixed_length": round((useful / t_many) / (n * self.tokens / t_fix), 3)}
 
     def _solve(self, batch: list) -> torch.Tensor:
         """assembly, 64-NFE solve, vocoder, int16 cast of one batch on the current stream -> PCM on the device"""
@@ -107,6 +132,14 @@ class Config5:
         elif partitioned:
             res = pipeline.run_two_stage(groups, self.stage1, self.stage2, self.device, overlap=False, collate=pipeline.regroup(B))
         else:
-            res = [self.stage2(b) for b in pipeline.regroup(B)(self.stage1(g) for g in groups)]
+            # one stream, the reference's order of stages; the host still runs one acoustic batch ahead of the device
+            res, pend = [], None
+            for b in pipeline.regroup(B)(self.stage1(g) for g in groups):
+                h = self.stage2_launch(b)
+                if pend is not None:
+                    res.append(self.stage2_finish(pend))
+                pend = h
+            if pend is not None:
+                res.append(self.stage2_finish(pend))
             torch.cuda.synchronize(self.device)
         return [r for batch in res for r in batch]

@@ -394,6 +394,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int HD64 = heads * 64;
+    // an idle slot (position max_len: a drained dialogue queue, or a slot past its last step) has nothing to attend to - without
+    // this exit it would walk max_len stale cache rows every step (block-uniform)
+    if (a.n_fixed < 0 && aloadi(a.state + SR * b) >= a.max_len) return;
     const int n = a.n_fixed >= 0 ? a.n_fixed
                                  : (a.n_fixed == -1 ? min(aloadi(a.state + SR * b) + 1, a.max_len) : min(aloadi(a.state + SR * b + 3), T2S_MAX_KEYS));
     const int64_t kvb = a.by_dialogue ? aloadi(a.state + SR * b + 4) : b;

@@ -58,11 +58,14 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--max_frames", type=int, default=None, help="frames per launch (sum over its utterances); default: chosen from the "
                    "directory's lengths among 8192 / 12288 / 16384 / 24576 by the cost of the packing in rounds of GEMM tiles "
                    "(dp.choose_max_frames); 14336 under --pipeline on (two rounds on the 224 CUs the acoustic stage owns)")
-    p.add_argument("--pipeline", type=str, choices=["auto", "on", "serial", "off"], default="auto",
-                   help="extension: with --t2s_ckpt, decode the text of the NEXT utterances on a CU-masked side stream while the acoustic "
-                        "model and the vocoder work on the current batch (covomix_amd/pipeline.py).  auto = on when there is text to "
-                        "decode; serial = the same batches on the same two streams one after the other (bit-identical output, for "
-                        "comparison); off = decode everything first, then one global packing (the round-4 flow)")
+    p.add_argument("--pipeline", type=str, choices=["auto", "batch", "on", "serial", "off"], default="auto",
+                   help="extension: how text2semantic (--t2s_ckpt) and the acoustic stage share the GPU.  batch (= auto when there is text "
+                        "to decode): ALL turns first, through 64 continuously refilled decode slots on the whole chip, then one global packing "
+                        "of the acoustic work - the fastest schedule measured (bench.py `c5`: the decode costs 4.7 ms per dialogue at 64 "
+                        "slots against 89 ms of solve; hiding it on a CU partition costs the solve 12.5 %% of the chip).  on: decode the "
+                        "NEXT utterances on a CU-masked side stream while the acoustic model and the vocoder work on the current batch "
+                        "(covomix_amd/pipeline.py: first audio sooner); serial = the batches of `on` on the same two streams one after "
+                        "the other (bit-identical output, for comparison); off = batch with the decode outside the timed region")
     p.add_argument("--hubert_ckpt", type=str, default=None, help="HuBERT checkpoint (fairseq layout): tokenise <name>.wav prompts "
                    "that have no <name>.hubert_code.npy (fairseq-hubert/get_fisher_semantic_tokens.py:23-24)")
     p.add_argument("--km_path", type=str, default=None, help="k-means model (joblib) for --hubert_ckpt")
@@ -161,9 +164,9 @@ def _tokenize(txt: str) -> torch.Tensor:
     return _TOKENIZER([remove_punctuation(txt).lower()], padding=True, truncation=True, return_tensors="pt").input_ids
 
 
-def _predict_turns(work, t2s, device, seed: int, batch: int = 8) -> dict:
+def _predict_turns(work, t2s, device, seed: int, slots: int = 64) -> dict:
     """(name, turn) -> predicted semantic tokens (int64 numpy).  work: list of (name, turn, source).  Sources that are
-    already tokens are read; the others are decoded by text2semantic on the GPU, `batch` turns per decode batch, every turn
+    already tokens are read; the others are decoded by text2semantic on the GPU through `slots` decode slots, every turn
     with its OWN stream of uniforms (seeded from (--seed, name, turn)): the tokens do not depend on batching or ranks."""
     out, todo = {}, []
     for name, k, (kind, v) in work:
@@ -174,16 +177,17 @@ def _predict_turns(work, t2s, device, seed: int, batch: int = 8) -> dict:
             todo.append((name, k, ids))
     if todo and t2s is None:
         raise RuntimeError("text sources need --t2s_ckpt")
-    for i in range(0, len(todo), batch):
-        group = todo[i:i + batch]
+    if todo:
+        # ALL turns in one call: t2s.generate_many runs them through 64 continuously refilled decode slots - a turn that has sampled its
+        # eos frees its slot for the next one on the device (the reference decodes turn by turn, dialogue_generation.py:297-304)
         dec = t2s._get_t2s()
         S, V, L = dec.d["streams"], dec.d["vocab"], dec.max_length
         uniforms = []
-        for name, k, _ in group:
+        for name, k, _ in todo:
             g = torch.Generator(device=device).manual_seed(_stable_seed(seed, name, k, 1))
             uniforms.append(torch.rand(L, S, V, device=device, generator=g))
-        toks = t2s.synthesis_sample_text2semantic([ids.to(device) for _, _, ids in group], uniforms=uniforms)
-        for (name, k, _), t in zip(group, toks):
+        toks = t2s.synthesis_sample_text2semantic([ids.to(device) for _, _, ids in todo], uniforms=uniforms, slots=slots)
+        for (name, k, _), t in zip(todo, toks):
             out[(name, k)] = t.cpu().numpy().astype(np.int64)
     return out
 
@@ -305,13 +309,14 @@ def run(dialogue: bool, argv=None) -> int:
     to_decode = sum(1 for _, _, (kind, _) in work if kind != "sem")
     mode = args.pipeline
     if mode == "auto":
-        mode = "on" if (t2s is not None and to_decode > 0) else "off"
+        mode = "batch" if (t2s is not None and to_decode > 0) else "off"
     if mode != "off" and t2s is None:
-        mode = "off"                                              # nothing to overlap: tokens come from files
+        mode = "off"                                              # nothing to decode: tokens come from files
+    two_stage = mode in ("on", "serial")
     from . import pipeline as pl
     # frames per launch: pipelined - two rounds of the N = 1024 products' tiles on the acoustic stage's CUs (the batches form while the
     # text is still being decoded: the lengths are not known up front); otherwise chosen from the directory's lengths below
-    max_frames = args.max_frames or (2 * pl.frames_per_launch(device) if mode != "off" else None)
+    max_frames = args.max_frames or (2 * pl.frames_per_launch(device) if two_stage else None)
     segments = {n: {} for n in mine}
     n_out = model._get_field().d["dim_out"]       # acoustic.py:647-650: 80 channels (twocondition_oneoutput) or as wide as cond
 
@@ -416,7 +421,9 @@ def run(dialogue: bool, argv=None) -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     batch_log_t[0] = t0
-    head_start = mode == "off" and len(mine) >= 2 * HEAD_START
+    if mode == "batch":     # ---- every turn of this rank through the continuously batched decode (timed), then ONE global packing
+        pred = _predict_turns(work, t2s, device, args.seed)
+    head_start = not two_stage and len(mine) >= 2 * HEAD_START
     if head_start:
         # ---- a large directory: the model inputs of the first HEAD_START utterances are read, their fullest first-fit-decreasing bin
         # is ENQUEUED, and the rest of the directory is read while the device works on it (reading is Python + numpy, ~0.7 ms per
@@ -437,7 +444,7 @@ def run(dialogue: bool, argv=None) -> int:
         lengths = [int(it[0].shape[0]) for it, _ in pool]
         for b in dp.pack_by_frames(list(range(len(pool))), lengths, max_frames, args.max_batch):
             frames += solve([pool[i] for i in b])
-    elif mode == "off":
+    elif not two_stage:
         pool = [x for n in mine for x in items_of(n, pred)]
         load_s = time.perf_counter() - t0                         # prompt files -> model inputs (host only)
         lengths = [int(it[0].shape[0]) for it, _ in pool]

@@ -516,7 +516,8 @@ def test_c5_pipeline_eight_dialogues_64nfe(tmp_path, monkeypatch):
 def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
     """--pipeline on (text2semantic of the next utterances on the CU-masked side stream under the solve of the current batch,
     covomix_amd/pipeline.py) writes BIT-IDENTICAL wav files to --pipeline serial (the same batches on the same two streams, one
-    after the other); --pipeline off (decode everything, one global packing: other batch compositions) agrees within 2 LSB.
+    after the other); --pipeline off (decode everything, one global packing: other batch compositions) agrees within 2 LSB, and
+    --pipeline auto (= batch, round 6: the same with the decode inside the timed region) equals off bit for bit.
     20 dialogues = three text2semantic groups, small --max_frames = several acoustic batches with carried-over leftovers.  One
     dialogue's prompt lies outside the split pairs' window: every schedule must warn and repeat that batch on the exact-fp32 kernels
     (the host runs a batch ahead: the flag arrives through a pinned snapshot taken on the CU-masked stream)."""
@@ -543,14 +544,15 @@ def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
             np.save(os.path.join(pdir, f"{n}{suf}.mel.npy"), ((g.randn(80, plen) * 2 - 6) * (30000.0 if i == 7 else 1.0)).astype(np.float32))
         np.save(os.path.join(tdir, f"{n}.text_ids.npy"), g.randint(1, 199, size=(1, 4 + i % 7)).astype(np.int64))
     out = {}
-    for mode in ("on", "serial", "off"):
+    for mode in ("on", "serial", "off", "auto"):
         sdir = os.path.join(tmp, "out_" + mode)
         with pytest.warns(UserWarning, match="saturat"):
             n = generation.run(True, ["--t2s_ckpt", os.path.join(tmp, "t2s.ckpt"), "--acous_ckpt", os.path.join(tmp, "acous.ckpt"),
                                       "--hifigan_ckpt", os.path.join(tmp, "voc", "g_00000001"), "--text_dir", tdir, "--prompt_dir", pdir,
                                       "--saved_dir", sdir, "--mode", "covomix", "--seed", "30", "--nfe", "8", "--max_frames", "300",
                                       "--pipeline", mode])
-        assert generation.run.last_stats["pipeline"] == mode
+        # (auto = batch: every turn through the continuously batched decode on the whole chip, then one global packing - round 6)
+        assert generation.run.last_stats["pipeline"] == ("batch" if mode == "auto" else mode)
         out[mode] = {nm: read(os.path.join(sdir, nm + ".wav"))[1] for nm in names if os.path.isfile(os.path.join(sdir, nm + ".wav"))}
         assert n == len(out[mode]) and n >= 15
     assert out["on"].keys() == out["serial"].keys() == out["off"].keys()
@@ -558,6 +560,7 @@ def test_cli_pipelined_schedule_matches_serial_and_off(tmp_path):
         assert np.array_equal(out["on"][nm], out["serial"][nm]), nm
         assert out["on"][nm].shape == out["off"][nm].shape
         assert np.abs(out["on"][nm].astype(np.int32) - out["off"][nm].astype(np.int32)).max() <= 2, nm
+        assert np.array_equal(out["auto"][nm], out["off"][nm]), nm          # the same tokens, the same global packing
 
 
 def test_cli_batch_outside_the_window_is_repeated_in_fp32_while_the_host_runs_ahead(tmp_path, monkeypatch):

@@ -124,6 +124,56 @@ def test_config5_pipelined_bits_equal_alternate_schedule(c5):
     assert not torch.equal(alt[0]["streams"], alt[1]["streams"])          # (different dialogues decode different tokens)
 
 
+def test_config5_64_per_decode_pass_bits_equal_8_per_pass(c5):
+    """Round 6: the decode batch is no longer capped at 8.  The schedule bench.py's `c5` reports and `--pipeline auto` runs - every
+    dialogue's text2semantic in ONE wide lock-step pass on the whole chip, then the acoustic batches, all on one stream - returns the SAME
+    tokens and the SAME PCM as the same schedule with small decode passes (here 24 dialogues: one pass of 24 slots against passes of 4)."""
+    n = 24
+    small = c5.run(n, 5, overlap=False, partitioned=False, B1=4)
+    big = c5.run(n, 5, overlap=False, partitioned=False, B1=24)
+    huge = c5.run(n, 5, overlap=False, partitioned=False, B1=64)
+    assert [r["j"] for r in small] == [r["j"] for r in big] == [r["j"] for r in huge] == list(range(n))
+    for a, b, c in zip(small, big, huge):
+        assert torch.equal(a["streams"], b["streams"]) and torch.equal(a["pcm"], b["pcm"])
+        assert torch.equal(a["streams"], c["streams"]) and torch.equal(a["pcm"], c["pcm"])
+
+
+def test_continuous_batching_on_dialogues_that_end_at_different_steps():
+    """Real dialogues sample their eos at different steps (text2semantic.py:803-818); a lock-step decode batch then runs half empty.
+    Full-size CoMix, dialogues whose last step is spread over 100 ... 608, 8 decode slots refilled on the device (t2s.generate_many):
+    every dialogue gets the tokens of its one-by-one decode, and the decode stage delivers >= 0.85 of the useful tokens/s of the
+    fixed-length case (every dialogue 608 steps through the same 8 slots) on a queue of 64 dialogues.  What is lost is the TAIL: when
+    the queue is empty the last dialogues finish in half-empty steps, and a step costs the same whatever runs in it - with only 32
+    dialogues (4 per slot) that alone caps the ratio at ~0.8 (measured 0.79), which is asserted too, lower."""
+    import time
+    import covomix_amd.synthetic as syn
+    from covomix_amd.t2s import TextToSemanticDecoder
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v) for k, v in syn.t2s_state_dict(syn.t2s_param_shapes(two_output=True, dim=512, dim_target=1024), seed=0).items()}
+    m = TextToSemanticDecoder(sd, dev, max_length=608)
+    g = torch.Generator().manual_seed(5)
+    N, slots, steps = 64, 8, 608
+    lims = torch.randint(100, steps + 1, (N,), generator=g).tolist()
+    srcs = [torch.randint(1, 30000, (1, 40 + j % 30), generator=g) for j in range(N)]
+    unis = [torch.rand(steps, 2, 502, generator=torch.Generator().manual_seed(100 + j)) for j in range(N)]
+
+    def timed(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+    m.generate_many(srcs, unis, slots=slots, ignore_eos=True, limits=[20] * N)                  # graphs and buffers of the timed shapes
+    m.generate_batch(srcs[:slots], unis[:slots], max_length=16, ignore_eos=True)
+    for n, bar in ((64, 0.85), (32, 0.72)):
+        res, t_many = timed(lambda: m.generate_many(srcs[:n], unis[:n], slots=slots, ignore_eos=True, limits=lims[:n]))
+        _, t_fix = timed(lambda: [m.generate_batch(srcs[w:w + slots], unis[w:w + slots], ignore_eos=True) for w in range(0, n, slots)])
+        ratio = (sum(lims[:n]) / t_many) / (n * steps / t_fix)
+        print(f"continuous batching, {n} dialogues on {slots} slots: {sum(lims[:n])} useful steps in {t_many * 1e3:.0f} ms; fixed length "
+              f"{n * steps} steps in {t_fix * 1e3:.0f} ms; ratio {ratio:.3f}")
+        for j in (0, 7, 8, 19, n - 1):
+            alone = m.generate_batch([srcs[j]], [unis[j][: lims[j]]], ignore_eos=True)[0]
+            assert res[j][1].shape == (2, lims[j]) and torch.equal(res[j][1], alone[1].cpu()), j
+        assert ratio >= bar, (n, ratio)
+
+
 def test_regroup_collate():
     from covomix_amd import pipeline
     out = list(pipeline.regroup(3)(iter([[1, 2], [3, 4, 5, 6], [7]])))

@@ -104,3 +104,19 @@ print("tokens and PCM of the pipelined schedule bit-identical to the alternate o
 tok_same = all(torch.equal(x["streams"], y["streams"]) for x, y in zip(ser, pip))
 lsb = max(int((x["pcm"].int() - y["pcm"].int()).abs().max()) for x, y in zip(ser, pip))
 print(f"against the serial single-stream schedule: tokens identical: {tok_same}; PCM max |difference| {lsb} LSB")
+
+# round 6: the decode batch is no longer capped at 8 - the same schedules with 32 / 64 dialogues per decode pass
+if os.environ.get("BIG", "1") == "1":
+    for b1 in (32, 64):
+        c5.run(min(ND, b1), B_SERIAL, overlap=False, partitioned=False, B1=b1)          # graphs / buffers of this decode batch
+        big, t = timed(lambda: c5.run(ND, B_SERIAL, overlap=False, partitioned=False, recs=RECS, B1=b1))
+        tok = all(torch.equal(x["streams"], y["streams"]) for x, y in zip(ser, big))
+        pcm = all(torch.equal(x["pcm"], y["pcm"]) for x, y in zip(ser, big))
+        print(f"serial, {b1} dialogues per decode pass (one plain stream, {B_SERIAL} per solve): {ND / t:6.2f} dialogues/s; tokens identical to the "
+              f"8-per-pass serial schedule: {tok}; PCM identical: {pcm}", flush=True)
+    for b1 in (16, 32):
+        c5.run(min(ND, 2 * b1), B_PIPE, overlap=True, B1=b1)
+        big, t = timed(lambda: c5.run(ND, B_PIPE, overlap=True, recs=RECS, B1=b1))
+        same = all(torch.equal(x["streams"], y["streams"]) and torch.equal(x["pcm"], y["pcm"]) for x, y in zip(pip, big))
+        print(f"pipelined, {b1} dialogues per decode pass (CU partition, {B_PIPE} per solve): {ND / t:6.2f} dialogues/s; bits equal to the 8-per-pass "
+              f"pipelined schedule: {same}", flush=True)
