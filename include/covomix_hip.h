@@ -30,7 +30,22 @@ extern "C" {
 #define CVX_ACT_SILU 2   /* SiLU            (time MLP, acoustic.py:364)            */
 #define CVX_ACT_TANH 3
 
-typedef void* cvx_stream_t;   /* hipStream_t */
+/* LAUNCH CONTEXT (version 107): what every entry point takes where it used to take a bare hipStream_t.  A plain host struct the
+ * CALLER owns and may keep for the life of the stream; the library only reads it during the call and keeps NOTHING about a stream
+ * between calls (no table, no lock: re-entrant per context; SURVEY.md section 8(b) "no global mutable state").  NULL = the null
+ * stream, no flag, the whole device. */
+typedef struct cvx_ctx {
+    void*     stream;     /* hipStream_t the call launches on */
+    uint32_t* sat_flag;   /* the sticky saturation flag of this stream: one 4-byte aligned uint32 of DEVICE memory the caller zeroed and
+                           * keeps alive (below), or NULL */
+    int32_t   n_cus;      /* compute units the stream owns (a CU-masked stream, cvx_stream_create_cu_mask); 0 = the device's: what the
+                           * persistent grids and the large / medium GEMM choice are sized from */
+    int32_t   flags;      /* CVX_CTX_* */
+} cvx_ctx;
+#define CVX_CTX_NO_SATURATION_FLAG 1   /* run the calls that write split (fp16 hi, lo) pairs WITHOUT the saturation bookkeeping: without
+                                        * this bit such a call refuses a context whose sat_flag is NULL (CVX_EINVAL) - a C caller cannot
+                                        * lose the safety net by forgetting it */
+typedef const cvx_ctx* cvx_stream_t;
 
 /* ABI version of the library: CVX_ABI_VERSION of the header it was built from.  The argument structs carry no size field, so a
  * caller built against another header version must not call in: compare once after loading (the ctypes binding does,
@@ -42,53 +57,48 @@ typedef void* cvx_stream_t;   /* hipStream_t */
  * HISTORY.md): cvx_t2s_decode_persistent, cvx_t2s_decode_xcd, cvx_embed_conv31_f32, CVX_GEMM_FLAG_TWO_STAGE / _MFMA32 (the superseded
  * large-problem GEMM forms: shapes the eight-phase kernel cannot take run on the 128 x 128 kernel).  107: round 6 - text2semantic
  * decode of up to 64 slots at independent positions with an on-device dialogue queue (continuous batching): cvx_t2s_decoder grew
- * uniform_steps / queue / dialogues / start, slot records are int32[8], uniforms and tokens are indexed by dialogue. */
+ * uniform_steps / queue / dialogues / start, slot records are int32[8], uniforms and tokens are indexed by dialogue; every entry point
+ * takes a LAUNCH CONTEXT (cvx_ctx: stream + caller-owned saturation flag + CU count) instead of a bare stream - REMOVED: the library's
+ * (device, stream) table and cvx_saturation_flag_bind / cvx_stream_set_cus / cvx_stream_cus. */
 #define CVX_ABI_VERSION 107
 int         cvx_version(void);
 const char* cvx_last_error_string(void);
 
 /* ------------------------------------------------------------------------
- * Sticky saturation flag: CALLER-OWNED, one uint32 of device memory per (device, stream) (round 4; until version 102 the
- * library allocated one per device on first use - a hidden hipMalloc and a word two host threads could clear under each other).
+ * Sticky saturation flag: CALLER-OWNED, one uint32 of device memory per stream, carried by the launch context (cvx_ctx.sat_flag;
+ * versions 104-106 kept a (device, stream) -> flag table inside the library, until 102 the library allocated one per device).
  * The split-precision path stores activations as (fp16 hi, fp16 lo) pairs times a power-of-two pre-scale chosen so that
  * the tensor's expected RMS sits at 2^4 (transformer: a weights-only gain model) or its measured max at 2^10 (vocoder):
  * 2^12 resp. 2^6 of headroom before `hi` saturates at 65504.  A checkpoint with one outlier row / channel can leave that
  * window; the pair is then CLAMPED and no longer represents the fp32 value.  Every kernel that writes split pairs (GEMM
  * epilogues incl. the transposed V^T store, AdaRMSNorm, attention, cvx_split_f16*, the HiFi-GAN convolutions and layout
- * converter) ORs bit 0 into the flag BOUND TO THE STREAM IT IS LAUNCHED ON when a value it stored exceeded 65504 in magnitude
+ * converter) ORs bit 0 into the flag OF THE CONTEXT IT IS LAUNCHED WITH when a value it stored exceeded 65504 in magnitude
  * (the attention kernel also when a softmax normaliser is not a positive finite number).  The flag is never cleared by a kernel:
  * reset it, run any number of calls, query once.  The host path (CoVoMixModel.synthesis_sample, Generator.__call__) does exactly
  * that and re-runs the call on the exact-fp32 kernels when the flag is set - a saturated result is never returned silently.
- *   cvx_saturation_flag_bind:  attach dev_flag (4-byte aligned device memory the caller zeroed and keeps alive) to stream s of the
- *                              current device; NULL detaches.  Several streams may share one flag (the side stream of a
- *                              two-stream schedule, a graph-capture stream).  A stream with no flag runs without the
- *                              bookkeeping (nothing is allocated, nothing is reported).  Host-side only: legal during capture.
- *   cvx_saturation_flag_reset: enqueue a clear of s's flag on s (no host synchronisation); CVX_EINVAL if s has none.
- *   cvx_saturation_flag_query: copy s's flag to *host_out behind everything enqueued on s (SYNCHRONISES s), then
+ * Several contexts may share one flag (the side stream of a two-stream schedule, a graph-capture stream).  A call that writes
+ * pairs with a context that has no flag returns CVX_EINVAL unless the context says CVX_CTX_NO_SATURATION_FLAG.
+ *   cvx_saturation_flag_reset: enqueue a clear of the context's flag on its stream (no host synchronisation); CVX_EINVAL without one.
+ *   cvx_saturation_flag_query: copy the flag to *host_out behind everything enqueued on the stream (SYNCHRONISES it), then
  *                              optionally enqueue a clear. */
-int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s);
-int cvx_saturation_flag_reset(cvx_stream_t s);
-int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t s);
+int cvx_saturation_flag_reset(cvx_stream_t ctx);
+int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t ctx);
 
 /* ------------------------------------------------------------------------
  * CU-partitioned streams (round 5): the text2semantic decode of the NEXT batch of dialogues (a latency chain of 34 dependent
  * launches per token that needs a handful of CUs; reference loop dialogue_generation.py:272-329, decode
- * covomix/covomix_model/text2semantic.py:749-848) runs UNDER the acoustic solve of the current one.  The large-problem GEMM is a
+ * covomix/covomix_model/text2semantic.py:749-848) can run UNDER the acoustic solve of the current one.  The large-problem GEMM is a
  * persistent kernel that owns every CU it gets for a whole launch, so a plain side stream would only be served at launch
  * boundaries: the two stages run on streams restricted to DISJOINT CU sets instead.
- *   cvx_stream_create_cu_mask: hipExtStreamCreateWithCUMask.  Bit k of the mask names CU (k / 8) of XCD (k % 8); inside an XCD
- *                              consecutive indices go round the four shader engines (measured on MI355X, tools/cu_mask_probe.hip).
- *                              One-block-per-CU kernels are only co-resident when every shader engine keeps the same number of
- *                              CUs, i.e. when the CUs per XCD are a multiple of 4 (tools/cu_mask_probe2.hip: 30 CUs per XCD ->
- *                              12 of 240 blocks wait for a second round; 28 -> none).  The stream belongs to the caller.
- *   cvx_stream_set_cus:        tell the library how many CUs stream s of the current device owns (0: forget): the persistent grids
- *                              (large-problem GEMM, vocoder pair kernel, skinny GEMM) and the large / medium GEMM choice are sized from
- *                              it instead of from the device's CU count.  Host-side bookkeeping only (legal during capture).
- *   cvx_stream_cus:            that number, or the device's CU count for a stream nobody described. */
-int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, cvx_stream_t* out);
-int cvx_stream_destroy(cvx_stream_t s);
-int cvx_stream_set_cus(cvx_stream_t s, int32_t n_cus);
-int cvx_stream_cus(cvx_stream_t s);
+ *   cvx_stream_create_cu_mask: hipExtStreamCreateWithCUMask -> *out_stream (a hipStream_t the caller owns; put it into a cvx_ctx
+ *                              together with n_cus = the number of mask bits).  Bit k of the mask names CU (k / 8) of XCD (k % 8);
+ *                              inside an XCD consecutive indices go round the four shader engines (measured on MI355X,
+ *                              tools/cu_mask_probe.hip).  One-block-per-CU kernels are only co-resident when every shader engine keeps
+ *                              the same number of CUs, i.e. when the CUs per XCD are a multiple of 4 (tools/cu_mask_probe2.hip: 30 CUs
+ *                              per XCD -> 12 of 240 blocks wait for a second round; 28 -> none).
+ *   cvx_stream_destroy:        hipStreamDestroy of such a stream. */
+int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** out_stream);
+int cvx_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------
  * C[M,N] = epilogue( [A | A2][M,K] * W[N,K]^T )      fp32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -126,6 +126,14 @@ class Respair16Args(C.Structure):
                 ("z_scale_dev", C.c_void_p), ("flags", C.c_int32), ("items", ItemLengths)]
 
 
+class Ctx(C.Structure):
+    """cvx_ctx: the launch context every entry point takes (stream, caller-owned saturation flag, CUs of the stream, flags)"""
+    _fields_ = [("stream", C.c_void_p), ("sat_flag", C.c_void_p), ("n_cus", C.c_int32), ("flags", C.c_int32)]
+
+
+CTX_NO_SATURATION_FLAG = 1
+
+
 class T2SLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("gamma_s", "wqkv_s", "wo_s", "gamma_c", "wq_c", "wo_c", "kv_c",
                                           "gamma_f", "w1", "b1", "w2", "b2", "k_cache", "v_cache")]
@@ -251,13 +259,10 @@ SIGNATURES = {
     "cvx_hifigan_post_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p]),
     "cvx_wav_to_int16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "cvx_saturation_flag_bind": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvx_saturation_flag_reset": (C.c_int, [C.c_void_p]),
     "cvx_saturation_flag_query": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.c_void_p]),
     "cvx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
     "cvx_stream_destroy": (C.c_int, [C.c_void_p]),
-    "cvx_stream_set_cus": (C.c_int, [C.c_void_p, C.c_int32]),
-    "cvx_stream_cus": (C.c_int, [C.c_void_p]),
     # ragged batches (cu_seqlens)
     "cvx_attention_varlen_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_float, C.c_void_p]),

@@ -43,7 +43,7 @@ extern "C" int cvx_rope_attention_f32(const float* qkv, const float* rope_cos, c
     CVX_REQUIRE(Bt >= 0 && T > 0 && H > 0, "rope_attention: bad shape");
     if (Bt == 0) return CVX_OK;
     const int64_t M = (int64_t)Bt * T, n = M * 3 * H * 32;
-    hipLaunchKernelGGL(rope_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(rope_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        qkv, rope_cos, rope_sin, workspace, M, T, H);
     CVX_CHECK_LAUNCH("cvx_rope_attention_f32");
     return cvx_attention_f32(workspace, out, nullptr, nullptr, Bt, T, H, scale, s);

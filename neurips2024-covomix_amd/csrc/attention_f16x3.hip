@@ -472,6 +472,7 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
     int n_qt = (T + qb - 1) / qb;
     const int n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
+    if (out_hi) CVX_REQUIRE_SAT(s);
     uint32_t* sat = cvx_sat_flag_for(s);
     // key-split groups for short launches (see the kernel): fewer than 2048 query rows = at most one 128-query block per CU (96 KiB of
     // LDS with three groups).
@@ -489,14 +490,14 @@ static int launch_attention_f16x3(const uint16_t* qk_hi, const uint16_t* qk_lo, 
 #endif
     }
 #define CVX_ATT_LAUNCH(NT_, NW_)                                                                                                          \
-    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_>), grid, dim3(64 * NW_), 0, reinterpret_cast<hipStream_t>(s),                       \
+    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_>), grid, dim3(64 * NW_), 0, cvx_hip_stream(s),                       \
                        reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
                        reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
                        out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \
                        T, Tp, H, n_groups, n_qt, scale * 1.44269504088896340736f, qk_scale_dev, v_scale_dev, out_scale_dev, cu_seqlens_dev, sat)
 #define CVX_ATT_LAUNCH_KS(NT_, KS_) CVX_ATT_LAUNCH_KW(NT_, 4, KS_)
 #define CVX_ATT_LAUNCH_KW(NT_, NW_, KS_)                                                                                                  \
-    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_, KS_>), grid, dim3(64 * NW_ * KS_), 0, reinterpret_cast<hipStream_t>(s),              \
+    hipLaunchKernelGGL((attention_f16x3_kernel<NT_, NW_, KS_>), grid, dim3(64 * NW_ * KS_), 0, cvx_hip_stream(s),              \
                        reinterpret_cast<const f16*>(qk_hi), reinterpret_cast<const f16*>(qk_lo),                                          \
                        reinterpret_cast<const f16*>(vt_hi), reinterpret_cast<const f16*>(vt_lo),                                          \
                        out, reinterpret_cast<f16*>(out_hi), reinterpret_cast<f16*>(out_lo),                                               \

@@ -207,9 +207,10 @@ extern "C" int cvx_attention_varlen_f32(const float* qkv, float* out, uint16_t* 
     CVX_REQUIRE(Bt >= 0 && max_T > 0 && H > 0, "attention: bad shape Bt=%d T=%d H=%d", Bt, max_T, H);
     CVX_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attention: pointers must be 16-byte aligned");
     if (Bt == 0) return CVX_OK;
+    if (out_hi) CVX_REQUIRE_SAT(s);
     const int n_qt = (max_T + QB - 1) / QB, n_groups = Bt * H;
     dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * n_qt));
-    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, cvx_hip_stream(s),
                        qkv, out, reinterpret_cast<_Float16*>(out_hi), reinterpret_cast<_Float16*>(out_lo),
                        max_T, H, n_groups, n_qt, scale * 1.44269504088896340736f, cu_seqlens_dev,
                        out_hi ? cvx_sat_flag_for(s) : nullptr);

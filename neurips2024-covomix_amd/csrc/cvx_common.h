@@ -13,13 +13,21 @@ void cvx_set_error(const char* fmt, ...);
 // granted so far: function attributes are per device, so a once-per-process flag is wrong for the second GPU a process
 // uses.  Thread-safe; a map lookup after the first call.
 void cvx_allow_dynamic_lds(const void* kernel, int bytes);
-// compute units of the current device (cached per device); cvx_stream_cus(s) (covomix_hip.h): of the CUs stream s owns
+// compute units of the current device (cached per device): what a launch context with n_cus == 0 stands for
 int cvx_device_cus();
-// Sticky saturation flag: one uint32 of CALLER-OWNED device memory per (device, stream), attached with
-// cvx_saturation_flag_bind (covomix_hip.h).  Every kernel that writes (fp16 hi, fp16 lo) split pairs clamps to +-65504 and ORs bit 0
-// into the flag of the stream it runs on when a value it stored was larger than that - the pair then no longer represents the
-// fp32 value and the caller must not trust the result.  NULL (no flag bound to the stream): the kernels skip the bookkeeping.
-uint32_t* cvx_sat_flag_for(cvx_stream_t s);
+// The launch context every entry point takes (covomix_hip.h: cvx_ctx / cvx_stream_t): the stream, the CALLER-OWNED sticky saturation
+// flag of that stream and the CUs the stream owns.  Nothing about a stream lives in the library (until version 106 a process-wide
+// (device, stream) table behind a mutex did: a hipGetDevice + lock + scan per launch, and a re-issued stream handle inherited it).
+static inline hipStream_t cvx_hip_stream(cvx_stream_t s) { return s ? reinterpret_cast<hipStream_t>(s->stream) : nullptr; }
+static inline int cvx_ctx_cus(cvx_stream_t s) { return (s && s->n_cus > 0) ? s->n_cus : cvx_device_cus(); }
+// Every kernel that writes (fp16 hi, fp16 lo) split pairs clamps to +-65504 and ORs bit 0 into the context's flag when a value it
+// stored was larger than that - the pair then no longer represents the fp32 value and the caller must not trust the result.  A call
+// that writes pairs REFUSES a context without a flag (CVX_REQUIRE_SAT) unless the caller waived the bookkeeping explicitly.
+static inline uint32_t* cvx_sat_flag_for(cvx_stream_t s) { return s ? s->sat_flag : nullptr; }
+#define CVX_REQUIRE_SAT(s)                                                                                                            \
+    CVX_REQUIRE((s) && ((s)->sat_flag || ((s)->flags & CVX_CTX_NO_SATURATION_FLAG)),                                                 \
+                "%s: this call writes split (fp16 hi, fp16 lo) pairs and its launch context carries no saturation flag: set "      \
+                "cvx_ctx.sat_flag (caller-owned device word), or CVX_CTX_NO_SATURATION_FLAG to run without the bookkeeping", __func__)
 
 #define CVX_REQUIRE(cond, ...)                       \
     do {                                             \

@@ -54,83 +54,7 @@ int cvx_device_cus()
     }
     return n_cu[dev];
 }
-// Per-(device, stream) bookkeeping, all CALLER-DRIVEN (no allocation, no per-device global):
-//   * the saturation flag (round 4): cvx_saturation_flag_bind attaches one uint32 of device memory to a (device, stream) pair; every
-//     entry point looks up the flag of the stream it launches on.  Two host threads / streams on one device each have their own flag,
-//     and a first launch inside a stream capture allocates nothing;
-//   * the CU count of a CU-masked stream (round 5, cvx_stream_set_cus): what the persistent grids are sized from.
-namespace {
-struct StreamInfo { int dev; hipStream_t st; uint32_t* flag; int cus; };
-std::mutex g_sat_mu;
-StreamInfo g_sat[256];
-int g_sat_n = 0;
-// (g_sat_mu held) entry of (dev, st), or NULL
-StreamInfo* stream_info(int dev, hipStream_t st)
-{
-    for (int i = 0; i < g_sat_n; ++i)
-        if (g_sat[i].dev == dev && g_sat[i].st == st) return &g_sat[i];
-    return nullptr;
-}
-void stream_info_drop_if_empty(StreamInfo* e)
-{
-    if (e && !e->flag && e->cus == 0) *e = g_sat[--g_sat_n];
-}
-}
-uint32_t* cvx_sat_flag_for(cvx_stream_t s)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_sat_mu);
-    StreamInfo* e = stream_info(dev, reinterpret_cast<hipStream_t>(s));
-    return e ? e->flag : nullptr;        // no flag bound to this stream: the kernels skip the bookkeeping
-}
-extern "C" int cvx_saturation_flag_bind(uint32_t* dev_flag, cvx_stream_t s)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { cvx_set_error("saturation_flag_bind: no current device"); return CVX_EHIP; }
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    CVX_REQUIRE((reinterpret_cast<uintptr_t>(dev_flag) & 3) == 0, "saturation_flag_bind: the flag must be 4-byte aligned");
-    std::lock_guard<std::mutex> lock(g_sat_mu);
-    StreamInfo* e = stream_info(dev, st);
-    if (e) {
-        e->flag = dev_flag;                                    // NULL unbinds
-        stream_info_drop_if_empty(e);
-        return CVX_OK;
-    }
-    if (!dev_flag) return CVX_OK;
-    CVX_REQUIRE(g_sat_n < 256, "saturation_flag_bind: more than 256 (device, stream) entries");
-    g_sat[g_sat_n++] = StreamInfo{dev, st, dev_flag, 0};
-    return CVX_OK;
-}
-extern "C" int cvx_stream_set_cus(cvx_stream_t s, int32_t n_cus)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { cvx_set_error("stream_set_cus: no current device"); return CVX_EHIP; }
-    CVX_REQUIRE(n_cus >= 0 && n_cus <= 4096, "stream_set_cus: bad CU count %d", n_cus);
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    std::lock_guard<std::mutex> lock(g_sat_mu);
-    StreamInfo* e = stream_info(dev, st);
-    if (e) {
-        e->cus = n_cus;
-        stream_info_drop_if_empty(e);
-        return CVX_OK;
-    }
-    if (n_cus == 0) return CVX_OK;
-    CVX_REQUIRE(g_sat_n < 256, "stream_set_cus: more than 256 (device, stream) entries");
-    g_sat[g_sat_n++] = StreamInfo{dev, st, nullptr, n_cus};
-    return CVX_OK;
-}
-extern "C" int cvx_stream_cus(cvx_stream_t s)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        std::lock_guard<std::mutex> lock(g_sat_mu);
-        const StreamInfo* e = stream_info(dev, reinterpret_cast<hipStream_t>(s));
-        if (e && e->cus > 0) return e->cus;
-    }
-    return cvx_device_cus();
-}
-extern "C" int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, cvx_stream_t* out)
+extern "C" int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** out)
 {
     CVX_REQUIRE(mask && out && n_words > 0 && n_words <= 64, "stream_create_cu_mask: bad arguments");
     int bits = 0;
@@ -139,30 +63,28 @@ extern "C" int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, 
     hipStream_t st = nullptr;
     const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask);
     if (e != hipSuccess) { cvx_set_error("stream_create_cu_mask: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e)); return CVX_EHIP; }
-    *out = reinterpret_cast<cvx_stream_t>(st);
-    return cvx_stream_set_cus(*out, bits);
+    *out = reinterpret_cast<void*>(st);
+    return CVX_OK;
 }
-extern "C" int cvx_stream_destroy(cvx_stream_t s)
+extern "C" int cvx_stream_destroy(void* stream)
 {
-    CVX_REQUIRE(s, "stream_destroy: the NULL stream");
-    (void)cvx_stream_set_cus(s, 0);
-    (void)cvx_saturation_flag_bind(nullptr, s);
-    const hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(s));
+    CVX_REQUIRE(stream, "stream_destroy: the NULL stream");
+    const hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) { cvx_set_error("stream_destroy: %s", hipGetErrorString(e)); return CVX_EHIP; }
     return CVX_OK;
 }
 extern "C" int cvx_saturation_flag_reset(cvx_stream_t s)
 {
     uint32_t* f = cvx_sat_flag_for(s);
-    CVX_REQUIRE(f, "saturation_flag_reset: no flag bound to this (device, stream): call cvx_saturation_flag_bind first");
-    if (hipMemsetAsync(f, 0, sizeof(uint32_t), reinterpret_cast<hipStream_t>(s)) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
+    CVX_REQUIRE(f && (reinterpret_cast<uintptr_t>(f) & 3) == 0, "saturation_flag_reset: the context carries no (4-byte aligned) saturation flag");
+    if (hipMemsetAsync(f, 0, sizeof(uint32_t), cvx_hip_stream(s)) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
     return CVX_OK;
 }
 extern "C" int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t s)
 {
     uint32_t* f = cvx_sat_flag_for(s);
-    CVX_REQUIRE(f && host_out, "saturation_flag_query: no flag bound to this (device, stream) / null output");
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    CVX_REQUIRE(f && host_out, "saturation_flag_query: the context carries no saturation flag / null output");
+    hipStream_t st = cvx_hip_stream(s);
     if (hipMemcpyAsync(host_out, f, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) { cvx_set_error("saturation_flag: read failed: %s", hipGetErrorString(hipGetLastError())); return CVX_EHIP; }
     if (reset && hipMemsetAsync(f, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
@@ -540,7 +462,7 @@ extern "C" int cvx_mel_magnitude_f32(const float* spec, float* mag, int64_t T, i
 {
     CVX_REQUIRE(spec && mag && T >= 0 && nb > 0 && nbp >= nb, "mel_magnitude: bad arguments");
     if (T == 0) return CVX_OK;
-    hipLaunchKernelGGL(mel_magnitude_kernel, dim3((unsigned)((T * nbp + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(mel_magnitude_kernel, dim3((unsigned)((T * nbp + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        spec, mag, T, nb, nbp);
     CVX_CHECK_LAUNCH("cvx_mel_magnitude_f32");
     return CVX_OK;
@@ -551,7 +473,7 @@ extern "C" int cvx_mel_log_transpose_f32(const float* x, float* y, int64_t T, in
     CVX_REQUIRE(x && y && T >= 0 && n_mels > 0, "mel_log_transpose: bad arguments");
     if (T == 0) return CVX_OK;
     hipLaunchKernelGGL(mel_log_transpose_kernel, dim3((unsigned)((T * n_mels + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(s), x, y, T, n_mels);
+                       cvx_hip_stream(s), x, y, T, n_mels);
     CVX_CHECK_LAUNCH("cvx_mel_log_transpose_f32");
     return CVX_OK;
 }
@@ -566,8 +488,9 @@ extern "C" int cvx_adarmsnorm_scaled_f32(const float* x, const float* gamma, con
     _Float16* y_lo = reinterpret_cast<_Float16*>(y_lo_);
     CVX_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0 && rows_per_group > 0, "adarmsnorm: bad shape rows=%ld D=%d", (long)rows, D);
     if (rows == 0) return CVX_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     dim3 grid((unsigned)((rows + 3) / 4));
+    if (y_hi) CVX_REQUIRE_SAT(s);
     uint32_t* sat = y_hi ? cvx_sat_flag_for(s) : nullptr;
     if (D <= 256)       hipLaunchKernelGGL(adarmsnorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
     else if (D <= 512)  hipLaunchKernelGGL(adarmsnorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, y_hi, y_lo, rows, D, rows_per_group, scale, eps, split_scale_dev, sat);
@@ -609,7 +532,7 @@ extern "C" int cvx_rownorm_scale_f32(const float* rowsq, int64_t rows, int32_t p
     CVX_REQUIRE(rowsq && out && rows >= 0 && parts > 0 && parts <= 64 && ld >= parts && (((uintptr_t)rowsq & 15) == 0 || (parts & 3) || (ld & 3)),
                 "rownorm_scale: bad arguments (rows=%ld parts=%d ld=%ld)", (long)rows, parts, (long)ld);
     if (rows == 0) return CVX_OK;
-    hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        rowsq, rows, parts, ld, scale, eps, out);
     CVX_CHECK_LAUNCH("cvx_rownorm_scale_f32");
     return CVX_OK;
@@ -659,7 +582,7 @@ __global__ void pow2_scale_kernel(const unsigned* __restrict__ amax_bits, float 
 extern "C" int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, float* scale_dev, uint32_t* scratch_dev, cvx_stream_t s)
 {
     CVX_REQUIRE(x && scale_dev && scratch_dev && n >= 0 && target > 0.f && ((uintptr_t)x & 15) == 0, "amax_pow2_scale: bad arguments");
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     if (hipMemsetAsync(scratch_dev, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("amax_pow2_scale: memset failed"); return CVX_EHIP; }
     if (n > 0) {
         const unsigned blocks = (unsigned)((n / 4 + 1023) / 1024 < 2048 ? (n / 4 + 1023) / 1024 + 1 : 2048);
@@ -677,7 +600,7 @@ extern "C" int cvx_amax_pow2_scale_f32(const float* x, int64_t n, float target, 
 extern "C" int cvx_pow2_scale_from_amax_f32(uint32_t* amax_bits_dev, float target, float* scale_dev, cvx_stream_t s)
 {
     CVX_REQUIRE(amax_bits_dev && scale_dev && target > 0.f, "pow2_scale_from_amax: bad arguments");
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits_dev, target, scale_dev);
     if (hipMemsetAsync(amax_bits_dev, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("pow2_scale_from_amax: memset failed"); return CVX_EHIP; }
     CVX_CHECK_LAUNCH("cvx_pow2_scale_from_amax_f32");
@@ -692,7 +615,7 @@ extern "C" int cvx_dwconv31_gelu_res_varlen_f32(const float* x, const float* w, 
     CVX_REQUIRE(x != y, "dwconv31: in-place operation is not supported");
     if (Bt == 0) return CVX_OK;
     dim3 grid((C + 255) / 256, (max_T + DW_TT - 1) / DW_TT, Bt);
-    hipLaunchKernelGGL(dwconv31_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, w, bias, y, max_T, C, cu_seqlens_dev);
+    hipLaunchKernelGGL(dwconv31_kernel, grid, dim3(256), 0, cvx_hip_stream(s), x, w, bias, y, max_T, C, cu_seqlens_dev);
     CVX_CHECK_LAUNCH("cvx_dwconv31_gelu_res_f32");
     return CVX_OK;
 }
@@ -708,8 +631,8 @@ extern "C" int cvx_gemm_skinny_f32(const float* A, int32_t lda, const float* W, 
     const size_t lds = (size_t)SK_M * (std::min(K, SK_KC) + 4) * sizeof(float);
     cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_skinny_kernel), (int)lds);
     const int64_t groups = ((int64_t)N + 127) / 128;                       // four 32-row tiles per block and trip
-    const unsigned grid = (unsigned)std::min<int64_t>(groups, (int64_t)cvx_stream_cus(s));
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(grid), dim3(256), lds, reinterpret_cast<hipStream_t>(s), A, lda, W, ldw, bias, C, ldc, M, N, K, act);
+    const unsigned grid = (unsigned)std::min<int64_t>(groups, (int64_t)cvx_ctx_cus(s));
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(grid), dim3(256), lds, cvx_hip_stream(s), A, lda, W, ldw, bias, C, ldc, M, N, K, act);
     CVX_CHECK_LAUNCH("cvx_gemm_skinny_f32");
     return CVX_OK;
 }
@@ -725,7 +648,7 @@ extern "C" int cvx_cfg_combine_axpy_f32(const float* f_c, const float* f_n, cons
 {
     CVX_REQUIRE(f_c && y && out && n >= 0, "cfg_axpy: bad arguments");
     if (n == 0) return CVX_OK;
-    hipLaunchKernelGGL(cfg_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(cfg_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        f_c, f_n, y, cond_scale, coef, out, out2, out3, n);
     CVX_CHECK_LAUNCH("cvx_cfg_combine_axpy_f32");
     return CVX_OK;
@@ -738,7 +661,7 @@ extern "C" int cvx_embed_gather_f32(const int64_t* ids, int32_t S, const float* 
     CVX_REQUIRE(table && out && S > 0 && E > 0 && Cc >= 0 && M >= 0, "embed_gather: bad arguments");
     CVX_REQUIRE(cond || cond_row || Cc == 0, "embed_gather: cond and cond_row both null");
     if (M == 0) return CVX_OK;
-    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)M), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)M), dim3(256), 0, cvx_hip_stream(s),
                        ids, S, table, E, n_rows_table, cond, cond_row, Cc, null_id, out);
     CVX_CHECK_LAUNCH("cvx_embed_gather_f32");
     return CVX_OK;
@@ -748,7 +671,7 @@ extern "C" int cvx_time_fourier_f32(const float* times, const float* w, float* o
 {
     CVX_REQUIRE(times && w && out && n >= 0 && half > 0, "time_fourier: bad arguments");
     if (n == 0) return CVX_OK;
-    hipLaunchKernelGGL(time_fourier_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(s), times, w, out, half);
+    hipLaunchKernelGGL(time_fourier_kernel, dim3(n), dim3(256), 0, cvx_hip_stream(s), times, w, out, half);
     CVX_CHECK_LAUNCH("cvx_time_fourier_f32");
     return CVX_OK;
 }
@@ -757,7 +680,7 @@ extern "C" int cvx_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, cvx_s
 {
     CVX_REQUIRE(wav && pcm && n >= 0, "wav_to_int16: bad arguments");
     if (n == 0) return CVX_OK;
-    hipLaunchKernelGGL(wav_to_int16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), wav, pcm, n);
+    hipLaunchKernelGGL(wav_to_int16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s), wav, pcm, n);
     CVX_CHECK_LAUNCH("cvx_wav_to_int16");
     return CVX_OK;
 }

@@ -330,7 +330,7 @@ struct PreSplitA { const _Float16* hi; const _Float16* lo; int64_t ld; const _Fl
 // 16x16x32 MFMA with swapped operands, transpose-free epilogue, persistent blocks; only problems whose epilogue can run 16-byte
 // vectors (N % 64 == 0, aligned pointers); false -> the caller falls back to the 128 x 128 kernel
 bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const _Float16* w_il, float acc_scale, const SplitOut& so,
-                           hipStream_t st);
+                           hipStream_t st, int n_cu);
 
 // gemm_f16x3_p8m.hip: 128 x 128 tiles, two wave groups on alternate K-tiles, for problems of fewer than 2048 rows (interleaved
 // A and W); ksplit > 1: K slices on separate blocks, scaled fp32 partial tiles to `partial` [ksplit][M][N] (the caller reduces)

@@ -432,8 +432,9 @@ extern "C" int cvx_split_f16_colscale_il(const float* W, int64_t ldw, int32_t N,
                 (((uintptr_t)W | (uintptr_t)colscale | (uintptr_t)out) & 15) == 0,
                 "split_f16_colscale_il: bad arguments (N=%d K=%d ldw=%ld cs_ld=%ld; K %% 32 == 0, 16-byte aligned rows)", N, K, (long)ldw, (long)cs_ld);
     if (n_sets == 0) return CVX_OK;
+    CVX_REQUIRE_SAT(s);
     const int64_t n = (int64_t)N * (K / 4);
-    hipLaunchKernelGGL(split_colscale_il_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(split_colscale_il_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        W, ldw, N, K, colscale, cs_ld, set_scale_dev, ss_ld, n_sets, scale, reinterpret_cast<f16*>(out), cvx_sat_flag_for(s));
     CVX_CHECK_LAUNCH("cvx_split_f16_colscale_il");
     return CVX_OK;
@@ -444,7 +445,8 @@ extern "C" int cvx_split_f16_dev(const float* w, uint16_t* hi, uint16_t* lo, int
 {
     CVX_REQUIRE(w && hi && n >= 0, "split_f16: bad arguments");      // lo == NULL: plain fp16 cast (saturating)
     if (n == 0) return CVX_OK;
-    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    CVX_REQUIRE_SAT(s);
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        w, reinterpret_cast<f16*>(hi), reinterpret_cast<f16*>(lo), n, scale, scale_dev, cvx_sat_flag_for(s));
     CVX_CHECK_LAUNCH("cvx_split_f16");
     return CVX_OK;
@@ -657,6 +659,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     if (single)
         CVX_REQUIRE(io && io->A_hi && a->K % (2 * BK) == 0 && (!a->A2 || a->K1 % (2 * BK) == 0),
                     "gemm_f16x3: the single-term mode (W_lo == NULL) needs a pre-split A and K (K1) a multiple of 64");
+    if ((io && (io->C_hi || io->Vt_hi)) || norm) CVX_REQUIRE_SAT(s);      // (the call stores split pairs)
     SplitOut so{nullptr, nullptr, 0, 1, nullptr, nullptr, 0};
     so.sat = cvx_sat_flag_for(s);
     PreSplitA A{nullptr, nullptr, 0, nullptr, nullptr, 0};
@@ -710,7 +713,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     const int map_mode = 1;             // XCD-aware block -> tile map (gemm_common.h)
     const int grid_m = map_mode == 1 ? ((tiles_m + 7) / 8) * 8 : tiles_m;
     dim3 grid((unsigned)(grid_m * tiles_n));
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     const f16* wh = reinterpret_cast<const f16*>(W_hi);
     const f16* wl = reinterpret_cast<const f16*>(W_lo);
     // Measured on MI355X (tools/bench_kernels.py, M=16000): the 256x256 tile wins on every transformer shape
@@ -724,7 +727,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
     // (CVX_GEMM_FLAG_MEDIUM forces it, CVX_GEMM_FLAG_NO_MEDIUM and the A/B kernel flags keep the large kernel.)
     bool medium = a->M < 2048 || a->N < 512;
     if (!medium && A.hi && w_il && a_il && io && !(io->flags & (CVX_GEMM_FLAG_NO_MEDIUM | CVX_GEMM_FLAG_ONE_TILE))) {
-        const long ncu = cvx_stream_cus(s);
+        const long ncu = cvx_ctx_cus(s);
         const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256), t192 = (long)((a->M + 191) / 192) * ((a->N + 255) / 256);
         const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
         // (the large kernel picks 192-row tiles - 0.8 of a 256-row tile's time - where that gives fewer, shorter rounds: gemm_f16x3_p8s.hip)
@@ -773,7 +776,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         // 16-byte aligned) run on the medium-problem kernel's 128 x 128 tiles, which asks for less (N % 16 == 0, 128-column RoPE groups).
         // (Rounds 2-4 also shipped a two-stage 256 x 256 kernel and an eight-phase form on the 32x32x16 MFMA as fallbacks and A/B
         //  partners: superseded, removed in round 5 - HISTORY.md has their numbers.)
-        if (!cvxg::launch_gemm_f16x3_p8s(*a, A, wh, acc_scale, so, st)) {
+        if (!cvxg::launch_gemm_f16x3_p8s(*a, A, wh, acc_scale, so, st, cvx_ctx_cus(s))) {
             CVX_REQUIRE(!dn, "gemm_f16x3: deferred norm (c_gamma_dev / c_rowsq / a_row_scale_dev) needs N %% 64 == 0 and 16-byte aligned epilogue "
                              "operands (M=%d N=%d K=%d)", a->M, a->N, a->K);
             CVX_REQUIRE(cvxg::launch_gemm_f16x3_p8m(*a, A, wh, acc_scale, so, 1, nullptr, st),

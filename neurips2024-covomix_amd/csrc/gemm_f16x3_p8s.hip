@@ -22,7 +22,7 @@
 //     loads) is a 16-byte (8-byte fp16) vector without register transposes.  Blocks that own V columns of a to_qkv projection run
 //     the UN-swapped product instead: a lane then holds 4 consecutive FRAMES of one head-dim column - what the transposed V^T store
 //     wants;
-//   * PERSISTENT blocks (one per CU of the stream, cvx_stream_cus) walk tile slots of an XCD-aware map; the tail of a tile fetches the
+//   * PERSISTENT blocks (one per CU of the stream, cvx_ctx.n_cus) walk tile slots of an XCD-aware map; the tail of a tile fetches the
 //     first six quarters of the next one.
 // LDS: 2 buffers x (A tile [256][128 B] | W tile [256][128 B]) = 128 KiB + 8 KiB dump area for the tail's dummy DMA.  Swizzle: 16-byte
 // chunk c of row r sits at chunk c ^ ((r >> 1) & 7), applied on the DMA source address and on the ds_read_b128 fragment address
@@ -285,7 +285,7 @@ int classify_epilogue(const cvx_gemm_args& a, const SplitOut& so)
 }
 
 bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16* w_il, float acc_scale, const SplitOut& so,
-                           hipStream_t st)
+                           hipStream_t st, int n_cu)
 {
     if (a.K % 32 != 0 || (A.hi2 && a.K1 % 32 != 0) || a.N % 64 != 0) return false;
     if ((int64_t)a.M * A.ld * 2 >= (int64_t)1 << 32 || (A.hi2 && (int64_t)a.M * A.ld2 * 2 >= (int64_t)1 << 32) ||
@@ -299,7 +299,7 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     if (!vec) return false;
     if (so.vt_hi && !(a.rope_cos && so.hi && !so.write_f32 && !a.residual && a.act == CVX_ACT_NONE)) return false;   // V^T only in QKV form
     const int tn = (a.N + 255) / 256;
-    const int n_cu = cvx_stream_cus(st);                         // CUs this stream owns (cvx_stream_set_cus; default: the device's)
+    // n_cu: CUs the launch context's stream owns (cvx_ctx.n_cus; default: the device's)
     // tile height: 256 rows, or 192 where rounds x height comes out smaller (a launch runs in rounds of one tile per CU and a tile's
     // time goes with its height).  so.dbg bits 16 / 32 pin 192 / 256 (CVX_GEMM_FLAG_TILE192 / _TILE256: A/B, bit-identity tests).
     const int cus8 = (n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8;

@@ -400,7 +400,7 @@ extern "C" int cvx_gemm_bias_act_f32(const cvx_gemm_args* a, cvx_stream_t s)
     const int rc = cvxg::validate_gemm_args(a);
     if (rc != CVX_OK) return rc;
     if (a->M == 0) return CVX_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     // Small-M problems (time tables, short utterances) use the 64-row tile to fill more CUs.
     const long blocks128 = (long)((a->M + 127) / 128) * ((a->N + BN - 1) / BN);
     if (a->M <= 64 || blocks128 < 256) return launch_gemm<1>(*a, st);

@@ -970,10 +970,9 @@ void launch_conv16_m16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
 // out smallest on this chip - 256 or 192 positions on the 32x32x16 kernel, or 160 on the 16x16x32 one (measured 13 % slower per
 // position, rocprofv3: 114 us for 256 blocks of 160 against 120.6 for 216 blocks of 192 on stage 0 of the bench shape, 8 x 5,000
 // positions - it wins where it fills the chip: 160 -> 216 -> 256 blocks there)
-void dispatch_conv16(const Conv16Args& k, int B, int n_ztiles, hipStream_t st)
+void dispatch_conv16(const Conv16Args& k, int B, int n_ztiles, hipStream_t st, int cus)
 {
     if (k.Np == 256) {
-        const int cus = cvx_stream_cus(reinterpret_cast<cvx_stream_t>(st));
         auto cost = [&](int rows) { const int64_t n = (int64_t)((k.L + rows - 1) / rows) * B * n_ztiles; return (double)((n + cus - 1) / cus * rows); };
         const double t256 = cost(256), t192 = cost(192), t160 = 1.13 * cost(160);
         if (t160 < t256 && t160 < t192) launch_conv16_m16<5, 4, 4>(k, B, n_ztiles, st);
@@ -1052,6 +1051,7 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
     CVX_REQUIRE((a->out_zhi == nullptr) == (a->out_zlo == nullptr) && (a->out_x || a->out_zhi) && (!a->accum || a->out_x),
                 "conv1d_f16x3: bad output combination");
     if (a->B == 0) return CVX_OK;
+    if (a->out_zhi) CVX_REQUIRE_SAT(s);
     Conv16Args k{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
                  reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
                  reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
@@ -1060,7 +1060,7 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
     k.zk[0] = a->ksize; k.zpad[0] = pad; k.zw[0] = 0;                  // one output-column tile, the plain layout
     k.out_bs = (long long)a->Lp * a->Np; k.out_base = (long long)a->halo_l * a->Np;
     k.ldo = a->Np; k.ostride = 1; k.ph_shift = 31; k.L_out = a->L;
-    dispatch_conv16(k, a->B, 1, reinterpret_cast<hipStream_t>(s));
+    dispatch_conv16(k, a->B, 1, cvx_hip_stream(s), cvx_ctx_cus(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_f16x3");
     return CVX_OK;
 }
@@ -1095,7 +1095,7 @@ extern "C" int cvx_hifigan_conv_transpose1d_f16x3(const cvx_convt16_args* a, cvx
     k.out_bs = (long long)a->Lp_out * a->Np_out; k.out_base = (long long)a->halo_out * a->Np_out;
     k.ldo = a->stride * a->Np_out; k.ostride = a->stride; k.ph_shift = __builtin_ctz((unsigned)a->Np_out); k.L_out = a->L_out;
     k.amax_out = a->amax_bits_dev;
-    dispatch_conv16(k, a->B, a->n_tiles, reinterpret_cast<hipStream_t>(s));
+    dispatch_conv16(k, a->B, a->n_tiles, cvx_hip_stream(s), cvx_ctx_cus(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_conv_transpose1d_f16x3");
     return CVX_OK;
 }
@@ -1105,9 +1105,10 @@ extern "C" int cvx_hifigan_split_channels_last(const float* x_cl, uint16_t* z_hi
 {
     CVX_REQUIRE(x_cl && z_hi && z_lo && n >= 0 && n % 4 == 0, "split_channels_last: bad arguments (n must be a multiple of 4)");
     if (n == 0) return CVX_OK;
+    CVX_REQUIRE_SAT(s);
     const int64_t n4 = n / 4;
-    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)cvx_stream_cus(s) * 16);
-    hipLaunchKernelGGL(cl_split_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(s), x_cl,
+    const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)cvx_ctx_cus(s) * 16);
+    hipLaunchKernelGGL(cl_split_kernel, dim3(grid), dim3(256), 0, cvx_hip_stream(s), x_cl,
                        reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), n4, slope, z_scale_dev, cvx_sat_flag_for(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_split_channels_last");
     return CVX_OK;
@@ -1121,7 +1122,7 @@ extern "C" int cvx_hifigan_post_channels_last_f32(const float* x_cl, const float
     if (B == 0) return CVX_OK;
     const size_t lds = (size_t)POST_ROWS * (Np + 1) * sizeof(float);
     cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&post_cl_kernel), (int)lds);
-    hipLaunchKernelGGL(post_cl_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), lds, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(post_cl_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), lds, cvx_hip_stream(s),
                        x_cl, w, bias, y, C, Np, L, Lp, halo_l, slope);
     CVX_CHECK_LAUNCH("cvx_hifigan_post_channels_last_f32");
     return CVX_OK;
@@ -1140,6 +1141,7 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
                 "resblock_pair_f16x3: buffers need %d zero rows in front of and behind the signal (halo_l=%d Lp=%d L=%d)",
                 h2 + pad1, a->halo_l, a->Lp, a->L);
     if (a->B == 0) return CVX_OK;
+    CVX_REQUIRE_SAT(s);                                                    // (the intermediate of the pair is a split pair)
     const bool big64 = a->Np == 64 && !(a->flags & 1);                    // default: 256-row tiles, one block per CU
     const int rows = (a->Np == 64 && !big64) ? 128 : 256;
     const int tm_out = rows - 2 * h2;
@@ -1150,8 +1152,8 @@ extern "C" int cvx_hifigan_resblock_pair_f16x3(const cvx_respair16_args* a, cvx_
                reinterpret_cast<const f16*>(a->c2.w_hi), reinterpret_cast<const f16*>(a->c2.w_lo), a->c1.bias, a->c2.bias,
                a->accum, a->out, a->B, a->L, a->Lp, a->ksize, a->dil, a->halo_l, tps, (int)n_tiles,
                a->c1.acc_scale, a->c2.acc_scale, a->out_scale, 0.1f, a->z_scale_dev, cvx_sat_flag_for(s), a->items};
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
-    const int cus = cvx_stream_cus(s);
+    hipStream_t st = cvx_hip_stream(s);
+    const int cus = cvx_ctx_cus(s);
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, (int64_t)cus * (big64 ? 1 : 2));      // two blocks per CU
 #define CVX_LAUNCH_PAIR(TNI_, NW_)                                                                                       \
     {                                                                                                                    \
@@ -1180,8 +1182,9 @@ extern "C" int cvx_hifigan_to_channels_last_scaled(const float* x, float* x_cl, 
     CVX_REQUIRE(x && (x_cl || z_hi) && ((z_hi == nullptr) == (z_lo == nullptr)) && B >= 0 && C > 0 && L > 0 && Cp >= C && Cp % 32 == 0 &&
                 halo_l >= 0 && Lp >= halo_l + L, "to_channels_last: bad arguments");
     if (B == 0) return CVX_OK;
+    if (z_hi) CVX_REQUIRE_SAT(s);
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
-    hipLaunchKernelGGL(cm_to_cl_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, x_cl,
+    hipLaunchKernelGGL(cm_to_cl_kernel, grid, dim3(256), 0, cvx_hip_stream(s), x, x_cl,
                        reinterpret_cast<f16*>(z_hi), reinterpret_cast<f16*>(z_lo), C, L, Lp, Cp, halo_l, slope, z_scale_dev,
                        z_hi ? cvx_sat_flag_for(s) : nullptr);
     CVX_CHECK_LAUNCH("cvx_hifigan_to_channels_last");
@@ -1195,7 +1198,7 @@ extern "C" int cvx_hifigan_from_channels_last(const float* x_cl, float* x, int32
                 "from_channels_last: bad arguments");
     if (B == 0) return CVX_OK;
     dim3 grid((unsigned)((L + 63) / 64), (unsigned)(Cp / 32), (unsigned)B);
-    hipLaunchKernelGGL(cl_to_cm_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x_cl, x, C, L, Lp, Cp, halo_l);
+    hipLaunchKernelGGL(cl_to_cm_kernel, grid, dim3(256), 0, cvx_hip_stream(s), x_cl, x, C, L, Lp, Cp, halo_l);
     CVX_CHECK_LAUNCH("cvx_hifigan_from_channels_last");
     return CVX_OK;
 }

@@ -238,7 +238,7 @@ extern "C" int cvx_hifigan_conv1d_f32(const cvx_conv_args* a, cvx_stream_t s)
     const int n_chunks = (a->Cin + CK - 1) / CK;
     const size_t lds = sizeof(float) * ((size_t)CK * X_LD + (size_t)a->ksize * cot * W_LD);
     dim3 grid((a->Lout + LT - 1) / LT, (a->Cout + cot - 1) / cot, a->B);
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     if (cot == 32) {
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv1d_mfma_kernel<1, false>), (int)lds);
         hipLaunchKernelGGL((conv1d_mfma_kernel<1, false>), grid, dim3(256), lds, st, *a, n_chunks, (unsigned*)nullptr);
@@ -265,7 +265,7 @@ extern "C" int cvx_hifigan_conv_transpose1d_f32(const cvx_conv_args* a, uint32_t
     const size_t lds = sizeof(float) * ((size_t)CK * X_LD + (size_t)nt_max * cot * W_LD);
     const int lm = (a->Lout + a->up - 1) / a->up;
     dim3 grid((lm + LT - 1) / LT, ((a->Cout + cot - 1) / cot) * a->up, a->B);
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     if (cot == 32) {
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv1d_mfma_kernel<1, true>), (int)lds);
         hipLaunchKernelGGL((conv1d_mfma_kernel<1, true>), grid, dim3(256), lds, st, *a, n_chunks, amax_bits_dev);
@@ -319,7 +319,7 @@ extern "C" int cvx_hifigan_post_f32(const float* x, const float* w, float bias, 
     CVX_REQUIRE(x && w && y && B >= 0 && Cin > 0 && L > 0, "hifigan_post: bad arguments");
     if (B == 0) return CVX_OK;
     dim3 grid((L + 255) / 256, B);
-    hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, w, bias, y, Cin, L, slope);
+    hipLaunchKernelGGL(post_kernel, grid, dim3(256), 0, cvx_hip_stream(s), x, w, bias, y, Cin, L, slope);
     CVX_CHECK_LAUNCH("cvx_hifigan_post_f32");
     return CVX_OK;
 }

@@ -197,7 +197,7 @@ extern "C" int cvx_hubert_conv0_gn_gelu_f32(const float* wav, int64_t n_samples,
     CVX_REQUIRE(n_samples >= k, "hubert_conv0: waveform shorter than one kernel (%ld samples)", (long)n_samples);
     const int64_t L = (n_samples - k) / stride + 1;
     CVX_REQUIRE(workspace_floats >= cvx_hubert_conv0_workspace_floats(L, C), "hubert_conv0: workspace too small");
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     const int nchunks = (int)((L + ST_ROWS - 1) / ST_ROWS);
     float* partial = workspace;
     float* mean = workspace + (int64_t)nchunks * C;
@@ -220,7 +220,7 @@ extern "C" int cvx_layernorm_f32(const float* x, const float* gamma, const float
     CVX_REQUIRE(x && gamma && beta && y && rows >= 0, "layernorm: bad arguments");
     CVX_REQUIRE(D > 0 && D % 4 == 0 && D <= 1024, "layernorm: D must be a multiple of 4, at most 1024 (D=%d)", D);
     if (rows == 0) return CVX_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (D <= 256)      hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, eps);
     else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, rows, D, eps);
@@ -234,7 +234,7 @@ extern "C" int cvx_hubert_group_pack_f32(const float* x, float* out, int32_t T, 
 {
     CVX_REQUIRE(x && out && T > 0 && D > 0 && groups > 0 && D % groups == 0 && halo >= 0, "hubert_group_pack: bad arguments");
     const int64_t n = (int64_t)(T + 2 * halo) * D;
-    hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), x, out, T, D, groups, halo);
+    hipLaunchKernelGGL(group_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s), x, out, T, D, groups, halo);
     CVX_CHECK_LAUNCH("cvx_hubert_group_pack_f32");
     return CVX_OK;
 }
@@ -244,7 +244,7 @@ extern "C" int cvx_kmeans_argmin_f32(const float* x, const float* dots, const fl
 {
     CVX_REQUIRE(x && dots && cnorm && labels && T >= 0 && D > 0 && K > 0, "kmeans_argmin: bad arguments");
     if (T == 0) return CVX_OK;
-    hipLaunchKernelGGL(kmeans_argmin_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(kmeans_argmin_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, cvx_hip_stream(s),
                        x, dots, cnorm, labels, margin, T, D, K);
     CVX_CHECK_LAUNCH("cvx_kmeans_argmin_f32");
     return CVX_OK;
@@ -280,7 +280,7 @@ extern "C" int cvx_resample_fir_f32(const float* x, int64_t n, const float* kern
 {
     CVX_REQUIRE(x && kern && out && n >= 0 && n_out >= 0 && up > 0 && down > 0 && width >= 0, "resample_fir: bad arguments");
     if (n_out == 0) return CVX_OK;
-    hipLaunchKernelGGL(resample_fir_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(resample_fir_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        x, kern, out, n, n_out, up, down, width, 2 * width + down);
     CVX_CHECK_LAUNCH("cvx_resample_fir_f32");
     return CVX_OK;
@@ -449,7 +449,7 @@ extern "C" int cvx_hubert_extract_features(const cvx_hubert_model* m, const floa
         CVX_TRY(lin(ly.fc2, P.ffs, ly.fc1.N, T, P.y, D, CVX_ACT_NONE, ly.fc2.bias, P.x, D, none, 1, P, s));
         CVX_TRY(cvx_layernorm_f32(P.y, ly.ln2_g, ly.ln2_b, P.x, T, D, 1e-5f, s));
     }
-    CVX_REQUIRE(hipMemcpyAsync(out, P.x, (size_t)T * D * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(s)) == hipSuccess,
+    CVX_REQUIRE(hipMemcpyAsync(out, P.x, (size_t)T * D * sizeof(float), hipMemcpyDeviceToDevice, cvx_hip_stream(s)) == hipSuccess,
                 "hubert_extract_features: output copy failed");
     return CVX_OK;
 }

@@ -658,7 +658,7 @@ extern "C" int cvx_geglu_f32(const float* h, float* out, int64_t rows, int32_t F
     CVX_REQUIRE(h && out && rows >= 0 && F > 0 && ld_out >= F, "geglu: bad arguments");
     if (rows == 0) return CVX_OK;
     const int64_t n = rows * ld_out;
-    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(s),
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cvx_hip_stream(s),
                        h, out, rows, F, ld_out);
     CVX_CHECK_LAUNCH("cvx_geglu_f32");
     return CVX_OK;
@@ -697,12 +697,12 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
 {
     const int rc = t2s_validate(d, n_steps);
     if (rc != CVX_OK) return rc;
-    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    hipStream_t st = cvx_hip_stream(s);
     const float scale = 0.125f;        // dim_head ** -0.5
     const int nb = d->batch;
     // two row pairs per wave (half the blocks, each staging the input vectors for twice the rows): on a CU-masked side stream (several
     // rounds of blocks per launch at batch 8) and from T2S_TWO_PAIRS_BATCH slots up; cvx_t2s_decoder.pairs_per_wave overrides
-    const bool few = d->pairs_per_wave > 0 ? d->pairs_per_wave >= 2 : (cvx_stream_cus(s) <= 64 || d->batch >= T2S_TWO_PAIRS_BATCH);
+    const bool few = d->pairs_per_wave > 0 ? d->pairs_per_wave >= 2 : (cvx_ctx_cus(s) <= 64 || d->batch >= T2S_TWO_PAIRS_BATCH);
     const int64_t cache_stride = (int64_t)d->max_len * d->inner;
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < d->depth; ++l) {

@@ -83,7 +83,7 @@ def resample(wav: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
     out = torch.empty(n_out, dtype=torch.float32, device=wav.device)
     k = torch.from_numpy(kern).to(wav.device)
     _lib.check(_lib.load().cvx_resample_fir_f32(wav.data_ptr(), n, k.data_ptr(), new, orig, width, out.data_ptr(), n_out,
-                                                torch.cuda.current_stream().cuda_stream), "cvx_resample_fir_f32")
+                                                ops._stream()), "cvx_resample_fir_f32")
     return out
 
 
@@ -272,7 +272,7 @@ class HubertEncoder:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty(T, self.dim, dtype=torch.float32, device=self.device)
         _lib.check(lib.cvx_hubert_extract_features(C.byref(m), wav.data_ptr(), wav.numel(), n_layers, out.data_ptr(),
-                                                   self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream),
+                                                   self._ws.data_ptr(), self._ws.numel(), ops._stream()),
                    "cvx_hubert_extract_features")
         return out
 

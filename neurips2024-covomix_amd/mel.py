@@ -99,7 +99,7 @@ def mel_spectrogram(y: torch.Tensor, n_fft: int = N_FFT, num_mels: int = N_MELS,
     yp[:, : yr.shape[1]] = yr
     n_pad = yr.shape[1]
     out = []
-    st = torch.cuda.current_stream().cuda_stream
+    st = ops._stream()
     for b in range(yp.shape[0]):
         sig = yp[b]
         T = (n_pad - n_fft) // hop_size + 1

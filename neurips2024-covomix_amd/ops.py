@@ -17,8 +17,26 @@ from ._lib import ConvArgs, GemmArgs, GemmNorm, GemmSplitIO
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
 
+# Launch contexts (include/covomix_hip.h: cvx_ctx): one caller-owned struct per (device, stream) - the stream handle, its sticky
+# saturation flag and the CUs it owns.  The library keeps nothing about a stream; everything an entry point needs travels in the
+# struct whose ADDRESS is passed where the C prototypes say cvx_stream_t.  Never freed (captured graphs do not hold them, but a
+# raw address in flight must stay valid; there are a handful per process).
+_CTX: dict = {}
+
+
+def ctx_of(stream: Optional["torch.cuda.Stream"] = None) -> "_lib.Ctx":
+    st = stream if stream is not None else torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    c = _CTX.get(key)
+    if c is None:
+        c = _lib.Ctx(st.cuda_stream, None, torch.cuda.get_device_properties(st.device).multi_processor_count, 0)
+        _CTX[key] = c
+    return c
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """What the entry points take as `cvx_stream_t`: the address of the current stream's launch context."""
+    return C.addressof(ctx_of())
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -366,6 +384,7 @@ def split_f16(w: torch.Tensor, with_lo: bool = True):
     scale = 2.0 ** (13 - math.floor(math.log2(amax))) if amax > 0 and math.isfinite(amax) else 1.0
     hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
     lo = torch.empty(w.shape, dtype=torch.float16, device=w.device) if with_lo else None
+    ensure_saturation_bound()
     _lib.check(_lib.load().cvx_split_f16(w.data_ptr(), hi.data_ptr(), _p(lo), w.numel(), scale, _stream()),
                "cvx_split_f16")
     return hi, lo, 1.0 / scale
@@ -425,19 +444,15 @@ def rownorm_scale(rowsq: torch.Tensor, rows: int, parts: int, out: torch.Tensor,
 
 
 # Saturation flags are CALLER-OWNED: one int32 of device memory per (device, stream), bound to the stream with
-# cvx_saturation_flag_bind; the kernels a stream runs OR bit 0 into THAT flag (two threads / streams on one device never see or
+# The kernels a stream runs OR bit 0 into the flag of the stream's launch context (two threads / streams on one device never see or
 # clear each other's).  Allocated once and never freed (their addresses are baked into captured HIP graphs).
 _SAT_FLAGS: dict = {}
 
 
-def _bind_saturation_flag(flag: torch.Tensor, stream_handle: int) -> None:
-    _lib.check(_lib.load().cvx_saturation_flag_bind(flag.data_ptr(), stream_handle), "cvx_saturation_flag_bind")
-
-
 def saturation_flag(stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
-    """The OWN flag of `stream` (default: the current stream), allocated and bound on first use.  A binding that was only lent to
-    the stream (saturation_share: torch hands stream handles out of a small pool, so a stream a caller just created may be the very
-    side / capture stream some earlier call borrowed) is replaced: whoever resets or queries a stream owns its flag."""
+    """The OWN flag of `stream` (default: the current stream), allocated and put into its launch context on first use.  A flag that
+    was only lent to the stream (saturation_share: torch hands stream handles out of a small pool, so a stream a caller just created
+    may be the very side / capture stream some earlier call borrowed) is replaced: whoever resets or queries a stream owns its flag."""
     st = stream if stream is not None else torch.cuda.current_stream()
     key = (st.device.index, st.cuda_stream)
     ent = _SAT_FLAGS.get(key)
@@ -446,39 +461,33 @@ def saturation_flag(stream: Optional["torch.cuda.Stream"] = None) -> torch.Tenso
         torch.cuda.current_stream(st.device).synchronize()        # (the zero fill is on the current stream; `stream` may be another)
         _SAT_FLAGS[key] = (f, key)
         _CAPTURE_OWNER.pop(key, None)
-        with torch.cuda.device(st.device):
-            _bind_saturation_flag(f, st.cuda_stream)
+        ctx_of(st).sat_flag = f.data_ptr()
         return f
     return ent[0]
 
 
 def saturation_share(src: "torch.cuda.Stream", dst: "torch.cuda.Stream") -> None:
     """Kernels launched on `dst` report into the flag of `src` until further notice, and their persistent grids are sized for the
-    CUs `src` owns (cvx_stream_set_cus): the capture stream of a HIP graph - and any side stream a call opens - belongs to the call
-    that runs on `src` (call it before every such use)."""
+    CUs `src` owns: the capture stream of a HIP graph - and any side stream a call opens - belongs to the call that runs on `src`
+    (call it before every such use)."""
     f = saturation_flag(src)
     skey = (src.device.index, src.cuda_stream)
     key = (dst.device.index, dst.cuda_stream)
     if key == skey:
         return
     _CAPTURE_OWNER[key] = src.cuda_stream
-    with torch.cuda.device(dst.device):
-        lib = _lib.load()
-        n = int(lib.cvx_stream_cus(src.cuda_stream))
-        full = torch.cuda.get_device_properties(dst.device).multi_processor_count
-        _lib.check(lib.cvx_stream_set_cus(dst.cuda_stream, 0 if n == full else n), "cvx_stream_set_cus")
+    ctx_of(dst).n_cus = ctx_of(src).n_cus
     ent = _SAT_FLAGS.get(key)
     if ent is None or ent[0] is not f:
         _SAT_FLAGS[key] = (f, skey)
-        with torch.cuda.device(dst.device):
-            _bind_saturation_flag(f, dst.cuda_stream)
+        ctx_of(dst).sat_flag = f.data_ptr()
 
 
 def ensure_saturation_bound() -> None:
-    """The split-pair kernels skip their saturation bookkeeping on a stream nobody bound a flag to (a documented C-ABI feature for
-    callers that do not want it).  The Python front ends never want that silently (round-4 advice): every one of them that launches
-    a split-pair kernel makes sure the current stream has a flag - allocated here on first use outside a capture; inside a capture an
-    unbound stream is an error (the stream that captures must have been shared with the calling stream: saturation_share)."""
+    """A call that writes split pairs refuses a launch context without a saturation flag (CVX_EINVAL; a C caller can waive the
+    bookkeeping with CVX_CTX_NO_SATURATION_FLAG).  The Python front ends never waive it: every one of them that launches a split-pair
+    kernel makes sure the current stream's context has a flag - allocated here on first use outside a capture; inside a capture a
+    stream without one is an error (the stream that captures must have been shared with the calling stream: saturation_share)."""
     st = torch.cuda.current_stream()
     if (st.device.index, st.cuda_stream) in _SAT_FLAGS:
         return
@@ -514,7 +523,9 @@ class CUPartition:
             out = C.c_void_p()
             with torch.cuda.device(idx):
                 _lib.check(lib.cvx_stream_create_cu_mask(m, words, C.byref(out)), "cvx_stream_create_cu_mask")
-            return torch.cuda.ExternalStream(out.value, device=self.device)
+            st = torch.cuda.ExternalStream(out.value, device=self.device)
+            ctx_of(st).n_cus = len(bits)               # (what the persistent grids and the GEMM kernel choice are sized from)
+            return st
         self.main = make(range(0, self.n_main))
         self.side = make(range(self.n_main, n))
 
@@ -544,11 +555,14 @@ def _destroy_partitions() -> None:
                 # torch's pinned-memory allocator keeps events of the streams its blocks were last copied on (the decode's state
                 # record travels by non_blocking copies on the side stream): give the blocks back BEFORE their stream goes, or the
                 # allocator touches a dead stream at process exit (SIGSEGV, tools/cu_mask_exit_probe.py)
+                # (without that call the streams are left to process teardown: destroying them under live pinned blocks is the crash)
                 if hasattr(torch._C, "_host_emptyCache"):
                     torch._C._host_emptyCache()
-                for st in (part.main, part.side):
-                    st.synchronize()
-                    lib.cvx_stream_destroy(st.cuda_stream)
+                    for st in (part.main, part.side):
+                        st.synchronize()
+                        _CTX.pop((st.device.index, st.cuda_stream), None)
+                        _SAT_FLAGS.pop((st.device.index, st.cuda_stream), None)
+                        lib.cvx_stream_destroy(st.cuda_stream)
         except Exception:               # noqa: BLE001 - interpreter shutdown: nothing left to report to
             pass
     _CU_PARTITIONS.clear()
@@ -563,8 +577,8 @@ def is_partition_stream(stream: Optional["torch.cuda.Stream"] = None) -> bool:
 def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:
     """CUs the library sizes persistent grids for on `stream` (default: the current stream)."""
     st = stream if stream is not None else torch.cuda.current_stream()
-    with torch.cuda.device(st.device):
-        return int(_lib.load().cvx_stream_cus(st.cuda_stream))
+    n = ctx_of(st).n_cus
+    return int(n) if n > 0 else torch.cuda.get_device_properties(st.device).multi_processor_count
 
 
 def saturation_reset() -> None:
@@ -673,6 +687,7 @@ def attention(qkv: torch.Tensor, out: Optional[torch.Tensor], Bt: int, T: int, H
     assert qkv.numel() == rows * 3 * H * 64 and (out is None or out.numel() == rows * H * 64)
     oh, ol = (None, None)
     if out_split is not None:
+        ensure_saturation_bound()
         oh, ol, _ = _pair(out_split, rows if isinstance(out_split, SplitIL) else None, H * 64)
         assert isinstance(out_split, SplitIL) or (out_split[0].is_contiguous() and out_split[0].numel() == rows * H * 64)
     if ragged is not None:

@@ -241,7 +241,7 @@ class TextToSemanticDecoder:
     def _run_steps(self, temperature: float, batch: int, n: int, cfg_scale: float = 1.0, queue: bool = False) -> None:
         """n token steps on the current stream without a graph."""
         _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale, queue)), n,
-                                                    torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+                                                    ops._stream()), "cvx_t2s_decode_steps")
 
     def _uniform_view(self, n: int) -> torch.Tensor:
         """[n, steps, streams, vocab] view of the uniform draws of the first n dialogues"""
@@ -325,7 +325,7 @@ class TextToSemanticDecoder:
 
         def launch():
             _lib.check(_lib.load().cvx_t2s_decode_steps(C.byref(self._descriptor(temperature, batch, cfg_scale, queue)), CHUNK,
-                                                        torch.cuda.current_stream().cuda_stream), "cvx_t2s_decode_steps")
+                                                        ops._stream()), "cvx_t2s_decode_steps")
         self.buf["state"].copy_(self._slot_records([]))
         launch()                                       # warm-up outside capture
         cur = torch.cuda.current_stream()

@@ -10,6 +10,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+from covomix_amd import ops  # noqa: E402  (ops._stream(): the launch context the entry points take)
+
 
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
@@ -37,13 +39,12 @@ def test_rope_attention(Bt, T, H):
     ws = torch.empty_like(qd)
     cs, sn = cos.float().cuda().contiguous(), sin.float().cuda().contiguous()
     _lib.check(_lib.load().cvx_rope_attention_f32(qd.data_ptr(), cs.data_ptr(), sn.data_ptr(), out.data_ptr(), Bt, T, H, 0.125,
-                                                  ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "cvx_rope_attention_f32")
+                                                  ws.data_ptr(), ops._stream()), "cvx_rope_attention_f32")
     assert rel(out, want) < 5e-6
     assert torch.equal(qd.cpu(), qkv)                     # the input is not modified
 
 
 def _packed(w, transposed=False):
-    from covomix_amd import ops
     return ops.hifigan_pack_weight(w, transposed).cuda()
 
 
@@ -73,25 +74,24 @@ def test_resblock_entry_point(C_, k, dils, L):
         a.Wp1[m], a.Wp2[m], a.b1[m], a.b2[m], a.dil[m] = p1.data_ptr(), p2.data_ptr(), c1.data_ptr(), c2.data_ptr(), dils[m]
     a.x, a.B, a.C, a.L, a.ksize = xd.data_ptr(), B, C_, L, k
     a.tmp, a.out, a.accum, a.out_scale = tmp.data_ptr(), out.data_ptr(), acc.data_ptr(), 1.0 / 3.0
-    _lib.check(_lib.load().cvx_hifigan_resblock_f32(C.byref(a), torch.cuda.current_stream().cuda_stream), "cvx_hifigan_resblock_f32")
+    _lib.check(_lib.load().cvx_hifigan_resblock_f32(C.byref(a), ops._stream()), "cvx_hifigan_resblock_f32")
     assert rel(out, want) < 5e-6
     assert torch.equal(xd.cpu(), x)
     a.out = a.x                                            # aliasing x is rejected
-    assert _lib.load().cvx_hifigan_resblock_f32(C.byref(a), torch.cuda.current_stream().cuda_stream) != 0
+    assert _lib.load().cvx_hifigan_resblock_f32(C.byref(a), ops._stream()) != 0
 
 
 def test_convt_and_pre_post_entry_points():
     from covomix_amd import _lib
     from covomix_amd._lib import ConvArgs
     g = torch.Generator().manual_seed(5)
-    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    lib, st = _lib.load(), ops._stream()
     B, Cin, Cout, L, k, u = 2, 62, 31, 300, 4, 2          # ups[3] of config_covomix: ConvTranspose1d(62, 31, 4, 2, padding=1)
     x = torch.randn(B, Cin, L, generator=g)
     w = torch.randn(Cin, Cout, k, generator=g) / (Cin * k) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
     want = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=(k - u) // 2)
     a = ConvArgs()
-    from covomix_amd import ops
     xd, wp, bd = x.cuda(), ops.hifigan_pack_conv_transpose1d(w, u, (k - u) // 2).cuda(), b.cuda()      # polyphase packing
     out = torch.empty(B, Cout, want.shape[2], device="cuda")
     a.x, a.B, a.Cin, a.Lin, a.Wp, a.bias = xd.data_ptr(), B, Cin, L, wp.data_ptr(), bd.data_ptr()
@@ -131,7 +131,6 @@ def test_resblock_f16x3_entry_point(C_, k, dils, L):
     """cvx_hifigan_resblock_f16x3: the operator-level ResBlock1 on the split-precision convolutions - the form the host
     runs (channels-last buffers, device-resident activation pre-scale) - against the fp64 torch restatement."""
     from types import SimpleNamespace
-    from covomix_amd import ops
     g = torch.Generator().manual_seed(C_ * 100 + k + 1)
     B = 2
     x = torch.randn(B, C_, L, generator=g) * 3.0
@@ -185,7 +184,6 @@ def test_resblock_pair_fused_kernel(C_, k, dil, L, B):
     tiles when B * ceil(L / (256 - (k-1))) exceeds the CU count) against the fp64 torch restatement of models.py:36-40,
     with the xs accumulate / scale of Generator.forward; the zero halos and padded channels stay zero."""
     from types import SimpleNamespace
-    from covomix_amd import ops
     g = torch.Generator().manual_seed(C_ * 1000 + k * 10 + dil)
     x = torch.randn(B, C_, L, generator=g) * 0.05                 # (small: the measured pre-scale does the work)
     w1 = torch.randn(C_, C_, k, generator=g) / (C_ * k) ** 0.5
@@ -240,7 +238,6 @@ def test_conv_transpose1d_polyphase(Cin, Cout, k, u, pad, L, B):
     """cvx_hifigan_conv_transpose1d_f32 (one stride-1 convolution per output phase) against torch's fp64 conv_transpose1d of
     leaky_relu(x) - the four upsamplers of config_covomix.json (models.py:85-88), a kernel shorter than the stride (phases
     that see no tap at all: bias only) and an odd one - and the fused max|out| against the tensor's own maximum."""
-    from covomix_amd import ops
     g = torch.Generator().manual_seed(Cin * 7 + k * 3 + u)
     x = torch.randn(B, Cin, L, generator=g)
     w = torch.randn(Cin, Cout, k, generator=g) / (Cin * k / u) ** 0.5

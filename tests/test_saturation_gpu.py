@@ -376,9 +376,10 @@ def test_vocoder_resblock_gain_outside_the_window_is_rerun_or_raises(monkeypatch
 
 def test_flags_are_per_stream_and_caller_owned(ops):
     """Round-3 review: the flag was ONE library-owned word per device, so a reset on one stream could clear what another
-    stream's kernels had raised.  Now the caller owns one word per (device, stream) (cvx_saturation_flag_bind): a saturating
-    launch on stream A flags A only, a reset / clean launch / query on stream B neither sees nor clears it, a stream without a
-    flag runs without bookkeeping, and a shared flag (capture stream, side stream) collects both streams."""
+    stream's kernels had raised.  Now the caller owns one word per (device, stream), carried by the stream's launch context
+    (cvx_ctx.sat_flag): a saturating launch on stream A flags A only, a reset / clean launch / query on stream B neither sees nor
+    clears it, a stream the Python front end meets for the first time gets its own flag, and a shared flag (capture stream, side
+    stream) collects both streams."""
     dev_ = dev()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(300, 256, generator=g).to(dev_)
@@ -395,7 +396,7 @@ def test_flags_are_per_stream_and_caller_owned(ops):
     with torch.cuda.stream(sa):
         assert ops.saturation_query(reset=False) != 0
         assert ops.saturation_flag().data_ptr() != ops.saturation_flag(sb).data_ptr()
-    # a stream nobody bound a flag to: no bookkeeping, nobody else's flag moves
+    # a stream met for the first time: its own flag (allocated by the front end), nobody else's flag moves
     with torch.cuda.stream(sb):
         ops.saturation_reset()
     with torch.cuda.stream(sc):
@@ -413,6 +414,41 @@ def test_flags_are_per_stream_and_caller_owned(ops):
     sc.synchronize()
     with torch.cuda.stream(sa):
         assert ops.saturation_query() != 0 and ops.saturation_query() == 0
+
+
+def test_c_caller_without_a_flag_is_refused_not_silently_unchecked(ops):
+    """Round-5 review: a C caller that launched a split-pair kernel on a stream nobody had bound a flag to got SILENT clamping (only
+    the Python front end refused).  Version 107: the flag travels in the launch context (cvx_ctx) of every call; a call that writes
+    split pairs with a context that carries none returns CVX_EINVAL - unless the context waives the bookkeeping explicitly
+    (CVX_CTX_NO_SATURATION_FLAG) - and the library keeps no per-stream state at all (two contexts on one stream with different flags
+    report into their own flags)."""
+    import ctypes as C
+    from covomix_amd import _lib
+    lib = _lib.load()
+    dev_ = dev()
+    x = torch.randn(64, 256, device=dev_)
+    x[3, 3] = 1e6
+    hi, lo = torch.empty(64, 256, dtype=torch.float16, device=dev_), torch.empty(64, 256, dtype=torch.float16, device=dev_)
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda ctx: lib.cvx_split_f16_dev(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), 1.0, None, C.addressof(ctx))
+    bare = _lib.Ctx(st, None, 0, 0)
+    assert call(bare) != 0 and b"saturation flag" in lib.cvx_last_error_string()
+    assert lib.cvx_saturation_flag_reset(C.addressof(bare)) != 0
+    waived = _lib.Ctx(st, None, 0, _lib.CTX_NO_SATURATION_FLAG)
+    assert call(waived) == 0
+    torch.cuda.synchronize()
+    assert float(hi.float().abs().max()) == 65504.0                   # clamped - the caller asked for no bookkeeping
+    f1, f2 = torch.zeros(1, dtype=torch.int32, device=dev_), torch.zeros(1, dtype=torch.int32, device=dev_)
+    torch.cuda.synchronize()
+    c1, c2 = _lib.Ctx(st, f1.data_ptr(), 0, 0), _lib.Ctx(st, f2.data_ptr(), 0, 0)
+    assert call(c1) == 0
+    x[3, 3] = 1.0
+    assert call(c2) == 0
+    v = C.c_uint32(0)
+    assert lib.cvx_saturation_flag_query(C.byref(v), 1, C.addressof(c1)) == 0 and v.value != 0
+    assert lib.cvx_saturation_flag_query(C.byref(v), 0, C.addressof(c2)) == 0 and v.value == 0
+    assert int(f1.item()) == 0                                        # (the query of c1 reset it)
+    assert lib.cvx_split_f16_dev(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), 1.0, None, None) != 0      # NULL context: no flag either
 
 
 def test_two_threads_two_models_one_device():
