@@ -304,9 +304,38 @@ class VectorField:
             ctx["sp"], ctx["hp"] = tt["sp"], tt["H"].data_ptr()
             if self._defers(ctx["M"], ws):
                 if tt["dn"] is None:
-                    tt["dn"] = self._deferred_norm_tables(table, tt["HS"], times_key)
-                ctx["dn"] = tt["dn"]
+                    # built by split-pair kernels (split_f16_colscale_il): cached only when the build itself stayed inside the window
+                    # (_tables_clean) - a clamped table must not outlive the call that is flagged for it
+                    clean0 = self._flag_clear()
+                    dn = self._deferred_norm_tables(table, tt["HS"], times_key)
+                    if tt.get("cached") and clean0 and self._flag_clear():
+                        tt["dn"], tt["dn_ready"] = dn, self._ready_event()
+                    ctx["dn"] = dn
+                else:
+                    self._wait(tt["dn_ready"])                                  # (built on another stream, maybe)
+                    ctx["dn"] = tt["dn"]
         return ctx
+
+    @staticmethod
+    def _flag_clear():
+        """Is the current stream's sticky saturation flag clear right now (one stream synchronisation)?  None when nothing can be
+        said: inside a stream capture, or with the checks switched off (CVX_SAT_CHECK=0)."""
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("CVX_SAT_CHECK", "1") != "1":
+            return None
+        return ops.saturation_query(reset=False) == 0
+
+    @staticmethod
+    def _wait(ev) -> None:
+        """the current stream waits for tables another stream may have built (not inside a capture: a capture starts after the
+        capturing call's own eager run and a stream synchronisation - everything cached is complete by then)"""
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_event(ev)
+
+    @staticmethod
+    def _ready_event():
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
 
     # ------------------------------------------------------------------ everything that depends on the evaluation times only
     TIME_CACHE = 2          # evaluation-time grids whose tables stay resident (each holds 0.22 GB per evaluation time once a batch deferred its norms)
@@ -323,7 +352,13 @@ class VectorField:
         if key is not None and key in self._time_cache:
             ent = self._time_cache.pop(key)
             self._time_cache[key] = ent                                        # most recently used last
+            self._wait(ent["ready"])                                           # (the tables may have been built on another stream)
             return ent
+        # The tables are built by split-precision kernels that can raise the sticky saturation flag (split_act_f16(temb), the f16x3
+        # GEMM of the table above 32 rows, the activation scales).  A call that builds them and is flagged is re-run in fp32 - but a
+        # CACHED clamped table would be reused by later calls under a clean flag: silently wrong.  So an entry is cached only when
+        # its build provably stayed inside the window: flag clear before AND after (two stream synchronisations per (model, grid)).
+        clean0 = self._flag_clear() if key is not None else None
         n = times.numel()
         four = torch.empty(n, d["dim"], dtype=torch.float32, device=self.device)
         ops.time_fourier(times, sd["sinu_pos_emb.0.weights"], four)
@@ -349,7 +384,9 @@ class VectorField:
             S, H, HS = self._activation_scales(table)
             p0, K = S.data_ptr(), self.N_KINDS
             ent.update(S=S, H=H, HS=HS, sp=[[[p0 + 4 * ((e * d["depth"] + i) * K + k) for k in range(K)] for i in range(d["depth"])] for e in range(n)])
-        if key is not None and not torch.cuda.is_current_stream_capturing():     # (tables made inside a capture belong to that graph's pool)
+        ent["ready"] = self._ready_event()
+        if key is not None and clean0 and self._flag_clear():     # (None inside a capture: tables made there belong to that graph's pool)
+            ent["cached"] = True
             while len(self._time_cache) >= self.TIME_CACHE:
                 old = next(iter(self._time_cache))
                 del self._time_cache[old]

@@ -378,12 +378,14 @@ def run(dialogue: bool, argv=None) -> int:
     pending: list = []
 
     def _finish(entry):
-        batch, y0, parts, flag, ev, nfr = entry
+        batch, y0, parts, flag, ev, nfr, st = entry
         ev.synchronize()
         if flag is not None and int(flag[0]) != 0:
             # a flagged batch is repeated with the per-call checks (the stage that saturated warns and re-runs in fp32, or raises
-            # under CVX_ON_SATURATION=raise)
-            parts, nfr = one_batch(batch, y0)
+            # under CVX_ON_SATURATION=raise) ON THE STREAM IT WAS ENQUEUED ON: the last batch of a two-stage run is collected after
+            # the runner has left its main stream - another stream owns other CUs, picks other GEMM kernels and does not own y0
+            with torch.cuda.stream(st):
+                parts, nfr = one_batch(batch, y0)
         _store(parts)
         now = time.perf_counter()
         batch_log.append((len(batch), sum(int(it[0].shape[0]) for it, _ in batch), nfr, now - batch_log_t[0]))
@@ -399,7 +401,7 @@ def run(dialogue: bool, argv=None) -> int:
         flag = ops.saturation_snapshot()
         ev = torch.cuda.Event()
         ev.record()
-        pending.append((batch, y0, parts, flag, ev, nfr))
+        pending.append((batch, y0, parts, flag, ev, nfr, torch.cuda.current_stream()))
         while len(pending) > 1:
             _finish(pending.pop(0))
         return nfr

@@ -207,6 +207,33 @@ def test_input_outside_the_window_is_rerun_in_fp32_or_raises(monkeypatch):
     assert rel_l2(ok, orc.sample(sd, inp["phoneme_ids"], inp["cond"], inp["y0"], 0.7, nfe=2)) < 1e-5
 
 
+def test_time_tables_built_by_a_flagged_call_are_not_cached():
+    """Round-5 advice: the per-(nfe, method) tables (time MLP, adaLN table, activation scales, deferred-norm weights) are built inside
+    the first call by split-precision kernels; if THAT call is flagged it alone is re-run in fp32 - a clamped table left in the cache
+    would be reused by every later call under a clean flag.  A checkpoint whose time MLP leaves the window (64 evaluation times: the
+    table product runs on the split-precision GEMM with split_act_f16(temb)): every call warns and returns the exact-fp32 result, and
+    nothing is cached; the healthy checkpoint caches its grid after the first call."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd.conditional_model import CoVoMixModel
+    sd = _full_width_state()
+    inp = syn.synthetic_inputs("vomix", 1, 80, 40, seed=5)
+    args = (inp["phoneme_ids"].cuda(), inp["cond"].cuda(), inp["mask"].cuda(), 0.7)
+    good = CoVoMixModel.from_state_dict(sd, nfe=64).eval().to("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        good.synthesis_sample(*args, y0=inp["y0"])
+    assert len(good._get_field()._time_cache) == 1
+    bad_sd = dict(sd)
+    bad_sd["sinu_pos_emb.1.bias"] = sd["sinu_pos_emb.1.bias"] + 3.0e5          # SiLU(3e5) = 3e5 > 65504: split_act_f16(temb) clamps
+    bad = CoVoMixModel.from_state_dict(bad_sd, nfe=64).eval().to("cuda:0")
+    ref = CoVoMixModel.from_state_dict(bad_sd, nfe=64, precision="fp32").eval().to("cuda:0").synthesis_sample(*args, y0=inp["y0"])
+    for _ in range(2):                                                         # the second call must not ride on a cached clamped table
+        with pytest.warns(UserWarning, match="saturat"):
+            out = bad.synthesis_sample(*args, y0=inp["y0"])
+        assert rel_l2(out, ref) < 1e-5
+        assert len(bad._get_field()._time_cache) == 0
+
+
 def test_nan_input_is_not_returned_as_a_finite_result(monkeypatch):
     """One NaN in the prompt mel / in the vocoder's mel: the fp32 reference returns NaN; the split path used to return finite
     numbers with the flag down (the clamps swallow NaN).  Now: flag -> fp32 re-run (NaN, like the reference) or a loud error."""
