@@ -546,7 +546,7 @@ def main():
         if os.path.isfile(pmc) and model.precision == "f16x3":      # the committed PMC passes profile the default precision
             try:
                 traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
-                # NOT measured by this run: PMC counters need their own rocprofv3 --pmc passes (tools/collect_profiles.sh)
+                # NOT measured by this run: PMC counters need their own rocprofv3 --pmc passes (tools/archive/collect_profiles.sh)
                 traffic_source = "profiles/pmc_summary.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
             except Exception:
                 traffic = None

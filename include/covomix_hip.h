@@ -93,8 +93,8 @@ int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t ct
  *   cvx_stream_create_cu_mask: hipExtStreamCreateWithCUMask -> *out_stream (a hipStream_t the caller owns; put it into a cvx_ctx
  *                              together with n_cus = the number of mask bits).  Bit k of the mask names CU (k / 8) of XCD (k % 8);
  *                              inside an XCD consecutive indices go round the four shader engines (measured on MI355X,
- *                              tools/cu_mask_probe.hip).  One-block-per-CU kernels are only co-resident when every shader engine keeps
- *                              the same number of CUs, i.e. when the CUs per XCD are a multiple of 4 (tools/cu_mask_probe2.hip: 30 CUs
+ *                              tools/archive/cu_mask_probe.hip).  One-block-per-CU kernels are only co-resident when every shader engine keeps
+ *                              the same number of CUs, i.e. when the CUs per XCD are a multiple of 4 (tools/archive/cu_mask_probe2.hip: 30 CUs
  *                              per XCD -> 12 of 240 blocks wait for a second round; 28 -> none).
  *   cvx_stream_destroy:        hipStreamDestroy of such a stream. */
 int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** out_stream);

@@ -398,7 +398,7 @@ class VectorField:
     # ------------------------------------------------------------------ deferred AdaptiveRMSNorm (large batches)
     DEFER_MIN_ROWS = int(os.environ.get("CVX_DEFER_NORM_ROWS", "8192"))
     DEFER_RULE = False       # (round 4 kept batches whose 256-row rounds came out part-empty - 18,000 / 20,480 rows - off this path; with the
-                             #  large-problem kernel's 192-row tiles, round 5, the path wins at every size from 8192 rows: tools/defer_rows_bench.py,
+                             #  large-problem kernel's 192-row tiles, round 5, the path wins at every size from 8192 rows: tools/archive/defer_rows_bench.py,
                              #  20,480 rows 448.7 vs 470.1 ms, 18,000 rows 404.2 vs 417.5, 9,300 rows 232.8 vs 242.1)
 
     def _defers(self, M: int, ws: dict) -> bool:

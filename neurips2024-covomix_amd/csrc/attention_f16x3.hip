@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 #ifndef CVX_ATT_WAVES
 #define CVX_ATT_WAVES 2
 #endif
-// ENERGY ABLATIONS (dev builds only, results are WRONG by construction; tools/attn_ablate.py): which part of the loop the
+// ENERGY ABLATIONS (dev builds only, results are WRONG by construction; tools/archive/attn_ablate.py): which part of the loop the
 // power-capped launch pays for.  bit 0: no L2 -> LDS DMA after the first tile (tiles stay resident); bit 1: no LDS fragment
 // reads after the first tile (K / V^T fragments stay in registers); bit 2: no v_exp_f32 (p = its argument); bit 3: no P.V
 // MFMAs; bit 4: no K.Q MFMAs.
@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_split4(f16* hi, f16* lo, int64_t off, cons
 #define CVX_ATT_SHORT_NW2 1
 #endif
 // NW = waves per block (4 or 8), 32 queries each.  The K / V^T tiles a block streams through LDS are shared by its waves:
-// with 8 waves (256 queries) the L2 -> LDS DMA bytes per score halve.  Round-3 ablations (tools/attn_ablate.py, Bt = 16,
+// with 8 waves (256 queries) the L2 -> LDS DMA bytes per score halve.  Round-3 ablations (tools/archive/attn_ablate.py, Bt = 16,
 // T = 1000, H = 16, NW = 4): DMA switched off after the first tile 177 instead of 211 us and 0.233
 // instead of 0.286 J (on zero operands, i.e. at full clock, 130 instead of 159 us); no LDS fragment reads -7 %; no
 // v_exp_f32 -1 %; no P.V MFMAs 140 us; no K.Q MFMAs 134 us.  Halving the DMA BYTES (NW = 8) does not buy the DMA-off time.

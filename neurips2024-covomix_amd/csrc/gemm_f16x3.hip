@@ -753,7 +753,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
 #ifdef CVX_DEV_FLAGS
         if (io->flags & 0x10000) ksplit = 1;               // (dev A/B: no K slices; 0x20000: two)
         if ((io->flags & 0x20000) && ksplit > 2) ksplit = 2;
-        if ((so.dbg & 4) && io->workspace)                 // stamps behind the split-K partials (tools/gemm_small_trace.py)
+        if ((so.dbg & 4) && io->workspace)                 // stamps behind the split-K partials (tools/archive/gemm_small_trace.py)
             so.trace = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(io->workspace) + ((size_t)100 << 20));
 #endif
         CVX_REQUIRE(cvxg::launch_gemm_f16x3_p8m(*a, A, wh, acc_scale, so, ksplit, ksplit > 1 ? io->workspace : nullptr, st),

@@ -20,7 +20,7 @@
 //     group 0, rows 32-63 in group 1; the sum is always group 0 + group 1: deterministic), so all eight waves run the epilogue.
 //   * XCD-aware block -> tile map: an XCD (block & 7, observed placement - speed only) owns whole W panels: the (at most 16) row
 //     tiles that share a W panel are dispatched back to back to ONE XCD, which fetches the panel from HBM once and serves the
-//     other seven reads from its L2; the (small) A operand is what every XCD reads.  tools/dma_probe2.hip: the LDS-DMA stream of
+//     other seven reads from its L2; the (small) A operand is what every XCD reads.  tools/archive/dma_probe2.hip: the LDS-DMA stream of
 //     the to_qkv / ff1 shapes at 1000 rows runs at 43-45 B/clk/CU with this map against 24-30 with row panels per XCD (the
 //     large-problem map), and a 128 x 128 x 32 K-tile at full matrix rate needs 42.
 //   * Optional split-K over blocks (ksplit > 1: K-slices ride in the unit index of the map): raw fp32 partial tiles to the
@@ -34,7 +34,7 @@ constexpr int MBUF_B = 2 * MT_B;                   // A | W
 constexpr int NBUF = 5;
 constexpr int MLDS_B = NBUF * MBUF_B;              // 160 KiB
 
-#ifdef CVX_DEV_FLAGS          // per-block s_memtime stamps of waves 0 and 4 (tools/gemm_small_trace.py; never in the shipped library)
+#ifdef CVX_DEV_FLAGS          // per-block s_memtime stamps of waves 0 and 4 (tools/archive/gemm_small_trace.py; never in the shipped library)
 #define CVX_P8M_STAMP(i) do { if (tr) { tr[i] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define CVX_P8M_STAMP(i) do { } while (0)

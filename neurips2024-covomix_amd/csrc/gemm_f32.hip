@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const cvx_gemm_args p,
         mfma_group<TM>(a, b, 3, acc);
         if constexpr (TM == 2) {
             // Issue order of this step (one scheduling region): memory instructions are spread ONE per MFMA
-            // instead of in bursts.  Measured on the probe (tools/mfma_probe.hip): a burst of 8 global loads
+            // instead of in bursts.  Measured on the probe (tools/archive/mfma_probe.hip): a burst of 8 global loads
             // costs 107 vs 135 TFLOP/s when the operands stream from HBM.
             //   q0: 4 frag reads | 8 x (MFMA, global load) | 4 x (2 MFMA, q1 frag read)
             //   q1: 4 x (4 MFMA, q2 frag read)

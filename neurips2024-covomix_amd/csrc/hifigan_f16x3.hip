@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     float omax = 0.f;
     // The residual / accumulate rows of one 32-position slice (TNI x 4 vectors each) are requested TOGETHER, ahead of the
     // slice's arithmetic: with a load in front of every store group the epilogue was a chain of 16-24 exposed HBM round
-    // trips per wave (tools/conv_trace.py: 22-28 us per block, as long as the k = 3 main loop).  Rows behind L are inside
+    // trips per wave (tools/archive/conv_trace.py: 22-28 us per block, as long as the k = 3 main loop).  Rows behind L are inside
     // the allocation (Lp >= halo + roundup(L, 256) + 64), so the loads need no predicate; the stores keep theirs.
 #pragma unroll
     for (int mi = 0; mi < TMI; ++mi) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
             atomicMax(p.amax_out, __float_as_uint(omax));        // (most waves cannot raise the maximum: no atomic)
     }
 #ifdef CVX_CONV_TRACE
-    // trace build (tools/conv_trace.py): with out_scale = 0 the fp32 output is all zero; the block leaves its 100 MHz stamps
+    // trace build (tools/archive/conv_trace.py): with out_scale = 0 the fp32 output is all zero; the block leaves its 100 MHz stamps
     // (start, end of the main loop, end) and its CU in its own first output row
     __syncthreads();
     if (tid == 0 && p.out_x && p.out_scale == 0.f && l0 < p.L) {

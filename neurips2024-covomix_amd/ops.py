@@ -501,9 +501,9 @@ def ensure_saturation_bound() -> None:
 class CUPartition:
     """Two streams of one device on DISJOINT sets of compute units: `main` (the acoustic solve and the vocoder) and `side` (the
     text2semantic decode of the next batch).  Bit k of a HIP CU mask names CU k // 8 of XCD k % 8 and consecutive indices of an XCD go
-    round its four shader engines (tools/cu_mask_probe.hip), so `side` takes the top `side_per_xcd` indices of every XCD
+    round its four shader engines (tools/archive/cu_mask_probe.hip), so `side` takes the top `side_per_xcd` indices of every XCD
     (side_per_xcd a multiple of 4: every shader engine keeps the same number of CUs, which one-block-per-CU kernels need to be
-    co-resident - tools/cu_mask_probe2.hip) and `main` the rest.  The streams live as long as the process."""
+    co-resident - tools/archive/cu_mask_probe2.hip) and `main` the rest.  The streams live as long as the process."""
 
     def __init__(self, device, side_per_xcd: int = 4):
         dev = torch.device(device)
@@ -554,7 +554,7 @@ def _destroy_partitions() -> None:
                 torch.cuda.synchronize()
                 # torch's pinned-memory allocator keeps events of the streams its blocks were last copied on (the decode's state
                 # record travels by non_blocking copies on the side stream): give the blocks back BEFORE their stream goes, or the
-                # allocator touches a dead stream at process exit (SIGSEGV, tools/cu_mask_exit_probe.py)
+                # allocator touches a dead stream at process exit (SIGSEGV, tools/archive/cu_mask_exit_probe.py)
                 # (without that call the streams are left to process teardown: destroying them under live pinned blocks is the crash)
                 if hasattr(torch._C, "_host_emptyCache"):
                     torch._C._host_emptyCache()

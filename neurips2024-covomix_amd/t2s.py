@@ -272,7 +272,7 @@ class TextToSemanticDecoder:
         """enqueue a copy of the records `src` [rows, SR] into pinned buffer k behind everything the current stream holds.
         On an ordinary stream: a non_blocking copy into pinned memory on the decode stream itself.  On a CU-masked stream of
         ops.CUPartition that form is NOT used: torch's pinned-memory allocator remembers the stream of such a copy, and a masked stream
-        destroyed at exit before the block is freed takes the process down (tools/cu_mask_exit_probe.py) - there the record is copied
+        destroyed at exit before the block is freed takes the process down (tools/archive/cu_mask_exit_probe.py) - there the record is copied
         device-to-device on the decode stream and a plain helper stream brings it to the host."""
         rows = src.shape[0]
         if via_helper:
