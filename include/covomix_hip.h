@@ -207,6 +207,8 @@ typedef struct {
 #define CVX_GEMM_FLAG_ONE_TILE 4    /* eight-phase 16x16x32 kernel: one output tile per block instead of persistent blocks (bit-identical results) */
 #define CVX_GEMM_FLAG_TILE192 64    /* large-problem kernel: 192-row tiles whatever the tile count (default: 192 where rounds x height come out smaller than with 256) */
 #define CVX_GEMM_FLAG_TILE256 128   /* ... 256-row tiles always (bit-identical results either way: A/B measurements) */
+#define CVX_GEMM_FLAG_TILE_MIXED 32 /* ... whole rounds of 256-row tiles + one launch of 192-row tiles over the rest, wherever such a split exists
+                                     * (default: where it is the cheapest of the three; bit-identical results) */
 int cvx_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n, float scale, cvx_stream_t s);
 /* n_sets interleaved split copies of ONE weight matrix with its COLUMNS scaled: out[s][n][il(k)] = split( W[n,k] * colscale[s*cs_ld + k] *
  * set_scale_dev[s*ss_ld] * scale ), each [N][K/32][hi 32 | lo 32] (the w_interleaved layout, row length 2K halves), K % 32 == 0.

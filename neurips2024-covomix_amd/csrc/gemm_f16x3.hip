@@ -681,6 +681,7 @@ static int gemm_f16x3_impl(const cvx_gemm_args* a, const uint16_t* W_hi, const u
         if (io->flags & CVX_GEMM_FLAG_ONE_TILE) so.dbg |= 8;      // scheduling only: same arithmetic, bit-identical results
         if (io->flags & CVX_GEMM_FLAG_TILE192) so.dbg |= 16;      // tile height of the large-problem kernel pinned (same bits either way)
         if (io->flags & CVX_GEMM_FLAG_TILE256) so.dbg |= 32;
+        if (io->flags & CVX_GEMM_FLAG_TILE_MIXED) so.dbg |= 64;
         if (io->Vt_hi || io->Vt_lo) {
             CVX_REQUIRE(io->Vt_hi && (io->Vt_lo || single) && so.hi && a->rope_cos && a->rope_cols > 0 && a->rope_cols % 128 == 0 &&
                         (a->N - a->rope_cols) * 2 == a->rope_cols && io->vt_ld >= ((a->rope_T + 15) / 16) * 16 && io->vt_ld % 8 == 0 &&

@@ -201,8 +201,9 @@ __device__ __forceinline__ void tile_mainloop(const cvx_gemm_args& p, const PreS
 template <bool HAS_A2, int EPI, int MI = 8>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
     const cvx_gemm_args p, const PreSplitA A, const f16* __restrict__ W, float acc_scale, SplitOut so,
-    int tiles_m, int tiles_n, int n_slots)
+    int tiles_m, int tiles_n, int n_slots, int m_base)
 {
+    // (m_base: first row of this launch - a problem may run as whole rounds of 256-row tiles plus a tail launch of 192-row tiles)
     // PERSISTENT over output tiles: block b walks tile slots b, b + gridDim.x, ... (gridDim.x is a multiple of 8, so all of
     // them sit on the XCD that owns their row panels: slot s -> XCD s & 7, row panel (s & 7) + 8 * ((s >> 3) / tiles_n)).
     // The LDS-DMA stream never stops at a tile boundary: the tail of a tile fetches the first six quarters of the next one,
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_p8s_kernel(
     auto tile_of_slot = [&](int s, int& m0, int& n0) {          // -> false for the padding slots of the XCD map
         const int xcd = s & 7, q = s >> 3;
         const int tm = xcd + 8 * (q / tiles_n), tn = q % tiles_n;
-        m0 = tm * (32 * MI); n0 = tn * 256;
+        m0 = m_base + tm * (32 * MI); n0 = tn * 256;
         return tm < tiles_m;
     };
     auto next_slot = [&](int s) {                                // next slot of this block that holds a real tile, or -1
@@ -303,18 +304,49 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
     // tile height: 256 rows, or 192 where rounds x height comes out smaller (a launch runs in rounds of one tile per CU and a tile's
     // time goes with its height).  so.dbg bits 16 / 32 pin 192 / 256 (CVX_GEMM_FLAG_TILE192 / _TILE256: A/B, bit-identity tests).
     const int cus8 = (n_cu / 8) * 8 > 0 ? (n_cu / 8) * 8 : 8;
-    // (a 192-row tile measures 0.81 of a 256-row one - 65.6 vs 81.3 us at 9,298 rows x N = 1024, one round each; W traffic per flop is 4/3 - so
-    //  it is priced at 0.8, not at its 0.75 of the rows: 5 rounds of 192 do not beat 4 of 256)
-    auto cost = [&](int h) { const long t = (long)((a.M + h - 1) / h) * tn; return ((t + cus8 - 1) / cus8) * (long)(h == 192 ? 205 : 256); };
-    const bool h192 = (so.dbg & 16) ? true : (so.dbg & 32) ? false : cost(192) < cost(256);
-    const int th = h192 ? 192 : 256;
-    const int tm = (a.M + th - 1) / th;
-    const int n_slots = ((tm + 7) / 8) * 8 * tn;                 // XCD map: an XCD owns whole row panels (padding slots are skipped)
+    // (a 192-row tile against a 256-row one, per round, measured at 18,596 rows in round 6 - profiles/r06_gemm_tile_forms.txt: 0.71-0.75 at
+    //  K = 1024 (to_qkv 63 vs 89 us, ff1 61 vs 83, to_out 61 vs 81), 0.79 at K = 2048 / 4096 (the W stream per flop is 4/3): priced at 0.75 /
+    //  0.8.  Round 5 priced every shape at 0.8 from one N = 1024 measurement and kept to_qkv of a 9,298-frame launch on 4 rounds of 256-row
+    //  tiles: 356 us against 315 for 5 rounds of 192.)
+    const long u192 = a.K <= 1024 ? 192 : 205;
+    auto cost = [&](int h) { const long t = (long)((a.M + h - 1) / h) * tn; return ((t + cus8 - 1) / cus8) * (long)(h == 192 ? u192 : 256); };
+    // MIXED (round 6): whole rounds of 256-row tiles, then ONE launch of 192-row tiles over the rows that are left - a ragged packed
+    // launch (9,298 utterance rows x 2 CFG branches = 18,596 rows, N = 4096) runs 4 full rounds + one short round instead of 5 rounds.
+    // r256 = row tiles of the first launch: the largest count whose tiles are whole rounds on this stream's CUs (and whole groups of 8
+    // row panels, the XCD map).  The launch boundary is NOT free: no prefetch across it, a drain and a ramp - ff1 at 18,596 rows
+    // measures 413.3 us mixed against 415.2 (256-row) where 4 x 83 + 61 = 393 was the model: ~20 us = 60 units.  So the form only wins
+    // where a whole round is saved at small round counts; it is bit-identical and stays selectable (CVX_GEMM_FLAG_TILE_MIXED).
+    long r256 = 0, cost_mixed = -1;
+    {
+        long step = cus8;                                           // smallest r with r * tn % cus8 == 0 ...
+        for (long r = 8; r <= cus8; r += 8) if ((r * tn) % cus8 == 0) { step = r; break; }
+        r256 = ((long)(a.M / 256) / step) * step;
+        const long rest = a.M - r256 * 256;
+        if (r256 > 0 && rest > 0) {
+            const long t = ((rest + 191) / 192) * tn;
+            cost_mixed = (r256 * tn / cus8) * 256 + ((t + cus8 - 1) / cus8) * u192 + 60;
+        }
+    }
+    const long c256 = cost(256), c192 = cost(192);
+    const bool pinned = (so.dbg & (16 | 32 | 64)) != 0;
+    const bool mixed = (so.dbg & 64) ? cost_mixed >= 0 : (!pinned && cost_mixed >= 0 && cost_mixed < c256 && cost_mixed < c192);
+    const bool h192 = (so.dbg & 16) ? true : (so.dbg & 32) ? false : c192 < c256;
     // persistent grid: one block per CU (136 KiB of LDS each), a multiple of 8; a next tile needs an even number of K-tiles
     // (the two LDS buffers alternate across the tile boundary), otherwise every tile gets its own block
-    int g = n_slots;
-    if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) g = n_slots < cus8 ? n_slots : cus8;
-    const dim3 grid((unsigned)g);
+    struct Part { int th, tm, n_slots, g, m_base; };
+    auto part = [&](int th, long rows, int m_base) {
+        Part q;
+        q.th = th; q.m_base = m_base;
+        q.tm = (int)((rows + th - 1) / th);
+        q.n_slots = ((q.tm + 7) / 8) * 8 * tn;                     // XCD map: an XCD owns whole row panels (padding slots are skipped)
+        q.g = q.n_slots;
+        if ((a.K / 32) % 2 == 0 && !(so.dbg & 8)) q.g = q.n_slots < cus8 ? q.n_slots : cus8;
+        return q;
+    };
+    Part parts[2];
+    int n_parts = 1;
+    if (mixed) { parts[0] = part(256, r256 * 256, 0); parts[1] = part(192, a.M - r256 * 256, (int)(r256 * 256)); n_parts = 2; }
+    else parts[0] = part(h192 ? 192 : 256, a.M, 0);
     int epi = classify_epilogue(a, so);
     if (epi == EPI_QKV && a.bias) epi = EPI_GENERIC;
     if (so.tw_gamma || so.rowsq || so.row_scale || so.res_hi) {         // deferred norm: its own instances, nothing else carries it
@@ -333,13 +365,18 @@ bool launch_gemm_f16x3_p8s(const cvx_gemm_args& a, const PreSplitA& A, const f16
                           (so.res_hi && (so.res_ld & 7) != 0))) return false;
     if (epi == EPI_GENERIC && so.vt_hi) return false;
     if (so.a2_scale && !(epi == EPI_BIAS_TW && so.a_scale)) return false;
-#define CVX_P8S_LAUNCH_MI(A2, E, MI_)                                                                                   \
+#define CVX_P8S_LAUNCH_MI(A2, E, MI_, Q)                                                                                \
     do {                                                                                                                \
         cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_f16x3_p8s_kernel<A2, E, MI_>), LDS_B);                \
-        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E, MI_>), grid, dim3(512), LDS_B, st, a, A, w_il, acc_scale, so, tm, tn, n_slots); \
+        hipLaunchKernelGGL((gemm_f16x3_p8s_kernel<A2, E, MI_>), dim3((unsigned)(Q).g), dim3(512), LDS_B, st, a, A, w_il, acc_scale, so,    \
+                           (Q).tm, tn, (Q).n_slots, (Q).m_base);                                                        \
     } while (0)
 #define CVX_P8S_LAUNCH(A2, E)                                                                                           \
-    do { if (h192) CVX_P8S_LAUNCH_MI(A2, E, 6); else CVX_P8S_LAUNCH_MI(A2, E, 8); } while (0)
+    do {                                                                                                                \
+        for (int pi = 0; pi < n_parts; ++pi) {                                                                          \
+            if (parts[pi].th == 192) CVX_P8S_LAUNCH_MI(A2, E, 6, parts[pi]); else CVX_P8S_LAUNCH_MI(A2, E, 8, parts[pi]); \
+        }                                                                                                               \
+    } while (0)
     if (A.hi2) {
         if (epi == EPI_BIAS) CVX_P8S_LAUNCH(true, EPI_BIAS); else if (epi == EPI_BIAS_TW) CVX_P8S_LAUNCH(true, EPI_BIAS_TW); else CVX_P8S_LAUNCH(true, EPI_GENERIC);
     } else {

@@ -275,30 +275,38 @@ def pack_by_frames(indices: Sequence[int], lengths: Sequence[int], max_frames: i
 def launch_cost(frames: int, cus: int = 256, dim: int = 1024) -> float:
     """Relative time of the transformer GEMMs of ONE packed launch of `frames` frames (both CFG branches: 2 x frames rows) in units
     of one round of 256 x 256 tiles at K = dim: the large-problem kernel runs in rounds of one tile per CU, with 256- or 192-row
-    tiles, whichever gives fewer, shorter rounds (gemm_f16x3_p8s.hip); per layer to_qkv (12 column tiles), to_out (4), ff1 (16), ff2
+    tiles, whichever gives fewer, shorter rounds, or whole rounds of 256-row tiles plus a tail launch of 192-row tiles (gemm_f16x3_p8s.hip); per layer to_qkv (12 column tiles), to_out (4), ff1 (16), ff2
     (4, K = 4 dim) and a skip combiner in every other layer (4, K = 2 dim).  A cost model for the packing only."""
     rows = 2 * int(frames)
     up = lambda a, b: -(-a // b)
     ct = lambda n: up(n, 256)
 
-    def rounds(tn):
-        return min(up(up(rows, 256) * tn, cus), 0.8 * up(up(rows, 192) * tn, cus))
+    def rounds(tn, f192=0.75):
+        # (a round of 192-row tiles costs 0.75 of a round of 256-row tiles at K = dim, 0.8 at K = 2 dim / 4 dim: gemm_f16x3_p8s.hip)
+        best = min(up(up(rows, 256) * tn, cus), f192 * up(up(rows, 192) * tn, cus))
+        # whole rounds of 256-row tiles + one launch of 192-row tiles over the rest (round 6; the launch boundary costs ~ a quarter round)
+        step = next((r for r in range(8, cus + 1, 8) if (r * tn) % cus == 0), cus)
+        r256 = (rows // 256) // step * step
+        rest = rows - 256 * r256
+        if r256 > 0 and rest > 0:
+            best = min(best, r256 * tn // cus + f192 * up(up(rest, 192) * tn, cus) + 0.25)
+        return best
     n1 = ct(dim)
-    return rounds(3 * n1) + rounds(n1) + rounds(4 * n1) + 4 * rounds(n1) + 0.5 * 2 * rounds(n1)
+    return rounds(3 * n1) + rounds(n1) + rounds(4 * n1) + 4 * rounds(n1, 0.8) + 0.5 * 2 * rounds(n1, 0.8)
 
 
 def choose_max_frames(lengths: Sequence[int], max_batch: int, cus: int = 256, candidates: Sequence[int] = (8192, 12288, 16384, 24576)) -> int:
     """Frames per launch for a directory: the candidate cap (scaled to the CUs the acoustic stage owns) whose first-fit-decreasing
     packing costs least under launch_cost - a directory whose tail would make a part-empty second launch is better off as one larger
     launch (more rounds: finer quantisation), e.g. 12,799 frames: 8,150 + 4,649 frames cost 13 + 9.75 units, one launch of 12,799 frames
-    20.25.  Ties go to the smaller cap (less workspace).  Deterministic in the lengths: every rank chooses alike."""
+    20.25.  Ties and gains below 1.5 % go to the smaller cap (less workspace).  Deterministic in the lengths: every rank chooses alike."""
     best, best_cost = None, None
     idx = list(range(len(lengths)))
     for c in candidates:
         cap = max(256, c * cus // 256)
         bins = pack_by_frames(idx, lengths, cap, max_batch)
         cost = sum(launch_cost(sum(int(lengths[i]) for i in b), cus) for b in bins)
-        if best_cost is None or cost < best_cost - 1e-9:
+        if best_cost is None or cost < best_cost * 0.985:          # (a bigger cap - more workspace - has to buy more than the model's noise)
             best, best_cost = cap, cost
     return int(best)
 

@@ -368,7 +368,9 @@ def test_launch_cost_model_and_frames_per_launch():
     full = dp.launch_cost(8192)                    # 16384 rows = 64 row panels: qkv 3 + out 1 + ff1 4 + ff2 4 + skip 1 rounds
     assert full == 13.0
     assert dp.launch_cost(8150) == 13.0            # (the last panel is ragged: same rounds)
-    assert dp.launch_cost(4649) == pytest.approx(2 + 0.8 + 3 + 4 * 0.8 + 0.8)      # N = 1024 products on 192-row tiles: one round at 0.8
+    # 9,298 rows: to_qkv 37 x 12 tiles = 2 rounds of 256-row tiles; N = 1024 products on 192-row tiles: one round at 0.75 (K = dim) / 0.8 (K > dim);
+    # ff1 (16 column tiles): 3 rounds of 256-row tiles, 4 of 192-row ones at 0.75 - the same; the mixed form pays its launch boundary
+    assert dp.launch_cost(4649) == pytest.approx(2 + 0.75 + 3 + 4 * 0.8 + 0.8)
     assert dp.launch_cost(4649) / 4649 > full / 8192                               # a part-empty launch costs more per frame
     assert dp.launch_cost(7168, cus=224) == 13.0                                   # the same whole rounds on 224 CUs
     lengths = [400, 1200, 451, 1149, 503, 1097, 555, 1044, 607, 993, 659, 941, 711, 889, 763, 837]      # the ragged test directory

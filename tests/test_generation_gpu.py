@@ -343,8 +343,8 @@ def test_cli_rate_matches_bench_path(tmp_path):
 
     def step():
         mel = model.synthesis_sample(ids, cond, mask, 0.7, y0=torch.randn(8, T, 80, device="cuda"))
-        return ops.wav_to_int16(gen(mel[:, P:].permute(0, 2, 1).contiguous()).squeeze(1).contiguous()).cpu()
-    step()
+        return ops.wav_to_int16(gen(mel[:, P:].permute(0, 2, 1).contiguous()).squeeze(1).contiguous())      # (stays on the device, like bench.py's step:
+    step()                                                                                                 #  no blocking copy ends the step - round-5 review)
     bench_rate = 0.0
     for _ in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -413,8 +413,8 @@ def test_cli_rate_on_ragged_directory(tmp_path):
 
     def step():
         mel = model.synthesis_sample(ids, cond, mask, 0.7, y0=torch.randn(8, T, 80, device="cuda"))
-        return ops.wav_to_int16(gen(mel[:, P:].permute(0, 2, 1).contiguous()).squeeze(1).contiguous()).cpu()
-    step()
+        return ops.wav_to_int16(gen(mel[:, P:].permute(0, 2, 1).contiguous()).squeeze(1).contiguous())      # (stays on the device, like bench.py's step:
+    step()                                                                                                 #  no blocking copy ends the step - round-5 review)
     bench_rate = 0.0
     for _ in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -425,7 +425,7 @@ def test_cli_rate_on_ragged_directory(tmp_path):
     print(f"ragged directory: CLI {cli_rate:.0f} generated frames/s vs bench-style loop {bench_rate:.0f}: ratio {cli_rate / bench_rate:.3f}")
     print(f"  {cli['seconds'] * 1e3:.1f} ms = inputs from files {cli['load_seconds'] * 1e3:.1f} ms + batches (utterances, frames, ms): "
           + ", ".join(f"({n}, {fr}, {sec * 1e3:.1f})" for n, fr, _, sec in cli["batches"]) + f"; max_frames {cli['max_frames']}")
-    assert cli["frames"] == gen_frames and cli_rate >= 0.88 * bench_rate
+    assert cli["frames"] == gen_frames and cli_rate >= 0.92 * bench_rate          # (measured 0.95 on the round-6 boxes)
 
 
 

@@ -1022,7 +1022,7 @@ def test_gemm_deferred_norm_producer_and_consumers(ops, M):
         ops.gemm(x, w, c, w_split=ws, w_il=wil, a_split=il, a_row_scale=rs)            # fp32 store with a row factor: not a consumer form
 
 
-@pytest.mark.parametrize("M", [2100, 9298])
+@pytest.mark.parametrize("M", [2100, 9298, 18596])
 def test_gemm_192_row_tiles_are_bit_identical_to_256_row_tiles(ops, M):
     """Round 5: the large-problem kernel in its 192-row form (three instead of four A tiles per M half; taken where rounds x height
     come out smaller, e.g. 9,298 rows x N = 1024: 196 tiles of 192 rows instead of 148 of 256) - every output element is the same
@@ -1082,11 +1082,12 @@ def test_gemm_192_row_tiles_are_bit_identical_to_256_row_tiles(ops, M):
                      write_f32=False, a_row_scale=rs); out.append(o2.buf.clone())
         torch.cuda.synchronize()
         return out
-    t256, t192, auto = run(16 | 128), run(16 | 64), run(16)
+    t256, t192, auto, mixed = run(16 | 128), run(16 | 64), run(16), run(16 | 32)
     assert len(t256) == len(t192) == 13
-    for k, (a, b, c_) in enumerate(zip(t256, t192, auto)):
+    for k, (a, b, c_, d_) in enumerate(zip(t256, t192, auto, mixed)):
         assert torch.equal(a, b), k
         assert torch.equal(a, c_), k
+        assert torch.equal(a, d_), k          # round 6: whole rounds of 256-row tiles + a tail launch of 192-row tiles (flag 32)
     assert rel_l2(t192[0], xs @ W1[0].double().T) < 1e-6
     assert rel_l2(t192[1], xs @ W1[0].double().T + b1.double() + r.double()) < 1e-6
     o_pair = t192[3].view(M, 64, 2, 32)
