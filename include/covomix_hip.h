@@ -427,6 +427,10 @@ typedef struct {
     cvx_item_lengths items;                      /* ragged batch (valid positions per item, of L) or {NULL, 0, 0} */
 } cvx_conv16_args;
 int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s);
+/* n (1..3) INDEPENDENT convolutions of one shape (B, L, Lp, Cp_in, Np, halo_l, items; kernel size, dilation, weights, inputs and outputs their
+ * own; outputs must not alias) as ONE launch: the same results as n calls above, bit for bit - the tiles of the short kernels fill the rounds
+ * of the long one (round 6: the three ResBlocks of a generator stage, kernel sizes 3 / 7 / 11, models.py:104-110). */
+int cvx_hifigan_conv1d_group_f16x3(const cvx_conv16_args* a, int32_t n, cvx_stream_t s);
 
 /* ResBlock1.forward (covomix/vocoder/models.py:35-42) on the split-precision convolution above - the operator-level
  * form of section 8(b)'s cvx_hifigan_resblock_* for the path the host actually runs: three times
@@ -452,6 +456,12 @@ typedef struct {
     cvx_item_lengths items;                      /* ragged batch (valid positions per item, of L) or {NULL, 0, 0} */
 } cvx_resblock16_args;
 int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stream_t s);
+/* The n (1..3) ResBlocks of ONE generator stage (models.py:104-110: xs = sum_j resblocks[j](x), / num_kernels): the results of
+ * cvx_hifigan_resblock_f16x3(&blocks[0]) ... (&blocks[n-1]), bit for bit, with the convolutions of different blocks that do not depend on
+ * each other sharing launches (cvx_hifigan_conv1d_group_f16x3; 18 -> 8 launches on a wide stage).  The blocks name the same x / z / shape, their
+ * OWN scratch (t, xa/za, xb/zb) and may share `out`, which their last convolutions accumulate into in block order (blocks[j].accum = out for
+ * j > 0).  Blocks that do not qualify (narrow stages: fused pair kernels; shared scratch) run one after the other. */
+int cvx_hifigan_resblock_stage_f16x3(const cvx_resblock16_args* blocks, int32_t n, cvx_stream_t s);
 
 /* One ResBlock1 pair  out = (c2(leaky_relu(c1(leaky_relu(x, .1)), .1)) + x (+ accum)) * out_scale  (models.py:36-40; c1:
  * dilation dil, c2: dilation 1, both kernel size ksize) as ONE kernel for the narrow stages (Np = 32 or 64): the

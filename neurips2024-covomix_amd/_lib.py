@@ -212,6 +212,8 @@ SIGNATURES = {
     "cvx_hifigan_convt_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "cvx_hifigan_resblock_f32": (C.c_int, [C.POINTER(ResblockArgs), C.c_void_p]),
     "cvx_hifigan_resblock_f16x3": (C.c_int, [C.POINTER(Resblock16Args), C.c_void_p]),
+    "cvx_hifigan_resblock_stage_f16x3": (C.c_int, [C.POINTER(Resblock16Args), C.c_int32, C.c_void_p]),
+    "cvx_hifigan_conv1d_group_f16x3": (C.c_int, [C.POINTER(Conv16Args), C.c_int32, C.c_void_p]),
     "cvx_hifigan_resblock_pair_f16x3": (C.c_int, [C.POINTER(Respair16Args), C.c_void_p]),
     "cvx_hifigan_conv_transpose1d_f32": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p]),
     "cvx_hifigan_conv_transpose1d_packed_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -131,6 +131,74 @@ extern "C" int cvx_hifigan_resblock_f16x3(const cvx_resblock16_args* a, cvx_stre
     return CVX_OK;
 }
 
+// The ResBlocks of one generator stage (models.py:104-110: xs = sum_j resblocks[j](x), / num_kernels) - the calls
+// cvx_hifigan_resblock_f16x3(&blocks[0]), ..., (&blocks[n-1]) with the SAME results, bit for bit, but with the convolutions that do not
+// depend on each other sharing a launch: the blocks read the same x / z, keep their own scratch, and only meet in `out`, which their last
+// convolutions accumulate into IN BLOCK ORDER (those stay one launch each).  Narrow stages (fused pair kernels) run block by block.
+extern "C" int cvx_hifigan_resblock_stage_f16x3(const cvx_resblock16_args* blocks, int32_t n, cvx_stream_t s)
+{
+    CVX_REQUIRE(blocks && n >= 1 && n <= 3, "hifigan_resblock_stage_f16x3: 1..3 ResBlocks per stage call (got %d)", n);
+    bool group = n > 1 && blocks[0].Np > 64;
+    for (int j = 1; j < n && group; ++j) {
+        const cvx_resblock16_args &a = blocks[j], &b = blocks[0];
+        group = a.x == b.x && a.z_hi == b.z_hi && a.z_lo == b.z_lo && a.B == b.B && a.L == b.L && a.Lp == b.Lp && a.Np == b.Np &&
+                a.halo_l == b.halo_l && a.z_scale_dev == b.z_scale_dev && a.items.item_len_dev == b.items.item_len_dev &&
+                a.items.mul == b.items.mul && a.items.add == b.items.add;
+        for (int h = 0; h < j && group; ++h)          // own scratch each (the grouped convolutions run concurrently)
+            group = a.t_hi != blocks[h].t_hi && a.xa != blocks[h].xa && a.xb != blocks[h].xb && a.za_hi != blocks[h].za_hi &&
+                    a.zb_hi != blocks[h].zb_hi;
+    }
+    if (!group) {
+        for (int j = 0; j < n; ++j) {
+            const int rc = cvx_hifigan_resblock_f16x3(&blocks[j], s);
+            if (rc != CVX_OK) return rc;
+        }
+        return CVX_OK;
+    }
+    for (int j = 0; j < n; ++j) {
+        const cvx_resblock16_args& a = blocks[j];
+        CVX_REQUIRE(a.x && a.out && a.xa && a.xb && a.z_hi && a.z_lo && a.t_hi && a.t_lo && a.za_hi && a.za_lo && a.zb_hi && a.zb_lo,
+                    "hifigan_resblock_stage_f16x3: null pointer in block %d", j);
+    }
+    cvx_conv16_args c[3];
+    for (int m = 0; m < 3; ++m) {
+        // t_j = split(leaky_relu(c1_j(z_j)))                                models.py:36-38 - all blocks in one launch
+        for (int j = 0; j < n; ++j) {
+            const cvx_resblock16_args& a = blocks[j];
+            CVX_REQUIRE(a.c1[m].w_hi && a.c2[m].w_hi && a.dil[m] > 0, "hifigan_resblock_stage_f16x3: missing weights / dilation of pair %d", m);
+            cvx_conv16_args& q = c[j];
+            q = cvx_conv16_args{};
+            q.B = a.B; q.L = a.L; q.Lp = a.Lp; q.Cp_in = a.Np; q.halo_l = a.halo_l; q.Np = a.Np; q.ksize = a.ksize;
+            q.z_slope = 0.1f; q.out_scale = 1.0f; q.z_scale_dev = a.z_scale_dev; q.items = a.items;
+            q.z_hi = m == 0 ? a.z_hi : (m == 1 ? a.za_hi : a.zb_hi); q.z_lo = m == 0 ? a.z_lo : (m == 1 ? a.za_lo : a.zb_lo);
+            q.dil = a.dil[m];
+            q.w_hi = a.c1[m].w_hi; q.w_lo = a.c1[m].w_lo; q.acc_scale = a.c1[m].acc_scale; q.bias = a.c1[m].bias;
+            q.out_zhi = a.t_hi; q.out_zlo = a.t_lo;
+        }
+        int rc = cvx_hifigan_conv1d_group_f16x3(c, n, s);
+        if (rc != CVX_OK) return rc;
+        // x'_j = c2_j(t_j) + x_j ; z'_j = split(leaky_relu(x'_j))           models.py:38-40
+        for (int j = 0; j < n; ++j) {
+            const cvx_resblock16_args& a = blocks[j];
+            cvx_conv16_args& q = c[j];
+            q.z_hi = a.t_hi; q.z_lo = a.t_lo; q.dil = 1;
+            q.w_hi = a.c2[m].w_hi; q.w_lo = a.c2[m].w_lo; q.acc_scale = a.c2[m].acc_scale; q.bias = a.c2[m].bias;
+            q.res = m == 0 ? a.x : (m == 1 ? a.xa : a.xb);
+            if (m < 2) {
+                q.out_x = m == 0 ? a.xa : a.xb;
+                q.out_zhi = m == 0 ? a.za_hi : a.zb_hi; q.out_zlo = m == 0 ? a.za_lo : a.zb_lo;
+            } else {                                                        // last pair: folds into the generator's xs, block after block
+                q.out_x = a.out; q.accum = a.accum; q.out_scale = a.out_scale; q.out_zhi = nullptr; q.out_zlo = nullptr;
+            }
+        }
+        if (m < 2) rc = cvx_hifigan_conv1d_group_f16x3(c, n, s);
+        else
+            for (int j = 0; j < n && rc == CVX_OK; ++j) rc = cvx_hifigan_conv1d_f16x3(&c[j], s);
+        if (rc != CVX_OK) return rc;
+    }
+    return CVX_OK;
+}
+
 extern "C" int cvx_hifigan_pre_post_f32(const cvx_conv_args* pre, const float* post_x, const float* post_w, float post_bias,
                                         float* post_y, int32_t B, int32_t C, int32_t L, float slope, cvx_stream_t s)
 {

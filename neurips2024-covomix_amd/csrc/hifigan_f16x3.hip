@@ -64,6 +64,14 @@ struct Conv16Args {
     uint32_t* amax_out;                // receives the bit pattern of max |out_x| (atomicMax) or NULL
 };
 
+// Kernel argument: ONE convolution, or (GRP) up to three INDEPENDENT convolutions of one shape that share a launch - blockIdx.z picks the
+// problem.  The three ResBlocks of a generator stage (kernel sizes 3 / 7 / 11) are independent until their results are summed
+// (models.py:104-110): launched one by one each of their convolutions is ~2.4 rounds of tiles (one round of 157 at the 250-channel stage
+// of the bench shape), launched together the tiles of the short kernels fill the rounds of the long one (problems ordered by
+// descending kernel size: longest tiles first).
+template <bool GRP> struct ConvKArgs { Conv16Args a; };
+template <> struct ConvKArgs<true> { Conv16Args a[3]; };
+
 // ds_read_b128 with an immediate byte offset, issued from asm: the compiler does not count it, the waits are explicit
 __device__ __forceinline__ f16x8 lds_read16(uint32_t addr, const int off)
 {
@@ -72,9 +80,10 @@ __device__ __forceinline__ f16x8 lds_read16(uint32_t addr, const int off)
     return v;
 }
 
-template <int TMI, int TNI, int WN>
-__global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
+template <int TMI, int TNI, int WN, bool GRP = false>
+__global__ __launch_bounds__(512) void conv_f16x3_kernel(const ConvKArgs<GRP> P)
 {
+    const Conv16Args& p = [&]() -> const Conv16Args& { if constexpr (GRP) return P.a[blockIdx.z]; else return P.a; }();
     constexpr int WM = 8 / WN;
     constexpr int NP = WN * TNI * 32;
     constexpr int TS = 256 / NP;                         // taps per weight stage
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
     float amax = 0.f;
     const int l0 = blockIdx.x * TMB;
     const int b = blockIdx.y;
-    const int zt = blockIdx.z;
+    const int zt = GRP ? 0 : (int)blockIdx.z;           // (grouped problems are plain convolutions: one output-column tile each)
     const int ksize = p.zk[zt], pad = p.zpad[zt];
     const f16* const w_hi = p.w_hi + p.zw[zt];
     const f16* const w_lo = p.w_lo + p.zw[zt];
@@ -320,9 +329,10 @@ __global__ __launch_bounds__(512) void conv_f16x3_kernel(const Conv16Args p)
 // pays is the tile height: 256 blocks of 160 positions 114.0 us against 120.6 us for 216 blocks of 192 (-5.5 %, 19 launches per
 // generator call).  So only the <5, 4, 4> instance is dispatched (dispatch_conv16), and only where it fills the chip better.
 // TM16 / TN16 = 16-position / 16-channel tiles per wave; WN waves side by side over the channels (8 / WN over the positions).
-template <int TM16, int TN16, int WN>
-__global__ __launch_bounds__(512) void conv_f16x3_m16_kernel(const Conv16Args p)
+template <int TM16, int TN16, int WN, bool GRP = false>
+__global__ __launch_bounds__(512) void conv_f16x3_m16_kernel(const ConvKArgs<GRP> P)
 {
+    const Conv16Args& p = [&]() -> const Conv16Args& { if constexpr (GRP) return P.a[blockIdx.z]; else return P.a; }();
 #define CVX_C16_MM(w, z, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(w, z, c, 0, 0, 0)
     constexpr int WM = 8 / WN;
     constexpr int NP = WN * TN16 * 16;
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(512) void conv_f16x3_m16_kernel(const Conv16Args p)
     float amax = 0.f;
     const int l0 = blockIdx.x * TMB;
     const int b = blockIdx.y;
-    const int zt = blockIdx.z;
+    const int zt = GRP ? 0 : (int)blockIdx.z;           // (grouped problems are plain convolutions: one output-column tile each)
     const int ksize = p.zk[zt], pad = p.zpad[zt];
     const f16* const w_hi = p.w_hi + p.zw[zt];
     const f16* const w_lo = p.w_lo + p.zw[zt];
@@ -948,40 +958,58 @@ __global__ __launch_bounds__(256) void cl_to_cm_kernel(const float* __restrict__
 }
 
 template <int TMI, int TNI, int WN>
-void launch_conv16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
+void launch_conv16(const Conv16Args* a, int n_grp, int B, int n_ztiles, hipStream_t st)
 {
     constexpr int tmb = (8 / WN) * TMI * 32;
     const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
-    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN>), (int)lds);
-    dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
-    hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN>), grid, dim3(512), lds, st, a);
+    if (n_grp > 0) {                  // n_grp independent problems of one shape: blockIdx.z = problem
+        ConvKArgs<true> P;
+        for (int g = 0; g < 3; ++g) P.a[g] = a[g < n_grp ? g : 0];
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN, true>), (int)lds);
+        dim3 grid((unsigned)((a[0].L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_grp);
+        hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN, true>), grid, dim3(512), lds, st, P);
+        return;
+    }
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_kernel<TMI, TNI, WN, false>), (int)lds);
+    dim3 grid((unsigned)((a[0].L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
+    hipLaunchKernelGGL((conv_f16x3_kernel<TMI, TNI, WN, false>), grid, dim3(512), lds, st, ConvKArgs<false>{a[0]});
 }
 template <int TM16, int TN16, int WN>
-void launch_conv16_m16(const Conv16Args& a, int B, int n_ztiles, hipStream_t st)
+void launch_conv16_m16(const Conv16Args* a, int n_grp, int B, int n_ztiles, hipStream_t st)
 {
     constexpr int tmb = (8 / WN) * TM16 * 16;
     const size_t lds = (size_t)LDS_HALVES * sizeof(f16);
-    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_m16_kernel<TM16, TN16, WN>), (int)lds);
-    dim3 grid((unsigned)((a.L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
-    hipLaunchKernelGGL((conv_f16x3_m16_kernel<TM16, TN16, WN>), grid, dim3(512), lds, st, a);
+    if (n_grp > 0) {
+        ConvKArgs<true> P;
+        for (int g = 0; g < 3; ++g) P.a[g] = a[g < n_grp ? g : 0];
+        cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_m16_kernel<TM16, TN16, WN, true>), (int)lds);
+        dim3 grid((unsigned)((a[0].L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_grp);
+        hipLaunchKernelGGL((conv_f16x3_m16_kernel<TM16, TN16, WN, true>), grid, dim3(512), lds, st, P);
+        return;
+    }
+    cvx_allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f16x3_m16_kernel<TM16, TN16, WN, false>), (int)lds);
+    dim3 grid((unsigned)((a[0].L + tmb - 1) / tmb), (unsigned)B, (unsigned)n_ztiles);
+    hipLaunchKernelGGL((conv_f16x3_m16_kernel<TM16, TN16, WN, false>), grid, dim3(512), lds, st, ConvKArgs<false>{a[0]});
 }
 
 // kernel instance by output tile width; Np = 256: one block per CU, and the block height is the one whose rounds x height comes
 // out smallest on this chip - 256 or 192 positions on the 32x32x16 kernel, or 160 on the 16x16x32 one (measured 13 % slower per
 // position, rocprofv3: 114 us for 256 blocks of 160 against 120.6 for 216 blocks of 192 on stage 0 of the bench shape, 8 x 5,000
 // positions - it wins where it fills the chip: 160 -> 216 -> 256 blocks there)
-void dispatch_conv16(const Conv16Args& k, int B, int n_ztiles, hipStream_t st, int cus)
+// k: the problem (n_grp == 0, n_ztiles output-column tiles) or n_grp problems of one shape (one column tile each)
+void dispatch_conv16(const Conv16Args* k, int n_grp, int B, int n_ztiles, hipStream_t st, int cus)
 {
-    if (k.Np == 256) {
-        auto cost = [&](int rows) { const int64_t n = (int64_t)((k.L + rows - 1) / rows) * B * n_ztiles; return (double)((n + cus - 1) / cus * rows); };
+    const int nz = n_grp > 0 ? n_grp : n_ztiles;
+    if (k[0].Np == 256) {
+        auto cost = [&](int rows) { const int64_t n = (int64_t)((k[0].L + rows - 1) / rows) * B * nz; return (double)((n + cus - 1) / cus * rows); };
         const double t256 = cost(256), t192 = cost(192), t160 = 1.13 * cost(160);
-        if (t160 < t256 && t160 < t192) launch_conv16_m16<5, 4, 4>(k, B, n_ztiles, st);
-        else if (t192 < t256) launch_conv16<3, 2, 4>(k, B, n_ztiles, st);
-        else launch_conv16<4, 2, 4>(k, B, n_ztiles, st);
+        if (t160 < t256 && t160 < t192) launch_conv16_m16<5, 4, 4>(k, n_grp, B, n_ztiles, st);
+        else if (t192 < t256) launch_conv16<3, 2, 4>(k, n_grp, B, n_ztiles, st);
+        else launch_conv16<4, 2, 4>(k, n_grp, B, n_ztiles, st);
     }
-    else if (k.Np == 128) launch_conv16<2, 2, 2>(k, B, n_ztiles, st);
-    else if (k.Np == 64) launch_conv16<1, 2, 1>(k, B, n_ztiles, st);
-    else launch_conv16<1, 1, 1>(k, B, n_ztiles, st);
+    else if (k[0].Np == 128) launch_conv16<2, 2, 2>(k, n_grp, B, n_ztiles, st);
+    else if (k[0].Np == 64) launch_conv16<1, 2, 1>(k, n_grp, B, n_ztiles, st);
+    else launch_conv16<1, 1, 1>(k, n_grp, B, n_ztiles, st);
 }
 
 // ---------------------------------------------------------------- fp32 channels-last -> split pair; conv_post on channels-last
@@ -1037,7 +1065,8 @@ __global__ __launch_bounds__(256) void post_cl_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s)
+// validate one convolution and fill the kernel's argument block
+static int build_conv16(const cvx_conv16_args* a, cvx_stream_t s, Conv16Args& k)
 {
     CVX_REQUIRE(a && a->z_hi && a->z_lo && a->w_hi && a->w_lo && a->bias, "conv1d_f16x3: null pointer");
     CVX_REQUIRE(a->B >= 0 && a->L > 0 && a->Cp_in > 0 && a->Cp_in % 32 == 0 &&
@@ -1050,18 +1079,55 @@ extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s
                 "conv1d_f16x3: buffers need %d zero rows in front and Lp >= halo_l + roundup(L, 256) + 64 (halo_l=%d Lp=%d)", pad, a->halo_l, a->Lp);
     CVX_REQUIRE((a->out_zhi == nullptr) == (a->out_zlo == nullptr) && (a->out_x || a->out_zhi) && (!a->accum || a->out_x),
                 "conv1d_f16x3: bad output combination");
-    if (a->B == 0) return CVX_OK;
     if (a->out_zhi) CVX_REQUIRE_SAT(s);
-    Conv16Args k{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
-                 reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
-                 reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
-                 a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev,
-                 a->out_zhi ? cvx_sat_flag_for(s) : nullptr, a->items, {}, {}, {}, 0, 0, 0, 0, 0, 0, nullptr};
+    k = Conv16Args{reinterpret_cast<const f16*>(a->z_hi), reinterpret_cast<const f16*>(a->z_lo),
+                   reinterpret_cast<const f16*>(a->w_hi), reinterpret_cast<const f16*>(a->w_lo), a->bias, a->res, a->accum, a->out_x,
+                   reinterpret_cast<f16*>(a->out_zhi), reinterpret_cast<f16*>(a->out_zlo),
+                   a->L, a->Lp, a->Cp_in, a->Np, a->ksize, a->dil, pad, a->halo_l, a->acc_scale, a->out_scale, a->z_slope, a->z_scale_dev,
+                   a->out_zhi ? cvx_sat_flag_for(s) : nullptr, a->items, {}, {}, {}, 0, 0, 0, 0, 0, 0, nullptr};
     k.zk[0] = a->ksize; k.zpad[0] = pad; k.zw[0] = 0;                  // one output-column tile, the plain layout
     k.out_bs = (long long)a->Lp * a->Np; k.out_base = (long long)a->halo_l * a->Np;
     k.ldo = a->Np; k.ostride = 1; k.ph_shift = 31; k.L_out = a->L;
-    dispatch_conv16(k, a->B, 1, cvx_hip_stream(s), cvx_ctx_cus(s));
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_conv1d_f16x3(const cvx_conv16_args* a, cvx_stream_t s)
+{
+    Conv16Args k;
+    const int rc = build_conv16(a, s, k);
+    if (rc != CVX_OK) return rc;
+    if (a->B == 0) return CVX_OK;
+    dispatch_conv16(&k, 0, a->B, 1, cvx_hip_stream(s), cvx_ctx_cus(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_f16x3");
+    return CVX_OK;
+}
+
+extern "C" int cvx_hifigan_conv1d_group_f16x3(const cvx_conv16_args* a, int32_t n, cvx_stream_t s)
+{
+    CVX_REQUIRE(a && n >= 1 && n <= 3, "conv1d_group_f16x3: 1..3 convolutions per launch (got %d)", n);
+    if (n == 1) return cvx_hifigan_conv1d_f16x3(a, s);
+    Conv16Args k[3];
+    int order[3] = {0, 1, 2};
+    for (int g = 0; g < n; ++g) {
+        CVX_REQUIRE(a[g].B == a[0].B && a[g].L == a[0].L && a[g].Lp == a[0].Lp && a[g].Cp_in == a[0].Cp_in && a[g].Np == a[0].Np &&
+                    a[g].halo_l == a[0].halo_l && a[g].items.item_len_dev == a[0].items.item_len_dev && a[g].items.mul == a[0].items.mul &&
+                    a[g].items.add == a[0].items.add,
+                    "conv1d_group_f16x3: the convolutions of a group share B, L, Lp, Cp_in, Np, halo_l and the item lengths");
+        for (int h = 0; h < g; ++h)
+            CVX_REQUIRE(!(a[g].out_x && a[g].out_x == a[h].out_x) && !(a[g].out_zhi && a[g].out_zhi == a[h].out_zhi),
+                        "conv1d_group_f16x3: the convolutions of a group run concurrently: their outputs must not alias");
+    }
+    // longest tiles first (the blocks of problem 0 are dispatched first): descending kernel size
+    for (int x = 0; x < n; ++x)
+        for (int y = x + 1; y < n; ++y)
+            if (a[order[y]].ksize > a[order[x]].ksize) { const int t = order[x]; order[x] = order[y]; order[y] = t; }
+    for (int g = 0; g < n; ++g) {
+        const int rc = build_conv16(&a[order[g]], s, k[g]);
+        if (rc != CVX_OK) return rc;
+    }
+    if (a[0].B == 0) return CVX_OK;
+    dispatch_conv16(k, n, a[0].B, 1, cvx_hip_stream(s), cvx_ctx_cus(s));
+    CVX_CHECK_LAUNCH("cvx_hifigan_conv1d_group_f16x3");
     return CVX_OK;
 }
 
@@ -1095,7 +1161,7 @@ extern "C" int cvx_hifigan_conv_transpose1d_f16x3(const cvx_convt16_args* a, cvx
     k.out_bs = (long long)a->Lp_out * a->Np_out; k.out_base = (long long)a->halo_out * a->Np_out;
     k.ldo = a->stride * a->Np_out; k.ostride = a->stride; k.ph_shift = __builtin_ctz((unsigned)a->Np_out); k.L_out = a->L_out;
     k.amax_out = a->amax_bits_dev;
-    dispatch_conv16(k, a->B, a->n_tiles, cvx_hip_stream(s), cvx_ctx_cus(s));
+    dispatch_conv16(&k, 0, a->B, a->n_tiles, cvx_hip_stream(s), cvx_ctx_cus(s));
     CVX_CHECK_LAUNCH("cvx_hifigan_conv_transpose1d_f16x3");
     return CVX_OK;
 }

@@ -1037,13 +1037,7 @@ def hifigan_conv1d_f16x3(z, wpk, bias, B: int, L: int, *, ksize: int, dil: int, 
     _lib.check(_lib.load().cvx_hifigan_conv1d_f16x3(C.byref(a), _stream()), "cvx_hifigan_conv1d_f16x3")
 
 
-def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, accum=None, out=None, out_scale: float = 1.0, z_scale=None,
-                           items=None) -> None:
-    """One ResBlock1 (three conv pairs) through the operator-level C entry point cvx_hifigan_resblock_f16x3.
-    block: list of 3 (c1, c2) pairs of objects with .w16 = hifigan_pack_weight_f16x3(...), .bias16, .k, .dil;
-    scratch: dict with t, rz0, rz1 (split pairs) and r0, r1 (fp32), all [B, Lp, Np] like x_cl / z."""
-    ensure_saturation_bound()
-    a = _lib.Resblock16Args()
+def _fill_resblock16(a, x_cl, z, block, B: int, L: int, scratch: dict, accum, out, out_scale: float, z_scale, items) -> None:
     narrow = x_cl.shape[2] <= 64              # fused pair kernel: no split pairs in HBM (z / t / rz0 / rz1 unused)
     zh, zl = z if z is not None else (None, None)
     assert narrow or z is not None
@@ -1065,7 +1059,30 @@ def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, acc
     a.accum, a.out, a.out_scale = _p(accum), out.data_ptr(), out_scale
     a.z_scale_dev = _sp(z_scale)
     _items(a.items, items)
+
+
+def hifigan_resblock_f16x3(x_cl, z, block, B: int, L: int, scratch: dict, *, accum=None, out=None, out_scale: float = 1.0, z_scale=None,
+                           items=None) -> None:
+    """One ResBlock1 (three conv pairs) through the operator-level C entry point cvx_hifigan_resblock_f16x3.
+    block: list of 3 (c1, c2) pairs of objects with .w16 = hifigan_pack_weight_f16x3(...), .bias16, .k, .dil;
+    scratch: dict with t, rz0, rz1 (split pairs) and r0, r1 (fp32), all [B, Lp, Np] like x_cl / z."""
+    ensure_saturation_bound()
+    a = _lib.Resblock16Args()
+    _fill_resblock16(a, x_cl, z, block, B, L, scratch, accum, out, out_scale, z_scale, items)
     _lib.check(_lib.load().cvx_hifigan_resblock_f16x3(C.byref(a), _stream()), "cvx_hifigan_resblock_f16x3")
+
+
+def hifigan_resblock_stage_f16x3(x_cl, z, blocks, B: int, L: int, scratches, out, *, out_scale: float = 1.0, z_scale=None, items=None) -> None:
+    """out = out_scale * sum_j ResBlock1_j(x) for the (up to 3) ResBlocks of one generator stage (models.py:104-110) through
+    cvx_hifigan_resblock_stage_f16x3: the convolutions of different blocks that do not depend on each other share launches; bit-identical
+    to calling hifigan_resblock_f16x3 block after block (accum = out from the second block on, out_scale on the last).
+    scratches: one scratch dict per block (t, rz0, rz1, r0, r1 - their own buffers)."""
+    ensure_saturation_bound()
+    n = len(blocks)
+    arr = (_lib.Resblock16Args * n)()
+    for j, block in enumerate(blocks):
+        _fill_resblock16(arr[j], x_cl, z, block, B, L, scratches[j], out if j > 0 else None, out, out_scale if j == n - 1 else 1.0, z_scale, items)
+    _lib.check(_lib.load().cvx_hifigan_resblock_stage_f16x3(arr, n, _stream()), "cvx_hifigan_resblock_stage_f16x3")
 
 
 def hifigan_resblock_pair_f16x3(x_cl, c1, c2, B: int, L: int, out, *, accum=None, out_scale: float = 1.0, z_scale=None, flags: int = 0,

@@ -40,6 +40,9 @@ class AttrDict(dict):
         self.__dict__ = self
 
 
+GROUP_STAGE = True      # wide stages: the ResBlocks of a stage share launches (tests flip it to compare against block after block)
+
+
 def get_padding(kernel_size: int, dilation: int = 1) -> int:
     return int((kernel_size * dilation - dilation) / 2)     # vocoder/utils.py:34-35
 
@@ -324,6 +327,9 @@ class Generator:
             buf["zs_scratch"] = torch.zeros(1, dtype=torch.int32, device=self.device)
             if Cp > 64:                           # (the narrow stages run one kernel per conv pair: no split pairs in HBM)
                 buf.update(z0=f16(), t=f16(), rz0=f16(), rz1=f16())
+                # the ResBlocks of a wide stage share launches (cvx_hifigan_resblock_stage_f16x3): every block needs its OWN scratch
+                buf["blk"] = [dict(t=buf["t"], rz0=buf["rz0"], rz1=buf["rz1"], r0=buf["r0"], r1=buf["r1"])] + \
+                             [dict(t=f16(), rz0=f16(), rz1=f16(), r0=f32(), r1=f32()) for _ in range(self.num_kernels - 1)]
             if len(self._cl) >= 12:
                 self._cl.clear()
             self._cl[key] = buf
@@ -352,6 +358,11 @@ class Generator:
         split(leaky_relu(x0) * zs): all channels-last."""
         narrow = "z0" not in buf
         nblk = len(blocks)
+        if not narrow and 1 < nblk <= 3 and nblk <= len(buf.get("blk", ())) and all(len(b) == 3 for b in blocks) and GROUP_STAGE:
+            # wide stage: the blocks' independent convolutions share launches (18 -> 8 per stage), same bits as block after block
+            ops.hifigan_resblock_stage_f16x3(buf["x0"], buf["z0"], blocks, B, L, buf["blk"][:nblk], buf["xs"],
+                                             out_scale=1.0 / self.num_kernels, z_scale=zs, items=items)
+            return
         for j, block in enumerate(blocks):
             if len(block) == 3:                   # one C call per ResBlock: cvx_hifigan_resblock_f16x3 (6 launches, or 3 fused pairs)
                 ops.hifigan_resblock_f16x3(buf["x0"], buf.get("z0"), block, B, L, buf, accum=buf["xs"] if j > 0 else None, out=buf["xs"],

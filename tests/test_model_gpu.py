@@ -256,6 +256,35 @@ def test_vocoder_full_size_properties_and_precisions():
     assert rel_l2(gens["f16x3"](mel[perm]), y16[perm]) < 1e-6
 
 
+@pytest.mark.parametrize("B,T", [(1, 1000), (3, 333)])
+def test_vocoder_grouped_resblock_stages_are_bit_identical_to_block_after_block(B, T):
+    """Round 6: on the wide stages (250 / 125 channels) the three ResBlocks of a stage (kernel sizes 3 / 7 / 11, models.py:104-110) share
+    launches - their convolutions are independent until the xs accumulate (cvx_hifigan_resblock_stage_f16x3 / cvx_hifigan_conv1d_group_f16x3:
+    18 -> 8 launches per stage).  Same arithmetic per output element, same accumulation order into xs: the waveform must equal, bit for
+    bit, the one the block-after-block schedule gives (and both the ragged and the unragged call)."""
+    import covomix_amd.synthetic as syn
+    from covomix_amd import vocoder
+    from covomix_amd.vocoder import AttrDict, Generator
+    h = AttrDict(syn.HIFIGAN_COVOMIX_CONFIG)
+    vsd = {k: torch.from_numpy(v) for k, v in syn.synth_state_dict(syn.hifigan_param_shapes(h), seed=0).items()}
+    gen = Generator(h).to("cuda:0")
+    gen.load_state_dict(vsd); gen.eval(); gen.remove_weight_norm()
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(9)) * 2 - 6).clamp(-11.52, 2.0).cuda()
+    lens = [T - 37 * i for i in range(B)]
+    assert vocoder.GROUP_STAGE
+    grouped = gen(mel).clone()
+    grouped_r = gen(mel, lengths=lens).clone() if B > 1 else None
+    vocoder.GROUP_STAGE = False
+    try:
+        plain = gen(mel).clone()
+        plain_r = gen(mel, lengths=lens).clone() if B > 1 else None
+    finally:
+        vocoder.GROUP_STAGE = True
+    assert torch.equal(grouped, plain)
+    if B > 1:
+        assert torch.equal(grouped_r, plain_r)
+
+
 def test_vocoder_repeated_calls_are_bit_identical_and_independent_of_the_previous_input():
     """Round 4: cvx_amax_pow2_scale_f32 left its maximum in the scratch word that the NEXT call's upsampler max-accumulates
     into, so a call's activation pre-scale depended on the previous call's input (first call of a shape != later calls by an
