@@ -178,17 +178,21 @@ def _predict_turns(work, t2s, device, seed: int, slots: int = 64) -> dict:
     if todo and t2s is None:
         raise RuntimeError("text sources need --t2s_ckpt")
     if todo:
-        # ALL turns in one call: t2s.generate_many runs them through 64 continuously refilled decode slots - a turn that has sampled its
-        # eos frees its slot for the next one on the device (the reference decodes turn by turn, dialogue_generation.py:297-304)
+        # ALL turns through t2s.generate_many: 64 continuously refilled decode slots - a turn that has sampled its eos frees its slot for
+        # the next one on the device (the reference decodes turn by turn, dialogue_generation.py:297-304).  In windows of 256 turns: the
+        # uniform draws of a window (8 MB per turn at 2048 steps) and its context k/v are resident while it decodes.
+        from .t2s import WINDOW
         dec = t2s._get_t2s()
         S, V, L = dec.d["streams"], dec.d["vocab"], dec.max_length
-        uniforms = []
-        for name, k, _ in todo:
-            g = torch.Generator(device=device).manual_seed(_stable_seed(seed, name, k, 1))
-            uniforms.append(torch.rand(L, S, V, device=device, generator=g))
-        toks = t2s.synthesis_sample_text2semantic([ids.to(device) for _, _, ids in todo], uniforms=uniforms, slots=slots)
-        for (name, k, _), t in zip(todo, toks):
-            out[(name, k)] = t.cpu().numpy().astype(np.int64)
+        for w in range(0, len(todo), WINDOW):
+            part = todo[w:w + WINDOW]
+            uniforms = []
+            for name, k, _ in part:
+                g = torch.Generator(device=device).manual_seed(_stable_seed(seed, name, k, 1))
+                uniforms.append(torch.rand(L, S, V, device=device, generator=g))
+            toks = t2s.synthesis_sample_text2semantic([ids.to(device) for _, _, ids in part], uniforms=uniforms, slots=slots)
+            for (name, k, _), t in zip(part, toks):
+                out[(name, k)] = t.cpu().numpy().astype(np.int64)
     return out
 
 
