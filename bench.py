@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 B, T, PROMPT, NFE, COND_SCALE = 8, 1000, 400, 32, 0.7
+_JSON_FD = None                                         # the process's original stdout once main() has pointed fd 1 at stderr
 FLOP_PER_FRAME = 64 * 255_784_960 + 281_398_000        # 16.65 GFLOP per mel frame
 PEAK_F32_MFMA = 157.3e12                                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA = 2.5e15                                  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak (not the 2:1 sparse figure)
@@ -451,6 +452,12 @@ def main():
         # started from a plain shell: become the launcher of N ranks (one process per GPU, free rendezvous port) - the
         # reference's own multi-GPU entry point spawns its ranks itself too (hifi-gan/train.py:268-278)
         sys.exit(dp.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    # stdout carries ONE JSON line and nothing else: C++ libraries write there too (gloo prints "[Gloo] Rank r is connected to n peer
+    # ranks" on every rank when its mesh comes up) - file descriptor 1 points at stderr from here on and the line goes to the saved one
+    sys.stdout.flush()
+    global _JSON_FD
+    json_fd = _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local = dp.init_from_env("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -614,7 +621,8 @@ def main():
                 out["c5"] = config5(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_sd)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -635,10 +643,10 @@ def _guarded_main():
         print(f"[bench.py rank {rank}/{world}] FAILED: {type(e).__name__}: {e}\n{tb[-2000:]}", file=sys.stderr, flush=True)
         if world > 1 and rank == 0:
             from covomix_amd import dp
-            print(json.dumps({"metric": "mel-frames/sec (VoMix 32-step + HiFi-GAN, Bx1000x80)", "value": None, "unit": "mel-frames/s",
+            line = json.dumps({"metric": "mel-frames/sec (VoMix 32-step + HiFi-GAN, Bx1000x80)", "value": None, "unit": "mel-frames/s",
                               "n_gpus": world, "error": f"rank 0: {type(e).__name__}: {str(e)[:500]}",
-                              "ranks": {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in dp.INFO.items()}}),
-                  flush=True)
+                              "ranks": {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in dp.INFO.items()}})
+            os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
         raise
 
 
