@@ -36,6 +36,10 @@ constexpr int T2S_MAX_KEYS = 4096;
 constexpr int T2S_MAX_DIM = 4096;     // floats of the staged input vector (16 KiB of LDS)
 constexpr int SR = 8;                 // int32 per slot record / dialogue record (cvx_t2s_decoder.state / .dialogues)
 constexpr int T2S_MAX_BATCH = 64;
+#ifndef CVX_T2S_STAGE_HALF
+#define CVX_T2S_STAGE_HALF 0
+#endif
+constexpr bool STAGE_HALF = CVX_T2S_STAGE_HALF != 0;   // (dev A/B) eight slots staged as two passes of four
 
 enum { MODE_QKV = 0, MODE_PLAIN = 1, MODE_RES = 2, MODE_GEGLU = 3, MODE_LOGITS = 4 };
 
@@ -179,34 +183,41 @@ __device__ __forceinline__ void stage_chunk(const GemvArgs& a, int bofs, int c, 
 {
     const int k = 1024 * c + 4 * (int)threadIdx.x;
     const float* const xg = a.x + (int64_t)bofs * a.x_stride + k;
-    f32x4 v[BQ];
+    const bool in = k < Kin;                          // (Kin is a multiple of 4; wave-uniform whenever it is a multiple of 256)
     f32x4 gk = {1.f, 1.f, 1.f, 1.f};
-    if (k < Kin) {                                    // (Kin is a multiple of 4; wave-uniform whenever it is a multiple of 256)
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) v[b] = aload4(xg + (int64_t)b * a.x_stride);      // (independent loads: one L2 round trip)
-        if (a.gamma) gk = aload4(a.gamma + k);
-    } else {                                          // zero padding of the last chunk: a partial strip multiplies it with zero weights
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) v[b] = z;
-    }
-#pragma unroll
-    for (int b = 0; b < BQ; ++b) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ss[b] = fmaf(v[b][e], v[b][e], ss[b]);
-        v[b] = v[b] * gk;
-    }
+    if (in && a.gamma) gk = aload4(a.gamma + k);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};             // zero padding of the last chunk: a partial strip multiplies it with zero weights
     const int t4 = 4 * (int)threadIdx.x;
     if (BQ == 1) {
-        *reinterpret_cast<f32x4*>(xs + t4) = v[0];
-    } else {
+        const f32x4 v = in ? aload4(xg) : z;
 #pragma unroll
-        for (int bp = 0; bp < BQ / 2; ++bp) {
-            const f32x4 lo = {v[2 * bp][0], v[2 * bp + 1][0], v[2 * bp][1], v[2 * bp + 1][1]};
-            const f32x4 hi = {v[2 * bp][2], v[2 * bp + 1][2], v[2 * bp][3], v[2 * bp + 1][3]};
-            float* const d = xs + ((size_t)bp * 1024 + t4) * 2;
-            *reinterpret_cast<f32x4*>(d) = lo;
-            *reinterpret_cast<f32x4*>(d + 4) = hi;
+        for (int e = 0; e < 4; ++e) ss[0] = fmaf(v[e], v[e], ss[0]);
+        *reinterpret_cast<f32x4*>(xs + t4) = v * gk;
+    } else {
+        // HB slots per pass: their 16-byte loads are independent (one L2 round trip per pass), then slot pair by slot pair with a
+        // scheduling barrier in between - left alone the scheduler keeps the raw values, the products and the interleaved copies of all
+        // eight slots live at once (96 registers on top of the weight strips: two blocks per CU).  BQ = 8 stages in two passes of four
+        // slots under -DCVX_T2S_STAGE_HALF=1 (dev): 152 -> 144 registers only - still three blocks per CU - for a second round trip: off.
+        constexpr int HB = (BQ == 8 && STAGE_HALF) ? 4 : BQ;
+#pragma unroll
+        for (int h = 0; h < BQ / HB; ++h) {
+            f32x4 v[HB];
+#pragma unroll
+            for (int b = 0; b < HB; ++b) v[b] = in ? aload4(xg + (int64_t)(h * HB + b) * a.x_stride) : z;
+#pragma unroll
+            for (int q = 0; q < HB / 2; ++q) {
+                const int bp = h * (HB / 2) + q;
+                const f32x4 va = v[2 * q], vb = v[2 * q + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ss[2 * bp] = fmaf(va[e], va[e], ss[2 * bp]); ss[2 * bp + 1] = fmaf(vb[e], vb[e], ss[2 * bp + 1]); }
+                const f32x4 pa = va * gk, pb = vb * gk;
+                const f32x4 lo = {pa[0], pb[0], pa[1], pb[1]};
+                const f32x4 hi = {pa[2], pb[2], pa[3], pb[3]};
+                float* const d = xs + ((size_t)bp * 1024 + t4) * 2;
+                *reinterpret_cast<f32x4*>(d) = lo;
+                *reinterpret_cast<f32x4*>(d + 4) = hi;
+                if (BQ >= 4) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
