@@ -256,11 +256,28 @@ def config2(dev, calls: int = 20):
 def timed_region(fn, dev_index=0):
     """fn() between two device synchronisations -> (result, seconds, {power_w, sclk_mhz, ...} of THAT region): boxes of the pool
     differ by several per cent, and every figure of the line must say which box state it was measured in."""
+    from covomix_amd import ops
     power = PowerSampler(device_index=dev_index)
     power.start()
-    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); t1 = time.perf_counter()
+    torch.cuda.synchronize(); c0 = ops.clock_stamps(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); t1 = time.perf_counter()
+    c1 = ops.clock_stamps(); torch.cuda.synchronize()
     info = power.stop(t0, t1)
-    return r, t1 - t0, {k: info.get(k) for k in ("power_w", "sclk_mhz", "power_samples")}
+    out = {k: info.get(k) for k in ("power_w", "sclk_mhz", "power_samples")}
+    out.update(effective_clock(c0, c1))
+    return r, t1 - t0, out
+
+
+def effective_clock(c0, c1) -> dict:
+    """Shader clock of a region from two ops.clock_stamps(): cycles counted / real time, per XCD (`sclk_mhz` is the hwmon file: ONE
+    XCD's momentary value, sampled every 0.1 s).  Lightly loaded configurations run at whatever clock a box's power management grants
+    each XCD: this is the figure that tells a slow box from a slow kernel there."""
+    d = (c1 - c0).cpu().double()
+    ok = (d[:, 1] > 0) & (d[:, 0] > 0)
+    if not bool(ok.any()):
+        return {"sclk_eff_mhz": None}
+    mhz = (d[ok, 0] / d[ok, 1] * 100.0).tolist()          # the real-time counter runs at 100 MHz
+    return {"sclk_eff_mhz": round(sum(mhz) / len(mhz), 1), "sclk_eff_mhz_xcd_min_max": [round(min(mhz), 1), round(max(mhz), 1)]}
 
 
 def config5(dev, dialogues: int = 56):
@@ -513,12 +530,16 @@ def main():
     if power:
         power.start()
     barrier()
+    clk0 = ops.clock_stamps()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     cpu0 = time.process_time()                           # CPU seconds of this process, all its threads
     for _ in range(args.steps):
         pcm = step()
     barrier()
     t1 = time.perf_counter()
+    clk1 = ops.clock_stamps()
+    torch.cuda.synchronize()
     host_cpu = time.process_time() - cpu0
     elapsed = t1 - t0
     timer.remove()
@@ -586,6 +607,7 @@ def main():
                          "ms_per_step": round(gemm_s / launches * all_launches / args.steps * 1e3, 3)},
         }
         out["roofline"].update(power_info)          # power_w, sclk_mhz, power_cap_w of the timed region (rank 0's GPU)
+        out["roofline"].update(effective_clock(clk0, clk1))
         # host budget: a rank drives ~10k launches/s from Python; `busy_cores` = CPU seconds of the process (all threads, the power
         # sampler included) per second of the timed region.  A rank whose share of the cgroup quota is below what it needs is
         # host-bound however fast the GPU is - the first thing to rule out when an N > 1 line comes in low.

@@ -265,6 +265,7 @@ SIGNATURES = {
     "cvx_saturation_flag_query": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.c_void_p]),
     "cvx_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
     "cvx_stream_destroy": (C.c_int, [C.c_void_p]),
+    "cvx_clock_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     # ragged batches (cu_seqlens)
     "cvx_attention_varlen_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_float, C.c_void_p]),

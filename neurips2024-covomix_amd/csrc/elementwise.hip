@@ -90,6 +90,25 @@ extern "C" int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_
     if (reset && hipMemsetAsync(f, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
     return CVX_OK;
 }
+// Clock stamps (bench.py): {shader-clock counter, 100 MHz real-time counter} per XCD, written by whichever block of that XCD comes last.
+// Two calls around a timed region give the shader clock the region actually ran at, per XCD - the hwmon file shows one XCD's
+// momentary value, and config 2's time differs between boxes that report the same one.
+namespace {
+__global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* __restrict__ out)
+{
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long t = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * (xcc & 7)] = t; out[2 * (xcc & 7) + 1] = r; }
+}
+}
+extern "C" int cvx_clock_stamps(uint64_t* stamps_dev, cvx_stream_t s)
+{
+    CVX_REQUIRE(stamps_dev && (reinterpret_cast<uintptr_t>(stamps_dev) & 7) == 0, "clock_stamps: null / unaligned output");
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, cvx_hip_stream(s), reinterpret_cast<unsigned long long*>(stamps_dev));
+    CVX_CHECK_LAUNCH("cvx_clock_stamps");
+    return CVX_OK;
+}
 extern "C" int cvx_version(void) { return CVX_ABI_VERSION; }
 
 namespace {

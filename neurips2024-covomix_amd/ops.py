@@ -581,6 +581,14 @@ def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:
     return int(n) if n > 0 else torch.cuda.get_device_properties(st.device).multi_processor_count
 
 
+def clock_stamps() -> torch.Tensor:
+    """[8, 2] int64 (enqueued on the current stream): per XCD the shader-clock cycle counter and the 100 MHz real-time counter.  The
+    difference of two calls = cycles / time of the region between them: the shader clock it ran at, per XCD (bench.py)."""
+    out = torch.zeros(8, 2, dtype=torch.int64, device=torch.cuda.current_device())
+    _lib.check(_lib.load().cvx_clock_stamps(out.data_ptr(), _stream()), "cvx_clock_stamps")
+    return out
+
+
 def saturation_reset() -> None:
     """Clear the current stream's sticky saturation flag (enqueued on that stream; no host synchronisation)."""
     saturation_flag()
