@@ -307,7 +307,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const PairInfo&
 // (Round 5 staged scalar-wise, four dependent L2 round trips per 1024 floats, ran the lane tree once per value - 96 exchanges per
 // pair at BQ = 8 against 20 now - and left the epilogue of all slots to lane 0.)  Per-(row, slot) arithmetic does not depend on BQ, PPW
 // or the grouping: same bits.
-template <int MODE, int BQ, int PPW>
+template <int MODE, int BQ, int PPW, bool LOOP = false>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
     __shared__ __attribute__((aligned(16))) float xs[BQ * 1024];
@@ -327,15 +327,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     PairInfo pi[PPW];
     RowChunk w[PPW];                                                    // the current chunk of the wave's weight rows (K <= 1024: all of them,
 #pragma unroll                                                          // loaded once for every group of slots the block walks)
-    for (int p = 0; p < PPW; ++p) {
-        pi[p] = pair_info<MODE>(a, (rb * 4 + wid) * PPW + p);
-        load_chunk(a, pi[p], 0, lane, w[p]);                            // weights first: in flight under the staging of x
-    }
+    for (int p = 0; p < PPW; ++p) pi[p] = pair_info<MODE>(a, (rb * 4 + wid) * PPW + p);
+    load_chunk(a, pi[0], 0, lane, w[0]);                                // weights first: in flight under the staging of x
+    // (the strips of a second row pair are requested BEHIND the staging, in flight under the first pair's dot products: 32 registers
+    //  fewer across the staging - 204 -> 170 VGPRs at two pairs per wave; with the group loop a template constant, 152 -> 118 at one)
     constexpr int SH = SlotShift<BQ>::value;
     const int myb = BQ == 1 ? 0 : lane >> SH;                          // the slot (of a group) whose results the lane tree leaves here
     const bool writer = (lane & ((1 << SH) - 1)) == 0;
+    // LOOP (dev hint cvx_t2s_decoder.group_loop > 1): the block walks a.gl groups of slots with its weight strips in registers; the default
+    // is ONE group per block - no loop, so nothing (the second pair's strips in particular) has to stay live across a back edge
+    const int n_g = LOOP ? a.gl : 1;
 #pragma unroll 1
-    for (int g = 0; g < a.gl; ++g) {
+    for (int g = 0; g < n_g; ++g) {
         const int bofs = (g0 + g) * BQ;
         Acc<BQ> acc0[PPW], acc1[PPW];
         float ss[BQ];
@@ -345,13 +348,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         for (int p = 0; p < PPW; ++p) { acc0[p].zero(); acc1[p].zero(); }
 #pragma unroll 1
         for (int c = 0; c < nchunk; ++c) {
-            if (c > 0 || (g > 0 && nchunk > 1)) {
-#pragma unroll
-                for (int p = 0; p < PPW; ++p) load_chunk(a, pi[p], c, lane, w[p]);
-            }
+            const bool reload = c > 0 || (g > 0 && nchunk > 1);
+            if (reload) load_chunk(a, pi[0], c, lane, w[0]);
             if (g | c) __syncthreads();                                 // (xs / red of the previous chunk / group are free)
             stage_chunk<BQ>(a, bofs, c, Kin, xs, ss);
             __syncthreads();
+            if (PPW > 1 && (reload || (g | c) == 0)) {
+#pragma unroll
+                for (int p = 1; p < PPW; ++p) load_chunk(a, pi[p], c, lane, w[p]);
+            }
 #pragma unroll
             for (int p = 0; p < PPW; ++p) {
                 // LOGITS: the staged vector holds `streams` slices; the pair's slice starts at sidx * K (one chunk: Kin <= 1024)
@@ -629,7 +634,6 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h,
 }
 
 
-constexpr int T2S_TWO_PAIRS_BATCH = 40;           // (CoMix, whole chip: 32 slots 366 vs 365 us per step, 64 slots 575 vs 489)
 constexpr int T2S_GROUP_LOOP = 1;   // default of cvx_t2s_decoder.group_loop: slot groups one block walks with its weight rows in registers
 template <int MODE, int BQ, int PPW>
 void launch_gemv_p(GemvArgs g, int pairs, int groups, hipStream_t st)
@@ -640,7 +644,12 @@ void launch_gemv_p(GemvArgs g, int pairs, int groups, hipStream_t st)
     while (g.gl < want && groups % (2 * g.gl) == 0) g.gl *= 2;
     g.gy = groups / g.gl;
     const unsigned grid = g.gy > 1 ? (unsigned)((g.n_blocks + 7) / 8 * 8 * g.gy) : (unsigned)g.n_blocks;
-    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW>), dim3(grid), dim3(256), 0, st, g);
+    if constexpr (PPW == 1 && BQ == 8) {
+        if (g.gl > 1) { hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW, true>), dim3(grid), dim3(256), 0, st, g); return; }
+    }
+    if (g.gl > 1) { g.gy *= g.gl; g.gl = 1; }          // (the group loop exists at one row pair per wave, eight slots per group only)
+    const unsigned grid1 = g.gy > 1 ? (unsigned)((g.n_blocks + 7) / 8 * 8 * g.gy) : (unsigned)g.n_blocks;
+    hipLaunchKernelGGL((gemv_kernel<MODE, BQ, PPW, false>), dim3(grid1), dim3(256), 0, st, g);
 }
 template <int MODE, int BQ>
 void launch_gemv_b(const GemvArgs& g, int pairs, int groups, bool two, hipStream_t st)
@@ -711,9 +720,10 @@ extern "C" int cvx_t2s_decode_steps(const cvx_t2s_decoder* d, int32_t n_steps, c
     hipStream_t st = cvx_hip_stream(s);
     const float scale = 0.125f;        // dim_head ** -0.5
     const int nb = d->batch;
-    // two row pairs per wave (half the blocks, each staging the input vectors for twice the rows): on a CU-masked side stream (several
-    // rounds of blocks per launch at batch 8) and from T2S_TWO_PAIRS_BATCH slots up; cvx_t2s_decoder.pairs_per_wave overrides
-    const bool few = d->pairs_per_wave > 0 ? d->pairs_per_wave >= 2 : (cvx_ctx_cus(s) <= 64 || d->batch >= T2S_TWO_PAIRS_BATCH);
+    // ONE row pair per wave everywhere since the kernel holds 118 VGPRs (four blocks per CU): 64 slots 462 vs 480 us per CoMix step with two
+    // pairs (170 VGPRs, two blocks), 32-CU side stream at 8 slots 434 vs 439 (round 5, at two blocks per CU either way, two pairs won there:
+    // 760 vs 813).  cvx_t2s_decoder.pairs_per_wave = 2 still selects the other form (same bits).
+    const bool few = d->pairs_per_wave >= 2;
     const int64_t cache_stride = (int64_t)d->max_len * d->inner;
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < d->depth; ++l) {
