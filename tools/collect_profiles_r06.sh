@@ -36,5 +36,5 @@ ff=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); fw=$(find $
 [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_summary.py $ff $fw $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1
 f=$(find $OUT/stats -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/gemm_by_grid.py $f > $OUT/gemm_by_grid.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
-tail -3 $OUT/*.log | cut -c1-300
+for f in $OUT/*.log; do tail -n 2 $f | cut -c1-200; done
 cut -c1-600 $OUT/bench_n1.json
