@@ -70,11 +70,18 @@ struct GemvArgs {
     int streams;
 };
 
+// x[l] + x[l ^ o] for o = 8 / 4 / 2 / 1 without an LDS permute: DPP row rotation (xor 8 inside a 16-lane row), the LDS crossbar's swizzle
+// (xor 4) and DPP quad permutes fused into the add - the pairings of the xor butterfly exactly, so the same bits as __shfl_xor
+__device__ __forceinline__ float xor_add8(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false)); }   // row_ror:8
+__device__ __forceinline__ float xor_add4(float v) { return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }
+__device__ __forceinline__ float xor_add2(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)); }
+__device__ __forceinline__ float xor_add1(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)); }
+
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    return xor_add1(xor_add2(xor_add4(xor_add8(v))));
 }
 
 constexpr int PF = 4;                                      // 4 x 256 floats per row in flight (K <= 1024 entirely)
@@ -153,15 +160,25 @@ __device__ __forceinline__ void load_chunk(const GemvArgs& a, const PairInfo& p,
 // the first log2(BQ) steps a lane keeps half of its values and hands the other half to its partner - which computes, for every value,
 // exactly the sums of the plain butterfly (own + partner's, fp addition commutes) with 2 BQ + ... instead of 6 BQ exchanges: the same
 // bits for every BQ.  Afterwards value b sits in the lanes with (lane >> (6 - log2 BQ)) == b.
+// One reduce-scatter step of the lane tree over H value pairs (v[j], v[j + H]): afterwards lanes with (lane & o) == 0 hold
+// v[j][l] + v[j][l ^ o] in v[j], the others v[j + H][l] + v[j + H][l ^ o].  o = 32 / 16: gfx950's v_permlane32_swap / v_permlane16_swap
+// exchange the upper half (odd rows) of one register with the lower half (even rows) of the other - one swap and one add per pair, no
+// selects, no LDS permute (round-6 first form: two selects + ds_bpermute + add).  o = 8: both sums by DPP row rotation, one select.
 template <int H, int N>
 __device__ __forceinline__ void tree_step(float (&v)[N], int lane, int o)
 {
-    const bool up = (lane & o) != 0;
 #pragma unroll
     for (int j = 0; j < H; ++j) {                     // (H is a template constant: v is indexed statically and stays in registers)
-        const float send = up ? v[j] : v[j + H];
-        const float keep = up ? v[j + H] : v[j];
-        v[j] = keep + __shfl_xor(send, o, 64);
+        if (o == 32) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + H]), false, false);
+            v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        } else if (o == 16) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + H]), false, false);
+            v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        } else {
+            const float t0 = xor_add8(v[j]), t1 = xor_add8(v[j + H]);
+            v[j] = (lane & 8) ? t1 : t0;
+        }
     }
 }
 template <int BQ>
@@ -170,9 +187,13 @@ __device__ __forceinline__ void lane_tree(float (&v)[BQ], int lane)
     if constexpr (BQ == 8) { tree_step<4>(v, lane, 32); tree_step<2>(v, lane, 16); tree_step<1>(v, lane, 8); }
     if constexpr (BQ == 4) { tree_step<2>(v, lane, 32); tree_step<1>(v, lane, 16); }
     if constexpr (BQ == 2) { tree_step<1>(v, lane, 32); }
-    constexpr int first = BQ == 8 ? 4 : BQ == 4 ? 8 : BQ == 2 ? 16 : 32;
-#pragma unroll
-    for (int o = first; o > 0; o >>= 1) v[0] += __shfl_xor(v[0], o, 64);
+    // the plain steps that are left (all lanes of a slot's group end up with the total)
+    if constexpr (BQ == 1) v[0] += __shfl_xor(v[0], 32, 64);
+    if constexpr (BQ <= 2) v[0] += __shfl_xor(v[0], 16, 64);
+    if constexpr (BQ <= 4) v[0] = xor_add8(v[0]);
+    v[0] = xor_add4(v[0]);
+    v[0] = xor_add2(v[0]);
+    v[0] = xor_add1(v[0]);
 }
 template <int BQ> struct SlotShift { static constexpr int value = BQ == 8 ? 3 : BQ == 4 ? 4 : BQ == 2 ? 5 : 6; };
 
@@ -435,14 +456,17 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, int h, int b, int h
             const int j = j0 + 16 * u + grp;
             float d = 0.f;
             if (j < n) d = k4[u][0] * q4[0] + k4[u][1] * q4[1] + k4[u][2] * q4[2] + k4[u][3] * q4[3];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            d = xor_add1(xor_add2(xor_add4(xor_add8(d))));              // the 16 lanes of a key (xor 8, 4, 2, 1: no LDS permute)
             d *= a.scale;
             if (j < n) { if (sub == 0) sc[j] = d; mx = fmaxf(mx, d); }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x128, 0xF, 0xF, false)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mx), 0x101F)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xF, 0xF, false)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xF, 0xF, false)));
     if (lane == 0) red[wid] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
