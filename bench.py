@@ -269,15 +269,15 @@ def timed_region(fn, dev_index=0):
 
 
 def effective_clock(c0, c1) -> dict:
-    """Shader clock of a region from two ops.clock_stamps(): cycles counted / real time, per XCD (`sclk_mhz` is the hwmon file: ONE
-    XCD's momentary value, sampled every 0.1 s).  Lightly loaded configurations run at whatever clock a box's power management grants
-    each XCD: this is the figure that tells a slow box from a slow kernel there."""
-    d = (c1 - c0).cpu().double()
-    ok = (d[:, 1] > 0) & (d[:, 0] > 0)
-    if not bool(ok.any()):
+    """Shader clock of a region from two ops.clock_stamps(): cycles counted / real time on every CU, per XCD (`sclk_mhz` is the hwmon
+    file: ONE XCD's momentary value, sampled every 0.1 s).  Lightly loaded configurations run at whatever clock a box's power management
+    grants each XCD: this is the figure that tells a slow box from a slow kernel there."""
+    from covomix_amd import ops
+    r = ops.clock_from_stamps(c0, c1)
+    if not r:
         return {"sclk_eff_mhz": None}
-    mhz = (d[ok, 0] / d[ok, 1] * 100.0).tolist()          # the real-time counter runs at 100 MHz
-    return {"sclk_eff_mhz": round(sum(mhz) / len(mhz), 1), "sclk_eff_mhz_xcd_min_max": [round(min(mhz), 1), round(max(mhz), 1)]}
+    return {"sclk_eff_mhz": round(r["mhz"], 1), "sclk_eff_mhz_xcd_min_max": [round(min(r["xcd_mhz"]), 1), round(max(r["xcd_mhz"]), 1)],
+            "sclk_eff_cus": r["cus"]}
 
 
 def config5(dev, dialogues: int = 56):

@@ -97,8 +97,9 @@ int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_stream_t ct
  *                              the same number of CUs, i.e. when the CUs per XCD are a multiple of 4 (tools/archive/cu_mask_probe2.hip: 30 CUs
  *                              per XCD -> 12 of 240 blocks wait for a second round; 28 -> none).
  *   cvx_stream_destroy:        hipStreamDestroy of such a stream. */
-/* Diagnostics (bench.py): stamps_dev[2 * xcd] = the shader-clock cycle counter, [2 * xcd + 1] = the 100 MHz real-time counter of XCD
- * xcd (16 uint64 of device memory).  Two calls around a region -> the shader clock that region ran at, per XCD. */
+/* Diagnostics (bench.py): stamps_dev is 2048 x 2 uint64 of ZEROED device memory; slot = xcd * 256 + HW_ID[15:8] (the CU's id bits) receives
+ * {that CU's shader-clock cycle counter, the 100 MHz real-time counter} (slots of CUs no block landed on stay zero).  Two calls around a
+ * busy region, paired slot by slot (the cycle counters of different CUs are not comparable) -> the shader clock the region ran at, per CU. */
 int cvx_clock_stamps(uint64_t* stamps_dev, cvx_stream_t ctx);
 int cvx_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** out_stream);
 int cvx_stream_destroy(void* stream);

@@ -90,22 +90,27 @@ extern "C" int cvx_saturation_flag_query(uint32_t* host_out, int32_t reset, cvx_
     if (reset && hipMemsetAsync(f, 0, sizeof(uint32_t), st) != hipSuccess) { cvx_set_error("saturation_flag: memset failed"); return CVX_EHIP; }
     return CVX_OK;
 }
-// Clock stamps (bench.py): {shader-clock counter, 100 MHz real-time counter} per XCD, written by whichever block of that XCD comes last.
-// Two calls around a timed region give the shader clock the region actually ran at, per XCD - the hwmon file shows one XCD's
-// momentary value, and config 2's time differs between boxes that report the same one.
+// Clock stamps (bench.py): {shader-clock cycle counter, 100 MHz real-time counter} PER COMPUTE UNIT: the cycle counter belongs to the CU
+// (stamps of two CUs of one XCD differ by arbitrary offsets - a per-XCD slot gave negative clocks over short regions), so a slot is
+// (XCD, the CU / shader-array / shader-engine bits of HW_ID) and the caller pairs the two stamps of the SAME slot.  Two calls around a
+// busy region give the shader clock it ran at, per CU; the hwmon file shows one XCD's momentary value, and config 2's time differs
+// between boxes that report the same one.  4096 short blocks: the dispatcher spreads them over (nearly) every CU.
 namespace {
 __global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* __restrict__ out)
 {
-    unsigned xcc;
+    unsigned xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    __builtin_amdgcn_s_sleep(64);                                        // (keeps the block resident long enough for the others to land elsewhere)
     const unsigned long long t = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) { out[2 * (xcc & 7)] = t; out[2 * (xcc & 7) + 1] = r; }
+    const unsigned slot = ((xcc & 7) << 8) | ((hwid >> 8) & 0xFF);      // HW_ID[15:8] = CU_ID, SH_ID, SE_ID
+    if (threadIdx.x == 0) { out[2 * slot] = t; out[2 * slot + 1] = r; }
 }
 }
 extern "C" int cvx_clock_stamps(uint64_t* stamps_dev, cvx_stream_t s)
 {
     CVX_REQUIRE(stamps_dev && (reinterpret_cast<uintptr_t>(stamps_dev) & 7) == 0, "clock_stamps: null / unaligned output");
-    hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, cvx_hip_stream(s), reinterpret_cast<unsigned long long*>(stamps_dev));
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(4096), dim3(64), 0, cvx_hip_stream(s), reinterpret_cast<unsigned long long*>(stamps_dev));
     CVX_CHECK_LAUNCH("cvx_clock_stamps");
     return CVX_OK;
 }

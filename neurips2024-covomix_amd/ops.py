@@ -582,11 +582,26 @@ def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:
 
 
 def clock_stamps() -> torch.Tensor:
-    """[8, 2] int64 (enqueued on the current stream): per XCD the shader-clock cycle counter and the 100 MHz real-time counter.  The
-    difference of two calls = cycles / time of the region between them: the shader clock it ran at, per XCD (bench.py)."""
-    out = torch.zeros(8, 2, dtype=torch.int64, device=torch.cuda.current_device())
+    """[2048, 2] int64 (enqueued on the current stream): per (XCD, CU) slot that CU's shader-clock cycle counter and the 100 MHz real-time
+    counter (zero where no block landed).  Pair two calls slot by slot with clock_from_stamps."""
+    out = torch.zeros(2048, 2, dtype=torch.int64, device=torch.cuda.current_device())
     _lib.check(_lib.load().cvx_clock_stamps(out.data_ptr(), _stream()), "cvx_clock_stamps")
     return out
+
+
+def clock_from_stamps(c0: torch.Tensor, c1: torch.Tensor) -> dict:
+    """Shader clock of the (busy) region between two clock_stamps() calls: cycles counted / real time on every CU that holds both stamps,
+    averaged per XCD -> {mhz (mean over XCDs), xcd_mhz (8 values), cus (CUs paired)}; {} when nothing could be paired."""
+    a, b = c0.cpu(), c1.cpu()
+    ok = (a[:, 1] != 0) & (b[:, 1] != 0)
+    d = (b - a).double()
+    ok &= (d[:, 1] > 0) & (d[:, 0] > 0)
+    if not bool(ok.any()):
+        return {}
+    mhz = torch.where(ok, d[:, 0] / d[:, 1].clamp_min(1.0) * 100.0, torch.zeros_like(d[:, 0])).view(8, 256)      # the real-time counter: 100 MHz
+    n = ok.view(8, 256).sum(dim=1)
+    per_xcd = [float(mhz[x].sum() / n[x]) for x in range(8) if int(n[x]) > 0]
+    return {"mhz": sum(per_xcd) / len(per_xcd), "xcd_mhz": per_xcd, "cus": int(ok.sum())}
 
 
 def saturation_reset() -> None:

@@ -261,22 +261,25 @@ def test_conv_transpose1d_polyphase(Cin, Cout, k, u, pad, L, B):
 
 
 def test_clock_stamps_give_a_plausible_shader_clock():
-    """cvx_clock_stamps (bench.py's effective clock per XCD): two calls around a busy region -> cycles / real time per XCD must be a
-    shader clock this chip can run at (0.09 ... 2.5 GHz), for every XCD of the device, and the real-time counter must advance at 100 MHz
-    (checked against the host's clock over the same region to 5 %)."""
+    """cvx_clock_stamps (bench.py's effective clock): two calls around a BUSY region, paired CU by CU (the cycle counter belongs to the CU:
+    stamps of different CUs are not comparable) -> cycles / real time must be a shader clock this chip can run at on every XCD, most CUs
+    must have been paired, and the real-time counter must advance at 100 MHz (checked against the host's clock over the region)."""
     import time
+    x = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):
+        x = torch.tanh(x) * 1.01                                   # (clocks up before the first stamp)
     torch.cuda.synchronize()
     c0 = ops.clock_stamps(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    x = torch.randn(4096, 4096, device="cuda")
-    for _ in range(40):
+    for _ in range(400):
         x = torch.tanh(x) * 1.01
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     c1 = ops.clock_stamps(); torch.cuda.synchronize()
-    d = (c1 - c0).cpu().double()
-    assert d.shape == (8, 2) and bool((d[:, 1] > 0).all()), d                      # every XCD got a block both times
-    mhz = d[:, 0] / d[:, 1] * 100.0
-    assert float(mhz.min()) > 90.0 and float(mhz.max()) < 2500.0, mhz
-    real_s = d[:, 1] / 100e6
-    assert abs(float(real_s.mean()) / (t1 - t0) - 1.0) < 0.25, (real_s, t1 - t0)   # (the stamps bracket the region a little wider than the host clock)
+    r = ops.clock_from_stamps(c0, c1)
+    assert r and r["cus"] >= 128 and len(r["xcd_mhz"]) == 8, r
+    assert 300.0 < min(r["xcd_mhz"]) and max(r["xcd_mhz"]) < 2500.0, r
+    a, b = c0.cpu(), c1.cpu()
+    ok = (a[:, 1] != 0) & (b[:, 1] != 0)
+    real_s = float((b[ok, 1] - a[ok, 1]).double().mean()) / 100e6
+    assert abs(real_s / (t1 - t0) - 1.0) < 0.25, (real_s, t1 - t0)
