@@ -302,6 +302,9 @@ def config5(dev, dialogues: int = 56):
     ser, ts, ps = timed_region(lambda: c5.run(dialogues, 8, overlap=False, partitioned=False, recs=recs, B1=8), idx)
     n_pip = min(dialogues, 28)
     pip, tp, pp = timed_region(lambda: c5.run(n_pip, 7, overlap=True, recs=recs[:n_pip]), idx)
+    # the acoustic stage alone (8 decoded dialogues: 64-NFE solve + vocoder + int16): what a free decode would leave
+    decoded = [dict(recs[i], streams=big[i]["streams"]) for i in range(8)]
+    _, t_solve, _ = timed_region(lambda: c5.stage2(decoded), idx)
     same = all(torch.equal(a["streams"], b["streams"]) and torch.equal(a["pcm"], b["pcm"]) for a, b in zip(ser, big))
     tok = all(torch.equal(a["streams"], b["streams"]) for a, b in zip(ser, pip))
     from covomix_amd import ops
@@ -309,6 +312,7 @@ def config5(dev, dialogues: int = 56):
     return {"workload": f"CoMix text2semantic (608 steps) + VoMix 64-NFE + HiFi-GAN, T = {c5.T} frames per dialogue, recipe weights",
             "best_schedule": "serial_64: 64 dialogues per text2semantic pass on the whole chip, 8 per acoustic batch, one stream (= --pipeline auto)",
             "dialogues_per_s": round(dialogues / tb, 3), "dialogues": dialogues, "mel_frames_per_s": round(dialogues * c5.T / tb, 1),
+            "solve_only_bound_dialogues_per_s": round(8 / t_solve, 3), "frac_of_solve_only_bound": round((dialogues / tb) / (8 / t_solve), 4),
             "serial_64": dict(dialogues_per_s=round(dialogues / tb, 3), dialogues=dialogues, **pb),
             "serial_8": dict(dialogues_per_s=round(dialogues / ts, 3), dialogues=dialogues, **ps),
             "pipelined_8": dict(dialogues_per_s=round(n_pip / tp, 3), dialogues=n_pip, cu_partition={"main": part.n_main, "side": part.n_side}, **pp),
